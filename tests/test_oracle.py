@@ -1,0 +1,181 @@
+"""CPU tests that pin the oracle (oracle/) as far as it can be pinned here.
+
+The reference holds no golden vectors and cannot be built -> "parity
+unpinned".  What is checked: the restated third-party arithmetic against 50-digit mpmath
+known answers, forward-dual Jacobians against central differences, the block
+elimination against a dense solve, and the LM optimum against scipy on the same residuals.
+"""
+import json
+import os
+import ctypes as C
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from vicalib_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "math_kat.json")))
+
+
+def _call3(fn, x, n_out):
+    out = np.zeros(n_out)
+    fn(ol._d(np.array(x, dtype=np.float64)), ol._d(out))
+    return out
+
+
+def test_project_known_answers():
+    for e in KAT["project"]:
+        pix, _, _ = ol.project(e["model"], np.array(e["ray"]), np.array(e["k"]))
+        np.testing.assert_allclose(pix, e["pix"], rtol=2e-13, atol=1e-10)
+
+
+def test_lie_known_answers():
+    L = ol.lib()
+    for e in KAT["so3_exp"]:
+        np.testing.assert_allclose(_call3(L.vco_so3_exp, e["w"], 4), e["q"], rtol=1e-14, atol=1e-16)
+    for e in KAT["so3_log"]:
+        np.testing.assert_allclose(_call3(L.vco_so3_log, e["q"], 3), e["w"], rtol=2e-13, atol=1e-17)
+    # Sophus' closed forms (1-cos t)/t^2, (t-sin t)/t^3 cancel for tiny t (and V := R below 1e-10):
+    # the translation part is only good to ~t/2 there; that behaviour is part of what is restated.
+    for e in KAT["se3_exp"]:
+        th = np.linalg.norm(e["d"][3:])
+        np.testing.assert_allclose(_call3(L.vco_se3_exp, e["d"], 7), e["T"], rtol=1e-12, atol=2e-8 if th < 1e-3 else 1e-14)
+    for e in KAT["se3_log"]:
+        th = 2 * np.linalg.norm(e["T"][:3])
+        np.testing.assert_allclose(_call3(L.vco_se3_log, e["T"], 6), e["d"], rtol=5e-12, atol=2e-8 if th < 1e-3 else 1e-13)
+    for e in KAT["gravity"]:
+        np.testing.assert_allclose(_call3(L.vco_gravity_vector, e["dir"], 3), e["g"], rtol=1e-14)
+
+
+def test_project_dual_jacobian_vs_central_difference():
+    rng = np.random.default_rng(0)
+    for e in KAT["project"][::7]:
+        ray = np.array(e["ray"]); k = np.array(e["k"])
+        if ray[0] ** 2 + ray[1] ** 2 < 1e-4 * ray[2] ** 2:
+            continue  # branch boundary / singular axis: skip the FD check there
+        _, dray, dk = ol.project(e["model"], ray, k)
+        h = 1e-6
+        for j in range(3):
+            d = np.zeros(3); d[j] = h
+            num = (ol.project(e["model"], ray + d, k)[0] - ol.project(e["model"], ray - d, k)[0]) / (2 * h)
+            np.testing.assert_allclose(dray[:, j], num, rtol=2e-6, atol=2e-6)
+        for j in range(len(k)):
+            d = np.zeros(len(k)); d[j] = h * max(1.0, abs(k[j]))
+            num = (ol.project(e["model"], ray, k + d)[0] - ol.project(e["model"], ray, k - d)[0]) / (2 * d[j])
+            np.testing.assert_allclose(dk[:, j], num, rtol=2e-6, atol=2e-5)
+
+
+def test_local_param_jacobians_match_plus():
+    L = ol.lib()
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        T = synth.se3_from_Rt(synth.so3_exp_matrix(rng.normal(size=3)), rng.normal(size=3))
+        J = np.zeros((7, 6)); L.vco_local_jac_se3(ol._d(T), ol._d(J))
+        h = 1e-6
+        for j in range(6):
+            d = np.zeros(6); d[j] = h
+            a = np.zeros(7); b = np.zeros(7)
+            L.vco_plus_se3(ol._d(T), ol._d(d), ol._d(a)); L.vco_plus_se3(ol._d(T), ol._d(-d), ol._d(b))
+            np.testing.assert_allclose(J[:, j], (a - b) / (2 * h), atol=1e-8)
+        J3 = np.zeros((4, 3)); L.vco_local_jac_so3(ol._d(T[:4].copy()), ol._d(J3))
+        for j in range(3):
+            d = np.zeros(3); d[j] = h
+            a = np.zeros(4); b = np.zeros(4)
+            L.vco_plus_so3(ol._d(T[:4].copy()), ol._d(d), ol._d(a)); L.vco_plus_so3(ol._d(T[:4].copy()), ol._d(-d), ol._d(b))
+            np.testing.assert_allclose(J3[:, j], (a - b) / (2 * h), atol=1e-8)
+
+
+def _small_problem(models=("poly3",), n=6, imu=False, seed=7):
+    return synth.generate(synth.Config(models=models, n_frames=n, imu=imu, seed=seed))
+
+
+@pytest.mark.parametrize("models", [("fov", "poly2"), ("poly3", "kb4"), ("linear",)])
+def test_reproj_block_matches_closed_form_and_fd(models):
+    """AutoDiff x local-param Jacobian == closed-form manifold Jacobian == FD of Plus."""
+    p = _small_problem(models, n=3)
+    o = ol.Oracle().load(p, init=False)
+    o.set_options(calibrate_imu=False)
+    o.prepare()
+    r0, f, c = o.residuals()
+    L = ol.lib()
+    for i in range(0, len(r0), 37):
+        nk = o.nk[c[i]]
+        r, Jf, Jr, Jt, Jk = o.reproj_block(i, nk)
+        np.testing.assert_allclose(r, r0[i], rtol=0, atol=1e-12)
+        T0, _ = o.frame(f[i]); K0, Tck0 = o.camera(c[i])
+        h = 1e-6
+        for j in range(6):
+            d = np.zeros(6); d[j] = h
+            vals = []
+            for s in (+1, -1):
+                Tn = np.zeros(7); L.vco_plus_se3(ol._d(T0), ol._d(s * d), ol._d(Tn))
+                o.set_frame(f[i], Tn); vals.append(o.residuals()[0][i].copy())
+            o.set_frame(f[i], T0)
+            np.testing.assert_allclose(Jf[:, j], (vals[0] - vals[1]) / (2 * h), rtol=1e-5, atol=1e-4)
+        for j in range(3):
+            d = np.zeros(3); d[j] = h
+            vals = []
+            for s in (+1, -1):
+                qn = np.zeros(4); L.vco_plus_so3(ol._d(Tck0[:4].copy()), ol._d(s * d), ol._d(qn))
+                o.set_camera(c[i], K0, np.concatenate([qn, Tck0[4:]])); vals.append(o.residuals()[0][i].copy())
+            o.set_camera(c[i], K0, Tck0)
+            np.testing.assert_allclose(Jr[:, j], (vals[0] - vals[1]) / (2 * h), rtol=1e-5, atol=1e-4)
+
+
+def test_block_elimination_equals_dense_solve():
+    p = _small_problem(("fov", "poly3"), n=8)
+    o = ol.Oracle().load(p)
+    o.set_options(calibrate_imu=False)
+    o.prepare()
+    lin = o.linearize()
+    n, D = o.n_frames, o.layout()["D"]
+    lam = np.zeros(n * 9 + D)
+    for f in range(n):
+        lam[f * 9:f * 9 + 6] = np.diag(lin["A"][f])[:6] * 1e-4
+    lam[n * 9:] = np.diag(lin["Hss"]) * 1e-4
+    a1, b1 = o.solve_normal(lam, dense=False)
+    a2, b2 = o.solve_normal(lam, dense=True)
+    np.testing.assert_allclose(a1, a2, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(b1, b2, rtol=1e-8, atol=1e-12)
+
+
+def test_cfg1_optimum_matches_scipy():
+    """BASELINE config 1 (single poly3, small grid, 50 frames): oracle LM optimum == scipy TRF optimum
+    of the same per-block soft-L1 objective (independent optimiser)."""
+    scipy_opt = pytest.importorskip("scipy.optimize")
+    p = synth.generate(synth.BASELINE_CONFIGS["cfg1"])
+    o = ol.Oracle().load(p)
+    o.set_options(calibrate_imu=False, function_tolerance=1e-14, max_iters=60)
+    o.solve()
+    K_lm, _ = o.camera(0)
+    rm = o.rmse()[0]
+    assert rm < 0.15          # vicalib-engine.cc:56 acceptance
+    # scipy on the oracle's own residual function, robustified per block by hand
+    o2 = ol.Oracle().load(p)
+    o2.set_options(calibrate_imu=False)
+    o2.prepare()
+    L = ol.lib()
+    T0 = o2.frames()[0]; K0, Tck = o2.camera(0)
+    n = o2.n_frames
+
+    def apply(x):
+        for f in range(n):
+            Tn = np.zeros(7); L.vco_plus_se3(ol._d(T0[f]), ol._d(x[6 * f:6 * f + 6]), ol._d(Tn)); o2.set_frame(f, Tn)
+        o2.set_camera(0, K0 + x[6 * n:], Tck)
+
+    def fun(x):
+        apply(x)
+        r = o2.residuals()[0]
+        s = (r * r).sum(axis=1)
+        rho = 2 * 0.25 * (np.sqrt(1 + s / 0.25) - 1)
+        w = np.sqrt(rho / np.maximum(s, 1e-300))
+        return (r * w[:, None]).ravel()
+
+    x0 = np.zeros(6 * n + 7)
+    sol = scipy_opt.least_squares(fun, x0, method="trf", x_scale="jac", xtol=1e-15, ftol=1e-15, gtol=1e-12, max_nfev=200)
+    K_sp = K0 + sol.x[6 * n:]
+    np.testing.assert_allclose(K_lm[:4], K_sp[:4], rtol=2e-6)
+    np.testing.assert_allclose(K_lm[4:], K_sp[4:], rtol=2e-4, atol=1e-7)
+    # and it recovers ground truth to the accuracy the noise allows
+    np.testing.assert_allclose(K_lm[:4], p.cam_K_gt[0][:4], rtol=2e-3)

@@ -1,0 +1,333 @@
+"""Deterministic synthetic calibration problems.
+
+Stands in for the reference's sensor front-end (vicalib-task.cc:247-372: conic
+detection -> PnP -> AddFrame/AddObservation, and vicalib-engine.cc:557 IMU
+handler): produces exactly the calls the reference makes on ViCalibrator --
+cameras with the engine's start values (vicalib-engine.cc:203-263), frames with
+an initial pose, per-(frame, camera) dot detections p_w = spacing * (i, j, 0)
+(vicalib-task.cc:357-358) and 200 Hz IMU samples generated through the
+reference's own measurement model (ceres-cost-functions.h:98-102).
+
+Everything is a pure function of (config, seed, frame index), so every rank of a
+multi-GPU run can build its own frame shard without communication.
+Pure numpy; no dependency on the HIP library or on oracle/.
+"""
+from __future__ import annotations
+
+import dataclasses
+import numpy as np
+
+MODEL_IDS = {"fov": 0, "poly2": 1, "poly3": 2, "poly": 2, "kb4": 3, "linear": 4}
+MODEL_NK = {0: 5, 1: 6, 2: 7, 3: 8, 4: 4}
+GRAVITY = 9.8007  # types.h:40-42
+
+GT_INTRINSICS = {
+    0: [330.0, 330.0, 320.0, 240.0, 0.92],
+    1: [400.0, 400.0, 320.0, 240.0, -0.28, 0.09],
+    2: [400.0, 400.0, 320.0, 240.0, -0.28, 0.09, -0.012],
+    3: [260.0, 260.0, 320.0, 240.0, -0.012, 0.004, -0.0015, 0.0002],
+    4: [400.0, 400.0, 320.0, 240.0],
+}
+GRIDS = {"small": (19, 10, 0.254 / 18.0), "large": (25, 36, 0.03156)}
+RDF_ROBOTICS = np.array([[0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
+
+
+# ----------------------------------------------------------------------------- rng
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def hash_uniform(seed: int, *keys) -> np.ndarray:
+    """Counter-based uniform(0,1): a pure function of (seed, keys...)."""
+    with np.errstate(over="ignore"):
+        h = np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
+        h = _splitmix64(np.asarray(h, dtype=np.uint64))
+        for k in keys:
+            k = np.asarray(k).astype(np.uint64)
+            h = _splitmix64(h ^ (k * np.uint64(0xD6E8FEB86659FD93)))
+    return ((h >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+def hash_normal(seed: int, *keys) -> np.ndarray:
+    u1 = hash_uniform(seed, *keys, 0x11)
+    u2 = hash_uniform(seed, *keys, 0x22)
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+# ----------------------------------------------------------------------------- lie helpers ([x,y,z,w] quaternions)
+def quat_from_matrix(R: np.ndarray) -> np.ndarray:
+    R = np.asarray(R, dtype=np.float64)
+    out = np.empty(R.shape[:-2] + (4,))
+    Rf = R.reshape(-1, 3, 3)
+    of = out.reshape(-1, 4)
+    for i, m in enumerate(Rf):
+        tr = m[0, 0] + m[1, 1] + m[2, 2]
+        if tr > 0:
+            s = np.sqrt(tr + 1.0) * 2
+            q = [(m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s, 0.25 * s]
+        elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+            s = np.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2
+            q = [0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s, (m[2, 1] - m[1, 2]) / s]
+        elif m[1, 1] > m[2, 2]:
+            s = np.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2
+            q = [(m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s, (m[0, 2] - m[2, 0]) / s]
+        else:
+            s = np.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
+            q = [(m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s, (m[1, 0] - m[0, 1]) / s]
+        q = np.array(q)
+        of[i] = q / np.linalg.norm(q)
+    return out
+
+
+def quat_to_matrix(q: np.ndarray) -> np.ndarray:
+    q = np.asarray(q, dtype=np.float64)
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    R = np.empty(q.shape[:-1] + (3, 3))
+    R[..., 0, 0] = 1 - 2 * (y * y + z * z); R[..., 0, 1] = 2 * (x * y - w * z); R[..., 0, 2] = 2 * (x * z + w * y)
+    R[..., 1, 0] = 2 * (x * y + w * z); R[..., 1, 1] = 1 - 2 * (x * x + z * z); R[..., 1, 2] = 2 * (y * z - w * x)
+    R[..., 2, 0] = 2 * (x * z - w * y); R[..., 2, 1] = 2 * (y * z + w * x); R[..., 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def so3_exp_matrix(w: np.ndarray) -> np.ndarray:
+    w = np.asarray(w, dtype=np.float64)
+    th = np.linalg.norm(w, axis=-1)[..., None, None]
+    K = np.zeros(w.shape[:-1] + (3, 3))
+    K[..., 0, 1] = -w[..., 2]; K[..., 0, 2] = w[..., 1]
+    K[..., 1, 0] = w[..., 2]; K[..., 1, 2] = -w[..., 0]
+    K[..., 2, 0] = -w[..., 1]; K[..., 2, 1] = w[..., 0]
+    th2 = th * th
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a = np.where(th > 1e-8, np.sin(th) / th, 1.0 - th2 / 6.0)
+        b = np.where(th > 1e-8, (1.0 - np.cos(th)) / th2, 0.5 - th2 / 24.0)
+    return np.eye(3) + a * K + b * (K @ K)
+
+
+def se3_from_Rt(R: np.ndarray, t: np.ndarray) -> np.ndarray:
+    """[qx,qy,qz,qw,tx,ty,tz] -- Sophus SE3 data order."""
+    return np.concatenate([quat_from_matrix(R), np.asarray(t, dtype=np.float64)], axis=-1)
+
+
+# ----------------------------------------------------------------------------- camera models (generator side)
+def project(model: int, K: np.ndarray, P: np.ndarray) -> np.ndarray:
+    """Pixel of camera-frame points P (...,3). Same formulas as SURVEY 9.1."""
+    X, Y, Z = P[..., 0], P[..., 1], P[..., 2]
+    if model == 3:
+        rxy = np.sqrt(X * X + Y * Y)
+        th = np.arctan2(rxy, Z)
+        th2 = th * th
+        r = th * (1 + th2 * (K[4] + th2 * (K[5] + th2 * (K[6] + th2 * K[7]))))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            c = np.where(rxy > 0, X / rxy, 1.0)
+            s = np.where(rxy > 0, Y / rxy, 0.0)
+        return np.stack([K[0] * r * c + K[2], K[1] * r * s + K[3]], axis=-1)
+    x, y = X / Z, Y / Z
+    r2 = x * x + y * y
+    if model == 0:
+        r = np.sqrt(r2)
+        w = K[4]
+        m = 2.0 * np.tan(w / 2.0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            fac = np.where(r2 < 1e-5, m / w, np.arctan(r * m) / (r * w))
+    elif model == 1:
+        fac = 1 + K[4] * r2 + K[5] * r2 * r2
+    elif model == 2:
+        fac = 1 + K[4] * r2 + K[5] * r2 * r2 + K[6] * r2 * r2 * r2
+    else:
+        fac = np.ones_like(r2)
+    return np.stack([K[0] * x * fac + K[2], K[1] * y * fac + K[3]], axis=-1)
+
+
+# ----------------------------------------------------------------------------- problem description
+@dataclasses.dataclass
+class Config:
+    models: tuple            # e.g. ("fov", "fov")
+    grid: str = "small"
+    n_frames: int = 50
+    imu: bool = False
+    seed: int = 1234
+    width: int = 640
+    height: int = 480
+    frame_rate: float = 20.0
+    imu_rate: float = 200.0
+    pixel_sigma: float = 0.1
+    pose_sigma_t: float = 0.01
+    pose_sigma_r: float = np.deg2rad(1.5)
+    first_frame: int = 0     # global index of the first frame generated (frame sharding)
+
+
+BASELINE_CONFIGS = {
+    # BASELINE.json "configs", in order
+    "cfg1": Config(models=("poly3",), grid="small", n_frames=50, imu=False),
+    "cfg2": Config(models=("fov", "fov"), grid="small", n_frames=500, imu=False),
+    "cfg3": Config(models=("kb4",), grid="small", n_frames=2000, imu=True),
+    "cfg4": Config(models=("poly3",) * 4, grid="large", n_frames=10000, imu=True),
+    "cfg5": Config(models=("fov", "kb4") * 4, grid="small", n_frames=50000, imu=True),
+}
+
+
+@dataclasses.dataclass
+class Problem:
+    cfg: Config
+    grid_points: np.ndarray      # (M,3)
+    cam_model: list              # model ids
+    cam_K_gt: list               # GT intrinsics
+    cam_K_init: list             # reference start values (vicalib-engine.cc:207-257)
+    cam_T_ck_gt: np.ndarray      # (C,7)
+    cam_T_ck_init: np.ndarray    # (C,7)
+    frame_time: np.ndarray       # (N,)
+    frame_T_wk_gt: np.ndarray    # (N,7)
+    frame_T_wk_init: np.ndarray  # (N,7)
+    frame_v_gt: np.ndarray       # (N,3)
+    tiles: list                  # [(frame, cam, dot_ids (n,), pix (n,2))]
+    imu_t: np.ndarray = None     # (S,)
+    imu_gyro: np.ndarray = None  # (S,3)
+    imu_accel: np.ndarray = None # (S,3)
+    imu_gt: dict = None
+
+    @property
+    def n_obs(self) -> int:
+        return int(sum(len(t[2]) for t in self.tiles))
+
+
+def _trajectory(cfg: Config, t: np.ndarray, grid_w: float, grid_h: float):
+    """Camera-0 pose in the world at times t: position (…,3), R_wc (…,3,3)."""
+    cx, cy = 0.5 * grid_w, 0.5 * grid_h
+    d = grid_w * (0.625 + 0.275 * np.sin(2 * np.pi * t / 6.3 + 1.0))      # in [0.35, 0.9] * grid_w
+    x = cx + 0.30 * grid_w * np.sin(2 * np.pi * t / 3.1)
+    y = cy + 0.30 * grid_h * np.sin(2 * np.pi * t / 4.7 + 0.5)
+    p = np.stack([x, y, -d], axis=-1)
+    # look roughly at a wandering point on the grid, then add roll
+    tx = cx + 0.25 * grid_w * np.sin(2 * np.pi * t / 5.3 + 2.0)
+    ty = cy + 0.25 * grid_h * np.sin(2 * np.pi * t / 3.7 + 0.3)
+    target = np.stack([tx, ty, np.zeros_like(t)], axis=-1)
+    z = target - p
+    z = z / np.linalg.norm(z, axis=-1, keepdims=True)
+    roll = np.deg2rad(25.0) * np.sin(2 * np.pi * t / 7.9 + 0.7)
+    up = np.stack([np.sin(roll), np.cos(roll), np.zeros_like(t)], axis=-1)   # image "down" ~ +y world
+    xax = np.cross(up, z)
+    xax = xax / np.linalg.norm(xax, axis=-1, keepdims=True)
+    yax = np.cross(z, xax)
+    R = np.stack([xax, yax, z], axis=-1)   # columns = camera axes in the world
+    return p, R
+
+
+def generate(cfg: Config) -> Problem:
+    gw, gh, sp = GRIDS[cfg.grid]
+    ii, jj = np.meshgrid(np.arange(gw), np.arange(gh), indexing="ij")
+    grid = np.stack([ii.ravel() * sp, jj.ravel() * sp, np.zeros(gw * gh)], axis=-1)
+    grid_w, grid_h = (gw - 1) * sp, (gh - 1) * sp
+    C = len(cfg.models)
+    models = [MODEL_IDS[m] for m in cfg.models]
+    seed = cfg.seed
+
+    # cameras ---------------------------------------------------------------------------
+    K_gt, K_init = [], []
+    T_ck_gt = np.zeros((C, 7)); T_ck_init = np.zeros((C, 7))
+    R_ck0 = RDF_ROBOTICS if cfg.imu else np.eye(3)
+    for c, m in enumerate(models):
+        base = np.array(GT_INTRINSICS[m])
+        jit = 1.0 + 0.02 * (2.0 * hash_uniform(seed + 17, c, np.arange(len(base))) - 1.0)
+        K_gt.append(base * jit)
+        k0 = [300.0, 300.0, cfg.width / 2.0, cfg.height / 2.0] + ([0.2] if m == 0 else [0.0] * (MODEL_NK[m] - 4))
+        K_init.append(np.array(k0))
+        # body -> camera c: camera c sits 0.06*c along camera-0 x (the rig's lateral axis), small rotation
+        w = np.deg2rad(3.0) * (2.0 * hash_uniform(seed + 29, c, np.arange(3)) - 1.0) * (c > 0)
+        R_c_c0 = so3_exp_matrix(w)                      # camera0 -> camera c rotation
+        t_c_c0 = -R_c_c0 @ np.array([0.06 * c, 0.0, 0.0])
+        R_ck = R_c_c0 @ R_ck0
+        T_ck_gt[c] = se3_from_Rt(R_ck, t_c_c0)
+        T_ck_init[c] = np.array([0, 0, 0, 1.0, 0, 0, 0])   # Sophus::SE3d(), vicalib-engine.cc:211
+    # frames ----------------------------------------------------------------------------
+    f_idx = cfg.first_frame + np.arange(cfg.n_frames)
+    ft = 1.0 + f_idx / cfg.frame_rate
+    p_c0, R_wc0 = _trajectory(cfg, ft, grid_w, grid_h)
+    R_wk = R_wc0 @ R_ck0                                 # body orientation
+    T_wk_gt = se3_from_Rt(R_wk, p_c0)
+    # velocity (world) by central difference of the analytic position
+    h = 1e-5
+    pp, _ = _trajectory(cfg, ft + h, grid_w, grid_h); pm, _ = _trajectory(cfg, ft - h, grid_w, grid_h)
+    v_gt = (pp - pm) / (2 * h)
+    # initial poses: the reference seeds T_wk = T_cw^-1 * T_ck with T_ck = identity (vicalib-task.cc:347-348),
+    # i.e. the (PnP-estimated) camera-0 pose; PnP error is modelled as a right perturbation.
+    dt = cfg.pose_sigma_t * hash_normal(seed + 41, f_idx[:, None], np.arange(3)[None, :])
+    dr = cfg.pose_sigma_r * hash_normal(seed + 43, f_idx[:, None], np.arange(3)[None, :])
+    R_init = R_wc0 @ so3_exp_matrix(dr)
+    t_init = p_c0 + np.einsum("nij,nj->ni", R_wc0, dt)
+    T_wk_init = se3_from_Rt(R_init, t_init)
+    # detections ------------------------------------------------------------------------
+    tiles = []
+    M = grid.shape[0]
+    for c, m in enumerate(models):
+        R_ck = quat_to_matrix(T_ck_gt[c, :4]); t_ck = T_ck_gt[c, 4:]
+        # p_k = R_wk^T (p_w - t_wk); p_c = R_ck p_k + t_ck
+        pk = np.einsum("nji,nmj->nmi", R_wk, grid[None, :, :] - p_c0[:, None, :])
+        pc = np.einsum("ij,nmj->nmi", R_ck, pk) + t_ck
+        pix = project(m, K_gt[c], pc)
+        ok = (pc[..., 2] > 1e-3) & (pix[..., 0] >= 5) & (pix[..., 0] <= cfg.width - 5) & (pix[..., 1] >= 5) & (pix[..., 1] <= cfg.height - 5)
+        # reject points whose incidence angle is outside a sane field of view (model extrapolation)
+        ang = np.arctan2(np.linalg.norm(pc[..., :2], axis=-1), pc[..., 2])
+        ok &= ang < np.deg2rad(75.0 if m == 3 else 55.0)
+        noise = cfg.pixel_sigma * hash_normal(seed + 5678, f_idx[:, None, None], c, np.arange(M)[None, :, None], np.arange(2)[None, None, :])
+        pix = pix + noise
+        for n in range(cfg.n_frames):
+            ids = np.nonzero(ok[n])[0]
+            if len(ids) >= 4:
+                tiles.append((n, c, ids.astype(np.int32), pix[n, ids]))
+    tiles.sort(key=lambda t: (t[0], t[1]))
+    prob = Problem(cfg, grid, models, K_gt, K_init, T_ck_gt, T_ck_init, ft, T_wk_gt, T_wk_init, v_gt, tiles)
+    if cfg.imu:
+        _add_imu(prob, grid_w, grid_h, R_ck0)
+    return prob
+
+
+def gravity_vector(g_dir) -> np.ndarray:
+    p, q = g_dir
+    return -GRAVITY * np.array([np.cos(p) * np.sin(q), -np.sin(p), np.cos(p) * np.cos(q)])
+
+
+def _add_imu(prob: Problem, grid_w: float, grid_h: float, R_ck0: np.ndarray) -> None:
+    cfg = prob.cfg
+    gt = dict(bg=np.array([0.002, -0.001, 0.0015]), ba=np.array([0.03, -0.02, 0.05]),
+              sg=np.array([1.01, 0.99, 1.005]), sa=np.array([0.995, 1.01, 0.99]),
+              g_dir=np.array([0.03, -0.02]), time_offset=0.003)
+    t0 = prob.frame_time[0] - 0.1
+    t1 = prob.frame_time[-1] + 0.1
+    k0 = int(np.floor(t0 * cfg.imu_rate)); k1 = int(np.ceil(t1 * cfg.imu_rate))
+    k = np.arange(k0, k1 + 1)
+    # the buffer compares (sample stamp + offset) with frame times (interpolation-buffer.h:122-125, :163-199):
+    # a sample stamped t_imu was taken at image-clock time t_imu + offset
+    t_imu = k / cfg.imu_rate
+    tb = t_imu + gt["time_offset"]
+    h = 1e-4
+    p0, R0 = _trajectory(cfg, tb, grid_w, grid_h)
+    pp, Rp = _trajectory(cfg, tb + h, grid_w, grid_h)
+    pm, Rm = _trajectory(cfg, tb - h, grid_w, grid_h)
+    a_w = (pp - 2 * p0 + pm) / (h * h)
+    Rk0 = R0 @ R_ck0; Rkp = Rp @ R_ck0; Rkm = Rm @ R_ck0
+    Wx = (Rkp - Rkm) / (2 * h) @ np.swapaxes(Rk0, -1, -2)          # [w_w]x = Rdot R^T
+    w_w = np.stack([Wx[:, 2, 1] - Wx[:, 1, 2], Wx[:, 0, 2] - Wx[:, 2, 0], Wx[:, 1, 0] - Wx[:, 0, 1]], axis=-1) * 0.5
+    g_w = gravity_vector(gt["g_dir"])
+    # k_w = R (z_g * s_g + b_g) ; k_a = R (z_a * s_a + b_a) - g_w   (ceres-cost-functions.h:98-102)
+    zg = (np.einsum("nji,nj->ni", Rk0, w_w) - gt["bg"]) / gt["sg"]
+    za = (np.einsum("nji,nj->ni", Rk0, a_w + g_w) - gt["ba"]) / gt["sa"]
+    zg = zg + 5.3088444e-5 * hash_normal(cfg.seed + 9001, k[:, None], np.arange(3)[None, :])
+    za = za + 0.001883649 * hash_normal(cfg.seed + 9002, k[:, None], np.arange(3)[None, :])
+    prob.imu_t, prob.imu_gyro, prob.imu_accel, prob.imu_gt = t_imu, zg, za, gt
+
+
+# ----------------------------------------------------------------------------- flat arrays for bulk ingest
+def flatten(prob: Problem):
+    """tile_frame, tile_cam, tile_off (T+1), p_w (n,3), p_c (n,2) in tile order."""
+    tf = np.array([t[0] for t in prob.tiles], dtype=np.int32)
+    tc = np.array([t[1] for t in prob.tiles], dtype=np.int32)
+    cnt = np.array([len(t[2]) for t in prob.tiles], dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    ids = np.concatenate([t[2] for t in prob.tiles]) if prob.tiles else np.zeros(0, np.int32)
+    pw = prob.grid_points[ids]
+    pc = np.concatenate([t[3] for t in prob.tiles]) if prob.tiles else np.zeros((0, 2))
+    return tf, tc, off, np.ascontiguousarray(pw), np.ascontiguousarray(pc)
