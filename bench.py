@@ -1,0 +1,161 @@
+#!/usr/bin/env python
+"""bench.py -- LM-iteration throughput of the calibration hot path on MI355X.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): stereo fov,fov rig, small
+grid (19x10 dots), 500 synthetic frames per GPU, intrinsics + extrinsics, no IMU.  A "step" is one
+Levenberg-Marquardt iteration of the real solver (Jacobian sweep over all corners + frame-block Schur
+elimination + reduced solve + manifold update + residual sweep of the trial point + accept/reject);
+complete solves are run back to back from the same initial state until exactly K iterations are done.
+N > 1: one process per GPU, frames sharded (weak scaling: 500 frames per rank), one all-reduce of the
+reduced system + one of the step scalars per iteration over RCCL (torch.distributed "nccl").
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=500, help="frames per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from vicalib_amd import synth
+    from vicalib_amd.lib import ViCalibrator
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- this rank's frame shard of the N*frames problem ------------------------------------------
+    cfg = synth.Config(models=("fov", "fov"), grid="small", n_frames=args.frames, imu=False, first_frame=rank * args.frames)
+    prob = synth.generate(cfg)
+    cal = ViCalibrator(local_rank).load_problem(prob)
+    cal.SetCalibrateImu(False)
+
+    comm = None
+    if world > 1:
+        from vicalib_amd.parallel import FrameShardComm
+        comm = FrameShardComm(device="cuda:%d" % local_rank, stream_ptr=cal.stream())
+        cal.set_shard(rank, world, comm)
+
+    cal.prepare()
+    n_obs_local = cal.num_observations()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    cal.run_iterations(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    done, jac_sweeps, res_sweeps = cal.run_iterations(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        no = torch.tensor([float(n_obs_local)], device="cuda", dtype=torch.float64)
+        dist.all_reduce(no)
+        n_obs_total = int(no.item())
+    else:
+        n_obs_total = n_obs_local
+
+    # ---- final accuracy of one complete solve (the metric's "final RMS reproj err") --------------------
+    cal2 = ViCalibrator(local_rank).load_problem(prob)
+    cal2.SetCalibrateImu(False)
+    if world > 1:
+        cal2.set_shard(rank, world, FrameShardComm(device="cuda:%d" % local_rank, stream_ptr=cal2.stream()))
+    cal2.Solve()
+    rmse = [float(x) for x in cal2.GetCameraProjRMSE()]
+
+    # ---- kernel-level roofline of the dominant kernel (HIP events on the calibrator's stream) --------
+    jac_ms, res_ms = cal.time_kernels(50)
+    n_tiles = cal.num_tiles()
+    kc = 5   # fov
+    # 18 B/corner + per tile [64 B in + 8*(21 + 6 + 6*S_c + 1) B out], S_c = 6 + K_c
+    bytes_jac = 18.0 * n_obs_local + n_tiles * (64 + 8 * (28 + 6 * (6 + kc)))
+    bytes_res = 18.0 * n_obs_local + n_tiles * (64 + 8)
+    flops_jac = 1050.0 * n_obs_local          # ~1.0-1.1 kflop per corner (fp64)
+    ach = flops_jac / (jac_ms * 1e-3) / 1e12
+    roofline = {"kernel": "k_reproj_jac", "bound": "mfma", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6,
+                "traffic": None, "hbm_gbs": bytes_jac / (jac_ms * 1e-3) / 1e9, "hbm_frac": bytes_jac / (jac_ms * 1e-3) / 8e12,
+                "avg_ms": jac_ms, "algorithmic_bytes": bytes_jac, "algorithmic_flops": flops_jac}
+    roofline_res = {"kernel": "k_reproj_res", "bound": "hbm", "achieved": bytes_res / (res_ms * 1e-3) / 1e9, "peak": 8000.0,
+                    "unit": "GB/s", "frac": bytes_res / (res_ms * 1e-3) / 8e12, "traffic": None, "avg_ms": res_ms,
+                    "algorithmic_bytes": bytes_res}
+
+    out = None
+    if rank == 0:
+        iters_per_s = done / dt
+        value = n_obs_total * iters_per_s
+        out = {
+            "metric": "corner_residuals_per_sec", "value": value, "unit": "corner-residuals/s (LM iterations x corners)",
+            "n_gpus": world, "steps": done, "warmup": args.warmup, "ms_per_step": 1e3 * dt / done, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg2: stereo fov,fov, small grid 19x10, %d frames/GPU, intrinsics+extrinsics, no IMU" % args.frames,
+                       "frames_total": args.frames * world, "corners_total": n_obs_total, "tiles_per_gpu": n_tiles,
+                       "parallelism": "frames sharded x%d, all-reduce of reduced system per LM iteration" % world},
+            "lm_iters_per_sec": iters_per_s, "jacobian_sweeps": jac_sweeps, "residual_sweeps": res_sweeps,
+            "final_rmse_px": rmse, "roofline": roofline, "roofline_residual_sweep": roofline_res,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(prob)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(prob):
+    """The CPU oracle (a port of the reference's autodiff + solver path, since Ceres cannot be built here)
+    timed on this host on a bounded sample of the same workload: full LM-iteration work units on the
+    first frames of the same problem, 4 threads (the reference's num_threads, vicalibrator.h:141)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    threads = 4
+    n_sub = min(100, len(prob.frame_time))
+    orc = ol.Oracle()
+    for c, m in enumerate(prob.cam_model):
+        orc.add_camera(m, prob.cam_K_init[c], prob.cam_T_ck_init[c])
+    for n in range(n_sub):
+        orc.add_frame(prob.frame_T_wk_init[n], prob.frame_time[n])
+    nobs = 0
+    for (f, c, ids, pix) in prob.tiles:
+        if f < n_sub:
+            orc.add_observations(f, c, prob.grid_points[ids], pix); nobs += len(ids)
+    orc.set_options(calibrate_imu=False, num_threads=threads)
+    orc.prepare(vis_mult=1)
+    orc.time_iterations(1)
+    iters = 0; t = 0.0
+    while t < 10.0 and iters < 400:
+        t += orc.time_iterations(4); iters += 4
+    return {"value": nobs * iters / t, "unit": "corner-residuals/s (LM iterations x corners)", "cores": threads, "kind": "port",
+            "sample": "%d LM-iteration work units (dual-number Jacobian sweep + block solve + cost sweep) on the first %d of %d frames (%d corners), %.1f s"
+                      % (iters, n_sub, len(prob.frame_time), nobs, t),
+            "lm_iters_per_sec_extrapolated_to_full": (nobs * iters / t) / prob.n_obs}
+
+
+if __name__ == "__main__":
+    main()

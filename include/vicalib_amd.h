@@ -1,0 +1,131 @@
+/* vicalib_amd.h -- C ABI of the MI355X-native calibration solver.
+ *
+ * Drop-in boundary for the optimisation core of arpg/vicalib: every entry point replaces one
+ * public member of visual_inertial_calibration::ViCalibrator (include/vicalib/vicalibrator.h:119-544),
+ * the header-only class that VicalibTask owns by value (vicalib-task.h:120) and drives from
+ * vicalib-task.cc / vicalib-engine.cc.  Plain pointers and sizes only; the library copies in and
+ * copies out, the handle is opaque, and nothing aborts: every call returns a status
+ * (the reference CHECK()s / LOG(FATAL)s instead, vicalibrator.h:254, :377, :396, :456).
+ *
+ * Conventions (same as the reference's parameter blocks):
+ *   SE3  = 7 doubles [qx qy qz qw tx ty tz]   (Sophus::SE3d::data(), vicalibrator.h:460, :604)
+ *   T_wk = pose of the rig ("k") in the world; T_ck maps rig coordinates into camera c
+ *   intrinsics = [fu fv u0 v0 distortion...]  (calibu parameter order, vicalib-engine.cc:207-257)
+ *
+ * The solver needs a HIP device (gfx950).  vc_create() fails with VC_ERR_NO_DEVICE on a machine
+ * without one; there is no CPU fallback.
+ */
+#ifndef VICALIB_AMD_H_
+#define VICALIB_AMD_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vc_calibrator vc_calibrator;
+
+enum {
+  VC_OK = 0,
+  VC_ERR_NO_DEVICE = -1,      /* no HIP device / HIP runtime error */
+  VC_ERR_BAD_ARG = -2,        /* index out of range, null pointer, unsupported model */
+  VC_ERR_RUNNING = -3,        /* setter called while the solver runs (reference: CHECK(!is_running_)) */
+  VC_ERR_TIME_ORDER = -4,     /* IMU timestamps not strictly increasing (vicalibrator.h:373-378) */
+  VC_ERR_TOO_MANY_POINTS = -5,/* more than 65536 distinct target points */
+  VC_ERR_NUMERIC = -6,        /* factorisation failed repeatedly */
+  VC_ERR_UNSUPPORTED = -7     /* feature of the reference not available in this build */
+};
+
+/* -models strings of vicalib-engine.cc:203-253, in this order */
+enum { VC_MODEL_FOV = 0, VC_MODEL_POLY2 = 1, VC_MODEL_POLY3 = 2, VC_MODEL_KB4 = 3, VC_MODEL_LINEAR = 4 };
+
+/* ViCalibrator() vicalibrator.h:124-155 + Clear() :232-249.  device = HIP ordinal. */
+int vc_create(vc_calibrator** out, int device);
+void vc_destroy(vc_calibrator* h);
+int vc_clear(vc_calibrator* h);                                   /* Clear() :232 */
+
+/* AddCamera(cam, T_ck) :332-342 -> camera id (>= 0) or error */
+int vc_add_camera(vc_calibrator* h, int model, const double* params, int nparams, int width, int height,
+                  const double T_ck[7]);
+int vc_fix_camera_intrinsics(vc_calibrator* h, int should_fix);   /* FixCameraIntrinsics :346 */
+/* AddFrame(T_wk, time) :355-367 -> frame id */
+int vc_add_frame(vc_calibrator* h, const double T_wk[7], double time);
+/* GetFrame(id)->t_wp_ = ... (vicalib-task.cc:347-348) */
+int vc_set_frame_pose(vc_calibrator* h, int frame, const double T_wk[7]);
+/* AddObservation(frame, cam, p_w, p_c, time) :385-468, in bulk: n corners of one (frame, camera) */
+int vc_add_observations(vc_calibrator* h, int frame, int camera, int n, const double* p_w /* n x 3 */,
+                        const double* p_c /* n x 2 */);
+/* AddImuMeasurements(gyro, accel, time) :370-380, in bulk */
+int vc_add_imu(vc_calibrator* h, int n, const double* gyro /* n x 3 */, const double* accel /* n x 3 */,
+               const double* time /* n */);
+
+int vc_set_sigmas(vc_calibrator* h, double gyro_sigma, double accel_sigma);       /* SetSigmas :290 */
+int vc_set_biases(vc_calibrator* h, const double biases[6]);                       /* SetBiases :301 */
+int vc_set_scale_factor(vc_calibrator* h, const double scale[6]);                  /* SetScaleFactor :308 */
+int vc_set_time_offset(vc_calibrator* h, double offset);                           /* SetTimeOffset :296 */
+int vc_set_function_tolerance(vc_calibrator* h, double tol);                       /* SetFunctionTolerance :277 */
+/* SetOptimizationFlags(bias_active, inertial_active, rotation_only, optimize_imu_time_offset) :252-260 */
+int vc_set_optimization_flags(vc_calibrator* h, int bias_active, int inertial_active, int rotation_only,
+                              int optimize_time_offset);
+/* gflags read inside the calibrator: FLAGS_max_iters (:142), FLAGS_calibrate_imu (:214, :651, :977),
+ * FLAGS_remove_outliers / FLAGS_outlier_threshold (:870, :995, :1024) */
+int vc_set_max_iters(vc_calibrator* h, int max_iters);
+int vc_set_calibrate_imu(vc_calibrator* h, int calibrate_imu);
+int vc_set_remove_outliers(vc_calibrator* h, int remove_outliers, double outlier_threshold);
+
+/* Start() :263 / IsRunning() :314 / Stop() :317; vc_solve = Start() + join (blocking SolveThread :919) */
+int vc_solve(vc_calibrator* h);
+int vc_start(vc_calibrator* h);
+int vc_is_running(vc_calibrator* h);
+int vc_stop(vc_calibrator* h);
+
+/* readers (fields of CalibrationStats, calibration-stats.h:34-42) */
+int vc_num_frames(vc_calibrator* h);                                               /* NumFrames :471 */
+int vc_num_cameras(vc_calibrator* h);                                              /* NumCameras :484 */
+int vc_get_camera(vc_calibrator* h, int camera, double* params, int* nparams, double T_ck[7]);   /* GetCamera :492 */
+int vc_get_frame(vc_calibrator* h, int frame, double T_wk[7], double v_w[3], double* time);      /* GetFrame :477 */
+int vc_get_biases(vc_calibrator* h, double biases[6]);                             /* GetBiases :286 */
+int vc_get_scale_factor(vc_calibrator* h, double scale[6]);                        /* GetScaleFactor :306 */
+int vc_get_gravity(vc_calibrator* h, double g_dir[2]);                             /* imu_.g_ :1020 */
+double vc_time_offset(vc_calibrator* h);                                           /* time_offset :474 */
+double vc_mean_squared_error(vc_calibrator* h);                                    /* MeanSquaredError :506 */
+int vc_get_camera_proj_rmse(vc_calibrator* h, double* rmse /* n_cameras */);       /* GetCameraProjRMSE :160 */
+unsigned vc_get_num_iterations(vc_calibrator* h);                                  /* GetNumIterations :283 */
+/* WriteCameraModels(filename) :208-229 (calibu rig XML) */
+int vc_write_camera_models(vc_calibrator* h, const char* filename);
+
+/* ---- engine-level entry points (no counterpart in the reference: it has no GPU, no sharding) ---- */
+/* Per-iteration record of the trust-region loop = the columns of the reference's log line (:698-707).
+ * rows of 10 doubles: iteration, cost, cost_change, gradient_max_norm, gradient_norm, step_norm,
+ * relative_decrease, trust_region_radius, accepted, stage */
+int vc_trace_len(vc_calibrator* h);
+int vc_get_trace(vc_calibrator* h, double* rows, int max_rows);
+/* Frame sharding across processes (one process per GPU): this handle holds frames
+ * [first_global_frame, first_global_frame + n_local) of a problem that world_size ranks solve together.
+ * allreduce_sum / allreduce_max are called on every LM iteration with a DEVICE pointer and must return
+ * only when the reduction is complete on the calibrator's stream (see vc_get_stream). */
+typedef int (*vc_allreduce_fn)(void* ctx, double* device_buf, int count, int op /*0 sum, 1 max*/);
+int vc_set_shard(vc_calibrator* h, int rank, int world_size, vc_allreduce_fn fn, void* ctx);
+void* vc_get_stream(vc_calibrator* h);    /* hipStream_t */
+/* Upload the problem and linearise once at the current state (stage flags as set): fills the device
+ * normal equations.  Used by the parity tests and the benchmark. */
+int vc_prepare(vc_calibrator* h);
+/* Copies of device results after vc_prepare / vc_linearize (any pointer may be NULL):
+ *   cost, per-frame H_pp (n x 36), g_p (n x 6), reduced S (D x D, undamped Schur complement), g_red (D),
+ *   H_ss diagonal (D), g_s (D) */
+int vc_linearize(vc_calibrator* h, double* cost, double* Hpp, double* gp, double* S, double* g_red,
+                 double* hss_diag, double* g_s);
+int vc_shared_dim(vc_calibrator* h);
+/* Runs exactly `iters` LM iterations of the real solver (complete solves back to back from the uploaded
+ * initial state, the last one cut short); returns the number of iterations run (>= 0) or an error. */
+int vc_run_iterations(vc_calibrator* h, int iters, int* jac_sweeps, int* res_sweeps);
+/* Per-tile reprojection residual sweep on the accepted state: cost (1/2 sum rho) and sum of squares */
+int vc_evaluate(vc_calibrator* h, double* cost, double* sum_sq);
+/* Times the dominant kernels with HIP events on the calibrator's stream: average ms per launch over reps */
+int vc_time_kernels(vc_calibrator* h, int reps, double* jac_ms, double* res_ms);
+long long vc_num_observations(vc_calibrator* h);
+int vc_num_tiles(vc_calibrator* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VICALIB_AMD_H_ */

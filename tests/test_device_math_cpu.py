@@ -1,0 +1,112 @@
+"""CPU checks of the arithmetic the HIP kernels are built from (vicalib_amd/csrc/vc_math.hpp, compiled
+for the host by tests/host_harness) against the oracle: closed-form projection Jacobians vs forward
+duals, and the unique-column tile Gram block + post-reduction rotations vs the oracle's normal equations
+(which come from AutoDiff x local-parameterisation Jacobians, as in the reference)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from vicalib_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_hh = None
+
+
+def hh():
+    global _hh
+    if _hh is None:
+        src = os.path.join(HERE, "host_harness", "harness.cpp")
+        so = os.path.join(HERE, "host_harness", "libvc_host_harness.so")
+        hdr = os.path.join(HERE, "..", "vicalib_amd", "csrc", "vc_math.hpp")
+        if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
+        _hh = C.CDLL(so)
+        _hh.hh_tile_gram.restype = C.c_double
+        _hh.hh_tile_resid.restype = C.c_double
+    return _hh
+
+
+d = ol._d
+NK = {0: 5, 1: 6, 2: 7, 3: 8, 4: 4}
+
+
+def test_closed_form_projection_jacobians_match_duals():
+    import json
+    kat = json.load(open(os.path.join(HERE, "golden", "math_kat.json")))
+    H = hh()
+    for e in kat["project"]:
+        ray = np.array(e["ray"]); k = np.array(e["k"]); m = e["model"]
+        pix = np.zeros(2); A = np.zeros((2, 3)); B = np.zeros((2, NK[m]))
+        H.hh_project(m, d(ray), d(k), d(pix), d(A), d(B))
+        np.testing.assert_allclose(pix, e["pix"], rtol=2e-13, atol=1e-10)
+        opix, odray, odk = ol.project(m, ray, k)
+        if m == 3 and ray[0] ** 2 + ray[1] ** 2 < 1e-10:
+            continue
+        np.testing.assert_allclose(A, odray, rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(B, odk, rtol=1e-9, atol=1e-7)
+
+
+@pytest.mark.parametrize("models,fix_k", [(("fov", "fov"), False), (("poly3", "kb4", "poly2"), False), (("linear", "kb4"), True)])
+def test_tile_gram_algebra_matches_oracle_normal_equations(models, fix_k):
+    p = synth.generate(synth.Config(models=models, n_frames=5, seed=11))
+    o = ol.Oracle().load(p)
+    o.set_options(calibrate_imu=False, fix_intrinsics=fix_k)
+    o.prepare(vis_mult=1)
+    lin = o.linearize()
+    lay = o.layout()
+    D = lay["D"]
+    H = hh()
+    n = o.n_frames
+    Aff = np.zeros((n, 6, 6)); gf = np.zeros((n, 6)); W = np.zeros((n, 6, max(D, 1))); Hss = np.zeros((D, D)); gs = np.zeros(D)
+    Gsum = {c: np.zeros(256) for c in range(len(models))}
+    cost = 0.0
+    flags = {}
+    for c in range(len(models)):
+        fl = (1 if lay["cam"][c][0] >= 0 else 0) | (2 if lay["cam"][c][1] >= 0 else 0) | (4 if lay["cam"][c][2] >= 0 else 0)
+        flags[c] = fl
+    for (f, c, ids, pix) in p.tiles:
+        T, _ = o.frame(f); K, Tck = o.camera(c)
+        G = np.zeros(256)
+        pw = np.ascontiguousarray(p.grid_points[ids]); uv = np.ascontiguousarray(pix)
+        cost += 0.5 * H.hh_tile_gram(p.cam_model[c], d(T), d(Tck), d(K), len(ids), d(pw), d(uv), C.c_double(1.0), d(G))
+        Gsum[c] += G
+        Hff = np.zeros(36); g6 = np.zeros(6); Wt = np.zeros(96)
+        H.hh_frame_blocks(d(G), d(Tck), len(K), flags[c], d(Hff), d(g6), None)
+        H.hh_frame_blocks(d(G), d(Tck), len(K), flags[c], None, None, d(Wt))
+        Aff[f] += Hff.reshape(6, 6); gf[f] += g6
+        col0 = min([x for x in lay["cam"][c] if x >= 0], default=0)
+        nc = (3 if flags[c] & 1 else 0) + (3 if flags[c] & 2 else 0) + (len(K) if flags[c] & 4 else 0)
+        W[f][:, col0:col0 + nc] += Wt.reshape(6, 16)[:, :nc]
+    for c in range(len(models)):
+        K, Tck = o.camera(c)
+        Hcc = np.zeros(256); gc = np.zeros(16)
+        H.hh_cam_block(d(Gsum[c]), d(Tck), len(K), flags[c], d(Hcc), d(gc))
+        col0 = min([x for x in lay["cam"][c] if x >= 0], default=0)
+        nc = (3 if flags[c] & 1 else 0) + (3 if flags[c] & 2 else 0) + (len(K) if flags[c] & 4 else 0)
+        Hss[col0:col0 + nc, col0:col0 + nc] += Hcc.reshape(16, 16)[:nc, :nc]
+        gs[col0:col0 + nc] += gc[:nc]
+    np.testing.assert_allclose(cost, lin["cost"], rtol=1e-12)
+    scale = np.abs(lin["A"]).max()
+    np.testing.assert_allclose(Aff, lin["A"][:, :6, :6], rtol=1e-8, atol=1e-9 * scale)
+    np.testing.assert_allclose(gf, lin["gf"][:, :6], rtol=1e-8, atol=1e-9 * np.abs(lin["gf"]).max())
+    if D:
+        np.testing.assert_allclose(W[:, :, :D], lin["W"][:, :6, :], rtol=1e-8, atol=1e-9 * np.abs(lin["W"]).max())
+        np.testing.assert_allclose(Hss, lin["Hss"], rtol=1e-8, atol=1e-9 * np.abs(lin["Hss"]).max())
+        np.testing.assert_allclose(gs, lin["gs"], rtol=1e-8, atol=1e-9 * np.abs(lin["gs"]).max())
+
+
+def test_manifold_updates_match_oracle_plus():
+    H = hh(); L = ol.lib()
+    rng = np.random.default_rng(3)
+    for sc in [1e-12, 1e-6, 1e-2, 0.7]:
+        T = synth.se3_from_Rt(synth.so3_exp_matrix(rng.normal(size=3)), rng.normal(size=3))
+        dl = rng.normal(size=6) * sc
+        a = np.zeros(7); b = np.zeros(7)
+        H.hh_se3_plus(d(T), d(dl), d(a)); L.vco_plus_se3(d(T), d(dl), d(b))
+        np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-15)
+        a = np.zeros(4); b = np.zeros(4)
+        H.hh_so3_plus(d(T[:4].copy()), d(dl[3:].copy()), d(a)); L.vco_plus_so3(d(T[:4].copy()), d(dl[3:].copy()), d(b))
+        np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-15)

@@ -1,0 +1,164 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on identical
+seeded inputs.  Floating point (f64) -> tolerance, stated per test; north_star asks <= 1e-6 relative on
+recovered parameters and per-iteration residual costs."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from vicalib_amd import synth
+from vicalib_amd.lib import ViCalibrator
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(cfg, **opts):
+    p = synth.generate(cfg)
+    cal = ViCalibrator(0).load_problem(p)
+    cal.SetCalibrateImu(False)
+    orc = ol.Oracle().load(p)
+    orc.set_options(calibrate_imu=False, **opts)
+    return p, cal, orc
+
+
+def _oracle_schur(lin):
+    A = lin["A"][:, :6, :6]; W = lin["W"][:, :6, :]; gf = lin["gf"][:, :6]
+    S = lin["Hss"].copy(); g = lin["gs"].copy()
+    for f in range(A.shape[0]):
+        if not np.any(A[f]):
+            continue
+        Y = np.linalg.solve(A[f], W[f]); z = np.linalg.solve(A[f], gf[f])
+        S -= W[f].T @ Y; g -= W[f].T @ z
+    return S, g
+
+
+@pytest.mark.parametrize("models", [("fov", "fov"), ("poly3", "kb4", "poly2"), ("linear", "kb4"), ("poly3",)])
+def test_linearisation_blocks_match_oracle(models):
+    p, cal, orc = _pair(synth.Config(models=models, n_frames=9, seed=21))
+    orc.prepare(vis_mult=1)
+    lin = orc.linearize()
+    g = cal.linearize()
+    assert abs(g["cost"] - lin["cost"]) <= 1e-11 * lin["cost"]
+    sc = np.abs(lin["A"]).max()
+    np.testing.assert_allclose(g["Hpp"], lin["A"][:, :6, :6], rtol=1e-8, atol=1e-10 * sc)
+    np.testing.assert_allclose(g["gp"], lin["gf"][:, :6], rtol=1e-8, atol=1e-10 * np.abs(lin["gf"]).max())
+    np.testing.assert_allclose(g["g_s"], lin["gs"], rtol=1e-8, atol=1e-10 * np.abs(lin["gs"]).max())
+    np.testing.assert_allclose(g["hss_diag"], np.diag(lin["Hss"]), rtol=1e-8)
+    S, gr = _oracle_schur(lin)
+    np.testing.assert_allclose(g["S"], S, rtol=1e-6, atol=1e-8 * np.abs(lin["Hss"]).max())
+    np.testing.assert_allclose(g["g_red"], gr, rtol=1e-6, atol=1e-8 * np.abs(lin["gs"]).max())
+
+
+def test_residual_sweep_matches_oracle():
+    p, cal, orc = _pair(synth.Config(models=("fov", "kb4"), n_frames=17, seed=5))
+    orc.prepare(vis_mult=1)
+    cost, sq = cal.evaluate()
+    r, _, _ = orc.residuals()
+    assert abs(cost - orc.evaluate_cost()) <= 1e-12 * cost
+    assert abs(sq - (r * r).sum()) <= 1e-12 * sq
+
+
+def _compare_solution(p, cal, orc, rtol=1e-6):
+    tg = cal.trace(); to = orc.trace()
+    assert len(tg) == len(to), (len(tg), len(to))
+    np.testing.assert_allclose(tg[:, 1], to[:, 1], rtol=rtol)          # per-iteration cost
+    np.testing.assert_array_equal(tg[:, 8], to[:, 8])                   # accept / reject decisions
+    for c in range(len(p.cam_model)):
+        Kg, Tg = cal.GetCamera(c); Ko, To = orc.camera(c)
+        np.testing.assert_allclose(Kg, Ko, rtol=rtol, atol=1e-9)
+        np.testing.assert_allclose(Tg, To, rtol=rtol, atol=1e-9)
+    Fo, _ = orc.frames()
+    np.testing.assert_allclose(cal.GetFrames(), Fo, rtol=rtol, atol=1e-9)
+    np.testing.assert_allclose(cal.GetCameraProjRMSE(), orc.rmse(), rtol=rtol)
+    assert abs(cal.MeanSquaredError() - orc.mse()) <= rtol * orc.mse()
+
+
+def test_cfg1_solve_matches_oracle():
+    """BASELINE config 1: single poly3, small grid, 50 frames, no IMU."""
+    p, cal, orc = _pair(synth.BASELINE_CONFIGS["cfg1"])
+    cal.Solve(); orc.solve()
+    _compare_solution(p, cal, orc)
+    assert cal.GetCameraProjRMSE()[0] < 0.15       # vicalib-engine.cc:56
+
+
+def test_cfg2_solve_matches_oracle():
+    """BASELINE config 2 (the benchmark workload): stereo fov,fov, small grid, 500 frames."""
+    p, cal, orc = _pair(synth.BASELINE_CONFIGS["cfg2"], num_threads=8)
+    cal.Solve(); orc.solve()
+    _compare_solution(p, cal, orc)
+    for c in range(2):
+        np.testing.assert_allclose(cal.GetCamera(c)[0][:4], p.cam_K_gt[c][:4], rtol=3e-3)
+
+
+def test_mixed_rig_with_outlier_removal_matches_oracle():
+    cfg = synth.Config(models=("kb4", "poly2", "fov"), n_frames=30, seed=77)
+    p = synth.generate(cfg)
+    # corrupt a few detections so that RemoveOutliers has something to do
+    rng = np.random.default_rng(0)
+    for k in rng.choice(len(p.tiles), 10, replace=False):
+        f, c, ids, pix = p.tiles[k]
+        pix[rng.integers(len(ids))] += rng.normal(size=2) * 8.0
+    cal = ViCalibrator(0).load_problem(p); cal.SetCalibrateImu(False); cal.SetRemoveOutliers(True, 2.0)
+    orc = ol.Oracle().load(p); orc.set_options(calibrate_imu=False, remove_outliers=True, outlier_threshold=2.0)
+    cal.Solve(); orc.solve()
+    _compare_solution(p, cal, orc)
+
+
+def test_ragged_and_empty_tiles():
+    """Tiles of 4..190 corners, a frame seen by one camera only, a frame with no observations at all."""
+    p = synth.generate(synth.Config(models=("poly3", "fov"), n_frames=12, seed=9))
+    p.tiles = [t for t in p.tiles if not (t[0] == 3) and not (t[0] == 5 and t[1] == 1)]
+    f, c, ids, pix = p.tiles[0]
+    p.tiles[0] = (f, c, ids[:5], pix[:5])
+    f, c, ids, pix = p.tiles[1]
+    p.tiles[1] = (f, c, ids[:65], pix[:65])
+    cal = ViCalibrator(0).load_problem(p); cal.SetCalibrateImu(False)
+    orc = ol.Oracle().load(p); orc.set_options(calibrate_imu=False)
+    cal.Solve(); orc.solve()
+    _compare_solution(p, cal, orc)
+
+
+def test_fixed_intrinsics_single_camera_has_no_shared_block():
+    p = synth.generate(synth.Config(models=("poly3",), n_frames=10, seed=4))
+    cal = ViCalibrator(0).load_problem(p, init=True); cal.SetCalibrateImu(False)
+    orc = ol.Oracle().load(p, init=True); orc.set_options(calibrate_imu=False, fix_intrinsics=True)
+    # start from GT intrinsics so that pose-only refinement is meaningful
+    cal = ViCalibrator(0)
+    cal.AddCamera(p.cam_model[0], p.cam_K_gt[0], p.cam_T_ck_init[0]); cal.FixCameraIntrinsics(True); cal.SetCalibrateImu(False)
+    orc = ol.Oracle(); orc.add_camera(p.cam_model[0], p.cam_K_gt[0], p.cam_T_ck_init[0]); orc.set_options(calibrate_imu=False, fix_intrinsics=True)
+    for n in range(len(p.frame_time)):
+        cal.AddFrame(p.frame_T_wk_init[n], p.frame_time[n]); orc.add_frame(p.frame_T_wk_init[n], p.frame_time[n])
+    for (f, c, ids, pix) in p.tiles:
+        cal.AddObservations(f, c, p.grid_points[ids], pix); orc.add_observations(f, c, p.grid_points[ids], pix)
+    cal.Solve(); orc.solve()
+    assert cal.shared_dim() == 0
+    _compare_solution(p, cal, orc)
+
+
+def test_full_size_properties_cfg2_scale():
+    """Size-independent properties at the benchmark size: monotone accepted costs, RMSE at the noise floor,
+    recovered extrinsic baseline, idempotence of a second solve."""
+    p = synth.generate(synth.BASELINE_CONFIGS["cfg2"])
+    cal = ViCalibrator(0).load_problem(p); cal.SetCalibrateImu(False)
+    cal.Solve()
+    tr = cal.trace()
+    acc = tr[tr[:, 8] == 1, 1]
+    assert np.all(np.diff(acc) < 0)
+    rm = cal.GetCameraProjRMSE()
+    assert np.all(np.abs(rm - p.cfg.pixel_sigma) < 0.01)
+    _, T1 = cal.GetCamera(1)
+    np.testing.assert_allclose(np.linalg.norm(T1[4:]), 0.06, rtol=2e-2)
+    K0 = cal.GetCamera(0)[0].copy()
+    cal.Solve()      # second solve from the optimum moves nothing (idempotence)
+    np.testing.assert_allclose(cal.GetCamera(0)[0], K0, rtol=1e-7)
+
+
+def test_async_start_poll_stop():
+    p = synth.generate(synth.BASELINE_CONFIGS["cfg1"])
+    cal = ViCalibrator(0).load_problem(p); cal.SetCalibrateImu(False)
+    cal.Start()
+    import time
+    t0 = time.time()
+    while cal.IsRunning() and time.time() - t0 < 60:
+        cal.GetNumIterations(); cal.MeanSquaredError(); time.sleep(0.005)
+    cal.Stop()
+    assert cal.GetCameraProjRMSE()[0] < 0.15

@@ -1,0 +1,79 @@
+// vc_device.h -- device-side views shared by the host driver (vc_calibrator.cpp)
+// and the HIP kernels (vc_kernels.hip).  HBM layout (see DESIGN.md "Data layout"):
+//   observations  tile-sorted SoA: obs_uv[n] (16 B) + obs_pt[n] (u16 index into points[]) = 18 B / corner
+//   tiles         (frame, camera) groups: tile_frame, tile_cam, tile_off[n_tiles+1]
+//   frame poses   n_frames x 8 doubles [q(4) t(3) pad], double-buffered (accepted / trial)
+//   cameras       n_cams x 24 doubles [T_ck(7) pad K(<=10) ...], double-buffered
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace vc {
+
+constexpr int kMaxCams = 8;
+constexpr int kGStride = 256;      // 16x16 Gram block per tile
+constexpr int kYStride = 96;       // 6 x 16 per tile
+constexpr int kFrStride = 40;      // per frame: L(21) z(6) g(6) lam(6) pad
+constexpr int kFrL = 0, kFrZ = 21, kFrG = 27, kFrLam = 33;
+constexpr int kNumScal = 8;        // gd, dld, step2, x2, g2, cost, gmax, spare
+enum { kScGd = 0, kScDld = 1, kScStep2 = 2, kScX2 = 3, kScG2 = 4, kScCost = 5, kScGmax = 6, kScSq = 7 };
+
+struct DevView {
+  int n_frames, n_cams, n_tiles, n_points, D, n_chunks, chunk_frames;
+  long long n_obs;
+  const double2* obs_uv;
+  const unsigned short* obs_pt;
+  const double* points;            // n_points x 3
+  const int* tile_frame;
+  const int* tile_cam;
+  const int* tile_off;             // n_tiles + 1
+  const int* frame_tile_off;       // n_frames + 1
+  const int* frame_cam_tile;       // n_frames x n_cams -> tile or -1
+  const int* cam_model;            // per camera
+  const int* cam_flags;            // kCamRotFree | kCamTransFree | kCamKFree
+  const int* cam_col0;             // first shared column of the camera
+  const int* col_cam;              // D: owning camera of a shared column (-1: IMU block)
+  const int* col_local;            // D: column inside the camera's tile block
+  double* poses[2];                // state double buffer
+  double* cams[2];
+  double* G;                       // n_tiles x 256
+  double* tile_cost;               // n_tiles
+  double* tile_sq;                 // n_tiles: sum of squared residuals (RMSE)
+  double* Y;                       // n_tiles x 96
+  double* fr;                      // n_frames x 40
+  double* fdiag;                   // n_frames x 6   clamped scaled diagonal (kept while reuse_diagonal)
+  double* fscale2;                 // n_frames x 6   Jacobi scale^2 (fixed per solve)
+  double* part;                    // n_chunks x part_stride
+  double* Sbuf;                    // D*D (S, no damping) + D (g_red) + D (H_ss diag) + D (g_s) + 2 (cost, spare)
+  double* sdiag;                   // D
+  double* sscale2;                 // D
+  double* slam;                    // D
+  double* delta_s;                 // D
+  double* fpart;                   // n_fblocks x kNumScal
+  double* scal;                    // kNumScal (frame sums) + kNumScal (shared-parameter terms)
+  int* flags;                      // [0]: frame Cholesky failures, [1]: reduced Cholesky failure
+  int part_stride;
+  int n_fblocks;
+};
+
+struct LmArgs {
+  double radius;
+  double mult;        // residual-block multiplicity of the visual terms (vicalibrator.h:641-649)
+  int cur;            // index of the accepted state buffer
+  int init_scale;     // first linearisation of a Solve: estimate the Jacobi scaling
+  int reuse_diag;     // LevenbergMarquardtStrategy::reuse_diagonal_
+};
+
+// launchers (vc_kernels.hip); all asynchronous on `s`
+void launch_reproj_jac(const DevView& v, const LmArgs& a, hipStream_t s);
+void launch_reproj_res(const DevView& v, int state, double mult, hipStream_t s);
+void launch_frame_prep(const DevView& v, const LmArgs& a, hipStream_t s);
+void launch_schur_reduce(const DevView& v, const LmArgs& a, hipStream_t s);
+void launch_reduced_solve(const DevView& v, const LmArgs& a, hipStream_t s);
+void launch_backsub_update(const DevView& v, const LmArgs& a, hipStream_t s);
+void launch_reduce_scalars(const DevView& v, const LmArgs& a, hipStream_t s);
+void launch_sum_tile_cost(const DevView& v, double* out_cost_sq /*2*/, hipStream_t s);
+void launch_cam_sq(const DevView& v, double* out /*n_cams x 2: sum sq, count*/, hipStream_t s);
+void launch_outlier_mask(const DevView& v, int state, const double* thresh /*device, n_cams*/, unsigned char* mask, hipStream_t s);
+
+}  // namespace vc

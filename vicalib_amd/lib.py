@@ -1,0 +1,212 @@
+"""ctypes binding of the C ABI (include/vicalib_amd.h) -- used by tests/ and bench.py.
+
+`ViCalibrator` mirrors the public API of the reference class of the same name
+(include/vicalib/vicalibrator.h:119-544): same method names and argument meaning, so the parity
+tests read like code written against the reference.  There is no fallback: if the HIP library is
+missing or no GPU is present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvicalib_amd.so")
+_lib = None
+
+VC_OK = 0
+ERRORS = {-1: "VC_ERR_NO_DEVICE", -2: "VC_ERR_BAD_ARG", -3: "VC_ERR_RUNNING", -4: "VC_ERR_TIME_ORDER",
+          -5: "VC_ERR_TOO_MANY_POINTS", -6: "VC_ERR_NUMERIC", -7: "VC_ERR_UNSUPPORTED"}
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
+
+# every symbol include/vicalib_amd.h declares
+SYMBOLS = [
+    "vc_create", "vc_destroy", "vc_clear", "vc_add_camera", "vc_fix_camera_intrinsics", "vc_add_frame", "vc_set_frame_pose",
+    "vc_add_observations", "vc_add_imu", "vc_set_sigmas", "vc_set_biases", "vc_set_scale_factor", "vc_set_time_offset",
+    "vc_set_function_tolerance", "vc_set_optimization_flags", "vc_set_max_iters", "vc_set_calibrate_imu", "vc_set_remove_outliers",
+    "vc_solve", "vc_start", "vc_is_running", "vc_stop", "vc_num_frames", "vc_num_cameras", "vc_get_camera", "vc_get_frame",
+    "vc_get_biases", "vc_get_scale_factor", "vc_get_gravity", "vc_time_offset", "vc_mean_squared_error", "vc_get_camera_proj_rmse",
+    "vc_get_num_iterations", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
+    "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_num_observations", "vc_num_tiles",
+]
+
+
+class VicalibError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VicalibError(f"{LIB_PATH} is missing: build it with vicalib_amd/csrc/build.sh (no CPU fallback exists)")
+        L = C.CDLL(LIB_PATH)
+        L.vc_time_offset.restype = C.c_double
+        L.vc_mean_squared_error.restype = C.c_double
+        L.vc_get_num_iterations.restype = C.c_uint
+        L.vc_get_stream.restype = C.c_void_p
+        L.vc_num_observations.restype = C.c_longlong
+        for name in ("vc_destroy",):
+            getattr(L, name).restype = None
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise VicalibError(f"{what} failed: {ERRORS.get(rc, rc)}")
+    return rc
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.c_void_p)
+
+
+class ViCalibrator:
+    def __init__(self, device: int = 0):
+        self.L = load()
+        self.h = C.c_void_p()
+        _check(self.L.vc_create(C.byref(self.h), int(device)), "vc_create")
+        self._cb = None
+        self.nk = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    # ---- reference API ---------------------------------------------------------------------
+    def AddCamera(self, model, params, T_ck, width=640, height=480):
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        self.nk.append(len(params))
+        return _check(self.L.vc_add_camera(self.h, int(model), _d(params), len(params), int(width), int(height), _d(T_ck)), "AddCamera")
+
+    def FixCameraIntrinsics(self, should_fix=True):
+        _check(self.L.vc_fix_camera_intrinsics(self.h, int(should_fix)), "FixCameraIntrinsics")
+
+    def AddFrame(self, T_wk, time):
+        return _check(self.L.vc_add_frame(self.h, _d(T_wk), C.c_double(time)), "AddFrame")
+
+    def SetFramePose(self, frame, T_wk):
+        _check(self.L.vc_set_frame_pose(self.h, int(frame), _d(T_wk)), "SetFramePose")
+
+    def AddObservations(self, frame, camera, p_w, p_c):
+        p_w = np.ascontiguousarray(p_w, dtype=np.float64); p_c = np.ascontiguousarray(p_c, dtype=np.float64)
+        _check(self.L.vc_add_observations(self.h, int(frame), int(camera), int(len(p_w)), _d(p_w), _d(p_c)), "AddObservation")
+
+    def AddImuMeasurements(self, gyro, accel, time):
+        time = np.ascontiguousarray(time, dtype=np.float64)
+        _check(self.L.vc_add_imu(self.h, int(len(time)), _d(gyro), _d(accel), _d(time)), "AddImuMeasurements")
+
+    def SetSigmas(self, g, a): _check(self.L.vc_set_sigmas(self.h, C.c_double(g), C.c_double(a)), "SetSigmas")
+    def SetBiases(self, b): _check(self.L.vc_set_biases(self.h, _d(b)), "SetBiases")
+    def SetScaleFactor(self, s): _check(self.L.vc_set_scale_factor(self.h, _d(s)), "SetScaleFactor")
+    def SetTimeOffset(self, o): _check(self.L.vc_set_time_offset(self.h, C.c_double(o)), "SetTimeOffset")
+    def SetFunctionTolerance(self, t): _check(self.L.vc_set_function_tolerance(self.h, C.c_double(t)), "SetFunctionTolerance")
+
+    def SetOptimizationFlags(self, bias_active, inertial_active, rotation_only, optimize_time_offset):
+        _check(self.L.vc_set_optimization_flags(self.h, int(bias_active), int(inertial_active), int(rotation_only), int(optimize_time_offset)), "SetOptimizationFlags")
+
+    def SetMaxIters(self, m): _check(self.L.vc_set_max_iters(self.h, int(m)), "max_iters")
+    def SetCalibrateImu(self, c): _check(self.L.vc_set_calibrate_imu(self.h, int(c)), "calibrate_imu")
+    def SetRemoveOutliers(self, r, th=2.0): _check(self.L.vc_set_remove_outliers(self.h, int(r), C.c_double(th)), "remove_outliers")
+
+    def Solve(self): return _check(self.L.vc_solve(self.h), "Solve")
+    def Start(self): _check(self.L.vc_start(self.h), "Start")
+    def IsRunning(self): return bool(self.L.vc_is_running(self.h))
+    def Stop(self): _check(self.L.vc_stop(self.h), "Stop")
+    def NumFrames(self): return self.L.vc_num_frames(self.h)
+    def NumCameras(self): return self.L.vc_num_cameras(self.h)
+
+    def GetCamera(self, c):
+        K = np.zeros(10); n = C.c_int(0); T = np.zeros(7)
+        _check(self.L.vc_get_camera(self.h, int(c), _d(K), C.byref(n), _d(T)), "GetCamera")
+        return K[:n.value].copy(), T
+
+    def GetFrame(self, f):
+        T = np.zeros(7); v = np.zeros(3); t = C.c_double(0)
+        _check(self.L.vc_get_frame(self.h, int(f), _d(T), _d(v), C.byref(t)), "GetFrame")
+        return T, v, t.value
+
+    def GetFrames(self):
+        n = self.NumFrames()
+        T = np.zeros((n, 7))
+        for f in range(n):
+            T[f] = self.GetFrame(f)[0]
+        return T
+
+    def GetBiases(self):
+        b = np.zeros(6); _check(self.L.vc_get_biases(self.h, _d(b)), "GetBiases"); return b
+
+    def GetScaleFactor(self):
+        s = np.zeros(6); _check(self.L.vc_get_scale_factor(self.h, _d(s)), "GetScaleFactor"); return s
+
+    def GetGravity(self):
+        g = np.zeros(2); _check(self.L.vc_get_gravity(self.h, _d(g)), "GetGravity"); return g
+
+    def time_offset(self): return self.L.vc_time_offset(self.h)
+    def MeanSquaredError(self): return self.L.vc_mean_squared_error(self.h)
+
+    def GetCameraProjRMSE(self):
+        r = np.zeros(max(self.NumCameras(), 1)); _check(self.L.vc_get_camera_proj_rmse(self.h, _d(r)), "GetCameraProjRMSE")
+        return r[:self.NumCameras()]
+
+    def GetNumIterations(self): return self.L.vc_get_num_iterations(self.h)
+    def WriteCameraModels(self, path): _check(self.L.vc_write_camera_models(self.h, path.encode()), "WriteCameraModels")
+
+    # ---- engine-level ------------------------------------------------------------------------
+    def load_problem(self, prob, init=True):
+        for c, m in enumerate(prob.cam_model):
+            self.AddCamera(m, prob.cam_K_init[c] if init else prob.cam_K_gt[c], prob.cam_T_ck_init[c] if init else prob.cam_T_ck_gt[c],
+                           prob.cfg.width, prob.cfg.height)
+        T = prob.frame_T_wk_init if init else prob.frame_T_wk_gt
+        for n in range(len(prob.frame_time)):
+            self.AddFrame(T[n], prob.frame_time[n])
+        for (f, c, ids, pix) in prob.tiles:
+            self.AddObservations(f, c, prob.grid_points[ids], pix)
+        if prob.imu_t is not None:
+            self.AddImuMeasurements(prob.imu_gyro, prob.imu_accel, prob.imu_t)
+        return self
+
+    def trace(self):
+        n = _check(self.L.vc_trace_len(self.h), "trace_len")
+        out = np.zeros((max(n, 1), 10))
+        _check(self.L.vc_get_trace(self.h, _d(out), n), "get_trace")
+        return out[:n]
+
+    def set_shard(self, rank, world, fn=None):
+        self._cb = ALLREDUCE_FN(fn) if fn is not None else None
+        _check(self.L.vc_set_shard(self.h, int(rank), int(world), self._cb, None), "set_shard")
+
+    def stream(self): return self.L.vc_get_stream(self.h)
+    def prepare(self): _check(self.L.vc_prepare(self.h), "prepare")
+    def shared_dim(self): return _check(self.L.vc_shared_dim(self.h), "shared_dim")
+
+    def linearize(self):
+        self.prepare()
+        n, D = self.NumFrames(), self.shared_dim()
+        cost = C.c_double(0); H = np.zeros((n, 6, 6)); g = np.zeros((n, 6)); S = np.zeros((D, D)); gr = np.zeros(D); hd = np.zeros(D); gs = np.zeros(D)
+        _check(self.L.vc_linearize(self.h, C.byref(cost), _d(H), _d(g), _d(S), _d(gr), _d(hd), _d(gs)), "linearize")
+        return dict(cost=cost.value, Hpp=H, gp=g, S=S, g_red=gr, hss_diag=hd, g_s=gs)
+
+    def evaluate(self):
+        cost = C.c_double(0); sq = C.c_double(0)
+        _check(self.L.vc_evaluate(self.h, C.byref(cost), C.byref(sq)), "evaluate")
+        return cost.value, sq.value
+
+    def run_iterations(self, iters):
+        j = C.c_int(0); r = C.c_int(0)
+        n = _check(self.L.vc_run_iterations(self.h, int(iters), C.byref(j), C.byref(r)), "run_iterations")
+        return n, j.value, r.value
+
+    def time_kernels(self, reps=20):
+        a = C.c_double(0); b = C.c_double(0)
+        _check(self.L.vc_time_kernels(self.h, int(reps), C.byref(a), C.byref(b)), "time_kernels")
+        return a.value, b.value
+
+    def num_observations(self): return int(self.L.vc_num_observations(self.h))
+    def num_tiles(self): return int(self.L.vc_num_tiles(self.h))
