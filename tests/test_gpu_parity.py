@@ -59,7 +59,8 @@ def test_residual_sweep_matches_oracle():
 
 def _compare_solution(p, cal, orc, rtol=1e-6):
     tg = cal.trace(); to = orc.trace()
-    assert len(tg) == len(to), (len(tg), len(to))
+    np.set_printoptions(linewidth=220, precision=6)
+    assert len(tg) == len(to), ("gpu", tg[:, [0, 1, 2, 5, 6, 7, 8]], "oracle", to[:, [0, 1, 2, 5, 6, 7, 8]])
     np.testing.assert_allclose(tg[:, 1], to[:, 1], rtol=rtol)          # per-iteration cost
     np.testing.assert_array_equal(tg[:, 8], to[:, 8])                   # accept / reject decisions
     for c in range(len(p.cam_model)):

@@ -284,6 +284,7 @@ struct vc_calibrator {
     launch_schur_reduce(dv, a, stream);
     int rc = do_allreduce(dv.Sbuf, D * D + 3 * D + 2, 0); if (rc) return rc;
     launch_reduced_solve(dv, a, stream);
+    launch_shared_update(dv, a, stream);
     launch_backsub_update(dv, a, stream);
     launch_reproj_res(dv, 1 - cur, (double)vis_mult, stream); ++res_sweeps;
     launch_reduce_scalars(dv, a, stream);

@@ -71,6 +71,7 @@ void launch_frame_prep(const DevView& v, const LmArgs& a, hipStream_t s);
 void launch_schur_reduce(const DevView& v, const LmArgs& a, hipStream_t s);
 void launch_reduced_solve(const DevView& v, const LmArgs& a, hipStream_t s);
 void launch_backsub_update(const DevView& v, const LmArgs& a, hipStream_t s);
+void launch_shared_update(const DevView& v, const LmArgs& a, hipStream_t s);
 void launch_reduce_scalars(const DevView& v, const LmArgs& a, hipStream_t s);
 void launch_sum_tile_cost(const DevView& v, double* out_cost_sq /*2*/, hipStream_t s);
 void launch_cam_sq(const DevView& v, double* out /*n_cams x 2: sum sq, count*/, hipStream_t s);

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64) void k_backsub_update(DevView v, LmArgs a) {
 }
 
 // scal[0..7]: sums over this rank's frames (+ trial cost of its tiles); scal[8..15]: shared-parameter terms
-// (identical on every rank).  Thread 0 also writes the trial state of the shared parameters.
+// (identical on every rank), written by k_shared_update.
 __global__ __launch_bounds__(256) void k_reduce_scalars(DevView v, LmArgs a) {
   __shared__ double red[256 * 7];
   const int tid = threadIdx.x;
@@ -477,7 +477,14 @@ __global__ __launch_bounds__(256) void k_reduce_scalars(DevView v, LmArgs a) {
     double* o = v.scal;
     o[kScGd] = red[0]; o[kScDld] = red[256]; o[kScStep2] = red[512]; o[kScX2] = red[768]; o[kScG2] = red[1024];
     o[kScCost] = 0.5 * red[1280]; o[kScGmax] = red[1536]; o[kScSq] = 0.0;
-    // shared parameters: trial state + their terms
+  }
+}
+
+// Trial state of the shared parameters (cams[1-cur] <- Plus(cams[cur], delta_s)) and their scalar terms
+// scal[8..15] (identical on every rank).  Runs before the trial residual sweep.
+__global__ void k_shared_update(DevView v, LmArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  {
     const int D = v.D;
     const double* gs = v.Sbuf + D * D + 2 * D;
     double gd = 0, dld = 0, step2 = 0, x2 = 0, g2 = 0, gmax = 0;
@@ -560,6 +567,9 @@ void launch_reduced_solve(const DevView& v, const LmArgs& a, hipStream_t s) {
 }
 void launch_backsub_update(const DevView& v, const LmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_backsub_update, dim3(v.n_fblocks), dim3(64), 0, s, v, a);
+}
+void launch_shared_update(const DevView& v, const LmArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_shared_update, dim3(1), dim3(64), 0, s, v, a);
 }
 void launch_reduce_scalars(const DevView& v, const LmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(256), 0, s, v, a);
