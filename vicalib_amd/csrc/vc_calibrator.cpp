@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -27,7 +28,7 @@
 
 using namespace vc;
 
-#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { last_hip_error = e_; return VC_ERR_NO_DEVICE; } } while (0)
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { last_hip_error = e_; if (std::getenv("VC_DEBUG")) std::fprintf(stderr, "[vicalib_amd] %s:%d %s -> %s\n", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); return VC_ERR_NO_DEVICE; } } while (0)
 
 namespace {
 
@@ -116,8 +117,10 @@ struct vc_calibrator {
   DBuf<double2> d_uv; DBuf<unsigned short> d_pt; DBuf<double> d_points;
   DBuf<int> d_tile_frame, d_tile_cam, d_tile_off, d_frame_tile_off, d_frame_cam_tile, d_cam_model, d_cam_flags, d_cam_col0,
       d_col_cam, d_col_local, d_flags;
-  DBuf<double> d_pose[2], d_cam[2], d_G, d_tile_cost, d_tile_sq, d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_sdiag,
-      d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init;
+  DBuf<double> d_pose[2], d_cam[2], d_G, d_tile_cost, d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_sdiag,
+      d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace;
+  DBuf<Ctrl> d_ctrl;
+  int trace_cap = 0;
   DBuf<unsigned char> d_mask;
   std::vector<int> h_tile_frame, h_tile_cam, h_tile_off, h_obs_index;   // h_obs_index: device corner -> host observation
   std::vector<int> cam_flags, cam_col0;
@@ -216,13 +219,17 @@ struct vc_calibrator {
     const int chunk_frames = std::max(8, (N + 255) / 256);
     const int n_chunks = std::max(1, (N + chunk_frames - 1) / chunk_frames);
     const int part_stride = D * D + D + C * kGStride;
-    const int n_fblocks = std::max(1, (N + 63) / 64);
-    HIP_OK(d_G.alloc((size_t)std::max(T, 1) * kGStride)); HIP_OK(d_tile_cost.alloc(std::max(T, 1))); HIP_OK(d_tile_sq.alloc(std::max(T, 1)));
+    HIP_OK(d_G.alloc((size_t)std::max(T, 1) * kGStride)); HIP_OK(d_tile_cost.alloc(std::max(T, 1))); HIP_OK(d_tile_trial.alloc((size_t)std::max(T, 1) * 2));
     HIP_OK(d_Y.alloc((size_t)std::max(T, 1) * kYStride)); HIP_OK(d_fr.alloc((size_t)std::max(N, 1) * kFrStride));
     HIP_OK(d_fdiag.alloc((size_t)std::max(N, 1) * 6)); HIP_OK(d_fscale2.alloc((size_t)std::max(N, 1) * 6));
     HIP_OK(d_part.alloc((size_t)n_chunks * part_stride)); HIP_OK(d_Sbuf.alloc((size_t)D * D + 3 * D + 2));
     HIP_OK(d_sdiag.alloc(D)); HIP_OK(d_sscale2.alloc(D)); HIP_OK(d_slam.alloc(D)); HIP_OK(d_delta_s.alloc(D));
-    HIP_OK(d_fpart.alloc((size_t)n_fblocks * kNumScal)); HIP_OK(d_scal.alloc(2 * kNumScal)); HIP_OK(d_flags.alloc(4));
+    HIP_OK(d_fpart.alloc((size_t)std::max(N, 1) * kNumScal));
+    trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); HIP_OK(d_ctrl.alloc(1));
+    HIP_OK(hipMemsetAsync(d_part.p, 0, (size_t)n_chunks * part_stride * sizeof(double), stream));
+    HIP_OK(hipMemsetAsync(d_fpart.p, 0, (size_t)std::max(N, 1) * kNumScal * sizeof(double), stream));
+    HIP_OK(d_scal.alloc(2 * kNumScal)); HIP_OK(d_flags.alloc(4));
+    HIP_OK(hipMemsetAsync(d_scal.p, 0, 2 * kNumScal * sizeof(double), stream));
     HIP_OK(d_tmp.alloc(64)); HIP_OK(d_mask.alloc(std::max<size_t>(idx.size(), 1)));
     HIP_OK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(int), stream));
     HIP_OK(hipMemsetAsync(d_delta_s.p, 0, std::max(D, 1) * sizeof(double), stream));
@@ -234,11 +241,11 @@ struct vc_calibrator {
     dv.cam_model = d_cam_model.p; dv.cam_flags = d_cam_flags.p; dv.cam_col0 = d_cam_col0.p;
     dv.col_cam = d_col_cam.p; dv.col_local = d_col_local.p;
     dv.poses[0] = d_pose[0].p; dv.poses[1] = d_pose[1].p; dv.cams[0] = d_cam[0].p; dv.cams[1] = d_cam[1].p;
-    dv.G = d_G.p; dv.tile_cost = d_tile_cost.p; dv.tile_sq = d_tile_sq.p; dv.Y = d_Y.p; dv.fr = d_fr.p;
+    dv.G = d_G.p; dv.tile_cost = d_tile_cost.p; dv.tile_trial = d_tile_trial.p; dv.Y = d_Y.p; dv.fr = d_fr.p;
     dv.fdiag = d_fdiag.p; dv.fscale2 = d_fscale2.p; dv.part = d_part.p; dv.Sbuf = d_Sbuf.p;
     dv.sdiag = d_sdiag.p; dv.sscale2 = d_sscale2.p; dv.slam = d_slam.p; dv.delta_s = d_delta_s.p;
     dv.fpart = d_fpart.p; dv.scal = d_scal.p; dv.flags = d_flags.p;
-    dv.part_stride = part_stride; dv.n_fblocks = n_fblocks;
+    dv.part_stride = part_stride; dv.ctrl = d_ctrl.p; dv.trace = d_trace.p;
     HIP_OK(d_pose_init.upload(poses, stream)); HIP_OK(d_cam_init.upload(camrec, stream));
     HIP_OK(hipStreamSynchronize(stream));   // the staging vectors above go out of scope
     device_dirty = false;
@@ -269,112 +276,93 @@ struct vc_calibrator {
     return VC_OK;
   }
 
-  // ---- one pass of the device pipeline ---------------------------------------------------------
-  struct PassResult { double cost, gmax, gnorm, gd, dld, step2, x2, new_cost; bool fail; };
+  // ---- one pass of the device pipeline (all asynchronous; the decision is taken on the device) ------
   int do_allreduce(double* p, int n, int op) {
     if (world > 1 && allreduce) { if (allreduce(allreduce_ctx, p, n, op) != 0) return VC_ERR_NO_DEVICE; }
     return VC_OK;
   }
-  int run_pass(bool linearize, bool init_scale, bool reuse_diag, double radius, PassResult* R) {
-    LmArgs a; a.radius = radius; a.mult = (double)vis_mult; a.cur = cur; a.init_scale = init_scale; a.reuse_diag = reuse_diag;
+  int enqueue_pass() {
     const int D = dv.D;
-    HIP_OK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(int), stream));
-    if (linearize) { launch_reproj_jac(dv, a, stream); ++jac_sweeps; }
-    launch_frame_prep(dv, a, stream);
-    launch_schur_reduce(dv, a, stream);
+    launch_reproj_jac(dv, stream);
+    launch_frame_prep(dv, stream);
+    launch_schur_reduce(dv, stream);
     int rc = do_allreduce(dv.Sbuf, D * D + 3 * D + 2, 0); if (rc) return rc;
-    launch_reduced_solve(dv, a, stream);
-    launch_shared_update(dv, a, stream);
-    launch_backsub_update(dv, a, stream);
-    launch_reproj_res(dv, 1 - cur, (double)vis_mult, stream); ++res_sweeps;
-    launch_reduce_scalars(dv, a, stream);
-    rc = do_allreduce(dv.scal, 6, 0); if (rc) return rc;
-    rc = do_allreduce(dv.scal + kScGmax, 1, 1); if (rc) return rc;
-    double h_scal[2 * kNumScal], h_cost[2]; int h_flags[4];
-    HIP_OK(hipMemcpyAsync(h_scal, dv.scal, sizeof(h_scal), hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipMemcpyAsync(h_cost, dv.Sbuf + (size_t)D * D + 3 * D, sizeof(h_cost), hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipMemcpyAsync(h_flags, dv.flags, sizeof(h_flags), hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipStreamSynchronize(stream));
-    const double* s = h_scal; const double* t = h_scal + kNumScal;
-    R->cost = h_cost[0];
-    R->gd = s[kScGd] + t[kScGd]; R->dld = s[kScDld] + t[kScDld];
-    R->step2 = s[kScStep2] + t[kScStep2]; R->x2 = s[kScX2] + t[kScX2];
-    R->gnorm = std::sqrt(s[kScG2] + t[kScG2]); R->gmax = std::max(s[kScGmax], t[kScGmax]);
-    R->new_cost = s[kScCost];
-    R->fail = (h_flags[0] != 0) || (h_flags[1] != 0);
+    launch_reduced_solve(dv, stream);
+    launch_trial(dv, stream);
+    if (world > 1) {
+      launch_final(dv, 1, stream);
+      rc = do_allreduce(dv.scal, 6, 0); if (rc) return rc;
+      rc = do_allreduce(dv.scal + kScGmax, 1, 1); if (rc) return rc;
+      launch_final(dv, 2, stream);
+    } else {
+      launch_final(dv, 0, stream);
+    }
     return VC_OK;
   }
-
-  // operator()(IterationSummary), vicalibrator.h:690-721
-  bool iteration_callback(const IterRecord& s) {
-    // UpdateImuWeights (:691) acts only when inertial && !rotation_only (:725)
-    ++num_iterations;
-    if (s.gnorm > 0 && s.gnorm < 1e-9) return false;   // :713-717
-    return true;
+  void init_ctrl(Ctrl* c) {
+    std::memset(c, 0, sizeof(Ctrl));
+    c->radius = 1e4; c->decrease_factor = 2.0;
+    c->ftol = function_tolerance; c->gtol = gradient_tolerance; c->ptol = parameter_tolerance; c->mult = (double)vis_mult;
+    c->cur = cur; c->reuse_diag = 0; c->need_lin = 1; c->init_scale = 1; c->max_iters = max_iters;
+    c->first = 1; c->trace_cap = trace_cap; c->stage = stage;
   }
 
-  // The trust-region loop (ceres::Solve :956 with LEVENBERG_MARQUARDT)
+  // The trust-region loop (ceres::Solve :956 with LEVENBERG_MARQUARDT).  The loop itself runs
+  // on the device (lm_decide in vc_kernels.hip); the host enqueues passes in batches and polls Ctrl::done.
   int solve_once(Termination* term, double* final_cost, long* nres) {
     if (device_dirty) { int rc = upload(); if (rc) return rc; }
     *nres = 2L * (long)dv.n_obs * vis_mult;
-    double radius = 1e4, decrease_factor = 2.0;
-    PassResult R;
-    int rc = run_pass(true, true, false, radius, &R); if (rc) return rc;
-    double cost = R.cost, gmax = R.gmax, gnorm = R.gnorm;
-    IterRecord last = {0, cost, 0, gmax, gnorm, 0, 0, radius, 1, stage};
-    trace.push_back(last);
-    if (gmax <= gradient_tolerance) { *final_cost = cost; *term = kConvergence; return VC_OK; }
-    int iter = 0, invalid = 0;
+    if (trace_cap < max_iters + 8) { trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); dv.trace = d_trace.p; }
+    Ctrl c;
+    init_ctrl(&c);
+    HIP_OK(hipMemcpyAsync(d_ctrl.p, &c, sizeof(Ctrl), hipMemcpyHostToDevice, stream));
+    const int batch = 6;
+    int guard = 0;
     while (true) {
-      if (!iteration_callback(last)) { *final_cost = cost; *term = kUserSuccess; return VC_OK; }
-      if (iter >= max_iters || !should_run) { *final_cost = cost; *term = kNoConvergence; return VC_OK; }
-      ++iter;
-      IterRecord rec = {iter, cost, 0, gmax, gnorm, 0, 0, radius, 0, stage};
-      const double model_change = -0.5 * R.gd + 0.5 * R.dld;
-      if (R.fail || !(model_change > 0)) {
-        if (++invalid >= 5) { trace.push_back(rec); *final_cost = cost; *term = kFailure; return VC_OK; }
-        radius *= 0.5; rec.radius = radius;
-        trace.push_back(rec); last = rec;
-        rc = run_pass(false, false, true, radius, &R); if (rc) return rc;
-        continue;
-      }
-      invalid = 0;
-      rec.step_norm = std::sqrt(R.step2);
-      const double xnorm = std::sqrt(R.x2);
-      if (rec.step_norm <= parameter_tolerance * (xnorm + parameter_tolerance)) {
-        trace.push_back(rec); *final_cost = cost; *term = kConvergence; return VC_OK;
-      }
-      rec.cost_change = cost - R.new_cost;
-      if (std::fabs(rec.cost_change) < function_tolerance * cost) {
-        trace.push_back(rec); *final_cost = cost; *term = kConvergence; return VC_OK;
-      }
-      rec.rho = rec.cost_change / model_change;
-      if (rec.rho > 1e-3) {
-        rec.accepted = 1;
-        cur = 1 - cur;
-        const double q = 2.0 * rec.rho - 1.0;
-        radius = radius / std::max(1.0 / 3.0, 1.0 - q * q * q);
-        radius = std::min(1e16, radius);
-        decrease_factor = 2.0;
-        rc = run_pass(true, false, false, radius, &R); if (rc) return rc;
-        cost = R.cost; gmax = R.gmax; gnorm = R.gnorm;
-        rec.cost = cost; rec.gmax = gmax; rec.gnorm = gnorm; rec.radius = radius;
-        trace.push_back(rec); last = rec;
-        if (gmax <= gradient_tolerance) { *final_cost = cost; *term = kConvergence; return VC_OK; }
-      } else {
-        radius = radius / decrease_factor; decrease_factor *= 2.0;
-        rec.radius = radius;
-        trace.push_back(rec); last = rec;
-        if (radius < 1e-32) { *final_cost = cost; *term = kConvergence; return VC_OK; }
-        rc = run_pass(false, false, true, radius, &R); if (rc) return rc;
-      }
+      for (int b = 0; b < batch; ++b) { int rc = enqueue_pass(); if (rc) return rc; }
+      HIP_OK(hipMemcpyAsync(&c, d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+      if (c.done || !should_run || ++guard > max_iters + 8) break;
     }
+    const int n = std::min(c.trace_len, trace_cap);
+    std::vector<double> rows((size_t)std::max(n, 1) * kTraceCols);
+    if (n) HIP_OK(hipMemcpy(rows.data(), d_trace.p, (size_t)n * kTraceCols * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+      const double* r = &rows[(size_t)i * kTraceCols];
+      IterRecord rec = {(int)r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], (int)r[8], (int)r[9]};
+      trace.push_back(rec);
+    }
+    cur = c.cur;
+    num_iterations += (unsigned)c.num_callbacks;
+    jac_sweeps += c.jac_sweeps; res_sweeps += c.res_sweeps;
+    last_iters = c.iter;
+    *final_cost = c.cost;
+    switch (c.done) {
+      case kDoneConvergence: *term = kConvergence; break;
+      case kDoneUserSuccess: *term = kUserSuccess; break;
+      case kDoneFailure: *term = kFailure; break;
+      default: *term = kNoConvergence; break;
+    }
+    return VC_OK;
+  }
+  int last_iters = 0;
+  // one pass with the decision logic on hold (parity hooks): linearise at the accepted state
+  int linearize_hold(double radius, double* cost) {
+    Ctrl c;
+    init_ctrl(&c);
+    c.hold = 1; c.radius = radius; c.first = 0;
+    HIP_OK(hipMemcpyAsync(d_ctrl.p, &c, sizeof(Ctrl), hipMemcpyHostToDevice, stream));
+    int rc = enqueue_pass(); if (rc) return rc;
+    HIP_OK(hipMemcpyAsync(&c, d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    if (cost) *cost = c.cost;
+    return VC_OK;
   }
 
   // per-camera RMSE, vicalibrator.h:958-971 (unrobustified, latest copy)
   int compute_rmse() {
     const int C = (int)cams.size();
-    launch_reproj_res(dv, cur, 1.0, stream); ++res_sweeps;
+    launch_reproj_res(dv, cur, 1.0, stream);
     launch_cam_sq(dv, d_tmp.p, stream);
     int rc = do_allreduce(d_tmp.p, 2 * C, 0); if (rc) return rc;
     double h[2 * kMaxCams];
@@ -640,11 +628,11 @@ int vc_shared_dim(vc_calibrator* h) { return h ? h->dv.D : VC_ERR_BAD_ARG; }
 int vc_linearize(vc_calibrator* h, double* cost, double* Hpp, double* gp, double* S, double* g_red, double* hss_diag, double* g_s) {
   NOT_RUNNING(h);
   if (h->device_dirty) { int rc = vc_prepare(h); if (rc) return rc; }
-  vc_calibrator::PassResult R;
+  double lin_cost = 0;
   // radius = +inf-like: lambda -> ~0 so that L L^T = H_pp to rounding; S is stored undamped anyway
-  int rc = h->run_pass(true, true, false, 1e300, &R); if (rc) return rc;
+  int rc = h->linearize_hold(1e300, &lin_cost); if (rc) return rc;
   const int N = h->dv.n_frames, D = h->dv.D;
-  if (cost) *cost = R.cost;
+  if (cost) *cost = lin_cost;
   std::vector<double> fr((size_t)N * kFrStride);
   if ((Hpp || gp) && N) {
     if (hipMemcpy(fr.data(), h->dv.fr, fr.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
@@ -693,12 +681,10 @@ int vc_run_iterations(vc_calibrator* h, int iters, int* jac_sweeps, int* res_swe
   while (done < iters && guard++ < iters + 4) {
     h->max_iters = std::min(mi, iters - done);
     rc = h->reset_state(); if (rc) break;
-    const size_t before = h->trace.size();
     Termination t; double fc; long nr;
     rc = h->solve_once(&t, &fc, &nr);
     if (rc) break;
-    int ran = 0;
-    for (size_t i = before; i < h->trace.size(); ++i) ran = std::max(ran, h->trace[i].iteration);
+    const int ran = h->last_iters;
     done += std::max(ran, 1);
   }
   h->max_iters = mi;
@@ -711,12 +697,14 @@ int vc_time_kernels(vc_calibrator* h, int reps, double* jac_ms, double* res_ms) 
   if (h->device_dirty) { int rc = vc_prepare(h); if (rc) return rc; }
   hipEvent_t e0, e1, e2;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) return VC_ERR_NO_DEVICE;
-  LmArgs a; a.radius = 1e4; a.mult = (double)std::max(1, h->vis_mult); a.cur = h->cur; a.init_scale = 0; a.reuse_diag = 1;
-  launch_reproj_jac(h->dv, a, h->stream); launch_reproj_res(h->dv, h->cur, a.mult, h->stream);   // warm
+  Ctrl c; h->init_ctrl(&c); c.hold = 1; if (c.mult < 1) c.mult = 1;
+  if (hipMemcpy(h->d_ctrl.p, &c, sizeof(Ctrl), hipMemcpyHostToDevice) != hipSuccess) return VC_ERR_NO_DEVICE;
+  const double mult = c.mult;
+  launch_reproj_jac(h->dv, h->stream); launch_reproj_res(h->dv, h->cur, mult, h->stream);   // warm
   (void)hipEventRecord(e0, h->stream);
-  for (int i = 0; i < reps; ++i) launch_reproj_jac(h->dv, a, h->stream);
+  for (int i = 0; i < reps; ++i) launch_reproj_jac(h->dv, h->stream);
   (void)hipEventRecord(e1, h->stream);
-  for (int i = 0; i < reps; ++i) launch_reproj_res(h->dv, h->cur, a.mult, h->stream);
+  for (int i = 0; i < reps; ++i) launch_reproj_res(h->dv, h->cur, mult, h->stream);
   (void)hipEventRecord(e2, h->stream);
   if (hipEventSynchronize(e2) != hipSuccess) return VC_ERR_NO_DEVICE;
   float m1 = 0, m2 = 0;

@@ -4,6 +4,8 @@
 //   tiles         (frame, camera) groups: tile_frame, tile_cam, tile_off[n_tiles+1]
 //   frame poses   n_frames x 8 doubles [q(4) t(3) pad], double-buffered (accepted / trial)
 //   cameras       n_cams x 24 doubles [T_ck(7) pad K(<=10) ...], double-buffered
+// The Levenberg-Marquardt control state (radius, accepted buffer, flags, iteration trace) lives on the
+// device (struct Ctrl): the host enqueues passes ahead of time and only polls `done`.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -15,8 +17,26 @@ constexpr int kGStride = 256;      // 16x16 Gram block per tile
 constexpr int kYStride = 96;       // 6 x 16 per tile
 constexpr int kFrStride = 40;      // per frame: L(21) z(6) g(6) lam(6) pad
 constexpr int kFrL = 0, kFrZ = 21, kFrG = 27, kFrLam = 33;
-constexpr int kNumScal = 8;        // gd, dld, step2, x2, g2, cost, gmax, spare
+constexpr int kNumScal = 8;
 enum { kScGd = 0, kScDld = 1, kScStep2 = 2, kScX2 = 3, kScG2 = 4, kScCost = 5, kScGmax = 6, kScSq = 7 };
+constexpr int kTraceCols = 10;     // iteration cost cost_change gmax gnorm step_norm rho radius accepted stage
+
+// termination codes in Ctrl::done (0 = keep running)
+enum { kRunning = 0, kDoneConvergence = 1, kDoneNoConvergence = 2, kDoneUserSuccess = 3, kDoneFailure = 4 };
+
+struct Ctrl {
+  double radius, decrease_factor, cost, gmax, gnorm, last_gnorm;
+  double ftol, gtol, ptol, mult;
+  double pend[kTraceCols];   // record of an accepted iteration waiting for the linearisation at the new point
+  int cur;            // index of the accepted state buffer
+  int reuse_diag;     // LevenbergMarquardtStrategy::reuse_diagonal_
+  int need_lin;       // the next pass re-linearises (Jacobian sweep)
+  int init_scale;     // first linearisation of a Solve: estimate the Jacobi scaling
+  int iter, invalid, done, max_iters;
+  int first, pending, trace_len, trace_cap;
+  int stage, hold, num_callbacks, jac_sweeps;
+  int res_sweeps, passes, pad0, pad1;
+};
 
 struct DevView {
   int n_frames, n_cams, n_tiles, n_points, D, n_chunks, chunk_frames;
@@ -37,8 +57,8 @@ struct DevView {
   double* poses[2];                // state double buffer
   double* cams[2];
   double* G;                       // n_tiles x 256
-  double* tile_cost;               // n_tiles
-  double* tile_sq;                 // n_tiles: sum of squared residuals (RMSE)
+  double* tile_cost;               // n_tiles   (Jacobian sweep: cost at the linearisation point)
+  double* tile_trial;              // n_tiles x 2: trial cost, sum of squared residuals
   double* Y;                       // n_tiles x 96
   double* fr;                      // n_frames x 40
   double* fdiag;                   // n_frames x 6   clamped scaled diagonal (kept while reuse_diagonal)
@@ -49,30 +69,22 @@ struct DevView {
   double* sscale2;                 // D
   double* slam;                    // D
   double* delta_s;                 // D
-  double* fpart;                   // n_fblocks x kNumScal
+  double* fpart;                   // n_frames x kNumScal: per-frame step terms
   double* scal;                    // kNumScal (frame sums) + kNumScal (shared-parameter terms)
-  int* flags;                      // [0]: frame Cholesky failures, [1]: reduced Cholesky failure
+  int* flags;                      // [0]: frame Cholesky failures, [1]: reduced Cholesky failure (per pass)
+  Ctrl* ctrl;
+  double* trace;                   // trace_cap x kTraceCols
   int part_stride;
-  int n_fblocks;
-};
-
-struct LmArgs {
-  double radius;
-  double mult;        // residual-block multiplicity of the visual terms (vicalibrator.h:641-649)
-  int cur;            // index of the accepted state buffer
-  int init_scale;     // first linearisation of a Solve: estimate the Jacobi scaling
-  int reuse_diag;     // LevenbergMarquardtStrategy::reuse_diagonal_
 };
 
 // launchers (vc_kernels.hip); all asynchronous on `s`
-void launch_reproj_jac(const DevView& v, const LmArgs& a, hipStream_t s);
-void launch_reproj_res(const DevView& v, int state, double mult, hipStream_t s);
-void launch_frame_prep(const DevView& v, const LmArgs& a, hipStream_t s);
-void launch_schur_reduce(const DevView& v, const LmArgs& a, hipStream_t s);
-void launch_reduced_solve(const DevView& v, const LmArgs& a, hipStream_t s);
-void launch_backsub_update(const DevView& v, const LmArgs& a, hipStream_t s);
-void launch_shared_update(const DevView& v, const LmArgs& a, hipStream_t s);
-void launch_reduce_scalars(const DevView& v, const LmArgs& a, hipStream_t s);
+void launch_reproj_jac(const DevView& v, hipStream_t s);
+void launch_frame_prep(const DevView& v, hipStream_t s);
+void launch_schur_reduce(const DevView& v, hipStream_t s);     // chunk partials + packed reduced system (Sbuf)
+void launch_reduced_solve(const DevView& v, hipStream_t s);    // damped solve + trial state of the shared parameters
+void launch_trial(const DevView& v, hipStream_t s);            // back-substitution + manifold update + trial residual sweep
+void launch_final(const DevView& v, int mode, hipStream_t s);  // mode 0: reduce + decide, 1: reduce only, 2: decide only
+void launch_reproj_res(const DevView& v, int state, double mult, hipStream_t s);   // plain residual sweep of a state buffer
 void launch_sum_tile_cost(const DevView& v, double* out_cost_sq /*2*/, hipStream_t s);
 void launch_cam_sq(const DevView& v, double* out /*n_cams x 2: sum sq, count*/, hipStream_t s);
 void launch_outlier_mask(const DevView& v, int state, const double* thresh /*device, n_cams*/, unsigned char* mask, hipStream_t s);
