@@ -122,6 +122,9 @@ int vc_run_iterations(vc_calibrator* h, int iters, int* jac_sweeps, int* res_swe
 int vc_evaluate(vc_calibrator* h, double* cost, double* sum_sq);
 /* Times the dominant kernels with HIP events on the calibrator's stream: average ms per launch over reps */
 int vc_time_kernels(vc_calibrator* h, int reps, double* jac_ms, double* res_ms);
+/* Average ms per launch of each stage of one LM pass (Jacobian sweep, frame elimination, Schur partials,
+ * reduced solve, trial sweep, decision), `reps` back-to-back launches each */
+int vc_time_stages(vc_calibrator* h, int reps, double out[6]);
 long long vc_num_observations(vc_calibrator* h);
 int vc_num_tiles(vc_calibrator* h);
 

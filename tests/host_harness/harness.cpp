@@ -9,9 +9,10 @@ using namespace vc;
 template <int MODEL>
 static double gram(const TileXf& x, const double* K, int n, const double* pw, const double* uv, double mult, double* G) {
   double cost = 0;
+  ModelPre pre; model_precompute(MODEL, K, &pre);
   for (int d = 0; d < n; ++d) {
     double r0[16], r1[16];
-    cost += corner_rows<MODEL>(x, K, pw + 3 * d, uv[2 * d], uv[2 * d + 1], mult, r0, r1);
+    cost += corner_rows<MODEL>(x, K, pre, pw + 3 * d, uv[2 * d], uv[2 * d + 1], mult, r0, r1);
     for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) G[i * 16 + j] += r0[i] * r0[j] + r1[i] * r1[j];
   }
   return cost;
@@ -19,12 +20,13 @@ static double gram(const TileXf& x, const double* K, int n, const double* pw, co
 template <int MODEL>
 static double resid(const TileXf& x, const double* K, int n, const double* pw, const double* uv, double* r) {
   double cost = 0;
-  for (int d = 0; d < n; ++d) cost += corner_residual<MODEL>(x, K, pw + 3 * d, uv[2 * d], uv[2 * d + 1], r + 2 * d);
+  ModelPre pre; model_precompute(MODEL, K, &pre);
+  for (int d = 0; d < n; ++d) cost += corner_residual<MODEL>(x, K, pre, pw + 3 * d, uv[2 * d], uv[2 * d + 1], r + 2 * d);
   return cost;
 }
 
 extern "C" {
-void hh_project(int model, const double* pc, const double* K, double* pix, double* A, double* B) { project_any<true>(model, pc, K, pix, A, B); }
+void hh_project(int model, const double* pc, const double* K, double* pix, double* A, double* B) { ModelPre pre; model_precompute(model, K, &pre); project_any<true>(model, pc, K, pre, pix, A, B); }
 double hh_tile_gram(int model, const double* T_wk, const double* T_ck, const double* K, int n, const double* pw, const double* uv,
                     double mult, double* G) {
   TileXf x; make_tile_xf(T_wk, T_ck, &x);

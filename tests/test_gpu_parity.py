@@ -104,6 +104,22 @@ def test_mixed_rig_with_outlier_removal_matches_oracle():
     _compare_solution(p, cal, orc)
 
 
+def test_eight_camera_rig_large_shared_block():
+    """cfg5-like rig (4 x fov + 4 x kb4) at small scale: D = 94 shared parameters -> workgroup-wide reduced
+    solve, 36 column-tile pairs in the Schur Gram, 8 tiles per frame."""
+    p, cal, orc = _pair(synth.Config(models=("fov", "kb4") * 4, n_frames=24, seed=31), num_threads=8)
+    orc.prepare(vis_mult=1)
+    lin = orc.linearize()
+    g = cal.linearize()
+    assert cal.shared_dim() == 94
+    S, gr = _oracle_schur(lin)
+    np.testing.assert_allclose(g["S"], S, rtol=1e-6, atol=1e-8 * np.abs(lin["Hss"]).max())
+    np.testing.assert_allclose(g["g_red"], gr, rtol=1e-6, atol=1e-8 * np.abs(lin["gs"]).max())
+    p, cal, orc = _pair(synth.Config(models=("fov", "kb4") * 4, n_frames=24, seed=31), num_threads=8)
+    cal.Solve(); orc.solve()
+    _compare_solution(p, cal, orc)
+
+
 def test_ragged_and_empty_tiles():
     """Tiles of 4..190 corners, a frame seen by one camera only, a frame with no observations at all."""
     p = synth.generate(synth.Config(models=("poly3", "fov"), n_frames=12, seed=9))

@@ -118,7 +118,7 @@ struct vc_calibrator {
   DBuf<int> d_tile_frame, d_tile_cam, d_tile_off, d_frame_tile_off, d_frame_cam_tile, d_cam_model, d_cam_flags, d_cam_col0,
       d_col_cam, d_col_local, d_flags;
   DBuf<double> d_pose[2], d_cam[2], d_G, d_tile_cost, d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_sdiag,
-      d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace;
+      d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total;
   DBuf<Ctrl> d_ctrl;
   int trace_cap = 0;
   DBuf<unsigned char> d_mask;
@@ -216,13 +216,13 @@ struct vc_calibrator {
     }
     cur = 0;
     for (int b = 0; b < 2; ++b) { HIP_OK(d_pose[b].upload(poses, stream)); HIP_OK(d_cam[b].upload(camrec, stream)); }
-    const int chunk_frames = std::max(8, (N + 255) / 256);
+    const int chunk_frames = std::max(4, (((N + 255) / 256) + 3) / 4 * 4);
     const int n_chunks = std::max(1, (N + chunk_frames - 1) / chunk_frames);
     const int part_stride = D * D + D + C * kGStride;
     HIP_OK(d_G.alloc((size_t)std::max(T, 1) * kGStride)); HIP_OK(d_tile_cost.alloc(std::max(T, 1))); HIP_OK(d_tile_trial.alloc((size_t)std::max(T, 1) * 2));
     HIP_OK(d_Y.alloc((size_t)std::max(T, 1) * kYStride)); HIP_OK(d_fr.alloc((size_t)std::max(N, 1) * kFrStride));
     HIP_OK(d_fdiag.alloc((size_t)std::max(N, 1) * 6)); HIP_OK(d_fscale2.alloc((size_t)std::max(N, 1) * 6));
-    HIP_OK(d_part.alloc((size_t)n_chunks * part_stride)); HIP_OK(d_Sbuf.alloc((size_t)D * D + 3 * D + 2));
+    HIP_OK(d_part.alloc((size_t)n_chunks * part_stride)); HIP_OK(d_part_total.alloc(part_stride)); HIP_OK(d_Sbuf.alloc((size_t)D * D + 3 * D + 2));
     HIP_OK(d_sdiag.alloc(D)); HIP_OK(d_sscale2.alloc(D)); HIP_OK(d_slam.alloc(D)); HIP_OK(d_delta_s.alloc(D));
     HIP_OK(d_fpart.alloc((size_t)std::max(N, 1) * kNumScal));
     trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); HIP_OK(d_ctrl.alloc(1));
@@ -242,7 +242,7 @@ struct vc_calibrator {
     dv.col_cam = d_col_cam.p; dv.col_local = d_col_local.p;
     dv.poses[0] = d_pose[0].p; dv.poses[1] = d_pose[1].p; dv.cams[0] = d_cam[0].p; dv.cams[1] = d_cam[1].p;
     dv.G = d_G.p; dv.tile_cost = d_tile_cost.p; dv.tile_trial = d_tile_trial.p; dv.Y = d_Y.p; dv.fr = d_fr.p;
-    dv.fdiag = d_fdiag.p; dv.fscale2 = d_fscale2.p; dv.part = d_part.p; dv.Sbuf = d_Sbuf.p;
+    dv.fdiag = d_fdiag.p; dv.fscale2 = d_fscale2.p; dv.part = d_part.p; dv.part_total = d_part_total.p; dv.Sbuf = d_Sbuf.p;
     dv.sdiag = d_sdiag.p; dv.sscale2 = d_sscale2.p; dv.slam = d_slam.p; dv.delta_s = d_delta_s.p;
     dv.fpart = d_fpart.p; dv.scal = d_scal.p; dv.flags = d_flags.p;
     dv.part_stride = part_stride; dv.ctrl = d_ctrl.p; dv.trace = d_trace.p;
@@ -284,10 +284,15 @@ struct vc_calibrator {
   int enqueue_pass() {
     const int D = dv.D;
     launch_reproj_jac(dv, stream);
-    launch_frame_prep(dv, stream);
-    launch_schur_reduce(dv, stream);
-    int rc = do_allreduce(dv.Sbuf, D * D + 3 * D + 2, 0); if (rc) return rc;
-    launch_reduced_solve(dv, stream);
+    launch_frame_schur(dv, stream);
+    int rc = VC_OK;
+    if (world > 1) {
+      launch_reduced(dv, 1, stream);
+      rc = do_allreduce(dv.Sbuf, D * D + 3 * D + 2, 0); if (rc) return rc;
+      launch_reduced(dv, 2, stream);
+    } else {
+      launch_reduced(dv, 0, stream);
+    }
     launch_trial(dv, stream);
     if (world > 1) {
       launch_final(dv, 1, stream);
@@ -712,6 +717,32 @@ int vc_time_kernels(vc_calibrator* h, int reps, double* jac_ms, double* res_ms) 
   if (jac_ms) *jac_ms = m1 / reps;
   if (res_ms) *res_ms = m2 / reps;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+  return VC_OK;
+}
+// Average ms per launch of every stage of one pass, each launched `reps` times back to back with the
+// decision logic on hold (state does not change).  out[0..5]: jac, frame_prep, schur_reduce, reduced, trial, final
+int vc_time_stages(vc_calibrator* h, int reps, double* out) {
+  NOT_RUNNING(h);
+  if (!out) return VC_ERR_BAD_ARG;
+  if (h->device_dirty) { int rc = vc_prepare(h); if (rc) return rc; }
+  Ctrl c; h->init_ctrl(&c); c.hold = 1; c.first = 0; if (c.mult < 1) c.mult = 1;
+  if (hipMemcpy(h->d_ctrl.p, &c, sizeof(Ctrl), hipMemcpyHostToDevice) != hipSuccess) return VC_ERR_NO_DEVICE;
+  if (h->enqueue_pass()) return VC_ERR_NO_DEVICE;
+  hipEvent_t ev[7];
+  for (int i = 0; i < 7; ++i) if (hipEventCreate(&ev[i]) != hipSuccess) return VC_ERR_NO_DEVICE;
+  hipStream_t s = h->stream;
+  for (int w = 0; w < 2; ++w) {   // first round warms clocks and caches
+    (void)hipEventRecord(ev[0], s); for (int i = 0; i < reps; ++i) launch_reproj_jac(h->dv, s);
+    (void)hipEventRecord(ev[1], s); for (int i = 0; i < reps; ++i) launch_frame_schur(h->dv, s);
+    (void)hipEventRecord(ev[2], s);
+    (void)hipEventRecord(ev[3], s); for (int i = 0; i < reps; ++i) launch_reduced(h->dv, 0, s);
+    (void)hipEventRecord(ev[4], s); for (int i = 0; i < reps; ++i) launch_trial(h->dv, s);
+    (void)hipEventRecord(ev[5], s); for (int i = 0; i < reps; ++i) launch_final(h->dv, 0, s);
+    (void)hipEventRecord(ev[6], s);
+    if (hipEventSynchronize(ev[6]) != hipSuccess) return VC_ERR_NO_DEVICE;
+  }
+  for (int i = 0; i < 6; ++i) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); out[i] = ms / reps; }
+  for (int i = 0; i < 7; ++i) (void)hipEventDestroy(ev[i]);
   return VC_OK;
 }
 long long vc_num_observations(vc_calibrator* h) { return h ? h->dv.n_obs : 0; }

@@ -64,6 +64,7 @@ struct DevView {
   double* fdiag;                   // n_frames x 6   clamped scaled diagonal (kept while reuse_diagonal)
   double* fscale2;                 // n_frames x 6   Jacobi scale^2 (fixed per solve)
   double* part;                    // n_chunks x part_stride
+  double* part_total;              // part_stride: fixed-order sum of the chunk partials
   double* Sbuf;                    // D*D (S, no damping) + D (g_red) + D (H_ss diag) + D (g_s) + 2 (cost, spare)
   double* sdiag;                   // D
   double* sscale2;                 // D
@@ -79,9 +80,9 @@ struct DevView {
 
 // launchers (vc_kernels.hip); all asynchronous on `s`
 void launch_reproj_jac(const DevView& v, hipStream_t s);
-void launch_frame_prep(const DevView& v, hipStream_t s);
-void launch_schur_reduce(const DevView& v, hipStream_t s);     // chunk partials + packed reduced system (Sbuf)
-void launch_reduced_solve(const DevView& v, hipStream_t s);    // damped solve + trial state of the shared parameters
+void launch_frame_schur(const DevView& v, hipStream_t s);      // frame elimination + per-chunk partial Schur sums
+// mode 0: packed reduced system (Sbuf) + damped solve + trial shared parameters; 1: Sbuf only; 2: solve only
+void launch_reduced(const DevView& v, int mode, hipStream_t s);
 void launch_trial(const DevView& v, hipStream_t s);            // back-substitution + manifold update + trial residual sweep
 void launch_final(const DevView& v, int mode, hipStream_t s);  // mode 0: reduce + decide, 1: reduce only, 2: decide only
 void launch_reproj_res(const DevView& v, int state, double mult, hipStream_t s);   // plain residual sweep of a state buffer

@@ -10,11 +10,11 @@
 //  k_reproj_jac      one wavefront per (frame,camera) tile: closed-form unique-column Jacobian rows per
 //                    corner (lane = corner), rows staged in wave-private LDS, tile Gram block
 //                    G = sum w u^T u accumulated on the matrix pipe (v_mfma_f64_16x16x4_f64)
-//  k_frame_prep      one wavefront per frame: H_pp, g_p from the tile Gram blocks, damping, 6x6 Cholesky,
-//                    Y = L^-1 W per tile (lanes = columns)
-//  k_schur_reduce    per frame chunk: sum Y^T Y, sum Y^T z, per-camera sum of G   (LDS staged)
-//  k_schur_final     fixed-order sum of the chunk partials + camera blocks -> packed reduced system
-//  k_reduced_solve   one workgroup: damped Cholesky in LDS, delta_s, trial state of the shared parameters
+//  k_frame_schur     one wavefront per frame: H_pp, g_p from the tile Gram blocks, damping, 6x6 Cholesky,
+//                    Y = L^-1 W per tile (lanes = columns); per chunk sum Y^T Y, sum Y^T z on the matrix pipe
+//  k_part_sum        fixed-order sum of the chunk partials, spread over many CUs
+//  k_reduced         one workgroup: camera blocks -> packed reduced system, damped Cholesky, delta_s, trial
+//                    state of the shared parameters
 //  k_trial           one wavefront per tile: back-substitution, T <- T exp(delta), trial residual sweep
 //  k_final           fixed-order reduction of the step scalars + the accept/reject decision (device Ctrl)
 #include <hip/hip_runtime.h>
@@ -30,6 +30,11 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane /* wave-uniform */) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+  return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum(double x) {      // result valid in lane 0
 #pragma unroll
@@ -54,6 +59,8 @@ __device__ __forceinline__ void jac_tile_body(const DevView& v, int cur, double 
   double K[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) K[i] = cam[kCamK + i];
+  ModelPre pre;
+  model_precompute(MODEL, K, &pre);
   v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   double cost = 0.0;
   double* mine = wl + lane * kDotStride;
@@ -62,7 +69,7 @@ __device__ __forceinline__ void jac_tile_body(const DevView& v, int cur, double 
     if (d < cnt) {
       const double2 uv = v.obs_uv[off + d];
       const double* pw = v.points + 3 * (size_t)v.obs_pt[off + d];
-      cost += corner_rows<MODEL>(x, K, pw, uv.x, uv.y, mult, mine, mine + 16);
+      cost += corner_rows<MODEL>(x, K, pre, pw, uv.x, uv.y, mult, mine, mine + 16);
     } else {
 #pragma unroll
       for (int i = 0; i < 32; ++i) mine[i] = 0.0;
@@ -115,11 +122,13 @@ template <int MODEL>
 __device__ __forceinline__ void res_tile_sweep(const DevView& v, const TileXf& x, const double* K, int off, int cnt, int lane,
                                                double* cost_out, double* sq_out) {
   double cost = 0.0, sq = 0.0;
+  ModelPre pre;
+  model_precompute(MODEL, K, &pre);
   for (int d = lane; d < cnt; d += 64) {
     const double2 uv = v.obs_uv[off + d];
     const double* pw = v.points + 3 * (size_t)v.obs_pt[off + d];
     double r[2];
-    cost += corner_residual<MODEL>(x, K, pw, uv.x, uv.y, r);
+    cost += corner_residual<MODEL>(x, K, pre, pw, uv.x, uv.y, r);
     sq += r[0] * r[0] + r[1] * r[1];
   }
   *cost_out = wave_sum(cost);
@@ -156,10 +165,12 @@ __global__ __launch_bounds__(256) void k_reproj_res(DevView v, int state, double
 template <int MODEL>
 __device__ __forceinline__ void mask_tile_body(const DevView& v, const TileXf& x, const double* K, int off, int cnt, int lane,
                                                double th, unsigned char* mask) {
+  ModelPre pre;
+  model_precompute(MODEL, K, &pre);
   for (int d = lane; d < cnt; d += 64) {
     const double2 uv = v.obs_uv[off + d];
     double r[2];
-    corner_residual<MODEL>(x, K, v.points + 3 * (size_t)v.obs_pt[off + d], uv.x, uv.y, r);
+    corner_residual<MODEL>(x, K, pre, v.points + 3 * (size_t)v.obs_pt[off + d], uv.x, uv.y, r);
     mask[off + d] = sqrt(r[0] * r[0] + r[1] * r[1]) > th ? 1 : 0;
   }
 }
@@ -186,23 +197,48 @@ __global__ __launch_bounds__(256) void k_outlier_mask(DevView v, int state, cons
 }
 
 // ------------------------------------------------------------------------------------------ frame elimination
-// One wavefront per frame.  Lanes 0..35 own the entries of H_pp, 36..41 those of g_p; every lane then
-// factors the 6x6 block redundantly (wave-uniform), and lanes own (tile, column) pairs of Y = L^-1 W.
-constexpr int kPrepLds = kMaxCams * 96 + 48;
-__global__ __launch_bounds__(256) void k_frame_prep(DevView v) {
-  __shared__ double sh[4 * kPrepLds];
+// k_frame_schur: one workgroup per chunk of frames, one wavefront per frame (groups of 4 frames).
+//  per frame   lanes 0..35 own the entries of H_pp, 36..41 those of g_p; every lane then factors the damped
+//              6x6 block redundantly (wave-uniform); lanes own (tile, column) pairs of Y = L^-1 W.
+//  per group   the 4 x 6 rows [Y_f | z_f] (dense over the shared columns) sit in LDS and their Gram matrix
+//              sum Y^T Y, sum Y^T z is accumulated on the matrix pipe (v_mfma_f64_16x16x4_f64), 16x16
+//              column-tile pairs distributed over the 4 wavefronts.
+//  per chunk   part = [ sum Y^T Y (D x D, upper) | sum Y^T z (D) | per-camera sum of G (C x 256) ]
+constexpr int kPrepPad = 48;
+constexpr int kMaxPairsPerWave = 9;      // 8 column tiles -> 36 pairs over 4 waves
+__device__ __forceinline__ int schur_ld(int D) { const int Dp = ((D + 1 + 15) / 16) * 16; return (Dp % 32 == 0) ? Dp + 16 : Dp; }
+
+__global__ __launch_bounds__(256) void k_frame_schur(DevView v) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int f = blockIdx.x * 4 + wave;
-  if (f >= v.n_frames) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int C = v.n_cams, D = v.D;
+  const int nT = (D + 1 + 15) / 16, ld = schur_ld(D), nPairs = nT * (nT + 1) / 2;
+  double* Gw = sh + wave * (C * kGStride + kPrepPad);
+  double* Hs = Gw + C * kGStride;
+  double* R = sh + 4 * (C * kGStride + kPrepPad);
   const int cur = ct->cur;
-  const int t0 = v.frame_tile_off[f], nt = v.frame_tile_off[f + 1] - t0;
-  double* Gs = sh + wave * kPrepLds;
-  double* Hs = Gs + kMaxCams * 96;
+  const int init_scale = ct->init_scale, reuse = ct->reuse_diag;
+  const double radius = ct->radius;
   const double* cams = v.cams[cur];
-  if (nt == 0) {     // frame without observations: nothing to eliminate, keeps its pose
-    if (lane == 0) {
+  const int chunk = blockIdx.x;
+  const int f0 = chunk * v.chunk_frames, f1 = min(f0 + v.chunk_frames, v.n_frames);
+  v4d acc[kMaxPairsPerWave];
+#pragma unroll
+  for (int i = 0; i < kMaxPairsPerWave; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double gsum[kMaxCams][4];
+#pragma unroll
+  for (int c = 0; c < kMaxCams; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gsum[c][q] = 0.0;
+
+  for (int fg = f0; fg < f1; fg += 4) {
+    const int f = fg + wave;
+    for (int i = lane; i < 6 * ld; i += 64) R[(wave * 6) * ld + i] = 0.0;
+    const int t0 = (f < f1) ? v.frame_tile_off[f] : 0;
+    const int nt = (f < f1) ? v.frame_tile_off[f + 1] - t0 : 0;
+    if (f < f1 && nt == 0 && lane == 0) {     // frame without observations: nothing to eliminate, keeps its pose
       const double* p = v.poses[cur] + (size_t)f * kPoseStride;
       double x2 = 0;
       for (int i = 0; i < 7; ++i) x2 += p[i] * p[i];
@@ -210,258 +246,254 @@ __global__ __launch_bounds__(256) void k_frame_prep(DevView v) {
       for (int i = 0; i < kNumScal; ++i) o[i] = 0.0;
       o[kScX2] = x2;
     }
-    return;
-  }
-  for (int i = lane; i < nt * 96; i += 64) Gs[i] = v.G[(size_t)(t0 + i / 96) * kGStride + (i % 96)];
-  wave_lds_sync();
-  double hval = 0.0;
-  if (lane < 42) {
-    for (int t = 0; t < nt; ++t) {
-      const int c = v.tile_cam[t0 + t];
-      double R[9];
-      quat_to_R(cams + (size_t)c * kCamStride, R);
-      const double* g = Gs + t * 96;
-      if (lane < 36) {
-        const int i = lane / 6, j = lane % 6, a = i / 3, ii = i % 3, b = j / 3, jj = j % 3;
-        double s = 0.0;
+    if (nt > 0) {
+      for (int m = 0; m < nt * 4; ++m) {       // full 16x16 Gram block of every tile of the frame
+        const int t = m >> 2, q = m & 3;
+        const double val = v.G[(size_t)(t0 + t) * kGStride + q * 64 + lane];
+        Gw[t * kGStride + q * 64 + lane] = val;
+        const int c = v.tile_cam[t0 + t];
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int k = 0; k < kMaxCams; ++k)
 #pragma unroll
-          for (int q = 0; q < 3; ++q) s += R[3 * p + ii] * g[(3 * a + p) * 16 + 3 * b + q] * R[3 * q + jj];
-        hval += (a == b) ? s : -s;
-      } else {
-        const int i = lane - 36, a = i / 3, ii = i % 3;
-        const int rc = 6 + model_nk(v.cam_model[c]);
-        double s = 0.0;
+          for (int qq = 0; qq < 4; ++qq) gsum[k][qq] += (k == c && qq == q) ? val : 0.0;
+      }
+      wave_lds_sync();
+      double hval = 0.0;
+      if (lane < 42) {
+        for (int t = 0; t < nt; ++t) {
+          const int c = v.tile_cam[t0 + t];
+          double Rm[9];
+          quat_to_R(cams + (size_t)c * kCamStride, Rm);
+          const double* g = Gw + t * kGStride;
+          if (lane < 36) {
+            const int i = lane / 6, j = lane % 6, a = i / 3, ii = i % 3, b = j / 3, jj = j % 3;
+            double s = 0.0;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) s += R[3 * p + ii] * g[(3 * a + p) * 16 + rc];
-        hval += (a == 0) ? -s : s;
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+              for (int q = 0; q < 3; ++q) s += Rm[3 * p + ii] * g[(3 * a + p) * 16 + 3 * b + q] * Rm[3 * q + jj];
+            hval += (a == b) ? s : -s;
+          } else {
+            const int i = lane - 36, a = i / 3, ii = i % 3;
+            const int rc = 6 + model_nk(v.cam_model[c]);
+            double s = 0.0;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) s += Rm[3 * p + ii] * g[(3 * a + p) * 16 + rc];
+            hval += (a == 0) ? -s : s;
+          }
+        }
+        Hs[lane] = hval;
+      }
+      wave_lds_sync();
+      double H[36], g6[6], lam[6];
+#pragma unroll
+      for (int i = 0; i < 36; ++i) H[i] = Hs[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) g6[i] = Hs[36 + i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double hd = H[i * 6 + i];
+        double sc2, dg;
+        if (init_scale) { sc2 = jacobi_scale2(hd); if (lane == 0) v.fscale2[(size_t)f * 6 + i] = sc2; }
+        else sc2 = v.fscale2[(size_t)f * 6 + i];
+        if (!reuse) { dg = lm_clamped_diag(hd, sc2); if (lane == 0) v.fdiag[(size_t)f * 6 + i] = dg; }
+        else dg = v.fdiag[(size_t)f * 6 + i];
+        lam[i] = dg / (radius * sc2);
+        H[i * 6 + i] = hd + lam[i];
+      }
+      if (!chol_small<6>(H)) {
+        if (lane == 0) atomicAdd(&v.flags[0], 1);
+#pragma unroll
+        for (int i = 0; i < 36; ++i) H[i] = (i % 7 == 0) ? 1.0 : 0.0;
+      }
+      double z[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) z[i] = g6[i];
+      fwd_solve<6>(H, z);
+      if (lane == 0) {
+        double* fr = v.fr + (size_t)f * kFrStride;
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) fr[kFrL + k++] = H[i * 6 + j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { fr[kFrZ + i] = z[i]; fr[kFrG + i] = g6[i]; fr[kFrLam + i] = lam[i]; R[(wave * 6 + i) * ld + D] = z[i]; }
+      }
+      for (int idx = lane; idx < nt * 16; idx += 64) {      // Y columns: lane -> (tile, column)
+        const int t = idx >> 4, j = idx & 15;
+        const int c = v.tile_cam[t0 + t];
+        const int flags = v.cam_flags[c], nk = model_nk(v.cam_model[c]);
+        const int nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
+        const int nc = nrot + ntr + ((flags & kCamKFree) ? nk : 0);
+        double w[6] = {0, 0, 0, 0, 0, 0};
+        if (j < nc) {
+          double Rm[9];
+          quat_to_R(cams + (size_t)c * kCamStride, Rm);
+          const double* g = Gw + t * kGStride;
+          double u[6];   // column of [Gaa Ea | GaB]
+          if (j < nrot) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) u[r] = -(g[r * 16 + 3] * Rm[j] + g[r * 16 + 4] * Rm[3 + j] + g[r * 16 + 5] * Rm[6 + j]);
+          } else {
+            const int jj = (j < nrot + ntr) ? j - nrot : 6 + (j - nrot - ntr);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) u[r] = g[r * 16 + jj];
+          }
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {   // w = Qa^T u, Qa = diag(-R, R)
+            w[i] = -(Rm[i] * u[0] + Rm[3 + i] * u[1] + Rm[6 + i] * u[2]);
+            w[3 + i] = Rm[i] * u[3] + Rm[3 + i] * u[4] + Rm[6 + i] * u[5];
+          }
+          fwd_solve<6>(H, w);
+          const int col = v.cam_col0[c] + j;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) R[(wave * 6 + r) * ld + col] = w[r];
+        }
+        double* Yt = v.Y + (size_t)(t0 + t) * kYStride;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) Yt[r * kUCols + j] = w[r];
       }
     }
-    Hs[lane] = hval;
-  }
-  wave_lds_sync();
-  double H[36], g6[6], lam[6];
+    __syncthreads();
+    {
+      int I = 0, J = 0, pi = 0;
+      for (int p = 0; p < nPairs; ++p) {
+        if ((p & 3) == wave) {
+          const double* ra = R + (lane >> 4) * ld + I * 16 + (lane & 15);
+          const double* rb = R + (lane >> 4) * ld + J * 16 + (lane & 15);
+          v4d a4 = acc[0];
 #pragma unroll
-  for (int i = 0; i < 36; ++i) H[i] = Hs[i];
+          for (int q = 0; q < kMaxPairsPerWave; ++q) a4 = (q == pi) ? acc[q] : a4;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) g6[i] = Hs[36 + i];
-  const int init_scale = ct->init_scale, reuse = ct->reuse_diag;
-  const double radius = ct->radius;
+          for (int ks = 0; ks < 6; ++ks) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[ks * 4 * ld], rb[ks * 4 * ld], a4, 0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const double hd = H[i * 6 + i];
-    double sc2, dg;
-    if (init_scale) { sc2 = jacobi_scale2(hd); if (lane == 0) v.fscale2[(size_t)f * 6 + i] = sc2; }
-    else sc2 = v.fscale2[(size_t)f * 6 + i];
-    if (!reuse) { dg = lm_clamped_diag(hd, sc2); if (lane == 0) v.fdiag[(size_t)f * 6 + i] = dg; }
-    else dg = v.fdiag[(size_t)f * 6 + i];
-    lam[i] = dg / (radius * sc2);
-    H[i * 6 + i] = hd + lam[i];
-  }
-  if (!chol_small<6>(H)) {
-    if (lane == 0) atomicAdd(&v.flags[0], 1);
-#pragma unroll
-    for (int i = 0; i < 36; ++i) H[i] = (i % 7 == 0) ? 1.0 : 0.0;
-  }
-  double z[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) z[i] = g6[i];
-  fwd_solve<6>(H, z);
-  if (lane == 0) {
-    double* fr = v.fr + (size_t)f * kFrStride;
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = 0; j <= i; ++j) fr[kFrL + k++] = H[i * 6 + j];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { fr[kFrZ + i] = z[i]; fr[kFrG + i] = g6[i]; fr[kFrLam + i] = lam[i]; }
-  }
-  // Y columns: lane -> (tile, column)
-  for (int idx = lane; idx < nt * 16; idx += 64) {
-    const int t = idx >> 4, j = idx & 15;
-    const int c = v.tile_cam[t0 + t];
-    const int flags = v.cam_flags[c], nk = model_nk(v.cam_model[c]);
-    const int nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
-    const int nc = nrot + ntr + ((flags & kCamKFree) ? nk : 0);
-    double w[6] = {0, 0, 0, 0, 0, 0};
-    if (j < nc) {
-      double R[9];
-      quat_to_R(cams + (size_t)c * kCamStride, R);
-      const double* g = Gs + t * 96;
-      double u[6];   // column of [Gaa Ea | GaB]
-      if (j < nrot) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) u[r] = -(g[r * 16 + 3] * R[j] + g[r * 16 + 4] * R[3 + j] + g[r * 16 + 5] * R[6 + j]);
-      } else if (j < nrot + ntr) {
-        const int jj = j - nrot;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) u[r] = g[r * 16 + jj];
-      } else {
-        const int jj = 6 + (j - nrot - ntr);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) u[r] = g[r * 16 + jj];
+          for (int q = 0; q < kMaxPairsPerWave; ++q) acc[q] = (q == pi) ? a4 : acc[q];
+          ++pi;
+        }
+        if (++J == nT) { ++I; J = I; }
       }
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {   // w = Qa^T u, Qa = diag(-R, R)
-        w[i] = -(R[i] * u[0] + R[3 + i] * u[1] + R[6 + i] * u[2]);
-        w[3 + i] = R[i] * u[3] + R[3 + i] * u[4] + R[6 + i] * u[5];
-      }
-      fwd_solve<6>(H, w);
     }
-    double* Yt = v.Y + (size_t)(t0 + t) * kYStride;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) Yt[r * kUCols + j] = w[r];
+    __syncthreads();
   }
-}
-
-// Partial Schur sums of one frame chunk: part = [ sum Y^T Y (upper, D x D) | sum Y^T z (D) | per-camera sum of G (C x 256) ]
-constexpr int kSchurBatchTiles = 64;    // tiles staged in LDS per batch (48 KB)
-__global__ __launch_bounds__(256) void k_schur_reduce(DevView v) {
-  __shared__ double Ys[kSchurBatchTiles * kYStride];
-  __shared__ double Zs[kSchurBatchTiles * 6];
-  if (v.ctrl->done) return;
-  const int chunk = blockIdx.x, tid = threadIdx.x;
-  const int f0 = chunk * v.chunk_frames, f1 = min(f0 + v.chunk_frames, v.n_frames);
-  const int D = v.D, C = v.n_cams;
   double* part = v.part + (size_t)chunk * v.part_stride;
-  const int t0 = v.frame_tile_off[f0], t1 = v.frame_tile_off[f1];
   {
-    double gsum[kMaxCams];
+    int I = 0, J = 0, pi = 0;
+    for (int p = 0; p < nPairs; ++p) {
+      if ((p & 3) == wave) {
+        v4d a4 = acc[0];
 #pragma unroll
-    for (int c = 0; c < kMaxCams; ++c) gsum[c] = 0.0;
-    for (int t = t0; t < t1; ++t) {
-      const double gv = v.G[(size_t)t * kGStride + tid];
-      const int c = v.tile_cam[t];
+        for (int q = 0; q < kMaxPairsPerWave; ++q) a4 = (q == pi) ? acc[q] : a4;
 #pragma unroll
-      for (int k = 0; k < kMaxCams; ++k) gsum[k] += (k == c) ? gv : 0.0;
-    }
-#pragma unroll
-    for (int c = 0; c < kMaxCams; ++c) if (c < C) part[D * D + D + c * kGStride + tid] = gsum[c];
-  }
-  const int nE = D * D + D;
-  // each thread owns entries e = tid, tid + 256, ... (at most 65 for D = 128); accumulate over batches of frames
-  double acc[4] = {0, 0, 0, 0};
-  const int frames_per_batch = max(1, kSchurBatchTiles / max(C, 1));
-  for (int fb = f0; fb < f1; fb += frames_per_batch) {
-    const int fe = min(fb + frames_per_batch, f1);
-    const int tb = v.frame_tile_off[fb], te = v.frame_tile_off[fe];
-    __syncthreads();
-    for (int i = tid; i < (te - tb) * kYStride; i += 256) Ys[i] = v.Y[(size_t)tb * kYStride + i];
-    for (int i = tid; i < (fe - fb) * 6; i += 256) Zs[i] = v.fr[(size_t)(fb + i / 6) * kFrStride + kFrZ + (i % 6)];
-    __syncthreads();
-    int slot = 0;
-    for (int e = tid; e < nE; e += 256, ++slot) {
-      double s = 0.0;
-      if (e < D * D) {
-        const int ra = e / D, rb = e % D;
-        if (rb >= ra) {
-          const int ca = v.col_cam[ra], cb = v.col_cam[rb];
-          if (ca >= 0 && cb >= 0) {
-            const int la = v.col_local[ra], lb = v.col_local[rb];
-            for (int f = fb; f < fe; ++f) {
-              const int ta = v.frame_cam_tile[f * C + ca], tb2 = v.frame_cam_tile[f * C + cb];
-              if (ta < 0 || tb2 < 0) continue;
-              const double* ya = Ys + (ta - tb) * kYStride + la;
-              const double* yb = Ys + (tb2 - tb) * kYStride + lb;
-#pragma unroll
-              for (int k = 0; k < 6; ++k) s += ya[k * kUCols] * yb[k * kUCols];
-            }
-          }
+        for (int g = 0; g < 4; ++g) {
+          const int row = I * 16 + (lane >> 4) + 4 * g, col = J * 16 + (lane & 15);
+          if (row < D) { if (col < D) part[row * D + col] = a4[g]; else if (col == D) part[D * D + row] = a4[g]; }
         }
-      } else {
-        const int ra = e - D * D;
-        const int ca = v.col_cam[ra];
-        if (ca >= 0) {
-          const int la = v.col_local[ra];
-          for (int f = fb; f < fe; ++f) {
-            const int ta = v.frame_cam_tile[f * C + ca];
-            if (ta < 0) continue;
-            const double* ya = Ys + (ta - tb) * kYStride + la;
-            const double* z = Zs + (f - fb) * 6;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) s += ya[k * kUCols] * z[k];
-          }
-        }
+        ++pi;
       }
-      if (slot < 4) acc[slot] += s; else part[e] = (fb == f0 ? 0.0 : part[e]) + s;
+      if (++J == nT) { ++I; J = I; }
     }
   }
-  int slot = 0;
-  for (int e = tid; e < nE && slot < 4; e += 256, ++slot) part[e] = acc[slot];
+  // per-camera sum of G over the chunk: combine the 4 wavefronts through LDS (fixed order)
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < kMaxCams; ++c)
+    if (c < C) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sh[wave * (C * kGStride) + c * kGStride + q * 64 + lane] = gsum[c][q];
+    }
+  __syncthreads();
+  for (int e = tid; e < C * kGStride; e += 256)
+    part[D * D + D + e] = (sh[e] + sh[C * kGStride + e]) + (sh[2 * C * kGStride + e] + sh[3 * C * kGStride + e]);
 }
 
+// Fixed-order sum of the chunk partials, spread over many CUs (one CU can only pull ~20-50 GB/s):
+// workgroup w owns 32 entries; thread (entry = tid & 31, slice = tid >> 5) sums the partials k = slice (mod 8),
+// the 8 slices are then added in order.  total[e] = sum_k part[k][e].
+__global__ __launch_bounds__(256) void k_part_sum(DevView v) {
+  __shared__ double sl[256];
+  if (v.ctrl->done) return;
+  const int tid = threadIdx.x, e = blockIdx.x * 32 + (tid & 31), ks = tid >> 5;
+  const int stride = v.part_stride, nch = v.n_chunks;
+  double s = 0.0;
+  if (e < stride) {
+#pragma unroll 8
+    for (int k = ks; k < nch; k += 8) s += v.part[(size_t)k * stride + e];
+  }
+  sl[tid] = s;
+  __syncthreads();
+  if (tid < 32 && e < stride) {
+    double t = sl[tid];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += sl[q * 32 + tid];
+    v.part_total[e] = t;
+  }
+}
+
+// Phase A of the reduced system (one workgroup):
 // Sbuf = [ S = H_ss - sum Y^T Y (full symmetric, undamped) | g_red | diag(H_ss) | g_s | cost, 0 ]
-__global__ __launch_bounds__(256) void k_schur_final(DevView v) {
-  __shared__ double gsum[kMaxCams * kGStride];
-  __shared__ double P[16 * 16];
-  __shared__ double T1[16 * 16];
-  __shared__ double red[256];
-  const Ctrl* ct = v.ctrl;
-  if (ct->done) return;
+struct FinalLds { double gsum[kMaxCams * kGStride]; double P[256]; double T1[256]; double red[256]; };
+__device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
   const int tid = threadIdx.x, D = v.D, C = v.n_cams;
   double* S = v.Sbuf;
   double* gred = S + D * D;
   double* hd = gred + D;
   double* gs = hd + D;
   double* sc = gs + D;
-  for (int e = tid; e < D * D + D; e += 256) {
-    double s = 0.0;
-    for (int k = 0; k < v.n_chunks; ++k) s += v.part[(size_t)k * v.part_stride + e];
-    if (e < D * D) S[e] = -s; else gred[e - D * D] = -s;
-  }
-  for (int c = 0; c < C; ++c) {
-    double s = 0.0;
-    for (int k = 0; k < v.n_chunks; ++k) s += v.part[(size_t)k * v.part_stride + D * D + D + c * kGStride + tid];
-    gsum[c * kGStride + tid] = s;
+  const int stride = v.part_stride;
+  for (int e = tid; e < stride; e += 256) {
+    const double t = v.part_total[e];
+    if (e < D * D) S[e] = -t;
+    else if (e < D * D + D) gred[e - D * D] = -t;
+    else L.gsum[e - D * D - D] = t;
   }
   {
     double s = 0.0;
+#pragma unroll 4
     for (int t = tid; t < v.n_tiles; t += 256) s += v.tile_cost[t];
-    red[tid] = s;
+    L.red[tid] = s;
   }
   for (int i = tid; i < D; i += 256) { hd[i] = 0.0; gs[i] = 0.0; }
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-  if (tid == 0) { sc[0] = 0.5 * red[0]; sc[1] = 0.0; }
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) L.red[tid] += L.red[tid + o]; __syncthreads(); }
+  if (tid == 0) { sc[0] = 0.5 * L.red[0]; sc[1] = 0.0; }
   // camera blocks H_cc = P^T G P, g_c = P^T G[:, r]   (P: u-columns -> shared columns of the camera)
   for (int c = 0; c < C; ++c) {
     const int flags = v.cam_flags[c], nk = model_nk(v.cam_model[c]);
     const int nu = 6 + nk, nc = cam_ncols(flags, nk), c0 = v.cam_col0[c];
     const int nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
-    const double* G = gsum + c * kGStride;
+    const double* G = L.gsum + c * kGStride;
     __syncthreads();
     {
       const int i = tid >> 4, a = tid & 15;     // P[i][a]
       double R[9];
-      quat_to_R(v.cams[ct->cur] + (size_t)c * kCamStride, R);
+      quat_to_R(v.cams[cur] + (size_t)c * kCamStride, R);
       double pv = 0.0;
       if (i < nu && a < nc) {
         if (a < nrot) { if (i >= 3 && i < 6) pv = -R[3 * (i - 3) + a]; }
         else if (a < nrot + ntr) { if (i == a - nrot) pv = 1.0; }
         else { if (i == 6 + (a - nrot - ntr)) pv = 1.0; }
       }
-      P[tid] = pv;
+      L.P[tid] = pv;
     }
     __syncthreads();
     {
       const int i = tid >> 4, a = tid & 15;     // T1[i][a] = sum_k G[i][k] P[k][a]; row 15 := g_c
       double s = 0.0;
-      if (i < nu && a < nc) for (int k = 0; k < nu; ++k) s += G[i * 16 + k] * P[k * 16 + a];
-      if (i == 15 && a < nc) { s = 0.0; for (int k = 0; k < nu; ++k) s += P[k * 16 + a] * G[k * 16 + nu]; }
-      T1[tid] = s;
+      if (i < nu && a < nc) for (int k = 0; k < nu; ++k) s += G[i * 16 + k] * L.P[k * 16 + a];
+      if (i == 15 && a < nc) { s = 0.0; for (int k = 0; k < nu; ++k) s += L.P[k * 16 + a] * G[k * 16 + nu]; }
+      L.T1[tid] = s;
     }
     __syncthreads();
     {
       const int b = tid >> 4, a = tid & 15;     // Hcc[b][a] = sum_i P[i][b] T1[i][a]
       if (a < nc && b < nc && a >= b) {
         double s = 0.0;
-        for (int i = 0; i < nu; ++i) s += P[i * 16 + b] * T1[i * 16 + a];
+        for (int i = 0; i < nu; ++i) s += L.P[i * 16 + b] * L.T1[i * 16 + a];
         S[(c0 + b) * D + c0 + a] += s;
         if (a == b) hd[c0 + a] = s;
       }
-      if (b == 15 && a < nc) { gred[c0 + a] += T1[15 * 16 + a]; gs[c0 + a] = T1[15 * 16 + a]; }
+      if (b == 15 && a < nc) { gred[c0 + a] += L.T1[15 * 16 + a]; gs[c0 + a] = L.T1[15 * 16 + a]; }
     }
   }
   __syncthreads();
@@ -469,26 +501,70 @@ __global__ __launch_bounds__(256) void k_schur_final(DevView v) {
     const int i = e / D, j = e % D;
     if (j < i) S[e] = S[j * D + i];
   }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------ reduced solve
-// One workgroup.  Damped Cholesky of the augmented matrix [S + Lambda, g; g^T, .] in LDS (the forward
-// substitution rides along as the extra row), back substitution, then the trial state of the shared
-// parameters (cams[1-cur] <- Plus(cams[cur], delta_s)) and their scalar terms scal[8..15].
-__global__ __launch_bounds__(256) void k_reduced_solve(DevView v) {
-  extern __shared__ __attribute__((aligned(16))) double M[];
-  __shared__ double red[6 * 256];
-  const Ctrl* ct = v.ctrl;
-  if (ct->done) return;
-  const int tid = threadIdx.x, D = v.D, ld = D + 1, cur = ct->cur;
-  double* col = M + (size_t)(D + 1) * ld;   // scaled pivot column
-  double* x = col + D + 1;
+// Phase B.  Damped Cholesky of the augmented matrix [S + Lambda, g; g^T, .] (the forward substitution
+// rides along as the extra row), back substitution, then the trial state of the shared parameters
+// (cams[1-cur] <- Plus(cams[cur], delta_s)) and their scalar terms scal[8..15].
+//   D <= 32: one wavefront, rows in registers, pivots exchanged with v_readlane (no barriers);
+//   D  > 32: workgroup-wide in LDS.
+constexpr int kSmallD = 62;   // rows 0..D (incl. the augmented row) must fit one wavefront
+__device__ void solve_small_wave(const DevView& v, const Ctrl* ct, int lane, double* M, double* x) {
+  const int D = v.D, ld = (D + 1) | 1;          // odd leading dimension: conflict-free column access
   const double* S = v.Sbuf;
   const double* gred = S + D * D;
   const double* hd = gred + D;
-  const double* gs = hd + D;
+  for (int e = lane; e < D * D; e += 64) M[(e / D) * ld + (e % D)] = S[e];
+  for (int i = lane; i < D; i += 64) M[D * ld + i] = gred[i];
+  wave_lds_sync();
+  if (lane < D) {
+    double sc2, dg;
+    if (ct->init_scale) { sc2 = jacobi_scale2(hd[lane]); v.sscale2[lane] = sc2; } else sc2 = v.sscale2[lane];
+    if (!ct->reuse_diag) { dg = lm_clamped_diag(hd[lane], sc2); v.sdiag[lane] = dg; } else dg = v.sdiag[lane];
+    const double lam = dg / (ct->radius * sc2);
+    v.slam[lane] = lam;
+    M[lane * ld + lane] += lam;
+  }
+  wave_lds_sync();
+  bool bad = false;
+  const bool row = lane <= D;
+  for (int j = 0; j < D; ++j) {
+    double d = M[j * ld + j];                     // same address in every lane: one broadcast read
+    if (!(d > 0.0)) { bad = true; d = 1.0; }
+    const double piv = sqrt(d);
+    double lij = 0.0;
+    if (row && lane > j) { lij = M[lane * ld + j] / piv; M[lane * ld + j] = lij; }
+    if (lane == j) M[j * ld + j] = piv;
+    wave_lds_sync();
+    if (row && lane > j) {
+      const int kend = min(lane, D - 1);
+      for (int k = j + 1; k <= kend; ++k) M[lane * ld + k] -= lij * M[k * ld + j];
+    }
+    wave_lds_sync();
+  }
+  if (bad && lane == 0) v.flags[1] = 1;
+  // y = L^-1 g sits in row D; delta_s = -L^-T y, pivots broadcast with v_readlane
+  double s = (lane < D) ? -M[D * ld + lane] : 0.0;
+  const double dinv = (lane < D) ? 1.0 / M[lane * ld + lane] : 0.0;
+  double mine = 0.0;
+  for (int j = D - 1; j >= 0; --j) {
+    const double xj = readlane_f64(s * dinv, j);
+    if (lane == j) mine = xj;
+    if (lane < j) s -= M[j * ld + lane] * xj;
+  }
+  if (lane < D) x[lane] = mine;
+}
+
+__device__ void solve_large_block(const DevView& v, const Ctrl* ct, double* M, double* x) {
+  const int tid = threadIdx.x, D = v.D, ld = D + 1;
+  double* col = M + (size_t)(D + 1) * ld;
+  const double* S = v.Sbuf;
+  const double* gred = S + D * D;
+  const double* hd = gred + D;
   for (int e = tid; e < D * D; e += 256) M[(e / D) * ld + (e % D)] = S[e];
-  for (int i = tid; i < D; i += 256) M[D * ld + i] = gred[i];     // augmented row
+  for (int i = tid; i < D; i += 256) M[D * ld + i] = gred[i];
   __syncthreads();
   for (int i = tid; i < D; i += 256) {
     double sc2, dg;
@@ -506,8 +582,8 @@ __global__ __launch_bounds__(256) void k_reduced_solve(DevView v) {
     const double piv = sqrt(d);
     for (int i = j + 1 + tid; i <= D; i += 256) col[i] = M[i * ld + j] / piv;
     __syncthreads();
-    if (tid == 0) { M[j * ld + j] = piv; if (bad) v.flags[1] = 1; }   // nobody reads M[j][j] again before the next barrier
-    const int n = D - j;                        // rows j+1 .. D (incl. the augmented row)
+    if (tid == 0) { M[j * ld + j] = piv; if (bad) v.flags[1] = 1; }
+    const int n = D - j;
     for (int idx = tid; idx < n * n; idx += 256) {
       const int i = j + 1 + idx / n, k = j + 1 + idx % n;
       if (k <= i && k < D) M[i * ld + k] -= col[i] * col[k];
@@ -515,21 +591,29 @@ __global__ __launch_bounds__(256) void k_reduced_solve(DevView v) {
     for (int i = j + 1 + tid; i <= D; i += 256) M[i * ld + j] = col[i];
     __syncthreads();
   }
-  // y = L^-1 g sits in row D; delta_s = -L^-T y
   for (int i = tid; i < D; i += 256) x[i] = -M[D * ld + i];
   __syncthreads();
-  if (D <= 48) {
-    if (tid == 0) for (int j = D - 1; j >= 0; --j) { double s = x[j]; for (int k = j + 1; k < D; ++k) s -= M[k * ld + j] * x[k]; x[j] = s / M[j * ld + j]; }
+  for (int j = D - 1; j >= 0; --j) {
+    if (tid == 0) x[j] /= M[j * ld + j];
+    __syncthreads();
+    const double xj = x[j];
+    for (int i = tid; i < j; i += 256) x[i] -= M[j * ld + i] * xj;
+    __syncthreads();
+  }
+}
+
+__device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dyn, double* red /* 6 x 256 */) {
+  const int tid = threadIdx.x, D = v.D, cur = ct->cur;
+  double* x;
+  if (D <= kSmallD) {
+    x = dyn + (kSmallD + 1) * (kSmallD + 2);
+    if (tid < 64 && D > 0) solve_small_wave(v, ct, tid, dyn, x);
     __syncthreads();
   } else {
-    for (int j = D - 1; j >= 0; --j) {
-      if (tid == 0) x[j] /= M[j * ld + j];
-      __syncthreads();
-      const double xj = x[j];
-      for (int i = tid; i < j; i += 256) x[i] -= M[j * ld + i] * xj;
-      __syncthreads();
-    }
+    x = dyn + (size_t)(D + 1) * (D + 1) + (D + 1);
+    solve_large_block(v, ct, dyn, x);
   }
+  const double* gs = v.Sbuf + (size_t)D * D + 2 * D;
   double gd = 0, dld = 0, step2 = 0, x2 = 0, g2 = 0, gmax = 0;
   for (int i = tid; i < D; i += 256) {
     const double d = x[i], g = gs[i];
@@ -546,21 +630,23 @@ __global__ __launch_bounds__(256) void k_reduced_solve(DevView v) {
     if (flags & kCamRotFree) {
       double q[4], w[3] = {x[cc], x[cc + 1], x[cc + 2]}, qi[4] = {cin[0], cin[1], cin[2], cin[3]};
       so3_plus(qi, w, q);
-      for (int i = 0; i < 4; ++i) { cout[i] = q[i]; const double e = q[i] - cin[i]; step2 += e * e; x2 += cin[i] * cin[i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const double e = q[i] - qi[i]; step2 += e * e; x2 += qi[i] * qi[i]; cout[i] = q[i]; }
       cc += 3;
     }
     if (flags & kCamTransFree) {
-      for (int i = 0; i < 3; ++i) { const double d = x[cc + i]; cout[4 + i] = cin[4 + i] + d; step2 += d * d; x2 += cin[4 + i] * cin[4 + i]; }
+      for (int i = 0; i < 3; ++i) { const double d = x[cc + i], o = cin[4 + i]; step2 += d * d; x2 += o * o; cout[4 + i] = o + d; }
       cc += 3;
     }
     if (flags & kCamKFree) {
-      for (int i = 0; i < nk; ++i) { const double d = x[cc + i]; cout[kCamK + i] = cin[kCamK + i] + d; step2 += d * d; x2 += cin[kCamK + i] * cin[kCamK + i]; }
+      for (int i = 0; i < nk; ++i) { const double d = x[cc + i], o = cin[kCamK + i]; step2 += d * d; x2 += o * o; cout[kCamK + i] = o + d; }
     }
   }
   red[tid] = gd; red[256 + tid] = dld; red[512 + tid] = step2; red[768 + tid] = x2; red[1024 + tid] = g2; red[1280 + tid] = gmax;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (tid < o) {
+#pragma unroll
       for (int k = 0; k < 5; ++k) red[k * 256 + tid] += red[k * 256 + tid + o];
       red[1280 + tid] = fmax(red[1280 + tid], red[1280 + tid + o]);
     }
@@ -571,6 +657,18 @@ __global__ __launch_bounds__(256) void k_reduced_solve(DevView v) {
     h[kScGd] = red[0]; h[kScDld] = red[256]; h[kScStep2] = red[512]; h[kScX2] = red[768]; h[kScG2] = red[1024];
     h[kScCost] = 0.0; h[kScGmax] = red[1280]; h[kScSq] = 0.0;
   }
+}
+
+// mode 0: phase A + phase B in one launch (single process); 1: phase A only (an all-reduce of Sbuf follows);
+// 2: phase B only
+__global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  __shared__ FinalLds fl;
+  __shared__ double red[6 * 256];
+  const Ctrl* ct = v.ctrl;
+  if (ct->done) return;
+  if (mode != 2) schur_final_phase(v, ct->cur, fl);
+  if (mode != 1) reduced_solve_phase(v, ct, dyn, red);
 }
 
 // ------------------------------------------------------------------------------------------ trial point
@@ -657,8 +755,7 @@ __device__ void trace_push(const DevView& v, Ctrl* c, const double* rec) {
   c->trace_len += 1;
   c->last_gnorm = rec[4];
 }
-__device__ void lm_decide(const DevView& v) {
-  Ctrl* c = v.ctrl;
+__device__ void lm_decide_local(const DevView& v, Ctrl* c) {
   const int D = v.D;
   const double* s = v.scal;
   const double* t = v.scal + kNumScal;
@@ -726,6 +823,11 @@ __device__ void lm_decide(const DevView& v) {
   }
 }
 
+__device__ void lm_decide(const DevView& v) {
+  Ctrl local = *v.ctrl;          // one burst of loads, one burst of stores
+  lm_decide_local(v, &local);
+  *v.ctrl = local;
+}
 // mode 0: reduce + decide, 1: reduce only (an all-reduce follows), 2: decide only
 __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
   __shared__ double red[256 * 7];
@@ -789,17 +891,24 @@ void launch_reproj_jac(const DevView& v, hipStream_t s) {
   const size_t lds = 4 * 64 * kDotStride * sizeof(double);
   hipLaunchKernelGGL(k_reproj_jac, dim3(tiles_grid(v)), dim3(256), lds, s, v);
 }
-void launch_frame_prep(const DevView& v, hipStream_t s) {
-  if (v.n_frames == 0) return;
-  hipLaunchKernelGGL(k_frame_prep, dim3((v.n_frames + 3) / 4), dim3(256), 0, s, v);
+void launch_frame_schur(const DevView& v, hipStream_t s) {
+  const int D = v.D;
+  const int Dp = ((D + 1 + 15) / 16) * 16, ld = (Dp % 32 == 0) ? Dp + 16 : Dp;
+  const size_t lds = ((size_t)4 * (v.n_cams * kGStride + kPrepPad) + (size_t)24 * ld) * sizeof(double);
+  static size_t granted = 0;
+  if (lds > 65536 && lds > granted) { (void)hipFuncSetAttribute((const void*)k_frame_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
+  hipLaunchKernelGGL(k_frame_schur, dim3(v.n_chunks), dim3(256), lds, s, v);
+  hipLaunchKernelGGL(k_part_sum, dim3((v.part_stride + 31) / 32), dim3(256), 0, s, v);
 }
-void launch_schur_reduce(const DevView& v, hipStream_t s) {
-  hipLaunchKernelGGL(k_schur_reduce, dim3(v.n_chunks), dim3(256), 0, s, v);
-  hipLaunchKernelGGL(k_schur_final, dim3(1), dim3(256), 0, s, v);
+static inline size_t reduced_lds(const DevView& v) {
+  return v.D <= kSmallD ? ((size_t)(kSmallD + 1) * (kSmallD + 2) + kSmallD + 1) * sizeof(double)
+                        : ((size_t)(v.D + 1) * (v.D + 1) + 2 * (v.D + 1)) * sizeof(double);
 }
-void launch_reduced_solve(const DevView& v, hipStream_t s) {
-  const size_t lds = ((size_t)(v.D + 1) * (v.D + 1) + 2 * (v.D + 1)) * sizeof(double);
-  hipLaunchKernelGGL(k_reduced_solve, dim3(1), dim3(256), lds, s, v);
+void launch_reduced(const DevView& v, int mode, hipStream_t s) {
+  const size_t lds = reduced_lds(v);
+  static size_t granted = 0;
+  if (lds > 30000 && lds > granted) { (void)hipFuncSetAttribute((const void*)k_reduced, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
+  hipLaunchKernelGGL(k_reduced, dim3(1), dim3(256), lds, s, v, mode);
 }
 void launch_trial(const DevView& v, hipStream_t s) {
   if (v.n_tiles == 0) return;

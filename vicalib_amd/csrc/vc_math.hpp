@@ -122,10 +122,17 @@ VC_HD void loss_cauchy100(double s, double* rho, double* rho1) {
   *rho1 = 1.0 / sum;
 }
 
+// per-camera constants that do not depend on the corner (fov: m = 2 tan(w/2), dm = dm/dw)
+struct ModelPre { double m, dm; };
+VC_HD void model_precompute(int model, const double* K, ModelPre* p) {
+  p->m = 0.0; p->dm = 0.0;
+  if (model == kFov) { p->m = 2.0 * tan(0.5 * K[4]); p->dm = 1.0 + 0.25 * p->m * p->m; }
+}
+
 // ---- camera projections with closed-form Jacobians (Calibu formulas) ----
 // A: 2x3 d pix / d p_c ; B: 2 x nk d pix / d K  (row-major). JAC=false skips A and B.
 template <bool JAC>
-VC_HD void project_radial(int model, const double* pc, const double* K, double* pix, double* A, double* B) {
+VC_HD void project_radial(int model, const double* pc, const double* K, const ModelPre& pre, double* pix, double* A, double* B) {
   const double iz = 1.0 / pc[2];
   const double x = pc[0] * iz, y = pc[1] * iz;
   const double r2 = x * x + y * y;
@@ -134,8 +141,7 @@ VC_HD void project_radial(int model, const double* pc, const double* K, double* 
   if (model == kFov) {
     const double w = K[4];
     if (w * w > 1e-5) {
-      const double m = 2.0 * tan(0.5 * w);
-      const double dm = 1.0 + 0.25 * m * m;
+      const double m = pre.m, dm = pre.dm;
       if (r2 < 1e-5) {
         fac = m / w;
         if (JAC) dk0 = dm / w - m / (w * w);
@@ -205,9 +211,9 @@ VC_HD void project_kb4(const double* pc, const double* K, double* pix, double* A
   }
 }
 template <bool JAC>
-VC_HD void project_any(int model, const double* pc, const double* K, double* pix, double* A, double* B) {
+VC_HD void project_any(int model, const double* pc, const double* K, const ModelPre& pre, double* pix, double* A, double* B) {
   if (model == kKb4) project_kb4<JAC>(pc, K, pix, A, B);
-  else project_radial<JAC>(model, pc, K, pix, A, B);
+  else project_radial<JAC>(model, pc, K, pre, pix, A, B);
 }
 
 // Per-tile constants: p_c = Rcw p_w + tcw, with R_ck kept for the post-reduction transform.
@@ -233,12 +239,12 @@ VC_HD void tile_point(const TileXf& x, const double* pw, double* pc) {
 // Robustified unique-column rows of one corner: row[i] = sqrt(w) [A_i | A_i x q | B_i | r_i | 0..],
 // w = mult * rho'(|r|^2); returns mult * rho(|r|^2) (twice the block's cost).
 template <int MODEL>
-VC_HD double corner_rows(const TileXf& x, const double* K, const double* pw, double u, double v, double mult,
+VC_HD double corner_rows(const TileXf& x, const double* K, const ModelPre& pre, const double* pw, double u, double v, double mult,
                          double* row0 /*16*/, double* row1 /*16*/) {
   constexpr int model = MODEL;
   double pc[3], pix[2], A[6], B[16];
   tile_point(x, pw, pc);
-  project_any<true>(model, pc, K, pix, A, B);
+  project_any<true>(model, pc, K, pre, pix, A, B);
   const double r0 = pix[0] - u, r1 = pix[1] - v;
   double rho, rho1;
   loss_soft_l1(r0 * r0 + r1 * r1, &rho, &rho1);
@@ -260,11 +266,11 @@ VC_HD double corner_rows(const TileXf& x, const double* K, const double* pw, dou
 }
 // Residual only: r[2]; returns rho(|r|^2).
 template <int MODEL>
-VC_HD double corner_residual(const TileXf& x, const double* K, const double* pw, double u, double v, double* r) {
+VC_HD double corner_residual(const TileXf& x, const double* K, const ModelPre& pre, const double* pw, double u, double v, double* r) {
   constexpr int model = MODEL;
   double pc[3], pix[2];
   tile_point(x, pw, pc);
-  project_any<false>(model, pc, K, pix, nullptr, nullptr);
+  project_any<false>(model, pc, K, pre, pix, nullptr, nullptr);
   r[0] = pix[0] - u; r[1] = pix[1] - v;
   double rho, rho1;
   loss_soft_l1(r[0] * r[0] + r[1] * r[1], &rho, &rho1);

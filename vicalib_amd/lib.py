@@ -28,7 +28,7 @@ SYMBOLS = [
     "vc_solve", "vc_start", "vc_is_running", "vc_stop", "vc_num_frames", "vc_num_cameras", "vc_get_camera", "vc_get_frame",
     "vc_get_biases", "vc_get_scale_factor", "vc_get_gravity", "vc_time_offset", "vc_mean_squared_error", "vc_get_camera_proj_rmse",
     "vc_get_num_iterations", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
-    "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_num_observations", "vc_num_tiles",
+    "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_num_observations", "vc_num_tiles",
 ]
 
 
@@ -207,6 +207,11 @@ class ViCalibrator:
         a = C.c_double(0); b = C.c_double(0)
         _check(self.L.vc_time_kernels(self.h, int(reps), C.byref(a), C.byref(b)), "time_kernels")
         return a.value, b.value
+
+    def time_stages(self, reps=50):
+        out = np.zeros(6)
+        _check(self.L.vc_time_stages(self.h, int(reps), _d(out)), "time_stages")
+        return dict(zip(["jac", "frame_schur", "-", "reduced", "trial", "final"], (out * 1e3).tolist()))
 
     def num_observations(self): return int(self.L.vc_num_observations(self.h))
     def num_tiles(self): return int(self.L.vc_num_tiles(self.h))
