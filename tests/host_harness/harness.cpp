@@ -4,6 +4,8 @@
 // of k_frame_prep / k_schur_final compute, serially.  Not part of the product library.
 #include <cstring>
 #include "../../vicalib_amd/csrc/vc_math.hpp"
+#include "../../vicalib_amd/csrc/vc_imu.hpp"
+#include "../../vicalib_amd/csrc/vc_imu_weights.hpp"
 using namespace vc;
 
 template <int MODEL>
@@ -59,5 +61,32 @@ void hh_cam_block(const double* G, const double* q_ck, int nk, int flags, double
 }
 void hh_se3_plus(const double* T, const double* d, double* o) { se3_plus(T, d, o); }
 void hh_so3_plus(const double* q, const double* w, double* o) { so3_plus(q, w, o); }
+// IMU block as the wavefront of k_imu_jac computes it: one derivative direction per "lane", then the
+// local-parameterisation Jacobians.  J out: 9 x 33 row-major in the oracle's column order
+// (T_j local 6, T_{j-1} local 6, v_j 3, v_{j-1} 3, g 2, b 6, sf 6, toff 1).
+void hh_imu_block(int n, const double* t, const double* w, const double* a, double t_start, double t_end, const double* w_sqrt,
+                  int rotation_only, const double* T2, const double* T1, const double* v2, const double* v1, const double* gdir,
+                  const double* b, const double* sf, double toff, double* r, double* J) {
+  ImuView buf = {t, w, a, n};
+  double Jg[35][9];
+  for (int d = 0; d < 35; ++d) imu_block_direction(buf, t_start, t_end, w_sqrt, rotation_only, T2, T1, v2, v1, gdir, b, sf, toff, d, r, Jg[d]);
+  double P2[42], P1[42];
+  local_jac_se3(T2, P2); local_jac_se3(T1, P1);
+  for (int row = 0; row < 9; ++row) {
+    double* o = J + row * 33;
+    for (int c = 0; c < 6; ++c) {
+      double s2 = 0, s1 = 0;
+      for (int i = 0; i < 7; ++i) { s2 += Jg[i][row] * P2[i * 6 + c]; s1 += Jg[7 + i][row] * P1[i * 6 + c]; }
+      o[c] = s2; o[6 + c] = s1;
+    }
+    for (int c = 0; c < 21; ++c) o[12 + c] = Jg[14 + c][row];
+  }
+}
+void hh_imu_weight(int n, const double* t, const double* w, const double* a, double t_start, double t_end, double toff,
+                   const double* T1, const double* v1, const double* T2, const double* b, const double* sf, const double* gdir,
+                   double gs, double as, double* w_sqrt) {
+  ImuView buf = {t, w, a, n};
+  imu_weight_sqrt(buf, t_start, t_end, toff, T1, v1, T2, b, sf, gdir, gs, as, w_sqrt);
+}
 int hh_chol6(double* M) { return chol_small<6>(M) ? 1 : 0; }
 }

@@ -110,3 +110,55 @@ def test_manifold_updates_match_oracle_plus():
         a = np.zeros(4); b = np.zeros(4)
         H.hh_so3_plus(d(T[:4].copy()), d(dl[3:].copy()), d(a)); L.vco_plus_so3(d(T[:4].copy()), d(dl[3:].copy()), d(b))
         np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-15)
+
+
+def test_imu_block_lane_duals_match_oracle():
+    """The device-side IMU residual (one derivative direction per lane, vc_imu.hpp) against the oracle's
+    Dual<35> block, in rotation-only mode with the 500*I weights and with dense covariance weights."""
+    p = synth.generate(synth.Config(models=("kb4",), n_frames=12, imu=True, seed=2))
+    o = ol.Oracle().load(p, init=False)
+    o.set_options(calibrate_imu=True)
+    gt = p.imu_gt
+    H = hh()
+    for rot_only in (1, 0):
+        o.set_flags(True, True, bool(rot_only), True)
+        o.set_imu_state(np.concatenate([gt["bg"], gt["ba"]]) * 0.7, np.concatenate([gt["sg"], gt["sa"]]), gt["g_dir"] * 0.9, 0.002)
+        # velocities: perturbed ground truth
+        for f in range(o.n_frames):
+            o.set_frame(f, p.frame_T_wk_gt[f], p.frame_v_gt[f] * 1.01)
+        o.prepare(vis_mult=1, imu_mult=1)
+        if not rot_only:
+            o.update_imu_weights()
+        W = o.imu_weights()
+        b, sfac, g, toff = o.imu_state()
+        for j in (1, 5, o.n_frames - 1):
+            r0, J0 = o.imu_block(j)
+            T2, v2 = o.frame(j); T1, v1 = o.frame(j - 1)
+            r = np.zeros(9); J = np.zeros((9, 33))
+            H.hh_imu_block(len(p.imu_t), d(p.imu_t), d(p.imu_gyro), d(p.imu_accel), C.c_double(p.frame_time[j - 1]), C.c_double(p.frame_time[j]),
+                           d(W[j - 1]), rot_only, d(T2), d(T1), d(v2), d(v1), d(g), d(b), d(sfac), C.c_double(toff), d(r), d(J))
+            np.testing.assert_allclose(r, r0, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(r0).max()))
+            np.testing.assert_allclose(J, J0, rtol=1e-8, atol=1e-8 * np.abs(J0).max())
+
+
+def test_imu_covariance_weights_match_oracle():
+    """UpdateImuWeights restated for the device (vc_imu_weights.hpp) against the oracle's version."""
+    p = synth.generate(synth.Config(models=("kb4",), n_frames=10, imu=True, seed=8))
+    o = ol.Oracle().load(p, init=False)
+    o.set_options(calibrate_imu=True)
+    gt = p.imu_gt
+    o.set_flags(True, True, False, True)
+    o.set_imu_state(np.concatenate([gt["bg"], gt["ba"]]), np.concatenate([gt["sg"], gt["sa"]]), gt["g_dir"], 0.0025)
+    for f in range(o.n_frames):
+        o.set_frame(f, p.frame_T_wk_gt[f], p.frame_v_gt[f])
+    o.prepare(vis_mult=1, imu_mult=1)
+    o.update_imu_weights()
+    W = o.imu_weights()
+    b, sfac, g, toff = o.imu_state()
+    H = hh()
+    for j in range(1, o.n_frames):
+        T2, _ = o.frame(j); T1, v1 = o.frame(j - 1)
+        w = np.zeros((9, 9))
+        H.hh_imu_weight(len(p.imu_t), d(p.imu_t), d(p.imu_gyro), d(p.imu_accel), C.c_double(p.frame_time[j - 1]), C.c_double(p.frame_time[j]),
+                        C.c_double(toff), d(T1), d(v1), d(T2), d(b), d(sfac), d(g), C.c_double(5.3088444e-5), C.c_double(0.001883649), d(w))
+        np.testing.assert_allclose(w, W[j - 1], rtol=1e-7, atol=1e-9 * np.abs(W[j - 1]).max())

@@ -1,0 +1,288 @@
+// vc_imu.hpp -- inertial residual of the calibration hot path, for the HIP kernels.
+//
+// Device-side counterpart of SwitchedFullImuCostFunction::operator() (ceres-cost-functions.h:402-484):
+// sample range under the camera<->IMU time offset (InterpolationBufferT::GetRange,
+// interpolation-buffer.h:208-226), classical RK4 on (p, q, v) with linearly interpolated gyro/accel
+// (IntegrateImuJet :139-177, GetPoseDerivativeJet :80-105, IntegratePoseJet :39-56: left-multiplied,
+// NOT renormalised quaternion), residual [log(T_pred T_j^-1); v_pred - v_j] times weight_sqrt (:468-477)
+// and the rotation-only switch (:479-482).
+//
+// The reference differentiates this with ceres::Jet<double,35>.  Here every lane of a wavefront carries
+// ONE derivative direction: the code is templated on the scalar and instantiated with D1 = (value, one
+// partial); lane d seeds global parameter d of the 35 (vicalibrator.h:620-632 block order).  The value
+// part is identical in all lanes, so branches stay wave-uniform.
+#pragma once
+#include "vc_math.hpp"
+
+namespace vc {
+
+struct D1 { double a, v; };
+VC_HD D1 mk(double a, double v = 0.0) { D1 r; r.a = a; r.v = v; return r; }
+VC_HD D1 operator+(D1 x, D1 y) { return mk(x.a + y.a, x.v + y.v); }
+VC_HD D1 operator-(D1 x, D1 y) { return mk(x.a - y.a, x.v - y.v); }
+VC_HD D1 operator-(D1 x) { return mk(-x.a, -x.v); }
+VC_HD D1 operator*(D1 x, D1 y) { return mk(x.a * y.a, x.a * y.v + x.v * y.a); }
+VC_HD D1 operator/(D1 x, D1 y) { const double inv = 1.0 / y.a, q = x.a * inv; return mk(q, (x.v - q * y.v) * inv); }
+VC_HD D1 operator+(D1 x, double s) { return mk(x.a + s, x.v); }
+VC_HD D1 operator+(double s, D1 x) { return mk(x.a + s, x.v); }
+VC_HD D1 operator-(D1 x, double s) { return mk(x.a - s, x.v); }
+VC_HD D1 operator-(double s, D1 x) { return mk(s - x.a, -x.v); }
+VC_HD D1 operator*(D1 x, double s) { return mk(x.a * s, x.v * s); }
+VC_HD D1 operator*(double s, D1 x) { return mk(x.a * s, x.v * s); }
+VC_HD D1 operator/(D1 x, double s) { const double inv = 1.0 / s; return mk(x.a * inv, x.v * inv); }
+VC_HD D1 operator/(double s, D1 y) { const double inv = 1.0 / y.a; return mk(s * inv, -s * inv * inv * y.v); }
+VC_HD bool operator<(D1 x, double y) { return x.a < y; }
+VC_HD bool operator>(D1 x, double y) { return x.a > y; }
+VC_HD D1 sqrt(D1 x) { const double s = ::sqrt(x.a); return mk(s, x.v / (2.0 * s)); }
+VC_HD D1 sin(D1 x) { return mk(::sin(x.a), ::cos(x.a) * x.v); }
+VC_HD D1 cos(D1 x) { return mk(::cos(x.a), -::sin(x.a) * x.v); }
+VC_HD D1 tan(D1 x) { const double t = ::tan(x.a); return mk(t, (1.0 + t * t) * x.v); }
+VC_HD D1 atan(D1 x) { return mk(::atan(x.a), x.v / (1.0 + x.a * x.a)); }
+VC_HD D1 fabs(D1 x) { return x.a < 0.0 ? -x : x; }
+VC_HD double val(double x) { return x; }
+VC_HD double val(D1 x) { return x.a; }
+template <class T> VC_HD T cst(double x);
+template <> VC_HD double cst<double>(double x) { return x; }
+template <> VC_HD D1 cst<D1>(double x) { return mk(x); }
+using ::sqrt; using ::sin; using ::cos; using ::tan; using ::atan; using ::fabs;
+
+// ---- scalar-generic quaternion / SE3 pieces (Sophus pre-1.0 + Eigen semantics) ----------
+template <class T> VC_HD void tq_mul(const T* a, const T* b, T* o) {
+  const T x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  const T y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  const T z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  const T w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+template <class T> VC_HD void tq_rotate(const T* q, const T* v, T* o) {   // Eigen _transformVector
+  const T ux = 2.0 * (q[1] * v[2] - q[2] * v[1]);
+  const T uy = 2.0 * (q[2] * v[0] - q[0] * v[2]);
+  const T uz = 2.0 * (q[0] * v[1] - q[1] * v[0]);
+  const T rx = v[0] + q[3] * ux + (q[1] * uz - q[2] * uy);
+  const T ry = v[1] + q[3] * uy + (q[2] * ux - q[0] * uz);
+  const T rz = v[2] + q[3] * uz + (q[0] * uy - q[1] * ux);
+  o[0] = rx; o[1] = ry; o[2] = rz;
+}
+template <class T> VC_HD void tq_matvec(const T* q, const T* v, T* o) {   // toRotationMatrix() * v  (SO3::Adj())
+  const T tx = 2.0 * q[0], ty = 2.0 * q[1], tz = 2.0 * q[2];
+  const T twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+  const T txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+  const T tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+  const T a = (1.0 - (tyy + tzz)) * v[0] + (txy - twz) * v[1] + (txz + twy) * v[2];
+  const T b = (txy + twz) * v[0] + (1.0 - (txx + tzz)) * v[1] + (tyz - twx) * v[2];
+  const T c = (txz - twy) * v[0] + (tyz + twx) * v[1] + (1.0 - (txx + tyy)) * v[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+template <class T> VC_HD void tso3_exp(const T* w, T* q) {
+  const T th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const T th = sqrt(th2);
+  T imag, real;
+  if (th < kSophusEps) {
+    const T th4 = th2 * th2;
+    imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
+    real = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
+  } else {
+    const T half = 0.5 * th;
+    imag = sin(half) / th;
+    real = cos(half);
+  }
+  q[0] = imag * w[0]; q[1] = imag * w[1]; q[2] = imag * w[2]; q[3] = real;
+}
+// log of the SE3 element [q, t] -> [upsilon, omega]  (Sophus SE3::log / SO3::logAndTheta)
+template <class T> VC_HD void tse3_log(const T* X, T* d) {
+  const T n2 = X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+  const T n = sqrt(n2);
+  const T qw = X[3];
+  T c;
+  if (n < kSophusEps) c = 2.0 / qw - 2.0 * n2 / (qw * qw * qw);
+  else if (fabs(qw) < kSophusEps) c = (qw > 0.0) ? 3.14159265358979323846 / n : -3.14159265358979323846 / n;
+  else c = 2.0 * atan(n / qw) / n;
+  const T th = c * n;
+  const T w0 = c * X[0], w1 = c * X[1], w2 = c * X[2];
+  d[3] = w0; d[4] = w1; d[5] = w2;
+  T k;
+  if (fabs(th) < kSophusEps) k = cst<T>(1.0 / 12.0);
+  else k = (1.0 - th / (2.0 * tan(th / 2.0))) / (th * th);
+  // V^-1 t = t - 1/2 w x t + k w x (w x t)
+  const T* t = X + 4;
+  const T c0 = w1 * t[2] - w2 * t[1], c1 = w2 * t[0] - w0 * t[2], c2 = w0 * t[1] - w1 * t[0];
+  const T e0 = w1 * c2 - w2 * c1, e1 = w2 * c0 - w0 * c2, e2 = w0 * c1 - w1 * c0;
+  d[0] = t[0] - 0.5 * c0 + k * e0;
+  d[1] = t[1] - 0.5 * c1 + k * e1;
+  d[2] = t[2] - 0.5 * c2 + k * e2;
+}
+
+// ---- sample range (interpolation-buffer.h:100-226) ----------------------------------------------------
+struct ImuView { const double* t; const double* w; const double* a; int n; };   // w, a: n x 3
+template <class T> struct Meas { T w[3], a[3], time; };
+
+// bracketing interval [i, i+1] of image-clock time `time` under offset `off` (samples shifted by +off)
+VC_HD int imu_bracket(const ImuView& b, double time, double off) {
+  int lo = 0, hi = b.n - 1;           // invariant: t[lo] + off <= time (or lo == 0)
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.t[mid] + off <= time) lo = mid; else hi = mid; }
+  return lo;
+}
+template <class T> VC_HD void imu_interp(const ImuView& b, int i, T off, double time, Meas<T>* m) {
+  const T ta = b.t[i] + off, tb = b.t[i + 1] + off;
+  const T f = (cst<T>(time) - ta) / (tb - ta);
+  const T omf = 1.0 - f;
+  for (int k = 0; k < 3; ++k) {
+    m->w[k] = b.w[3 * i + k] * omf + b.w[3 * (i + 1) + k] * f;
+    m->a[k] = b.a[3 * i + k] * omf + b.a[3 * (i + 1) + k] * f;
+  }
+  m->time = cst<T>(time);
+}
+template <class T> VC_HD void imu_shift(const ImuView& b, int i, T off, Meas<T>* m) {
+  for (int k = 0; k < 3; ++k) { m->w[k] = cst<T>(b.w[3 * i + k]); m->a[k] = cst<T>(b.a[3 * i + k]); }
+  m->time = b.t[i] + off;
+}
+// Range description: first = element(t0), interior samples k0 .. k1 (inclusive, may be empty), last = element(t1).
+struct ImuRange { int valid; int i0, first_end; int k0, k1; int i1, last_end; };   // *_end: 1 = clamp to an end sample
+VC_HD void imu_element_index(const ImuView& b, double time, double off, int* idx, int* end_clamp) {
+  // GetElement :160-204: clamp to the first / last sample outside the buffer, bracketing interval inside
+  if (b.t[0] + off > time) { *idx = 0; *end_clamp = 1; return; }
+  if (b.t[b.n - 1] + off <= time) { *idx = b.n - 1; *end_clamp = 1; return; }
+  *idx = imu_bracket(b, time, off); *end_clamp = 0;
+}
+VC_HD ImuRange imu_range(const ImuView& b, double t0, double t1, double off) {
+  ImuRange r; r.valid = 0; r.k0 = 0; r.k1 = -1; r.i0 = r.i1 = 0; r.first_end = r.last_end = 0;
+  if (b.n < 2) return r;
+  if (!(t0 >= b.t[0] + off && t0 <= b.t[b.n - 1] + off)) return r;   // HasElement :122-125
+  r.valid = 1;
+  imu_element_index(b, t0, off, &r.i0, &r.first_end);
+  // GetNext :100-117: interior samples are stored samples idx+1.. with time + off <= t1
+  int k = r.i0 + 1;
+  r.k0 = k;
+  while (k < b.n && !(b.t[k] + off > t1)) ++k;
+  r.k1 = k - 1;
+  imu_element_index(b, t1, off, &r.i1, &r.last_end);
+  return r;
+}
+template <class T> VC_HD void imu_range_get(const ImuView& b, const ImuRange& r, T off, double t0, double t1, int which, Meas<T>* m) {
+  // which: 0 = first, 1 .. n_int = interior, n_int + 1 = last
+  const int n_int = r.k1 - r.k0 + 1;
+  if (which == 0) { if (r.first_end) imu_shift(b, r.i0, off, m); else imu_interp(b, r.i0, off, t0, m); }
+  else if (which <= n_int) imu_shift(b, r.k0 + which - 1, off, m);
+  else { if (r.last_end) imu_shift(b, r.i1, off, m); else imu_interp(b, r.i1, off, t1, m); }
+}
+
+// ---- RK4 (ceres-cost-functions.h:39-177) --------------------------------------------------------------
+template <class T> struct PoseV { T q[4], p[3], v[3]; };
+template <class T> VC_HD void imu_integrate_pose(const PoseV<T>& s, const T* k, T dt, PoseV<T>* y) {
+  const T wdt[3] = {k[3] * dt, k[4] * dt, k[5] * dt};
+  T rq[4];
+  tso3_exp(wdt, rq);
+  for (int i = 0; i < 3; ++i) { y->p[i] = s.p[i] + k[i] * dt; y->v[i] = s.v[i] + k[6 + i] * dt; }
+  tq_mul(rq, s.q, y->q);
+}
+template <class T> VC_HD void imu_pose_derivative(const PoseV<T>& s, const T* g_w, const Meas<T>& z0, const Meas<T>& z1,
+                                                 const T* b, const T* sf, T dt, T* k) {
+  const T alpha = (z1.time - (z0.time + dt)) / (z1.time - z0.time);
+  const T oma = 1.0 - alpha;
+  T u[3], o[3];
+  for (int i = 0; i < 3; ++i) k[i] = s.v[i];
+  for (int i = 0; i < 3; ++i) u[i] = (z0.w[i] * alpha + z1.w[i] * oma) * sf[i] + b[i];
+  tq_matvec(s.q, u, o);
+  for (int i = 0; i < 3; ++i) k[3 + i] = o[i];
+  for (int i = 0; i < 3; ++i) u[i] = (z0.a[i] * alpha + z1.a[i] * oma) * sf[3 + i] + b[3 + i];
+  tq_rotate(s.q, u, o);
+  for (int i = 0; i < 3; ++i) k[6 + i] = o[i] - g_w[i];
+}
+template <class T> VC_HD void imu_rk4_step(PoseV<T>* s, const Meas<T>& z0, const Meas<T>& z1, const T* b, const T* sf, const T* g_w) {
+  if (val(z1.time) == val(z0.time)) return;       // :150-152
+  const T dt = z1.time - z0.time;
+  T k1[9], k2[9], k3[9], k4[9], k[9];
+  PoseV<T> y;
+  imu_pose_derivative(*s, g_w, z0, z1, b, sf, cst<T>(0.0), k1);
+  imu_integrate_pose(*s, k1, dt * 0.5, &y);
+  imu_pose_derivative(y, g_w, z0, z1, b, sf, dt / 2.0, k2);
+  imu_integrate_pose(*s, k2, dt * 0.5, &y);
+  imu_pose_derivative(y, g_w, z0, z1, b, sf, dt / 2.0, k3);
+  imu_integrate_pose(*s, k3, dt, &y);
+  imu_pose_derivative(y, g_w, z0, z1, b, sf, dt, k4);
+  for (int i = 0; i < 9; ++i) k[i] = k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i];
+  imu_integrate_pose(*s, k, dt / 6.0, &y);
+  *s = y;
+}
+// types.h:94-104
+template <class T> VC_HD void imu_gravity(const T* dir, T* out) {
+  const double g = 9.8007;
+  const T sp = sin(dir[0]), cp = cos(dir[0]), sq = sin(dir[1]), cq = cos(dir[1]);
+  out[0] = (cp * sq) * (-g);
+  out[1] = (-1.0 * sp) * (-g);
+  out[2] = (cp * cq) * (-g);
+}
+
+// The residual. Parameters: T2 = frame j [q t], T1 = frame j-1, v2, v1, gdir(2), b(6), sf(6), toff.
+// w_sqrt 9x9 row-major; r <- (r^T W)^T; rotation-only zeroes rows 0-2, 6-8. Empty range -> r = 0.
+template <class T>
+VC_HD void imu_residual(const ImuView& buf, double t_start, double t_end, const double* w_sqrt, int rotation_only,
+                        const T* T2, const T* T1, const T* v2, const T* v1, const T* gdir, const T* b, const T* sf, T toff, T* r) {
+  const ImuRange rg = imu_range(buf, t_start, t_end, val(toff));
+  if (!rg.valid) { for (int i = 0; i < 9; ++i) r[i] = cst<T>(0.0); return; }
+  T gw[3];
+  imu_gravity(gdir, gw);
+  PoseV<T> s;
+  for (int i = 0; i < 4; ++i) s.q[i] = T1[i];
+  for (int i = 0; i < 3; ++i) { s.p[i] = T1[4 + i]; s.v[i] = v1[i]; }
+  const int n_meas = (rg.k1 - rg.k0 + 1) + 2;
+  Meas<T> z0, z1;
+  imu_range_get(buf, rg, toff, t_start, t_end, 0, &z0);
+  for (int m = 1; m < n_meas; ++m) {
+    imu_range_get(buf, rg, toff, t_start, t_end, m, &z1);
+    imu_rk4_step(&s, z0, z1, b, sf, gw);
+    z0 = z1;
+  }
+  // rel = T_pred * T2^-1 (SE3 product: SO3 part renormalised), then log
+  T qc[4] = {-T2[0], -T2[1], -T2[2], T2[3]};
+  T nt[3] = {T2[4] * -1.0, T2[5] * -1.0, T2[6] * -1.0}, ti[3];
+  tq_rotate(qc, nt, ti);
+  T rel[7], tr[3];
+  tq_mul(s.q, qc, rel);
+  const T nrm = sqrt(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2] + rel[3] * rel[3]);
+  for (int i = 0; i < 4; ++i) rel[i] = rel[i] / nrm;
+  tq_rotate(s.q, ti, tr);
+  for (int i = 0; i < 3; ++i) rel[4 + i] = s.p[i] + tr[i];
+  T raw[9];
+  tse3_log(rel, raw);
+  for (int i = 0; i < 3; ++i) raw[6 + i] = s.v[i] - v2[i];
+  for (int j = 0; j < 9; ++j) {
+    T acc = cst<T>(0.0);
+    for (int i = 0; i < 9; ++i) acc = acc + raw[i] * w_sqrt[i * 9 + j];
+    r[j] = acc;
+  }
+  if (rotation_only) for (int i = 0; i < 3; ++i) { r[i] = cst<T>(0.0); r[6 + i] = cst<T>(0.0); }
+}
+
+// LocalParamSe3::ComputeJacobian (local-param-se3.h:28-91): 7x6 row-major d(T exp(delta))/d(delta) at 0,
+// global [q(4), t(3)], local [upsilon, omega].
+VC_HD void local_jac_se3(const double* x, double* J) {
+  for (int i = 0; i < 42; ++i) J[i] = 0.0;
+  const double q1 = x[0], q2 = x[1], q3 = x[2], q0 = x[3];
+  J[0 * 6 + 3] = 0.5 * q0; J[0 * 6 + 4] = -0.5 * q3; J[0 * 6 + 5] = 0.5 * q2;
+  J[1 * 6 + 3] = 0.5 * q3; J[1 * 6 + 4] = 0.5 * q0; J[1 * 6 + 5] = -0.5 * q1;
+  J[2 * 6 + 3] = -0.5 * q2; J[2 * 6 + 4] = 0.5 * q1; J[2 * 6 + 5] = 0.5 * q0;
+  J[3 * 6 + 3] = -0.5 * q1; J[3 * 6 + 4] = -0.5 * q2; J[3 * 6 + 5] = -0.5 * q3;
+  J[4 * 6 + 0] = 1.0 - 2.0 * (q2 * q2 + q3 * q3); J[4 * 6 + 1] = 2.0 * (q1 * q2 - q0 * q3); J[4 * 6 + 2] = 2.0 * (q1 * q3 + q0 * q2);
+  J[5 * 6 + 0] = 2.0 * (q1 * q2 + q0 * q3); J[5 * 6 + 1] = 1.0 - 2.0 * (q1 * q1 + q3 * q3); J[5 * 6 + 2] = 2.0 * (q2 * q3 - q0 * q1);
+  J[6 * 6 + 0] = 2.0 * (q1 * q3 - q0 * q2); J[6 * 6 + 1] = 2.0 * (q2 * q3 + q0 * q1); J[6 * 6 + 2] = 1.0 - 2.0 * (q1 * q1 + q2 * q2);
+}
+
+// One lane's share of the IMU block: residual values r[9] and the partials of all 9 rows with respect to
+// global parameter `dir` (0..34 in the block order of vicalibrator.h:628-632; dir < 0: values only).
+VC_HD void imu_block_direction(const ImuView& buf, double t_start, double t_end, const double* w_sqrt, int rotation_only,
+                               const double* T2, const double* T1, const double* v2, const double* v1, const double* gdir,
+                               const double* b, const double* sf, double toff, int dir, double* r, double* dr) {
+  D1 P[35];
+  for (int i = 0; i < 7; ++i) { P[i] = mk(T2[i]); P[7 + i] = mk(T1[i]); }
+  for (int i = 0; i < 3; ++i) { P[14 + i] = mk(v2[i]); P[17 + i] = mk(v1[i]); }
+  P[20] = mk(gdir[0]); P[21] = mk(gdir[1]);
+  for (int i = 0; i < 6; ++i) { P[22 + i] = mk(b[i]); P[28 + i] = mk(sf[i]); }
+  P[34] = mk(toff);
+  for (int i = 0; i < 35; ++i) P[i].v = (i == dir) ? 1.0 : 0.0;
+  D1 res[9];
+  imu_residual<D1>(buf, t_start, t_end, w_sqrt, rotation_only, P, P + 7, P + 14, P + 17, P + 20, P + 22, P + 28, P[34], res);
+  for (int i = 0; i < 9; ++i) { r[i] = res[i].a; dr[i] = res[i].v; }
+}
+
+}  // namespace vc
