@@ -179,3 +179,88 @@ def test_async_start_poll_stop():
         cal.GetNumIterations(); cal.MeanSquaredError(); time.sleep(0.005)
     cal.Stop()
     assert cal.GetCameraProjRMSE()[0] < 0.15
+
+
+# ------------------------------------------------------------------------------------------ inertial path
+def _vi_problem(n_frames=40, seed=5, models=("kb4",)):
+    return synth.generate(synth.Config(models=models, n_frames=n_frames, imu=True, seed=seed))
+
+
+@pytest.mark.parametrize("rot_only", [True, False])
+def test_imu_blocks_match_oracle(rot_only):
+    """Weighted J^T J / J^T r / cost of every IMU block (lane-per-direction duals on the GPU vs Dual<35> oracle)."""
+    p = _vi_problem(16)
+    gt = p.imu_gt
+    cal = ViCalibrator(0).load_problem(p, init=False)
+    orc = ol.Oracle().load(p, init=False)
+    orc.set_options(calibrate_imu=True)
+    b0 = np.concatenate([gt["bg"], gt["ba"]]) * 0.8; s0 = np.concatenate([gt["sg"], gt["sa"]])
+    for o in (orc,):
+        o.set_flags(True, True, rot_only, True)
+        o.set_imu_state(b0, s0, np.zeros(2), 0.002)      # the reference has no gravity setter: g starts at 0
+    cal.SetOptimizationFlags(True, True, rot_only, True)
+    cal.SetBiases(b0); cal.SetScaleFactor(s0); cal.SetTimeOffset(0.002)
+    orc.prepare(vis_mult=1, imu_mult=1)
+    cal.linearize()
+    H, g, c = cal.imu_blocks()
+    perm = list(range(0, 6)) + [12, 13, 14] + list(range(6, 12)) + [15, 16, 17] + list(range(18, 33))
+    for j in range(1, orc.n_frames):
+        r, J = orc.imu_block(j)
+        J = J[:, perm]
+        s = float(r @ r)
+        rho = 1e4 * np.log(1.0 + s / 1e4); w = 1.0 / (1.0 + s / 1e4)     # ceres::CauchyLoss form (cancels for tiny s)
+        np.testing.assert_allclose(c[j - 1], rho, rtol=1e-6, atol=1e-12)
+        Ho = w * J.T @ J; go = w * J.T @ r
+        np.testing.assert_allclose(H[j - 1], Ho, rtol=1e-7, atol=1e-9 * np.abs(Ho).max())
+        np.testing.assert_allclose(g[j - 1], go, rtol=1e-7, atol=1e-9 * np.abs(go).max())
+
+
+def _compare_vi(p, cal, orc, rtol=1e-6):
+    tg = cal.trace(); to = orc.trace()
+    np.set_printoptions(linewidth=220, precision=6)
+    assert len(tg) == len(to), ("gpu", tg[:, [0, 1, 2, 5, 6, 7, 8, 9]], "oracle", to[:, [0, 1, 2, 5, 6, 7, 8, 9]])
+    np.testing.assert_allclose(tg[:, 1], to[:, 1], rtol=rtol)
+    np.testing.assert_array_equal(tg[:, 8], to[:, 8])
+    for c in range(len(p.cam_model)):
+        Kg, Tg = cal.GetCamera(c); Ko, To = orc.camera(c)
+        np.testing.assert_allclose(Kg, Ko, rtol=rtol, atol=1e-8)
+        np.testing.assert_allclose(Tg, To, rtol=rtol, atol=1e-8)
+    Fo, Vo = orc.frames()
+    np.testing.assert_allclose(cal.GetFrames(), Fo, rtol=rtol, atol=1e-8)
+    np.testing.assert_allclose(cal.GetVelocities(), Vo, rtol=rtol, atol=1e-7)
+    b, s, g, toff = orc.imu_state()
+    np.testing.assert_allclose(cal.GetBiases(), b, rtol=rtol, atol=1e-9)
+    np.testing.assert_allclose(cal.GetScaleFactor(), s, rtol=rtol, atol=1e-9)
+    np.testing.assert_allclose(cal.GetGravity(), g, rtol=rtol, atol=1e-9)
+    assert abs(cal.time_offset() - toff) <= rtol * abs(toff) + 1e-10
+    np.testing.assert_allclose(cal.GetCameraProjRMSE(), orc.rmse(), rtol=rtol)
+
+
+def test_rotation_only_stage_matches_oracle():
+    """Stages A (visual) + B (inertial, rotation only): 2x visual + 1x IMU multiplicities, block-tridiagonal chain."""
+    p = _vi_problem(24)
+    cal = ViCalibrator(0).load_problem(p)
+    orc = ol.Oracle().load(p); orc.set_options(calibrate_imu=True, max_iters=60)
+    # stop after stage B: cap the stage machine by running with scale/bias flags that end the schedule early is not
+    # possible in the reference; instead compare the full schedule in the next test and the first two stages here
+    # through the trace rows of stages 0 and 1.
+    cal.SetMaxIters(60)
+    cal.Solve(); orc.solve()
+    tg = cal.trace(); to = orc.trace()
+    sel_g = tg[tg[:, 9] <= 1]; sel_o = to[to[:, 9] <= 1]
+    assert len(sel_g) == len(sel_o)
+    np.testing.assert_allclose(sel_g[:, 1], sel_o[:, 1], rtol=1e-6)
+
+
+def test_full_visual_inertial_calibration_matches_oracle():
+    """All stages A-D (vicalibrator.h:976-1016) on a mono kb4 + IMU problem: per-iteration costs, intrinsics,
+    T_ck, poses, velocities, biases, scale factors, gravity, time offset."""
+    p = _vi_problem(80)
+    cal = ViCalibrator(0).load_problem(p)
+    orc = ol.Oracle().load(p); orc.set_options(calibrate_imu=True, max_iters=100, num_threads=8)
+    cal.SetMaxIters(100)
+    cal.Solve(); orc.solve()
+    _compare_vi(p, cal, orc)
+    gt = p.imu_gt
+    assert abs(cal.time_offset() - gt["time_offset"]) < 5e-4
+    np.testing.assert_allclose(cal.GetBiases()[:3], gt["bg"], atol=3e-4)

@@ -120,6 +120,9 @@ struct vc_calibrator {
   DBuf<double> d_pose[2], d_cam[2], d_G, d_tile_cost, d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_sdiag,
       d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total;
   DBuf<Ctrl> d_ctrl;
+  DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt, d_segH, d_segg, d_seg_cost, d_seg_trial,
+      d_cA, d_cB, d_cP, d_cQ, d_cW, d_cdelta, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init;
+  size_t wsqrt_frames = 0;       // number of frames the device weight_sqrt_ array was initialised for
   int trace_cap = 0;
   DBuf<unsigned char> d_mask;
   std::vector<int> h_tile_frame, h_tile_cam, h_tile_off, h_obs_index;   // h_obs_index: device corner -> host observation
@@ -154,8 +157,18 @@ struct vc_calibrator {
       for (int i = 0; i < nc; ++i) { col_cam.push_back(c); col_local.push_back(i); }
       o += nc;
     }
+    for (int a = 0; a < 15; ++a) imu_param_col[a] = -1;
+    if (imu_on()) {
+      auto add = [&](int first, int n) { for (int i = 0; i < n; ++i) { imu_param_col[first + i] = o++; col_cam.push_back(-1); col_local.push_back(0); } };
+      if (!rotation_only) add(0, 2);            // gravity: constant while rotation-only (vicalibrator.h:657-660, :986)
+      if (is_bias_active) add(2, 6);            // :663-666, :990
+      if (is_scale_active) add(8, 6);           // :668-671, :994
+      if (optimize_time_offset) add(14, 1);     // :673-676
+    }
     return o;
   }
+  bool imu_on() const { return calibrate_imu && is_inertial_active; }
+  int imu_param_col[15];
 
   int upload() {
     HIP_OK(hipSetDevice(device));
@@ -218,7 +231,7 @@ struct vc_calibrator {
     for (int b = 0; b < 2; ++b) { HIP_OK(d_pose[b].upload(poses, stream)); HIP_OK(d_cam[b].upload(camrec, stream)); }
     const int chunk_frames = std::max(4, (((N + 255) / 256) + 3) / 4 * 4);
     const int n_chunks = std::max(1, (N + chunk_frames - 1) / chunk_frames);
-    const int part_stride = D * D + D + C * kGStride;
+    const int part_stride = D * D + D + C * kGStride + (imu_on() ? kGStride : 0);
     HIP_OK(d_G.alloc((size_t)std::max(T, 1) * kGStride)); HIP_OK(d_tile_cost.alloc(std::max(T, 1))); HIP_OK(d_tile_trial.alloc((size_t)std::max(T, 1) * 2));
     HIP_OK(d_Y.alloc((size_t)std::max(T, 1) * kYStride)); HIP_OK(d_fr.alloc((size_t)std::max(N, 1) * kFrStride));
     HIP_OK(d_fdiag.alloc((size_t)std::max(N, 1) * 6)); HIP_OK(d_fscale2.alloc((size_t)std::max(N, 1) * 6));
@@ -247,6 +260,41 @@ struct vc_calibrator {
     dv.fpart = d_fpart.p; dv.scal = d_scal.p; dv.flags = d_flags.p;
     dv.part_stride = part_stride; dv.ctrl = d_ctrl.p; dv.trace = d_trace.p;
     HIP_OK(d_pose_init.upload(poses, stream)); HIP_OK(d_cam_init.upload(camrec, stream));
+    // ---- inertial terms ------------------------------------------------------------------------------
+    std::vector<double> vels((size_t)std::max(N, 1) * 4, 0.0), imus(16, 0.0), ftime(std::max(N, 1), 0.0);
+    for (int f = 0; f < N; ++f) { std::memcpy(&vels[(size_t)f * 4], frames[f].v, 24); ftime[f] = frames[f].time; }
+    imus[0] = g_dir[0]; imus[1] = g_dir[1];
+    for (int i = 0; i < 6; ++i) { imus[2 + i] = biases[i]; imus[8 + i] = scale[i]; }
+    imus[14] = time_offset;
+    for (int b = 0; b < 2; ++b) { HIP_OK(d_vel[b].upload(vels, stream)); HIP_OK(d_imus[b].upload(imus, stream)); }
+    HIP_OK(d_vel_init.upload(vels, stream)); HIP_OK(d_imus_init.upload(imus, stream));
+    HIP_OK(d_frame_time.upload(ftime, stream));
+    dv.imu_on = imu_on() ? 1 : 0; dv.rotation_only = rotation_only ? 1 : 0;
+    dv.weights_on = (is_inertial_active && !rotation_only) ? 1 : 0;
+    dv.n_imu = (int)imu_t.size();
+    dv.gyro_sigma = gyro_sigma; dv.accel_sigma = accel_sigma;
+    for (int a = 0; a < 15; ++a) dv.imu_param_col[a] = imu_param_col[a];
+    dv.ldw = (((D + 1 + 15) / 16) * 16 % 32 == 0) ? ((D + 1 + 15) / 16) * 16 + 16 : ((D + 1 + 15) / 16) * 16;
+    if (dv.imu_on) {
+      HIP_OK(d_imu_t.upload(imu_t, stream)); HIP_OK(d_imu_w.upload(imu_w, stream)); HIP_OK(d_imu_a.upload(imu_a, stream));
+      const size_t ns = (size_t)std::max(N - 1, 1);
+      if (wsqrt_frames != (size_t)N) {          // initial weight 500 * I (vicalibrator.h:616); later stages keep the current weights
+        std::vector<double> w(ns * 81, 0.0);
+        for (size_t k = 0; k < ns; ++k) for (int i = 0; i < 9; ++i) w[k * 81 + i * 10] = 500.0;
+        HIP_OK(d_wsqrt.upload(w, stream)); wsqrt_frames = (size_t)N;
+        HIP_OK(hipStreamSynchronize(stream));
+      }
+      HIP_OK(d_segH.alloc(ns * 33 * 33)); HIP_OK(d_segg.alloc(ns * 33)); HIP_OK(d_seg_cost.alloc(ns)); HIP_OK(d_seg_trial.alloc(ns));
+      const size_t nf = (size_t)std::max(N, 1);
+      HIP_OK(d_cA.alloc(nf * 81)); HIP_OK(d_cB.alloc(nf * 81)); HIP_OK(d_cP.alloc(nf * 81)); HIP_OK(d_cQ.alloc(nf * 81));
+      HIP_OK(d_cW.alloc(nf * 9 * dv.ldw)); HIP_OK(d_cdelta.alloc(nf * 9)); HIP_OK(d_cg.alloc(nf * 9)); HIP_OK(d_clam.alloc(nf * 9));
+      HIP_OK(d_cdiag.alloc(nf * 9)); HIP_OK(d_cscale2.alloc(nf * 9));
+    }
+    dv.imu_t = d_imu_t.p; dv.imu_w = d_imu_w.p; dv.imu_a = d_imu_a.p; dv.frame_time = d_frame_time.p;
+    dv.vel[0] = d_vel[0].p; dv.vel[1] = d_vel[1].p; dv.imus[0] = d_imus[0].p; dv.imus[1] = d_imus[1].p;
+    dv.wsqrt = d_wsqrt.p; dv.segH = d_segH.p; dv.segg = d_segg.p; dv.seg_cost = d_seg_cost.p; dv.seg_trial = d_seg_trial.p;
+    dv.cA = d_cA.p; dv.cB = d_cB.p; dv.cP = d_cP.p; dv.cQ = d_cQ.p; dv.cW = d_cW.p; dv.cdelta = d_cdelta.p; dv.cg = d_cg.p;
+    dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p;
     HIP_OK(hipStreamSynchronize(stream));   // the staging vectors above go out of scope
     device_dirty = false;
     return VC_OK;
@@ -257,6 +305,8 @@ struct vc_calibrator {
     for (int b = 0; b < 2; ++b) {
       HIP_OK(hipMemcpyAsync(d_pose[b].p, d_pose_init.p, (size_t)dv.n_frames * kPoseStride * 8, hipMemcpyDeviceToDevice, stream));
       HIP_OK(hipMemcpyAsync(d_cam[b].p, d_cam_init.p, (size_t)dv.n_cams * kCamStride * 8, hipMemcpyDeviceToDevice, stream));
+      HIP_OK(hipMemcpyAsync(d_vel[b].p, d_vel_init.p, (size_t)std::max(dv.n_frames, 1) * 4 * 8, hipMemcpyDeviceToDevice, stream));
+      HIP_OK(hipMemcpyAsync(d_imus[b].p, d_imus_init.p, 16 * 8, hipMemcpyDeviceToDevice, stream));
     }
     return VC_OK;
   }
@@ -266,9 +316,15 @@ struct vc_calibrator {
     std::vector<double> poses((size_t)N * kPoseStride), camrec((size_t)C * kCamStride);
     if (N) HIP_OK(hipMemcpyAsync(poses.data(), dv.poses[cur], poses.size() * 8, hipMemcpyDeviceToHost, stream));
     if (C) HIP_OK(hipMemcpyAsync(camrec.data(), dv.cams[cur], camrec.size() * 8, hipMemcpyDeviceToHost, stream));
+    std::vector<double> vels((size_t)std::max(N, 1) * 4, 0.0), imus(16, 0.0);
+    if (N) HIP_OK(hipMemcpyAsync(vels.data(), dv.vel[cur], (size_t)N * 4 * 8, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(imus.data(), dv.imus[cur], 16 * 8, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
     std::lock_guard<std::mutex> lk(result_mutex);
-    for (int f = 0; f < N; ++f) std::memcpy(frames[f].T, &poses[(size_t)f * kPoseStride], 56);
+    for (int f = 0; f < N; ++f) { std::memcpy(frames[f].T, &poses[(size_t)f * kPoseStride], 56); std::memcpy(frames[f].v, &vels[(size_t)f * 4], 24); }
+    g_dir[0] = imus[0]; g_dir[1] = imus[1];
+    for (int i = 0; i < 6; ++i) { biases[i] = imus[2 + i]; scale[i] = imus[8 + i]; }
+    time_offset = imus[14];
     for (int c = 0; c < C; ++c) {
       std::memcpy(cams[c].T_ck, &camrec[(size_t)c * kCamStride], 56);
       std::memcpy(cams[c].K, &camrec[(size_t)c * kCamStride + kCamK], cams[c].nk * 8);
@@ -283,6 +339,20 @@ struct vc_calibrator {
   }
   int enqueue_pass() {
     const int D = dv.D;
+    if (dv.imu_on) {
+      if (world > 1) return VC_ERR_UNSUPPORTED;      // frame-sharded IMU chain: separator handling not built yet
+      launch_reproj_jac(dv, stream);
+      launch_imu_jac(dv, stream);
+      launch_imu_weights(dv, stream);                // iteration callback's UpdateImuWeights (vicalibrator.h:691)
+      launch_chain_solve_a(dv, stream);
+      launch_part_sum(dv, stream);
+      launch_reduced(dv, 0, stream);
+      launch_chain_solve_b(dv, stream);
+      launch_reproj_res(dv, 3, 0.0, stream);
+      launch_imu_res(dv, 3, stream);
+      launch_final(dv, 0, stream);
+      return VC_OK;
+    }
     launch_reproj_jac(dv, stream);
     launch_frame_schur(dv, stream);
     int rc = VC_OK;
@@ -308,6 +378,7 @@ struct vc_calibrator {
     std::memset(c, 0, sizeof(Ctrl));
     c->radius = 1e4; c->decrease_factor = 2.0;
     c->ftol = function_tolerance; c->gtol = gradient_tolerance; c->ptol = parameter_tolerance; c->mult = (double)vis_mult;
+    c->imu_mult = (double)imu_mult;
     c->cur = cur; c->reuse_diag = 0; c->need_lin = 1; c->init_scale = 1; c->max_iters = max_iters;
     c->first = 1; c->trace_cap = trace_cap; c->stage = stage;
   }
@@ -316,11 +387,12 @@ struct vc_calibrator {
   // on the device (lm_decide in vc_kernels.hip); the host enqueues passes in batches and polls Ctrl::done.
   int solve_once(Termination* term, double* final_cost, long* nres) {
     if (device_dirty) { int rc = upload(); if (rc) return rc; }
-    *nres = 2L * (long)dv.n_obs * vis_mult;
+    *nres = 2L * (long)dv.n_obs * vis_mult + (dv.imu_on ? 9L * imu_mult * std::max(0, dv.n_frames - 1) : 0L);
     if (trace_cap < max_iters + 8) { trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); dv.trace = d_trace.p; }
     Ctrl c;
     init_ctrl(&c);
     HIP_OK(hipMemcpyAsync(d_ctrl.p, &c, sizeof(Ctrl), hipMemcpyHostToDevice, stream));
+    if (dv.imu_on) launch_imu_weights(dv, stream);     // UpdateImuWeights() before ceres::Solve (vicalibrator.h:955)
     const int batch = 6;
     int guard = 0;
     while (true) {
@@ -394,13 +466,40 @@ struct vc_calibrator {
     return VC_OK;
   }
 
+  // Gravity initialisation, vicalibrator.h:927-949: accel at the middle frame's time (offset 0), rotated into the world
+  void init_gravity() {
+    const int N = (int)frames.size(), n = (int)imu_t.size();
+    gravity_initialized = true;
+    if (N == 0 || n == 0) return;
+    const HostFrame& fr = frames[N / 2];
+    double a[3];
+    const double time = fr.time;
+    if (imu_t[0] > time) { for (int k = 0; k < 3; ++k) a[k] = imu_a[k]; }
+    else if (imu_t[n - 1] <= time || n < 2) { for (int k = 0; k < 3; ++k) a[k] = imu_a[3 * (size_t)(n - 1) + k]; }
+    else {
+      int lo = 0, hi = n - 1;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (imu_t[mid] <= time) lo = mid; else hi = mid; }
+      const double f = (time - imu_t[lo]) / (imu_t[lo + 1] - imu_t[lo]);
+      for (int k = 0; k < 3; ++k) a[k] = imu_a[3 * (size_t)lo + k] * (1.0 - f) + imu_a[3 * (size_t)(lo + 1) + k] * f;
+    }
+    const double nrm = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    const double gb[3] = {a[0] / nrm, a[1] / nrm, a[2] / nrm};
+    double gw[3];
+    quat_rotate(fr.T, gb, gw);
+    const double p = std::asin(gw[1]);
+    const double q = std::asin(-gw[0] / std::cos(p));
+    g_dir[0] = p; g_dir[1] = q;
+  }
+
   // SolveThread, vicalibrator.h:919-1040
   int solve() {
     is_finished = false;
     int status = VC_OK, guard = 0;
     while (should_run && !is_finished && guard++ < 64) {
       if (is_visual_active) vis_mult += 1;                      // SetupProblem re-adds every block (:641-649)
-      if (calibrate_imu) { status = VC_ERR_UNSUPPORTED; break; }   // inertial stages: next milestone
+      if (calibrate_imu && is_inertial_active) imu_mult += 1;   // :651-655
+      if (calibrate_imu && remove_outliers) { status = VC_ERR_UNSUPPORTED; break; }   // per-copy outlier multiplicities: not built yet
+      if (is_inertial_active && !rotation_only && !gravity_initialized) init_gravity();   // :927-949
       device_dirty = true;                                      // constancy flags may have changed
       bool stage_done = false;
       int inner = 0;
@@ -455,7 +554,7 @@ int vc_clear(vc_calibrator* h) {
   h->cams.clear(); h->frames.clear(); h->o_frame.clear(); h->o_cam.clear(); h->o_pw.clear(); h->o_pc.clear(); h->o_removed.clear();
   h->mse = 0; h->num_iterations = 0; h->is_bias_active = false; h->is_scale_active = false; h->is_inertial_active = false;
   h->is_visual_active = true; h->rotation_only = true; h->is_finished = false; h->gravity_initialized = false;
-  h->outliers_removed = false; h->vis_mult = 0; h->imu_mult = 0; h->trace.clear(); h->stage = 0; h->device_dirty = true;
+  h->outliers_removed = false; h->vis_mult = 0; h->imu_mult = 0; h->wsqrt_frames = 0; h->imu_w.clear(); h->imu_a.clear(); h->imu_t.clear(); h->imu_end_time = -1.0; h->trace.clear(); h->stage = 0; h->device_dirty = true;
   return VC_OK;
 }
 
@@ -627,6 +726,7 @@ void* vc_get_stream(vc_calibrator* h) { return h ? (void*)h->stream : nullptr; }
 int vc_prepare(vc_calibrator* h) {
   NOT_RUNNING(h);
   if (h->vis_mult == 0) h->vis_mult = 1;
+  if (h->imu_on() && h->imu_mult == 0) h->imu_mult = 1;
   return h->upload();
 }
 int vc_shared_dim(vc_calibrator* h) { return h ? h->dv.D : VC_ERR_BAD_ARG; }
@@ -743,6 +843,17 @@ int vc_time_stages(vc_calibrator* h, int reps, double* out) {
   }
   for (int i = 0; i < 6; ++i) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); out[i] = ms / reps; }
   for (int i = 0; i < 7; ++i) (void)hipEventDestroy(ev[i]);
+  return VC_OK;
+}
+// Weighted J^T J (33 x 33), J^T r (33) and cost of every IMU block after vc_linearize, columns
+// [frame j: pose 6, velocity 3 | frame j-1: pose 6, velocity 3 | g 2, b 6, sf 6, time offset 1]
+int vc_get_imu_blocks(vc_calibrator* h, double* H, double* g, double* cost) {
+  NOT_RUNNING(h);
+  if (!h->dv.imu_on) return VC_ERR_BAD_ARG;
+  const size_t ns = (size_t)std::max(h->dv.n_frames - 1, 0);
+  if (H && hipMemcpy(H, h->dv.segH, ns * 33 * 33 * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
+  if (g && hipMemcpy(g, h->dv.segg, ns * 33 * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
+  if (cost && hipMemcpy(cost, h->dv.seg_cost, ns * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
   return VC_OK;
 }
 long long vc_num_observations(vc_calibrator* h) { return h ? h->dv.n_obs : 0; }

@@ -26,7 +26,7 @@ enum { kRunning = 0, kDoneConvergence = 1, kDoneNoConvergence = 2, kDoneUserSucc
 
 struct Ctrl {
   double radius, decrease_factor, cost, gmax, gnorm, last_gnorm;
-  double ftol, gtol, ptol, mult;
+  double ftol, gtol, ptol, mult, imu_mult;
   double pend[kTraceCols];   // record of an accepted iteration waiting for the linearisation at the new point
   int cur;            // index of the accepted state buffer
   int reuse_diag;     // LevenbergMarquardtStrategy::reuse_diagonal_
@@ -76,18 +76,56 @@ struct DevView {
   Ctrl* ctrl;
   double* trace;                   // trace_cap x kTraceCols
   int part_stride;
+  // ---- inertial terms (SwitchedFullImuCostFunction, one block per consecutive frame pair) ----------------
+  int imu_on;                      // FLAGS_calibrate_imu && is_inertial_active_: IMU blocks are in the problem
+  int rotation_only;               // optimize_rotation_only_ (residual switch, ceres-cost-functions.h:479-482)
+  int weights_on;                  // UpdateImuWeights acts (vicalibrator.h:725)
+  int n_imu;                       // IMU samples
+  const double* imu_t;             // n_imu
+  const double* imu_w;             // n_imu x 3 gyro
+  const double* imu_a;             // n_imu x 3 accel
+  const double* frame_time;        // n_frames
+  double* vel[2];                  // n_frames x 4, double-buffered like poses
+  double* imus[2];                 // 16: g(2) b(6) sf(6) toff(1) pad
+  int imu_param_col[15];           // shared column of g0 g1 b0..5 sf0..5 toff, -1 = constant
+  double gyro_sigma, accel_sigma;
+  double* wsqrt;                   // (n_frames-1) x 81  weight_sqrt_ of every IMU cost
+  double* segH;                    // (n_frames-1) x 33 x 33  weighted J^T J, columns [frame j (9) | frame j-1 (9) | imu (15)]
+  double* segg;                    // (n_frames-1) x 33       weighted J^T r
+  double* seg_cost;                // (n_frames-1)  imu_mult * rho at the linearisation point
+  double* seg_trial;               // (n_frames-1)  same at the trial point
+  // ---- block-tridiagonal frame chain (9 x 9 blocks: pose 6 + velocity 3), cyclic reduction ----------------
+  double* cA;                      // n_frames x 81  diagonal blocks, then their Cholesky factors
+  double* cB;                      // n_frames x 81  coupling to the next active frame (rows f, cols next)
+  double* cP;                      // n_frames x 81  L^-1 B_prev^T of an eliminated frame
+  double* cQ;                      // n_frames x 81  L^-1 B_self
+  double* cW;                      // n_frames x 9 x ldw: columns 0..D-1 W -> Y = L^-1 W, column D: g -> z
+  double* cdelta;                  // n_frames x 9
+  double* cg;                      // n_frames x 9  gradient
+  double* clam;                    // n_frames x 9
+  double* cdiag;                   // n_frames x 9
+  double* cscale2;                 // n_frames x 9
+  int ldw;
 };
 
 // launchers (vc_kernels.hip); all asynchronous on `s`
 void launch_reproj_jac(const DevView& v, hipStream_t s);
+void launch_part_sum(const DevView& v, hipStream_t s);         // fixed-order sum of the chunk partials
 void launch_frame_schur(const DevView& v, hipStream_t s);      // frame elimination + per-chunk partial Schur sums
 // mode 0: packed reduced system (Sbuf) + damped solve + trial shared parameters; 1: Sbuf only; 2: solve only
 void launch_reduced(const DevView& v, int mode, hipStream_t s);
 void launch_trial(const DevView& v, hipStream_t s);            // back-substitution + manifold update + trial residual sweep
 void launch_final(const DevView& v, int mode, hipStream_t s);  // mode 0: reduce + decide, 1: reduce only, 2: decide only
-void launch_reproj_res(const DevView& v, int state, double mult, hipStream_t s);   // plain residual sweep of a state buffer
+void launch_reproj_res(const DevView& v, int state, double mult, hipStream_t s);   // residual sweep; state 0/1 buffer, 2 accepted, 3 trial (mult from Ctrl)
 void launch_sum_tile_cost(const DevView& v, double* out_cost_sq /*2*/, hipStream_t s);
 void launch_cam_sq(const DevView& v, double* out /*n_cams x 2: sum sq, count*/, hipStream_t s);
 void launch_outlier_mask(const DevView& v, int state, const double* thresh /*device, n_cams*/, unsigned char* mask, hipStream_t s);
+
+// inertial path (vc_imu_kernels.hip)
+void launch_imu_jac(const DevView& v, hipStream_t s);
+void launch_imu_res(const DevView& v, int state_sel, hipStream_t s);        // 2: accepted -> seg_cost-like eval into seg_trial, 3: trial
+void launch_imu_weights(const DevView& v, hipStream_t s);                   // weight_sqrt_ from the accepted state
+void launch_chain_solve_a(const DevView& v, hipStream_t s);                 // assemble + cyclic-reduction elimination + Gram partials
+void launch_chain_solve_b(const DevView& v, hipStream_t s);                 // back-substitution + trial frame state
 
 }  // namespace vc

@@ -20,32 +20,9 @@
 #include <hip/hip_runtime.h>
 #include "vc_math.hpp"
 #include "vc_device.h"
+#include "vc_kutil.hpp"
 
 namespace vc {
-
-typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int kDotStride = 34;   // doubles per corner in LDS: 2 rows x 16 + 2 pad (272 B: conflict-free b128 stores)
-
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-__device__ __forceinline__ double readlane_f64(double x, int lane /* wave-uniform */) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum(double x) {      // result valid in lane 0
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-  return x;
-}
-__device__ __forceinline__ double wave_allsum(double x) {   // result in every lane, fixed order
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-  return x;
-}
 
 // ------------------------------------------------------------------------------------------ Jacobian sweep
 template <int MODEL>
@@ -149,6 +126,12 @@ __global__ __launch_bounds__(256) void k_reproj_res(DevView v, int state, double
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
   if (tile >= v.n_tiles) return;
+  if (state >= 2) {            // 2: accepted buffer, 3: trial buffer of the running solve (multiplicity from Ctrl)
+    const Ctrl* ct = v.ctrl;
+    if (ct->done) return;
+    state = (state == 3) ? 1 - ct->cur : ct->cur;
+    mult = ct->mult;
+  }
   const int f = v.tile_frame[tile], c = v.tile_cam[tile];
   const double* cam = v.cams[state] + (size_t)c * kCamStride;
   TileXf x;
@@ -432,7 +415,7 @@ __global__ __launch_bounds__(256) void k_part_sum(DevView v) {
 
 // Phase A of the reduced system (one workgroup):
 // Sbuf = [ S = H_ss - sum Y^T Y (full symmetric, undamped) | g_red | diag(H_ss) | g_s | cost, 0 ]
-struct FinalLds { double gsum[kMaxCams * kGStride]; double P[256]; double T1[256]; double red[256]; };
+struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[256]; double T1[256]; double red[256]; };
 __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
   const int tid = threadIdx.x, D = v.D, C = v.n_cams;
   double* S = v.Sbuf;
@@ -451,6 +434,7 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
     double s = 0.0;
 #pragma unroll 4
     for (int t = tid; t < v.n_tiles; t += 256) s += v.tile_cost[t];
+    if (v.imu_on) for (int t = tid; t < v.n_frames - 1; t += 256) s += v.seg_cost[t];
     L.red[tid] = s;
   }
   for (int i = tid; i < D; i += 256) { hd[i] = 0.0; gs[i] = 0.0; }
@@ -497,6 +481,20 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
     }
   }
   __syncthreads();
+  if (v.imu_on) {      // shared IMU parameters: sum over the blocks of their 15 x 15 Hessian and gradient
+    const double* Hi = L.gsum + C * kGStride;
+    const int a = tid >> 4, b = tid & 15;
+    if (a < 15) {
+      const int ca = v.imu_param_col[a];
+      if (ca >= 0) {
+        if (b < 15) {
+          const int cb = v.imu_param_col[b];
+          if (cb >= ca) { S[ca * D + cb] += Hi[a * 16 + b]; if (a == b) hd[ca] = Hi[a * 16 + a]; }
+        } else { gred[ca] += Hi[a * 16 + 15]; gs[ca] = Hi[a * 16 + 15]; }
+      }
+    }
+    __syncthreads();
+  }
   for (int e = tid; e < D * D; e += 256) {
     const int i = e / D, j = e % D;
     if (j < i) S[e] = S[j * D + i];
@@ -640,6 +638,15 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
     }
     if (flags & kCamKFree) {
       for (int i = 0; i < nk; ++i) { const double d = x[cc + i], o = cin[kCamK + i]; step2 += d * d; x2 += o * o; cout[kCamK + i] = o + d; }
+    }
+  }
+  if (v.imu_on && tid == 64) {     // g(2) b(6) sf(6) toff(1): plain additive parameters
+    const double* iin = v.imus[cur];
+    double* iout = v.imus[1 - cur];
+    for (int a = 0; a < 16; ++a) iout[a] = iin[a];
+    for (int a = 0; a < 15; ++a) {
+      const int col = v.imu_param_col[a];
+      if (col >= 0) { const double d = x[col], o = iin[a]; step2 += d * d; x2 += o * o; iout[a] = o + d; }
     }
   }
   red[tid] = gd; red[256 + tid] = dld; red[512 + tid] = step2; red[768 + tid] = x2; red[1024 + tid] = g2; red[1280 + tid] = gmax;
@@ -841,6 +848,7 @@ __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
       s[6] = fmax(s[6], p[kScGmax]);
     }
     for (int t = tid; t < v.n_tiles; t += 256) s[5] += v.tile_trial[2 * t];
+    if (v.imu_on) for (int t = tid; t < v.n_frames - 1; t += 256) s[5] += v.seg_trial[t];
     for (int k = 0; k < 7; ++k) red[k * 256 + tid] = s[k];
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -891,6 +899,9 @@ void launch_reproj_jac(const DevView& v, hipStream_t s) {
   const size_t lds = 4 * 64 * kDotStride * sizeof(double);
   hipLaunchKernelGGL(k_reproj_jac, dim3(tiles_grid(v)), dim3(256), lds, s, v);
 }
+void launch_part_sum(const DevView& v, hipStream_t s) {
+  hipLaunchKernelGGL(k_part_sum, dim3((v.part_stride + 31) / 32), dim3(256), 0, s, v);
+}
 void launch_frame_schur(const DevView& v, hipStream_t s) {
   const int D = v.D;
   const int Dp = ((D + 1 + 15) / 16) * 16, ld = (Dp % 32 == 0) ? Dp + 16 : Dp;
@@ -898,7 +909,7 @@ void launch_frame_schur(const DevView& v, hipStream_t s) {
   static size_t granted = 0;
   if (lds > 65536 && lds > granted) { (void)hipFuncSetAttribute((const void*)k_frame_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
   hipLaunchKernelGGL(k_frame_schur, dim3(v.n_chunks), dim3(256), lds, s, v);
-  hipLaunchKernelGGL(k_part_sum, dim3((v.part_stride + 31) / 32), dim3(256), 0, s, v);
+  launch_part_sum(v, s);
 }
 static inline size_t reduced_lds(const DevView& v) {
   return v.D <= kSmallD ? ((size_t)(kSmallD + 1) * (kSmallD + 2) + kSmallD + 1) * sizeof(double)

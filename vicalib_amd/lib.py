@@ -28,7 +28,7 @@ SYMBOLS = [
     "vc_solve", "vc_start", "vc_is_running", "vc_stop", "vc_num_frames", "vc_num_cameras", "vc_get_camera", "vc_get_frame",
     "vc_get_biases", "vc_get_scale_factor", "vc_get_gravity", "vc_time_offset", "vc_mean_squared_error", "vc_get_camera_proj_rmse",
     "vc_get_num_iterations", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
-    "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_num_observations", "vc_num_tiles",
+    "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_num_observations", "vc_num_tiles",
 ]
 
 
@@ -132,6 +132,13 @@ class ViCalibrator:
         _check(self.L.vc_get_frame(self.h, int(f), _d(T), _d(v), C.byref(t)), "GetFrame")
         return T, v, t.value
 
+    def GetVelocities(self):
+        n = self.NumFrames()
+        v = np.zeros((n, 3))
+        for f in range(n):
+            v[f] = self.GetFrame(f)[1]
+        return v
+
     def GetFrames(self):
         n = self.NumFrames()
         T = np.zeros((n, 7))
@@ -212,6 +219,12 @@ class ViCalibrator:
         out = np.zeros(6)
         _check(self.L.vc_time_stages(self.h, int(reps), _d(out)), "time_stages")
         return dict(zip(["jac", "frame_schur", "-", "reduced", "trial", "final"], (out * 1e3).tolist()))
+
+    def imu_blocks(self):
+        ns = max(self.NumFrames() - 1, 0)
+        H = np.zeros((ns, 33, 33)); g = np.zeros((ns, 33)); c = np.zeros(ns)
+        _check(self.L.vc_get_imu_blocks(self.h, _d(H), _d(g), _d(c)), "imu_blocks")
+        return H, g, c
 
     def num_observations(self): return int(self.L.vc_num_observations(self.h))
     def num_tiles(self): return int(self.L.vc_num_tiles(self.h))
