@@ -1,0 +1,76 @@
+"""Worker for the world_size-2 tests (launched with torch.distributed.run).
+mode cpu : gloo, host buffers -- the frame partition + all-reduce callback + additivity of the packed reduced
+           system [S | g_red | diag H_ss | g_s | cost], checked with the CPU oracle (no GPU, no HIP library).
+mode gpu : gloo with device tensors (two ranks share the one GPU of the test box; NCCL refuses that) -- the
+           sharded HIP solve against the single-process solve."""
+import os
+import sys
+import ctypes
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+from vicalib_amd import synth  # noqa: E402
+from vicalib_amd.parallel import FrameShardComm, frame_shard  # noqa: E402
+
+N_TOTAL = 40
+MODELS = ("fov", "poly3")
+
+
+def packed_reduced_system(orc):
+    lin = orc.linearize()
+    A = lin["A"][:, :6, :6]; W = lin["W"][:, :6, :]; gf = lin["gf"][:, :6]
+    S = lin["Hss"].copy(); g = lin["gs"].copy()
+    for f in range(A.shape[0]):
+        if not np.any(A[f]):
+            continue
+        S -= W[f].T @ np.linalg.solve(A[f], W[f]); g -= W[f].T @ np.linalg.solve(A[f], gf[f])
+    return np.concatenate([S.ravel(), g, np.diag(lin["Hss"]), lin["gs"], [lin["cost"], 0.0]])
+
+
+def main(mode):
+    rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = frame_shard(N_TOTAL, rank, world)
+    shard = synth.generate(synth.Config(models=MODELS, n_frames=hi - lo, first_frame=lo, seed=13))
+    full = synth.generate(synth.Config(models=MODELS, n_frames=N_TOTAL, seed=13))
+    if mode == "cpu":
+        import oracle_lib as ol
+        orc = ol.Oracle().load(shard); orc.set_options(calibrate_imu=False); orc.prepare(vis_mult=1)
+        buf = np.ascontiguousarray(packed_reduced_system(orc))
+        comm = FrameShardComm(device="cpu")
+        rc = comm(None, buf.ctypes.data, buf.size, 0)
+        assert rc == 0 and comm.calls == 1
+        ref = ol.Oracle().load(full); ref.set_options(calibrate_imu=False); ref.prepare(vis_mult=1)
+        want = packed_reduced_system(ref)
+        np.testing.assert_allclose(buf, want, rtol=1e-9, atol=1e-9 * np.abs(want).max())
+        mx = np.array([float(rank + 1)])
+        comm(None, mx.ctypes.data, 1, 1)
+        assert mx[0] == world
+    else:
+        from vicalib_amd.lib import ViCalibrator
+        cal = ViCalibrator(0).load_problem(shard); cal.SetCalibrateImu(False)
+        comm = FrameShardComm(device="cuda:0", stream_ptr=cal.stream())
+        cal.set_shard(rank, world, comm)
+        cal.Solve()
+        assert comm.calls > 0
+        ref = ViCalibrator(0).load_problem(full); ref.SetCalibrateImu(False); ref.Solve()
+        for c in range(len(MODELS)):
+            np.testing.assert_allclose(cal.GetCamera(c)[0], ref.GetCamera(c)[0], rtol=1e-8)
+            np.testing.assert_allclose(cal.GetCamera(c)[1], ref.GetCamera(c)[1], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(cal.GetFrames(), ref.GetFrames()[lo:hi], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(cal.GetCameraProjRMSE(), ref.GetCameraProjRMSE(), rtol=1e-8)
+        tg = cal.trace(); tr = ref.trace()
+        assert len(tg) == len(tr)
+        np.testing.assert_allclose(tg[:, 1], tr[:, 1], rtol=1e-9)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
