@@ -1,0 +1,8 @@
+import sys; sys.path.insert(0,'.')
+from vicalib_amd import synth
+from vicalib_amd.lib import ViCalibrator
+p = synth.generate(synth.BASELINE_CONFIGS['cfg2'])
+cal = ViCalibrator(0).load_problem(p); cal.SetCalibrateImu(False); cal.prepare()
+cal.time_stages(20)
+st = cal.debug_stamps()
+print([int(st[i+1]-st[i]) for i in range(6)], 'cycles between stamps 0..6 (100MHz const clock?)')

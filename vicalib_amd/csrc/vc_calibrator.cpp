@@ -258,7 +258,7 @@ struct vc_calibrator {
     dv.fdiag = d_fdiag.p; dv.fscale2 = d_fscale2.p; dv.part = d_part.p; dv.part_total = d_part_total.p; dv.Sbuf = d_Sbuf.p;
     dv.sdiag = d_sdiag.p; dv.sscale2 = d_sscale2.p; dv.slam = d_slam.p; dv.delta_s = d_delta_s.p;
     dv.fpart = d_fpart.p; dv.scal = d_scal.p; dv.flags = d_flags.p;
-    dv.part_stride = part_stride; dv.ctrl = d_ctrl.p; dv.trace = d_trace.p;
+    dv.part_stride = part_stride; dv.ctrl = d_ctrl.p; dv.trace = d_trace.p; dv.dbg = (long long*)(d_tmp.p + 24);
     HIP_OK(d_pose_init.upload(poses, stream)); HIP_OK(d_cam_init.upload(camrec, stream));
     // ---- inertial terms ------------------------------------------------------------------------------
     std::vector<double> vels((size_t)std::max(N, 1) * 4, 0.0), imus(16, 0.0), ftime(std::max(N, 1), 0.0);
@@ -855,6 +855,10 @@ int vc_get_imu_blocks(vc_calibrator* h, double* H, double* g, double* cost) {
   if (g && hipMemcpy(g, h->dv.segg, ns * 33 * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
   if (cost && hipMemcpy(cost, h->dv.seg_cost, ns * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
   return VC_OK;
+}
+int vc_get_debug_stamps(vc_calibrator* h, long long* out) {
+  if (!h || !out) return VC_ERR_BAD_ARG;
+  return hipMemcpy(out, h->dv.dbg, 32 * 8, hipMemcpyDeviceToHost) == hipSuccess ? VC_OK : VC_ERR_NO_DEVICE;
 }
 long long vc_num_observations(vc_calibrator* h) { return h ? h->dv.n_obs : 0; }
 int vc_num_tiles(vc_calibrator* h) { return h ? h->dv.n_tiles : 0; }

@@ -74,6 +74,7 @@ struct DevView {
   double* scal;                    // kNumScal (frame sums) + kNumScal (shared-parameter terms)
   int* flags;                      // [0]: frame Cholesky failures, [1]: reduced Cholesky failure (per pass)
   Ctrl* ctrl;
+  long long* dbg;                  // 32 cycle-counter stamps (profiling aid)
   double* trace;                   // trace_cap x kTraceCols
   int part_stride;
   // ---- inertial terms (SwitchedFullImuCostFunction, one block per consecutive frame pair) ----------------

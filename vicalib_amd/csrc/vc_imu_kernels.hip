@@ -344,10 +344,13 @@ __global__ __launch_bounds__(256) void k_cr_elim(DevView v, int s) {
   const double* A = v.cA + (size_t)e * 81;
 #pragma unroll
   for (int i = 0; i < 81; ++i) L[i] = A[i];
-  if (!chol_small<9>(L)) {
+  double dinv[9];
+  if (!chol_small<9>(L, dinv)) {
     if (lane == 0) atomicAdd(&v.flags[0], 1);
 #pragma unroll
     for (int i = 0; i < 81; ++i) L[i] = (i % 10 == 0) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dinv[i] = 1.0;
   }
   if (lane < 45) {      // store the factor (lower triangle) over A
     int r = 0, acc = 0;
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(256) void k_cr_elim(DevView v, int s) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) x[k] = Wf[k * ldw + (c - 18)];
     }
-    fwd_solve<9>(L, x);
+    fwd_solve_inv<9>(L, dinv, x);
     if (c < 9) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) v.cP[(size_t)e * 81 + k * 9 + c] = x[k];

@@ -284,15 +284,18 @@ __global__ __launch_bounds__(256) void k_frame_schur(DevView v) {
         lam[i] = dg / (radius * sc2);
         H[i * 6 + i] = hd + lam[i];
       }
-      if (!chol_small<6>(H)) {
+      double dinv[6];
+      if (!chol_small<6>(H, dinv)) {
         if (lane == 0) atomicAdd(&v.flags[0], 1);
 #pragma unroll
         for (int i = 0; i < 36; ++i) H[i] = (i % 7 == 0) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dinv[i] = 1.0;
       }
       double z[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) z[i] = g6[i];
-      fwd_solve<6>(H, z);
+      fwd_solve_inv<6>(H, dinv, z);
       if (lane == 0) {
         double* fr = v.fr + (size_t)f * kFrStride;
         int k = 0;
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(256) void k_frame_schur(DevView v) {
             w[i] = -(Rm[i] * u[0] + Rm[3 + i] * u[1] + Rm[6 + i] * u[2]);
             w[3 + i] = Rm[i] * u[3] + Rm[3 + i] * u[4] + Rm[6 + i] * u[5];
           }
-          fwd_solve<6>(H, w);
+          fwd_solve_inv<6>(H, dinv, w);
           const int col = v.cam_col0[c] + j;
 #pragma unroll
           for (int r = 0; r < 6; ++r) R[(wave * 6 + r) * ld + col] = w[r];
@@ -416,7 +419,9 @@ __global__ __launch_bounds__(256) void k_part_sum(DevView v) {
 // Phase A of the reduced system (one workgroup):
 // Sbuf = [ S = H_ss - sum Y^T Y (full symmetric, undamped) | g_red | diag(H_ss) | g_s | cost, 0 ]
 struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[256]; double T1[256]; double red[256]; };
+#define VC_STAMP(i) do { if (threadIdx.x == 0) v.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
 __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
+  VC_STAMP(0);
   const int tid = threadIdx.x, D = v.D, C = v.n_cams;
   double* S = v.Sbuf;
   double* gred = S + D * D;
@@ -430,6 +435,7 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
     else if (e < D * D + D) gred[e - D * D] = -t;
     else L.gsum[e - D * D - D] = t;
   }
+  VC_STAMP(1);
   {
     double s = 0.0;
 #pragma unroll 4
@@ -441,6 +447,7 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if (tid < o) L.red[tid] += L.red[tid + o]; __syncthreads(); }
   if (tid == 0) { sc[0] = 0.5 * L.red[0]; sc[1] = 0.0; }
+  VC_STAMP(2);
   // camera blocks H_cc = P^T G P, g_c = P^T G[:, r]   (P: u-columns -> shared columns of the camera)
   for (int c = 0; c < C; ++c) {
     const int flags = v.cam_flags[c], nk = model_nk(v.cam_model[c]);
@@ -481,6 +488,7 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
     }
   }
   __syncthreads();
+  VC_STAMP(3);
   if (v.imu_on) {      // shared IMU parameters: sum over the blocks of their 15 x 15 Hessian and gradient
     const double* Hi = L.gsum + C * kGStride;
     const int a = tid >> 4, b = tid & 15;
@@ -509,48 +517,67 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
 //   D <= 32: one wavefront, rows in registers, pivots exchanged with v_readlane (no barriers);
 //   D  > 32: workgroup-wide in LDS.
 constexpr int kSmallD = 62;   // rows 0..D (incl. the augmented row) must fit one wavefront
-__device__ void solve_small_wave(const DevView& v, const Ctrl* ct, int lane, double* M, double* x) {
-  const int D = v.D, ld = (D + 1) | 1;          // odd leading dimension: conflict-free column access
+// Lane i keeps row i of the augmented matrix in registers (static indices: all loops over columns are
+// unrolled to DMAX); the freshly scaled pivot column is exchanged through LDS as one contiguous vector
+// (broadcast reads, no dependent read-modify-write chains).  Lt: DMAX x ldt, x: D.
+template <int DMAX>
+__device__ void solve_small_wave(const DevView& v, const Ctrl* ct, int lane, double* Lt, double* x) {
+  const int D = v.D;
+  constexpr int ldt = DMAX + 2;
   const double* S = v.Sbuf;
   const double* gred = S + D * D;
   const double* hd = gred + D;
-  for (int e = lane; e < D * D; e += 64) M[(e / D) * ld + (e % D)] = S[e];
-  for (int i = lane; i < D; i += 64) M[D * ld + i] = gred[i];
-  wave_lds_sync();
+  double row[DMAX];
+#pragma unroll
+  for (int k = 0; k < DMAX; ++k) row[k] = (k < D && lane <= D) ? (lane < D ? S[lane * D + k] : gred[k]) : 0.0;
+  double lam = 0.0;
   if (lane < D) {
     double sc2, dg;
     if (ct->init_scale) { sc2 = jacobi_scale2(hd[lane]); v.sscale2[lane] = sc2; } else sc2 = v.sscale2[lane];
     if (!ct->reuse_diag) { dg = lm_clamped_diag(hd[lane], sc2); v.sdiag[lane] = dg; } else dg = v.sdiag[lane];
-    const double lam = dg / (ct->radius * sc2);
+    lam = dg / (ct->radius * sc2);
     v.slam[lane] = lam;
-    M[lane * ld + lane] += lam;
   }
-  wave_lds_sync();
+#pragma unroll
+  for (int k = 0; k < DMAX; ++k) row[k] += (k == lane) ? lam : 0.0;
   bool bad = false;
-  const bool row = lane <= D;
   for (int j = 0; j < D; ++j) {
-    double d = M[j * ld + j];                     // same address in every lane: one broadcast read
+    double mine = 0.0;
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) mine = (k == j) ? row[k] : mine;
+    double d = readlane_f64(mine, j);
     if (!(d > 0.0)) { bad = true; d = 1.0; }
-    const double piv = sqrt(d);
-    double lij = 0.0;
-    if (row && lane > j) { lij = M[lane * ld + j] / piv; M[lane * ld + j] = lij; }
-    if (lane == j) M[j * ld + j] = piv;
+    const double ipiv = fast_rsqrt(d);
+    const double lij = (lane == j) ? d * ipiv : mine * ipiv;
+    if (lane >= j && lane <= D) Lt[j * ldt + lane] = lij;          // column j of L, contiguous over the rows
     wave_lds_sync();
-    if (row && lane > j) {
-      const int kend = min(lane, D - 1);
-      for (int k = j + 1; k <= kend; ++k) M[lane * ld + k] -= lij * M[k * ld + j];
+    double colv[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) colv[k] = Lt[j * ldt + k];
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) {
+      const bool upd = (k > j) && (k <= lane) && (k < D);
+      row[k] = upd ? row[k] - lij * colv[k] : ((k == j) ? lij : row[k]);
     }
-    wave_lds_sync();
   }
   if (bad && lane == 0) v.flags[1] = 1;
-  // y = L^-1 g sits in row D; delta_s = -L^-T y, pivots broadcast with v_readlane
-  double s = (lane < D) ? -M[D * ld + lane] : 0.0;
-  const double dinv = (lane < D) ? 1.0 / M[lane * ld + lane] : 0.0;
+  // delta_s = -L^-T y.  Lt row i is column i of L: L[j][i] for j >= i, and y_i = L[D][i] at index D.
+  wave_lds_sync();
+  double c[DMAX];
+#pragma unroll
+  for (int j = 0; j < DMAX; ++j) c[j] = (j < D && lane < D && j >= lane) ? Lt[lane * ldt + j] : 0.0;
+  double s = (lane < D) ? -Lt[lane * ldt + D] : 0.0;
+  double dinv = 1.0;
+#pragma unroll
+  for (int j = 0; j < DMAX; ++j) dinv = (j == lane && j < D) ? 1.0 / c[j] : dinv;
   double mine = 0.0;
   for (int j = D - 1; j >= 0; --j) {
     const double xj = readlane_f64(s * dinv, j);
+    double cj = 0.0;
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) cj = (k == j) ? c[k] : cj;
     if (lane == j) mine = xj;
-    if (lane < j) s -= M[j * ld + lane] * xj;
+    if (lane < j) s -= cj * xj;
   }
   if (lane < D) x[lane] = mine;
 }
@@ -603,14 +630,20 @@ __device__ void solve_large_block(const DevView& v, const Ctrl* ct, double* M, d
 __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dyn, double* red /* 6 x 256 */) {
   const int tid = threadIdx.x, D = v.D, cur = ct->cur;
   double* x;
+  VC_STAMP(4);
   if (D <= kSmallD) {
     x = dyn + (kSmallD + 1) * (kSmallD + 2);
-    if (tid < 64 && D > 0) solve_small_wave(v, ct, tid, dyn, x);
+    if (tid < 64 && D > 0) {
+      if (D <= 16) solve_small_wave<16>(v, ct, tid, dyn, x);
+      else if (D <= 32) solve_small_wave<32>(v, ct, tid, dyn, x);
+      else solve_small_wave<kSmallD>(v, ct, tid, dyn, x);
+    }
     __syncthreads();
   } else {
     x = dyn + (size_t)(D + 1) * (D + 1) + (D + 1);
     solve_large_block(v, ct, dyn, x);
   }
+  VC_STAMP(5);
   const double* gs = v.Sbuf + (size_t)D * D + 2 * D;
   double gd = 0, dld = 0, step2 = 0, x2 = 0, g2 = 0, gmax = 0;
   for (int i = tid; i < D; i += 256) {
@@ -618,11 +651,12 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
     v.delta_s[i] = d;
     gd += g * d; dld += v.slam[i] * d * d; g2 += g * g; gmax = fmax(gmax, fabs(g));
   }
+  for (int i = tid; i < v.n_cams * kCamStride; i += 256) v.cams[1 - cur][i] = v.cams[cur][i];
+  __syncthreads();
   if (tid < v.n_cams) {
     const int c = tid;
     const double* cin = v.cams[cur] + (size_t)c * kCamStride;
     double* cout = v.cams[1 - cur] + (size_t)c * kCamStride;
-    for (int i = 0; i < kCamStride; ++i) cout[i] = cin[i];
     const int flags = v.cam_flags[c], nk = model_nk(v.cam_model[c]);
     int cc = v.cam_col0[c];
     if (flags & kCamRotFree) {
@@ -649,16 +683,23 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
       if (col >= 0) { const double d = x[col], o = iin[a]; step2 += d * d; x2 += o * o; iout[a] = o + d; }
     }
   }
+  // only threads < max(D, 65) hold terms: stage them, one wavefront adds them in fixed order
   red[tid] = gd; red[256 + tid] = dld; red[512 + tid] = step2; red[768 + tid] = x2; red[1024 + tid] = g2; red[1280 + tid] = gmax;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) {
+  if (tid < 64) {
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
 #pragma unroll
-      for (int k = 0; k < 5; ++k) red[k * 256 + tid] += red[k * 256 + tid + o];
-      red[1280 + tid] = fmax(red[1280 + tid], red[1280 + tid + o]);
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + 64 * q;
+      a0 += red[i]; a1 += red[256 + i]; a2 += red[512 + i]; a3 += red[768 + i]; a4 += red[1024 + i]; a5 = fmax(a5, red[1280 + i]);
     }
-    __syncthreads();
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3); a4 = wave_sum(a4);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a5 = fmax(a5, __shfl_down(a5, o, 64));
+    if (tid == 0) { red[0] = a0; red[256] = a1; red[512] = a2; red[768] = a3; red[1024] = a4; red[1280] = a5; }
   }
+  __syncthreads();
+  VC_STAMP(6);
   if (tid == 0) {
     double* h = v.scal + kNumScal;
     h[kScGd] = red[0]; h[kScDld] = red[256]; h[kScStep2] = red[512]; h[kScX2] = red[768]; h[kScG2] = red[1024];

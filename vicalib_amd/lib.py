@@ -28,7 +28,7 @@ SYMBOLS = [
     "vc_solve", "vc_start", "vc_is_running", "vc_stop", "vc_num_frames", "vc_num_cameras", "vc_get_camera", "vc_get_frame",
     "vc_get_biases", "vc_get_scale_factor", "vc_get_gravity", "vc_time_offset", "vc_mean_squared_error", "vc_get_camera_proj_rmse",
     "vc_get_num_iterations", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
-    "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_num_observations", "vc_num_tiles",
+    "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
 ]
 
 
@@ -225,6 +225,11 @@ class ViCalibrator:
         H = np.zeros((ns, 33, 33)); g = np.zeros((ns, 33)); c = np.zeros(ns)
         _check(self.L.vc_get_imu_blocks(self.h, _d(H), _d(g), _d(c)), "imu_blocks")
         return H, g, c
+
+    def debug_stamps(self):
+        out = np.zeros(32, dtype=np.int64)
+        _check(self.L.vc_get_debug_stamps(self.h, out.ctypes.data_as(C.c_void_p)), "debug_stamps")
+        return out
 
     def num_observations(self): return int(self.L.vc_num_observations(self.h))
     def num_tiles(self): return int(self.L.vc_num_tiles(self.h))
