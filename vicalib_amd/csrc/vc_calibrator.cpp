@@ -124,6 +124,9 @@ struct vc_calibrator {
       d_cA, d_cB, d_cP, d_cQ, d_cW, d_cdelta, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init;
   size_t wsqrt_frames = 0;       // number of frames the device weight_sqrt_ array was initialised for
   int trace_cap = 0;
+  struct Pinned { Ctrl up; Ctrl down; double trace[64 * kTraceCols]; };
+  Pinned* pin = nullptr;        // page-locked staging (async copies without a bounce buffer)
+  int expected_passes = 8;       // passes the previous solve needed: size of the first batch of the next one
   DBuf<unsigned char> d_mask;
   std::vector<int> h_tile_frame, h_tile_cam, h_tile_off, h_obs_index;   // h_obs_index: device corner -> host observation
   std::vector<int> cam_flags, cam_col0;
@@ -131,6 +134,7 @@ struct vc_calibrator {
   ~vc_calibrator() {
     stop();
     if (stream) (void)hipStreamDestroy(stream);
+    if (pin) (void)hipHostFree(pin);
   }
   void stop() {
     should_run = false;
@@ -302,12 +306,7 @@ struct vc_calibrator {
   // device-to-device reset of the state to what upload() put there (benchmark restarts)
   int reset_state() {
     cur = 0;
-    for (int b = 0; b < 2; ++b) {
-      HIP_OK(hipMemcpyAsync(d_pose[b].p, d_pose_init.p, (size_t)dv.n_frames * kPoseStride * 8, hipMemcpyDeviceToDevice, stream));
-      HIP_OK(hipMemcpyAsync(d_cam[b].p, d_cam_init.p, (size_t)dv.n_cams * kCamStride * 8, hipMemcpyDeviceToDevice, stream));
-      HIP_OK(hipMemcpyAsync(d_vel[b].p, d_vel_init.p, (size_t)std::max(dv.n_frames, 1) * 4 * 8, hipMemcpyDeviceToDevice, stream));
-      HIP_OK(hipMemcpyAsync(d_imus[b].p, d_imus_init.p, 16 * 8, hipMemcpyDeviceToDevice, stream));
-    }
+    launch_reset_state(dv, d_pose_init.p, d_cam_init.p, d_vel_init.p, d_imus_init.p, stream);
     return VC_OK;
   }
   // copy the accepted device state back into the host problem
@@ -389,21 +388,28 @@ struct vc_calibrator {
     if (device_dirty) { int rc = upload(); if (rc) return rc; }
     *nres = 2L * (long)dv.n_obs * vis_mult + (dv.imu_on ? 9L * imu_mult * std::max(0, dv.n_frames - 1) : 0L);
     if (trace_cap < max_iters + 8) { trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); dv.trace = d_trace.p; }
-    Ctrl c;
-    init_ctrl(&c);
-    HIP_OK(hipMemcpyAsync(d_ctrl.p, &c, sizeof(Ctrl), hipMemcpyHostToDevice, stream));
+    if (!pin) HIP_OK(hipHostMalloc((void**)&pin, sizeof(Pinned), hipHostMallocDefault));
+    init_ctrl(&pin->up);
+    HIP_OK(hipMemcpyAsync(d_ctrl.p, &pin->up, sizeof(Ctrl), hipMemcpyHostToDevice, stream));
     if (dv.imu_on) launch_imu_weights(dv, stream);     // UpdateImuWeights() before ceres::Solve (vicalibrator.h:955)
-    const int batch = 6;
-    int guard = 0;
+    // First batch = what the previous solve needed (repeated solves of similar problems: no wasted launches,
+    // one host sync per solve); then small top-up batches until the device reports `done`.
+    int batch = std::max(1, std::min(expected_passes, max_iters + 1)), guard = 0;
+    const size_t trace_bytes = (size_t)std::min(trace_cap, 64) * kTraceCols * 8;
     while (true) {
       for (int b = 0; b < batch; ++b) { int rc = enqueue_pass(); if (rc) return rc; }
-      HIP_OK(hipMemcpyAsync(&c, d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipMemcpyAsync(&pin->down, d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipMemcpyAsync(pin->trace, d_trace.p, trace_bytes, hipMemcpyDeviceToHost, stream));
       HIP_OK(hipStreamSynchronize(stream));
-      if (c.done || !should_run || ++guard > max_iters + 8) break;
+      if (pin->down.done || !should_run || ++guard > max_iters + 8) break;
+      batch = 2;
     }
+    const Ctrl c = pin->down;
+    expected_passes = std::max(1, c.passes);
     const int n = std::min(c.trace_len, trace_cap);
     std::vector<double> rows((size_t)std::max(n, 1) * kTraceCols);
-    if (n) HIP_OK(hipMemcpy(rows.data(), d_trace.p, (size_t)n * kTraceCols * 8, hipMemcpyDeviceToHost));
+    if (n <= 64) std::memcpy(rows.data(), pin->trace, (size_t)n * kTraceCols * 8);
+    else HIP_OK(hipMemcpy(rows.data(), d_trace.p, (size_t)n * kTraceCols * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) {
       const double* r = &rows[(size_t)i * kTraceCols];
       IterRecord rec = {(int)r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], (int)r[8], (int)r[9]};

@@ -118,6 +118,7 @@ void launch_reduced(const DevView& v, int mode, hipStream_t s);
 void launch_trial(const DevView& v, hipStream_t s);            // back-substitution + manifold update + trial residual sweep
 void launch_final(const DevView& v, int mode, hipStream_t s);  // mode 0: reduce + decide, 1: reduce only, 2: decide only
 void launch_reproj_res(const DevView& v, int state, double mult, hipStream_t s);   // residual sweep; state 0/1 buffer, 2 accepted, 3 trial (mult from Ctrl)
+void launch_reset_state(const DevView& v, const double* pose0, const double* cam0, const double* vel0, const double* imu0, hipStream_t s);
 void launch_sum_tile_cost(const DevView& v, double* out_cost_sq /*2*/, hipStream_t s);
 void launch_cam_sq(const DevView& v, double* out /*n_cams x 2: sum sq, count*/, hipStream_t s);
 void launch_outlier_mask(const DevView& v, int state, const double* thresh /*device, n_cams*/, unsigned char* mask, hipStream_t s);
