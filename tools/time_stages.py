@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0,'.')
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vicalib_amd import synth
 from vicalib_amd.lib import ViCalibrator
 cfgs = {

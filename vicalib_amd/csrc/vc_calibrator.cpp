@@ -233,13 +233,14 @@ struct vc_calibrator {
     }
     cur = 0;
     for (int b = 0; b < 2; ++b) { HIP_OK(d_pose[b].upload(poses, stream)); HIP_OK(d_cam[b].upload(camrec, stream)); }
-    const int chunk_frames = std::max(4, (((N + 255) / 256) + 3) / 4 * 4);
+    // one wavefront per frame, 4 frames per group: up to 2048 chunks (= partial sums) before chunks grow
+    const int chunk_frames = std::max(4, (((N + 2047) / 2048) + 3) / 4 * 4);
     const int n_chunks = std::max(1, (N + chunk_frames - 1) / chunk_frames);
     const int part_stride = D * D + D + C * kGStride + (imu_on() ? kGStride : 0);
     HIP_OK(d_G.alloc((size_t)std::max(T, 1) * kGStride)); HIP_OK(d_tile_cost.alloc(std::max(T, 1))); HIP_OK(d_tile_trial.alloc((size_t)std::max(T, 1) * 2));
     HIP_OK(d_Y.alloc((size_t)std::max(T, 1) * kYStride)); HIP_OK(d_fr.alloc((size_t)std::max(N, 1) * kFrStride));
     HIP_OK(d_fdiag.alloc((size_t)std::max(N, 1) * 6)); HIP_OK(d_fscale2.alloc((size_t)std::max(N, 1) * 6));
-    HIP_OK(d_part.alloc((size_t)n_chunks * part_stride)); HIP_OK(d_part_total.alloc(part_stride)); HIP_OK(d_Sbuf.alloc((size_t)D * D + 3 * D + 2));
+    HIP_OK(d_part.alloc((size_t)n_chunks * part_stride)); HIP_OK(d_part_total.alloc((size_t)part_stride * ((n_chunks + 63) / 64))); HIP_OK(d_Sbuf.alloc((size_t)D * D + 3 * D + 2));
     HIP_OK(d_sdiag.alloc(D)); HIP_OK(d_sscale2.alloc(D)); HIP_OK(d_slam.alloc(D)); HIP_OK(d_delta_s.alloc(D));
     HIP_OK(d_fpart.alloc((size_t)std::max(N, 1) * kNumScal));
     trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); HIP_OK(d_ctrl.alloc(1));
@@ -250,6 +251,8 @@ struct vc_calibrator {
     HIP_OK(d_tmp.alloc(64)); HIP_OK(d_mask.alloc(std::max<size_t>(idx.size(), 1)));
     HIP_OK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(int), stream));
     HIP_OK(hipMemsetAsync(d_delta_s.p, 0, std::max(D, 1) * sizeof(double), stream));
+    for (int c = 0; c < kMaxCams; ++c) { dv.cd[c].model = 0; dv.cd[c].flags = 0; dv.cd[c].col0 = 0; dv.cd[c].ncols = 0; }
+    for (int c = 0; c < C; ++c) { dv.cd[c].model = cams[c].model; dv.cd[c].flags = cam_flags[c]; dv.cd[c].col0 = cam_col0[c]; dv.cd[c].ncols = cam_ncols(cam_flags[c], cams[c].nk); }
     dv.n_frames = N; dv.n_cams = C; dv.n_tiles = T; dv.n_points = (int)pmap.size(); dv.D = D;
     dv.n_chunks = n_chunks; dv.chunk_frames = chunk_frames; dv.n_obs = (long long)idx.size();
     dv.obs_uv = d_uv.p; dv.obs_pt = d_pt.p; dv.points = d_points.p;

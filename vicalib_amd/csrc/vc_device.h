@@ -15,8 +15,8 @@ namespace vc {
 constexpr int kMaxCams = 8;
 constexpr int kGStride = 256;      // 16x16 Gram block per tile
 constexpr int kYStride = 96;       // 6 x 16 per tile
-constexpr int kFrStride = 40;      // per frame: L(21) z(6) g(6) lam(6) pad
-constexpr int kFrL = 0, kFrZ = 21, kFrG = 27, kFrLam = 33;
+constexpr int kFrStride = 48;      // per frame: L(21) z(6) g(6) lam(6) 1/diag(L)(6) pad
+constexpr int kFrL = 0, kFrZ = 21, kFrG = 27, kFrLam = 33, kFrDinv = 39;
 constexpr int kNumScal = 8;
 enum { kScGd = 0, kScDld = 1, kScStep2 = 2, kScX2 = 3, kScG2 = 4, kScCost = 5, kScGmax = 6, kScSq = 7 };
 constexpr int kTraceCols = 10;     // iteration cost cost_change gmax gnorm step_norm rho radius accepted stage
@@ -38,7 +38,11 @@ struct Ctrl {
   int res_sweeps, passes, pad0, pad1;
 };
 
+// per-camera descriptor, carried in the kernel arguments (scalar loads, no dependent global look-ups)
+struct CamDesc { int model, flags, col0, ncols; };
+
 struct DevView {
+  CamDesc cd[kMaxCams];
   int n_frames, n_cams, n_tiles, n_points, D, n_chunks, chunk_frames;
   long long n_obs;
   const double2* obs_uv;

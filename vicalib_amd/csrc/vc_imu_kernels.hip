@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
             hval += (a == b) ? s : -s;
           } else {
             const int i = lane - 36, a = i / 3, ii = i % 3;
-            const int rc = 6 + model_nk(v.cam_model[c]);
+            const int rc = 6 + model_nk(v.cd[c].model);
             double s = 0.0;
 #pragma unroll
             for (int p = 0; p < 3; ++p) s += Rm[3 * p + ii] * g[(3 * a + p) * 16 + rc];
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
       for (int idx = lane; idx < nt * 16; idx += 64) {
         const int t = idx >> 4, j = idx & 15;
         const int c = v.tile_cam[t0 + t];
-        const int flags = v.cam_flags[c], nk = model_nk(v.cam_model[c]);
+        const int flags = v.cd[c].flags, nk = model_nk(v.cd[c].model);
         const int nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
         const int nc = nrot + ntr + ((flags & kCamKFree) ? nk : 0);
         if (j < nc) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
 #pragma unroll
             for (int r = 0; r < 6; ++r) u[r] = g[r * 16 + jj];
           }
-          const int col = v.cam_col0[c] + j;
+          const int col = v.cd[c].col0 + j;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             Wf[i * ldw + col] = -(Rm[i] * u[0] + Rm[3 + i] * u[1] + Rm[6 + i] * u[2]);

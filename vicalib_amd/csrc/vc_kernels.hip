@@ -42,11 +42,24 @@ __device__ __forceinline__ void jac_tile_body(const DevView& v, int cur, double 
   v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
   double cost = 0.0;
   double* mine = wl + lane * kDotStride;
+  // software prefetch: the corner of the NEXT pass (detection + target point) is in flight while this pass computes
+  double2 uv_n = make_double2(0.0, 0.0);
+  double pw_n[3] = {0.0, 0.0, 0.0};
+  if (lane < cnt) {
+    uv_n = v.obs_uv[off + lane];
+    const double* pp = v.points + 3 * (size_t)v.obs_pt[off + lane];
+    pw_n[0] = pp[0]; pw_n[1] = pp[1]; pw_n[2] = pp[2];
+  }
   for (int base = 0; base < cnt; base += 64) {
     const int d = base + lane;
+    const double2 uv = uv_n;
+    const double pw[3] = {pw_n[0], pw_n[1], pw_n[2]};
+    if (d + 64 < cnt) {
+      uv_n = v.obs_uv[off + d + 64];
+      const double* pp = v.points + 3 * (size_t)v.obs_pt[off + d + 64];
+      pw_n[0] = pp[0]; pw_n[1] = pp[1]; pw_n[2] = pp[2];
+    }
     if (d < cnt) {
-      const double2 uv = v.obs_uv[off + d];
-      const double* pw = v.points + 3 * (size_t)v.obs_pt[off + d];
       cost += corner_rows<MODEL>(x, K, pre, pw, uv.x, uv.y, mult, mine, mine + 16);
     } else {
 #pragma unroll
@@ -56,16 +69,29 @@ __device__ __forceinline__ void jac_tile_body(const DevView& v, int cur, double 
     const int nd = min(64, cnt - base);
     const int nsteps = (nd + 1) >> 1;          // one MFMA covers 2 corners x 2 residual rows (K = 4)
     const double* src = wl + (lane >> 5) * kDotStride + (lane & 31);
-    int k = 0;
-    for (; k + 1 < nsteps; k += 2) {           // two independent accumulators hide the MFMA dependency latency
-      const double u0 = src[2 * k * kDotStride];
-      const double u1 = src[(2 * k + 2) * kDotStride];
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, u0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, u1, acc1, 0, 0, 0);
-    }
-    if (k < nsteps) {
-      const double u0 = src[2 * k * kDotStride];
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, u0, acc0, 0, 0, 0);
+    if (nsteps == 32) {
+      // full pass: fetch all 32 operands first (conflict-free ds_read_b64), then issue the MFMAs back to back on
+      // two independent accumulators -- the matrix pipe never waits on an LDS round trip
+      double u[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) u[k] = src[2 * k * kDotStride];
+#pragma unroll
+      for (int k = 0; k < 32; k += 2) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u[k], u[k], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(u[k + 1], u[k + 1], acc1, 0, 0, 0);
+      }
+    } else {
+      int k = 0;
+      for (; k + 1 < nsteps; k += 2) {
+        const double u0 = src[2 * k * kDotStride];
+        const double u1 = src[(2 * k + 2) * kDotStride];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, u0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, u1, acc1, 0, 0, 0);
+      }
+      if (k < nsteps) {
+        const double u0 = src[2 * k * kDotStride];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, u0, acc0, 0, 0, 0);
+      }
     }
     wave_lds_sync();
   }
@@ -86,7 +112,7 @@ __global__ __launch_bounds__(256) void k_reproj_jac(DevView v) {
   double* wl = lds + wave * 64 * kDotStride;
   const int cur = ct->cur;
   const double mult = ct->mult;
-  switch (v.cam_model[v.tile_cam[tile]]) {   // wave-uniform
+  switch (v.cd[v.tile_cam[tile]].model) {   // wave-uniform
     case kFov: jac_tile_body<kFov>(v, cur, mult, tile, lane, wl); break;
     case kPoly2: jac_tile_body<kPoly2>(v, cur, mult, tile, lane, wl); break;
     case kPoly3: jac_tile_body<kPoly3>(v, cur, mult, tile, lane, wl); break;
@@ -141,7 +167,7 @@ __global__ __launch_bounds__(256) void k_reproj_res(DevView v, int state, double
 #pragma unroll
   for (int i = 0; i < 8; ++i) K[i] = cam[kCamK + i];
   double cost, sq;
-  res_tile_dispatch(v, v.cam_model[c], x, K, v.tile_off[tile], v.tile_off[tile + 1] - v.tile_off[tile], lane, &cost, &sq);
+  res_tile_dispatch(v, v.cd[c].model, x, K, v.tile_off[tile], v.tile_off[tile + 1] - v.tile_off[tile], lane, &cost, &sq);
   if (lane == 0) { v.tile_trial[2 * tile] = mult * cost; v.tile_trial[2 * tile + 1] = sq; }
 }
 
@@ -171,7 +197,7 @@ __global__ __launch_bounds__(256) void k_outlier_mask(DevView v, int state, cons
 #pragma unroll
   for (int i = 0; i < 8; ++i) K[i] = cam[kCamK + i];
   const double th = thresh[c];
-  switch (v.cam_model[c]) {
+  switch (v.cd[c].model) {
     case kFov: mask_tile_body<kFov>(v, x, K, off, cnt, lane, th, mask); break;
     case kPoly2: mask_tile_body<kPoly2>(v, x, K, off, cnt, lane, th, mask); break;
     case kPoly3: mask_tile_body<kPoly3>(v, x, K, off, cnt, lane, th, mask); break;
@@ -192,7 +218,8 @@ constexpr int kPrepPad = 48;
 constexpr int kMaxPairsPerWave = 9;      // 8 column tiles -> 36 pairs over 4 waves
 __device__ __forceinline__ int schur_ld(int D) { const int Dp = ((D + 1 + 15) / 16) * 16; return (Dp % 32 == 0) ? Dp + 16 : Dp; }
 
-__global__ __launch_bounds__(256) void k_frame_schur(DevView v) {
+template <int MAXC, int MAXP, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
@@ -208,12 +235,12 @@ __global__ __launch_bounds__(256) void k_frame_schur(DevView v) {
   const double* cams = v.cams[cur];
   const int chunk = blockIdx.x;
   const int f0 = chunk * v.chunk_frames, f1 = min(f0 + v.chunk_frames, v.n_frames);
-  v4d acc[kMaxPairsPerWave];
+  v4d acc[MAXP];
 #pragma unroll
-  for (int i = 0; i < kMaxPairsPerWave; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
-  double gsum[kMaxCams][4];
+  for (int i = 0; i < MAXP; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double gsum[MAXC][4];
 #pragma unroll
-  for (int c = 0; c < kMaxCams; ++c)
+  for (int c = 0; c < MAXC; ++c)
 #pragma unroll
     for (int q = 0; q < 4; ++q) gsum[c][q] = 0.0;
 
@@ -231,15 +258,19 @@ __global__ __launch_bounds__(256) void k_frame_schur(DevView v) {
       o[kScX2] = x2;
     }
     if (nt > 0) {
-      for (int m = 0; m < nt * 4; ++m) {       // full 16x16 Gram block of every tile of the frame
-        const int t = m >> 2, q = m & 3;
-        const double val = v.G[(size_t)(t0 + t) * kGStride + q * 64 + lane];
-        Gw[t * kGStride + q * 64 + lane] = val;
-        const int c = v.tile_cam[t0 + t];
+      for (int t = 0; t < nt; ++t) {           // full 16x16 Gram block of every tile of the frame
+        double val[4];
 #pragma unroll
-        for (int k = 0; k < kMaxCams; ++k)
+        for (int q = 0; q < 4; ++q) val[q] = v.G[(size_t)(t0 + t) * kGStride + q * 64 + lane];
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq) gsum[k][qq] += (k == c && qq == q) ? val : 0.0;
+        for (int q = 0; q < 4; ++q) Gw[t * kGStride + q * 64 + lane] = val[q];
+        const int c = v.tile_cam[t0 + t];      // wave-uniform: scalar branch, one camera's accumulators touched
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k)
+          if (k == c) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gsum[k][q] += val[q];
+          }
       }
       wave_lds_sync();
       double hval = 0.0;
@@ -259,7 +290,7 @@ __global__ __launch_bounds__(256) void k_frame_schur(DevView v) {
             hval += (a == b) ? s : -s;
           } else {
             const int i = lane - 36, a = i / 3, ii = i % 3;
-            const int rc = 6 + model_nk(v.cam_model[c]);
+            const int rc = 6 + model_nk(v.cd[c].model);
             double s = 0.0;
 #pragma unroll
             for (int p = 0; p < 3; ++p) s += Rm[3 * p + ii] * g[(3 * a + p) * 16 + rc];
@@ -305,12 +336,12 @@ __global__ __launch_bounds__(256) void k_frame_schur(DevView v) {
 #pragma unroll
           for (int j = 0; j <= i; ++j) fr[kFrL + k++] = H[i * 6 + j];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { fr[kFrZ + i] = z[i]; fr[kFrG + i] = g6[i]; fr[kFrLam + i] = lam[i]; R[(wave * 6 + i) * ld + D] = z[i]; }
+        for (int i = 0; i < 6; ++i) { fr[kFrZ + i] = z[i]; fr[kFrG + i] = g6[i]; fr[kFrLam + i] = lam[i]; fr[kFrDinv + i] = dinv[i]; R[(wave * 6 + i) * ld + D] = z[i]; }
       }
       for (int idx = lane; idx < nt * 16; idx += 64) {      // Y columns: lane -> (tile, column)
         const int t = idx >> 4, j = idx & 15;
         const int c = v.tile_cam[t0 + t];
-        const int flags = v.cam_flags[c], nk = model_nk(v.cam_model[c]);
+        const int flags = v.cd[c].flags, nk = model_nk(v.cd[c].model);
         const int nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
         const int nc = nrot + ntr + ((flags & kCamKFree) ? nk : 0);
         double w[6] = {0, 0, 0, 0, 0, 0};
@@ -333,7 +364,7 @@ __global__ __launch_bounds__(256) void k_frame_schur(DevView v) {
             w[3 + i] = Rm[i] * u[3] + Rm[3 + i] * u[4] + Rm[6 + i] * u[5];
           }
           fwd_solve_inv<6>(H, dinv, w);
-          const int col = v.cam_col0[c] + j;
+          const int col = v.cd[c].col0 + j;
 #pragma unroll
           for (int r = 0; r < 6; ++r) R[(wave * 6 + r) * ld + col] = w[r];
         }
@@ -351,11 +382,11 @@ __global__ __launch_bounds__(256) void k_frame_schur(DevView v) {
           const double* rb = R + (lane >> 4) * ld + J * 16 + (lane & 15);
           v4d a4 = acc[0];
 #pragma unroll
-          for (int q = 0; q < kMaxPairsPerWave; ++q) a4 = (q == pi) ? acc[q] : a4;
+          for (int q = 0; q < MAXP; ++q) a4 = (q == pi) ? acc[q] : a4;
 #pragma unroll
           for (int ks = 0; ks < 6; ++ks) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[ks * 4 * ld], rb[ks * 4 * ld], a4, 0, 0, 0);
 #pragma unroll
-          for (int q = 0; q < kMaxPairsPerWave; ++q) acc[q] = (q == pi) ? a4 : acc[q];
+          for (int q = 0; q < MAXP; ++q) acc[q] = (q == pi) ? a4 : acc[q];
           ++pi;
         }
         if (++J == nT) { ++I; J = I; }
@@ -370,7 +401,7 @@ __global__ __launch_bounds__(256) void k_frame_schur(DevView v) {
       if ((p & 3) == wave) {
         v4d a4 = acc[0];
 #pragma unroll
-        for (int q = 0; q < kMaxPairsPerWave; ++q) a4 = (q == pi) ? acc[q] : a4;
+        for (int q = 0; q < MAXP; ++q) a4 = (q == pi) ? acc[q] : a4;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int row = I * 16 + (lane >> 4) + 4 * g, col = J * 16 + (lane & 15);
@@ -384,7 +415,7 @@ __global__ __launch_bounds__(256) void k_frame_schur(DevView v) {
   // per-camera sum of G over the chunk: combine the 4 wavefronts through LDS (fixed order)
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < kMaxCams; ++c)
+  for (int c = 0; c < MAXC; ++c)
     if (c < C) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) sh[wave * (C * kGStride) + c * kGStride + q * 64 + lane] = gsum[c][q];
@@ -395,17 +426,20 @@ __global__ __launch_bounds__(256) void k_frame_schur(DevView v) {
 }
 
 // Fixed-order sum of the chunk partials, spread over many CUs (one CU can only pull ~20-50 GB/s):
-// workgroup w owns 32 entries; thread (entry = tid & 31, slice = tid >> 5) sums the partials k = slice (mod 8),
-// the 8 slices are then added in order.  total[e] = sum_k part[k][e].
+// workgroup (x, y) owns 32 entries and the slab of kSlab partials y; thread (entry = tid & 31, slice = tid >> 5)
+// sums the slab's partials k = slice (mod 8), the 8 slices are then added in order:
+//   part_total[y][e] = sum_{k in slab y} part[k][e];   the slabs are added by the consumer (k_reduced).
+constexpr int kSlab = 64;
 __global__ __launch_bounds__(256) void k_part_sum(DevView v) {
   __shared__ double sl[256];
   if (v.ctrl->done) return;
   const int tid = threadIdx.x, e = blockIdx.x * 32 + (tid & 31), ks = tid >> 5;
-  const int stride = v.part_stride, nch = v.n_chunks;
+  const int stride = v.part_stride;
+  const int k0 = blockIdx.y * kSlab, k1 = min(k0 + kSlab, v.n_chunks);
   double s = 0.0;
   if (e < stride) {
 #pragma unroll 8
-    for (int k = ks; k < nch; k += 8) s += v.part[(size_t)k * stride + e];
+    for (int k = k0 + ks; k < k1; k += 8) s += v.part[(size_t)k * stride + e];
   }
   sl[tid] = s;
   __syncthreads();
@@ -413,7 +447,7 @@ __global__ __launch_bounds__(256) void k_part_sum(DevView v) {
     double t = sl[tid];
 #pragma unroll
     for (int q = 1; q < 8; ++q) t += sl[q * 32 + tid];
-    v.part_total[e] = t;
+    v.part_total[(size_t)blockIdx.y * stride + e] = t;
   }
 }
 
@@ -430,8 +464,11 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
   double* gs = hd + D;
   double* sc = gs + D;
   const int stride = v.part_stride;
+  const int nslab = (v.n_chunks + kSlab - 1) / kSlab;
   for (int e = tid; e < stride; e += 256) {
-    const double t = v.part_total[e];
+    double t = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < nslab; ++k) t += v.part_total[(size_t)k * stride + e];
     if (e < D * D) S[e] = -t;
     else if (e < D * D + D) gred[e - D * D] = -t;
     else L.gsum[e - D * D - D] = t;
@@ -451,8 +488,8 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
   VC_STAMP(2);
   // camera blocks H_cc = P^T G P, g_c = P^T G[:, r]   (P: u-columns -> shared columns of the camera)
   for (int c = 0; c < C; ++c) {
-    const int flags = v.cam_flags[c], nk = model_nk(v.cam_model[c]);
-    const int nu = 6 + nk, nc = cam_ncols(flags, nk), c0 = v.cam_col0[c];
+    const int flags = v.cd[c].flags, nk = model_nk(v.cd[c].model);
+    const int nu = 6 + nk, nc = cam_ncols(flags, nk), c0 = v.cd[c].col0;
     const int nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
     const double* G = L.gsum + c * kGStride;
     __syncthreads();
@@ -517,7 +554,7 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
 // (cams[1-cur] <- Plus(cams[cur], delta_s)) and their scalar terms scal[8..15].
 //   D <= 32: one wavefront, rows in registers, pivots exchanged with v_readlane (no barriers);
 //   D  > 32: workgroup-wide in LDS.
-constexpr int kSmallD = 62;   // rows 0..D (incl. the augmented row) must fit one wavefront
+constexpr int kSmallD = 32;   // above this the workgroup-wide LDS factorisation is faster
 // Lane i keeps row i of the augmented matrix in registers (static indices: all loops over columns are
 // unrolled to DMAX); the freshly scaled pivot column is exchanged through LDS as one contiguous vector
 // (broadcast reads, no dependent read-modify-write chains).  Lt: DMAX x ldt, x: D.
@@ -609,10 +646,12 @@ __device__ void solve_large_block(const DevView& v, const Ctrl* ct, double* M, d
     for (int i = j + 1 + tid; i <= D; i += 256) col[i] = M[i * ld + j] / piv;
     __syncthreads();
     if (tid == 0) { M[j * ld + j] = piv; if (bad) v.flags[1] = 1; }
-    const int n = D - j;
-    for (int idx = tid; idx < n * n; idx += 256) {
-      const int i = j + 1 + idx / n, k = j + 1 + idx % n;
-      if (k <= i && k < D) M[i * ld + k] -= col[i] * col[k];
+    {   // trailing update on a 16 x 16 thread grid (no integer divisions on the per-column path)
+      const int ti = tid >> 4, tj = tid & 15;
+      for (int i = j + 1 + ti; i <= D; i += 16) {
+        const double ci = col[i];
+        for (int k = j + 1 + tj; k <= i && k < D; k += 16) M[i * ld + k] -= ci * col[k];
+      }
     }
     for (int i = j + 1 + tid; i <= D; i += 256) M[i * ld + j] = col[i];
     __syncthreads();
@@ -636,8 +675,7 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
     x = dyn + (kSmallD + 1) * (kSmallD + 2);
     if (tid < 64 && D > 0) {
       if (D <= 16) solve_small_wave<16>(v, ct, tid, dyn, x);
-      else if (D <= 32) solve_small_wave<32>(v, ct, tid, dyn, x);
-      else solve_small_wave<kSmallD>(v, ct, tid, dyn, x);
+      else solve_small_wave<32>(v, ct, tid, dyn, x);
     }
     __syncthreads();
   } else {
@@ -658,8 +696,8 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
     const int c = tid;
     const double* cin = v.cams[cur] + (size_t)c * kCamStride;
     double* cout = v.cams[1 - cur] + (size_t)c * kCamStride;
-    const int flags = v.cam_flags[c], nk = model_nk(v.cam_model[c]);
-    int cc = v.cam_col0[c];
+    const int flags = v.cd[c].flags, nk = model_nk(v.cd[c].model);
+    int cc = v.cd[c].col0;
     if (flags & kCamRotFree) {
       double q[4], w[3] = {x[cc], x[cc + 1], x[cc + 2]}, qi[4] = {cin[0], cin[1], cin[2], cin[3]};
       so3_plus(qi, w, q);
@@ -725,22 +763,38 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
 // T_trial = T exp(delta_p), residual sweep of the tile at the trial state.  The first tile of a frame
 // also publishes the frame's trial pose and its step terms.
 __global__ __launch_bounds__(256) void k_trial(DevView v) {
+  __shared__ double ds_s[kMaxCams * 16 + 16];     // delta_s of the workgroup's cameras is read many times: keep it in LDS
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
+  for (int i = threadIdx.x; i < v.D; i += 256) if (i < kMaxCams * 16 + 16) ds_s[i] = v.delta_s[i];
+  __syncthreads();
   if (tile >= v.n_tiles) return;
   const int cur = ct->cur;
+  const double mult = ct->mult;
   const int f = v.tile_frame[tile], c = v.tile_cam[tile];
   const int t0 = v.frame_tile_off[f], nt = v.frame_tile_off[f + 1] - t0;
   const double* fr = v.fr + (size_t)f * kFrStride;
+  const double* pin = v.poses[cur] + (size_t)f * kPoseStride;
+  const double* cam = v.cams[1 - cur] + (size_t)c * kCamStride;
+  // issue everything whose address is known now: factor, pose, trial camera
+  double Lr[21], zr[6], di[6], Tin[7], camr[16];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) Lr[i] = fr[kFrL + i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { zr[i] = fr[kFrZ + i]; di[i] = fr[kFrDinv + i]; }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) Tin[i] = pin[i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) camr[i] = cam[i];
   double y[6] = {0, 0, 0, 0, 0, 0};
+  const bool small_d = v.D <= kMaxCams * 16 + 16;
   for (int idx = lane; idx < nt * 16; idx += 64) {
     const int t = idx >> 4, j = idx & 15;
-    const int cc = v.tile_cam[t0 + t];
-    const int nc = cam_ncols(v.cam_flags[cc], model_nk(v.cam_model[cc]));
-    if (j < nc) {
-      const double dj = v.delta_s[v.cam_col0[cc] + j];
+    const CamDesc cd = v.cd[v.tile_cam[t0 + t]];
+    if (j < cd.ncols) {
+      const double dj = small_d ? ds_s[cd.col0 + j] : v.delta_s[cd.col0 + j];
       const double* Yt = v.Y + (size_t)(t0 + t) * kYStride + j;
 #pragma unroll
       for (int k = 0; k < 6; ++k) y[k] += Yt[k * kUCols] * dj;
@@ -752,29 +806,25 @@ __global__ __launch_bounds__(256) void k_trial(DevView v) {
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int j = 0; j < 6; ++j) L[i * 6 + j] = (j <= i) ? fr[kFrL + (k++)] : 0.0;
+      for (int j = 0; j < 6; ++j) L[i * 6 + j] = (j <= i) ? Lr[k++] : 0.0;
   }
 #pragma unroll
-  for (int k = 0; k < 6; ++k) y[k] = wave_allsum(y[k]) + fr[kFrZ + k];
-  bwd_solve<6>(L, y);
+  for (int k = 0; k < 6; ++k) y[k] = wave_allsum(y[k]) + zr[k];
+  bwd_solve_inv<6>(L, di, y);
   double d[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) d[i] = -y[i];
-  const double* pin = v.poses[cur] + (size_t)f * kPoseStride;
-  double Tin[7], Tout[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) Tin[i] = pin[i];
+  double Tout[7];
   se3_plus(Tin, d, Tout);
-  const double* cam = v.cams[1 - cur] + (size_t)c * kCamStride;
   TileXf x;
-  make_tile_xf(Tout, cam, &x);
+  make_tile_xf(Tout, camr, &x);
   double K[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) K[i] = cam[kCamK + i];
+  for (int i = 0; i < 8; ++i) K[i] = camr[kCamK + i];
   double cost, sq;
-  res_tile_dispatch(v, v.cam_model[c], x, K, v.tile_off[tile], v.tile_off[tile + 1] - v.tile_off[tile], lane, &cost, &sq);
+  res_tile_dispatch(v, v.cd[c].model, x, K, v.tile_off[tile], v.tile_off[tile + 1] - v.tile_off[tile], lane, &cost, &sq);
   if (lane == 0) {
-    v.tile_trial[2 * tile] = ct->mult * cost;
+    v.tile_trial[2 * tile] = mult * cost;
     v.tile_trial[2 * tile + 1] = sq;
     if (tile == t0) {
       double* pout = v.poses[1 - cur] + (size_t)f * kPoseStride;
@@ -951,15 +1001,20 @@ void launch_reproj_jac(const DevView& v, hipStream_t s) {
   hipLaunchKernelGGL(k_reproj_jac, dim3(tiles_grid(v)), dim3(256), lds, s, v);
 }
 void launch_part_sum(const DevView& v, hipStream_t s) {
-  hipLaunchKernelGGL(k_part_sum, dim3((v.part_stride + 31) / 32), dim3(256), 0, s, v);
+  hipLaunchKernelGGL(k_part_sum, dim3((v.part_stride + 31) / 32, (v.n_chunks + kSlab - 1) / kSlab), dim3(256), 0, s, v);
 }
 void launch_frame_schur(const DevView& v, hipStream_t s) {
   const int D = v.D;
   const int Dp = ((D + 1 + 15) / 16) * 16, ld = (Dp % 32 == 0) ? Dp + 16 : Dp;
   const size_t lds = ((size_t)4 * (v.n_cams * kGStride + kPrepPad) + (size_t)24 * ld) * sizeof(double);
-  static size_t granted = 0;
-  if (lds > 65536 && lds > granted) { (void)hipFuncSetAttribute((const void*)k_frame_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
-  hipLaunchKernelGGL(k_frame_schur, dim3(v.n_chunks), dim3(256), lds, s, v);
+  const int nT = (D + 1 + 15) / 16;
+  auto go = [&](auto kern) {
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(v.n_chunks), dim3(256), lds, s, v);
+  };
+  if (v.n_cams <= 2 && nT <= 2) go(k_frame_schur<2, 1, 2>);
+  else if (v.n_cams <= 4 && nT <= 4) go(k_frame_schur<4, 3, 2>);
+  else go(k_frame_schur<kMaxCams, kMaxPairsPerWave, 2>);
   launch_part_sum(v, s);
 }
 static inline size_t reduced_lds(const DevView& v) {
