@@ -122,23 +122,276 @@ __global__ __launch_bounds__(64) void k_imu_res(DevView v, int sel) {
   v.seg_trial[s] = ct->imu_mult * rho;
 }
 
-// UpdateImuWeights from the accepted state (vicalibrator.h:723-799)
-__global__ __launch_bounds__(64) void k_imu_weights(DevView v) {
+// UpdateImuWeights from the accepted state (vicalibrator.h:723-799), one wavefront per IMU block.
+// The 10x10 / 10x9 / 9x10 / 9x6 Jacobian chains of the covariance propagation (types.h:427-595) live in
+// wave-private LDS; every product is computed lane-per-entry.  The state itself (and the small quaternion
+// Jacobian blocks) is propagated redundantly in every lane, which keeps all branches wave-uniform.
+// The weight is stored as W = L^-T with  J Sigma J^T = L L^T  (Cholesky): W W^T = (J Sigma J^T)^-1 exactly as
+// for the reference's symmetric square root (vicalibrator.h:783-796), and cost, gradient and Gauss-Newton
+// Hessian of the block depend on W only through W W^T -- same optimisation, no 9x9 eigen-decomposition.
+template <int M, int K, int N>
+__device__ __forceinline__ void wmm(const double* A, const double* B, double* C, int lane) {   // C = A B
+  for (int e = lane; e < M * N; e += 64) {
+    const int i = e / N, j = e % N;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < K; ++q) s += A[i * K + q] * B[q * N + j];
+    C[e] = s;
+  }
+}
+template <int M, int K, int N>
+__device__ __forceinline__ void wmm_add(const double* Add, const double* A, const double* B, double* C, int lane) {   // C = Add + A B
+  for (int e = lane; e < M * N; e += 64) {
+    const int i = e / N, j = e % N;
+    double s = Add[e];
+#pragma unroll
+    for (int q = 0; q < K; ++q) s += A[i * K + q] * B[q * N + j];
+    C[e] = s;
+  }
+}
+struct WLds { double dy_db[60], dy_dy0[100], dk_db[54], dk_dy[90], dy_dk[90], dy_dy[100], kt_db[54], kt_dy[90], kc_db[54], kc_dy[90], tmp[100], Sigma[100], J[90], P[81]; };
+
+__device__ void w_fill_pose_derivative(WLds& L, const WState& s, const double* zg, const double* za, const double* b, int lane) {
+  // dk_db (9x6): rows 3..5 <- R (gyro bias), rows 6..8 <- R (accel bias); dk_dy (9x10): dv/dv, d(Rw)/dq, d(Ra)/dq
+  for (int i = lane; i < 54; i += 64) L.dk_db[i] = 0.0;
+  for (int i = lane; i < 90; i += 64) L.dk_dy[i] = 0.0;
+  wave_lds_sync();
+  if (lane == 0) {
+    double R[9], m1[12], m2[12];
+    quat_to_R(s.q, R);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { L.dk_db[(3 + i) * 6 + j] = R[3 * i + j]; L.dk_db[(6 + i) * 6 + 3 + j] = R[3 * i + j]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) L.dk_dy[i * 10 + 7 + i] = 1.0;
+    w_dqx_dq(s.q, zg, m1); w_dqx_dq(s.q, b, m2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) L.dk_dy[(3 + i) * 10 + 3 + j] = m1[i * 4 + j] + m2[i * 4 + j];
+    w_dqx_dq(s.q, za, m1); w_dqx_dq(s.q, b + 3, m2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) L.dk_dy[(6 + i) * 10 + 3 + j] = m1[i * 4 + j] + m2[i * 4 + j];
+  }
+  wave_lds_sync();
+}
+__device__ void w_fill_integrate_pose(WLds& L, const WState& s, const double* k, double dt, WState* y, int lane) {
+  const double wdt[3] = {k[3] * dt, k[4] * dt, k[5] * dt};
+  double rq[4];
+  so3_exp(wdt, rq);
+  for (int i = 0; i < 3; ++i) { y->p[i] = s.p[i] + k[i] * dt; y->v[i] = s.v[i] + k[6 + i] * dt; }
+  quat_mul(rq, s.q, y->q);
+  for (int i = lane; i < 90; i += 64) L.dy_dk[i] = 0.0;
+  for (int i = lane; i < 100; i += 64) L.dy_dy[i] = 0.0;
+  wave_lds_sync();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { L.dy_dk[i * 9 + i] = dt; L.dy_dk[(7 + i) * 9 + 6 + i] = dt; L.dy_dy[i * 10 + i] = 1.0; L.dy_dy[(7 + i) * 10 + 7 + i] = 1.0; }
+    double a[16], e[12], ae[12], d2[16];
+    w_dq1q2_dq1(s.q, a); w_dqexp_dw(wdt, e);
+    mm(a, e, ae, 4, 4, 3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) L.dy_dk[(3 + i) * 9 + 3 + j] = ae[i * 3 + j] * dt;
+    w_dq1q2_dq2(rq, d2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) L.dy_dy[(3 + i) * 10 + 3 + j] = d2[i * 4 + j];
+  }
+  wave_lds_sync();
+}
+__device__ void w_step(WLds& L, WState* st, const Meas<double>& z0, const Meas<double>& z1, const double* b, const double* sf,
+                       const double* g, double sg2, double sa2, int lane) {
+  const double dt = z1.time - z0.time;
+  if (dt == 0) return;
+  for (int i = lane; i < 60; i += 64) L.dy_db[i] = 0.0;
+  for (int i = lane; i < 100; i += 64) L.dy_dy0[i] = (i % 11 == 0) ? 1.0 : 0.0;
+  for (int i = lane; i < 54; i += 64) L.kt_db[i] = 0.0;
+  for (int i = lane; i < 90; i += 64) L.kt_dy[i] = 0.0;
+  wave_lds_sync();
+  const double tau[4] = {0.0, dt / 2, dt / 2, dt}, hh[3] = {dt * 0.5, dt * 0.5, dt}, wgt[4] = {1.0, 2.0, 2.0, 1.0};
+  WState cur = *st, y;
+  double ksum[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) ksum[i] = 0.0;
+#pragma unroll 1
+  for (int stage = 0; stage < 4; ++stage) {
+    // k = f(cur) and its partials
+    const double alpha = (z1.time - (z0.time + tau[stage])) / (z1.time - z0.time);
+    double zg[3], za[3], u[3], o[3], R[9], kc[9];
+    for (int i = 0; i < 3; ++i) { zg[i] = z0.w[i] * alpha + z1.w[i] * (1.0 - alpha); za[i] = z0.a[i] * alpha + z1.a[i] * (1.0 - alpha); }
+    for (int i = 0; i < 3; ++i) kc[i] = cur.v[i];
+    quat_to_R(cur.q, R);
+    for (int i = 0; i < 3; ++i) u[i] = zg[i] * sf[i] + b[i];
+    for (int i = 0; i < 3; ++i) kc[3 + i] = R[3 * i] * u[0] + R[3 * i + 1] * u[1] + R[3 * i + 2] * u[2];
+    for (int i = 0; i < 3; ++i) u[i] = za[i] * sf[3 + i] + b[3 + i];
+    quat_rotate(cur.q, u, o);
+    for (int i = 0; i < 3; ++i) kc[6 + i] = o[i] - g[i];
+    w_fill_pose_derivative(L, cur, zg, za, b, lane);
+    wmm_add<9, 10, 6>(L.dk_db, L.dk_dy, L.dy_db, L.kc_db, lane);      // dk/db  = dk_db + dk_dy dy_db
+    wmm<9, 10, 10>(L.dk_dy, L.dy_dy0, L.kc_dy, lane);                  // dk/dy0 = dk_dy dy_dy0
+    wave_lds_sync();
+    const double wg = wgt[stage];
+    for (int i = lane; i < 54; i += 64) L.kt_db[i] += wg * L.kc_db[i];
+    for (int i = lane; i < 90; i += 64) L.kt_dy[i] += wg * L.kc_dy[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ksum[i] += wg * kc[i];
+    if (stage < 3) {
+      w_fill_integrate_pose(L, *st, kc, hh[stage], &y, lane);
+      wmm<10, 9, 6>(L.dy_dk, L.kc_db, L.dy_db, lane);
+      wmm_add<10, 9, 10>(L.dy_dy, L.dy_dk, L.kc_dy, L.dy_dy0, lane);
+      wave_lds_sync();
+      cur = y;
+    }
+  }
+  w_fill_integrate_pose(L, *st, ksum, dt / 6.0, &y, lane);
+  wmm<10, 9, 6>(L.dy_dk, L.kt_db, L.dy_db, lane);
+  wmm_add<10, 9, 10>(L.dy_dy, L.dy_dk, L.kt_dy, L.dy_dy0, lane);
+  wave_lds_sync();
+  wmm<10, 10, 10>(L.dy_dy0, L.Sigma, L.tmp, lane);
+  wave_lds_sync();
+  for (int e = lane; e < 100; e += 64) {     // Sigma <- F Sigma F^T + G R G^T
+    const int i = e / 10, j = e % 10;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) s += L.tmp[i * 10 + q] * L.dy_dy0[j * 10 + q];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) s += L.dy_db[i * 6 + q] * (q < 3 ? sg2 : sa2) * L.dy_db[j * 6 + q];
+    L.dy_dy[e] = s;
+  }
+  wave_lds_sync();
+  for (int e = lane; e < 100; e += 64) L.Sigma[e] = L.dy_dy[e];
+  wave_lds_sync();
+  *st = y;
+}
+
+__global__ __launch_bounds__(256) void k_imu_weights(DevView v) {
+  __shared__ WLds lds[4];
   const Ctrl* ct = v.ctrl;
   if (ct->done || !v.weights_on) return;
-  const int s = blockIdx.x * 64 + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + wave;
   if (s >= v.n_frames - 1) return;
+  WLds& L = lds[wave];
   const int st = ct->cur, j = s + 1;
   const double* im = v.imus[st];
-  double T1[7], T2[7], v1[3], b[6], sf[6], g[2];
+  double T1[7], T2[7], b[6], sf[6], g2[2], gw[3];
+#pragma unroll
   for (int i = 0; i < 7; ++i) { T1[i] = v.poses[st][(size_t)(j - 1) * kPoseStride + i]; T2[i] = v.poses[st][(size_t)j * kPoseStride + i]; }
-  for (int i = 0; i < 3; ++i) v1[i] = v.vel[st][(size_t)(j - 1) * 4 + i];
+#pragma unroll
   for (int i = 0; i < 6; ++i) { b[i] = im[2 + i]; sf[i] = im[8 + i]; }
-  g[0] = im[0]; g[1] = im[1];
-  double w[81];
-  for (int i = 0; i < 81; ++i) w[i] = v.wsqrt[(size_t)s * 81 + i];
-  imu_weight_sqrt(imu_view(v), v.frame_time[j - 1], v.frame_time[j], im[14], T1, v1, T2, b, sf, g, v.gyro_sigma, v.accel_sigma, w);
-  for (int i = 0; i < 81; ++i) v.wsqrt[(size_t)s * 81 + i] = w[i];
+  g2[0] = im[0]; g2[1] = im[1];
+  const double toff = im[14];
+  const double t_start = v.frame_time[j - 1], t_end = v.frame_time[j];
+  const ImuView buf = imu_view(v);
+  const ImuRange rg = imu_range(buf, t_start, t_end, toff);
+  if (!rg.valid) return;                       // keeps its current weight (vicalibrator.h:731-733)
+  imu_gravity(g2, gw);
+  WState sx;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sx.q[i] = T1[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { sx.p[i] = T1[4 + i]; sx.v[i] = v.vel[st][(size_t)(j - 1) * 4 + i]; }
+  for (int e = lane; e < 100; e += 64) L.Sigma[e] = 0.0;
+  wave_lds_sync();
+  const double sg2 = v.gyro_sigma * v.gyro_sigma, sa2 = v.accel_sigma * v.accel_sigma;
+  const int n_meas = (rg.k1 - rg.k0 + 1) + 2;
+  Meas<double> z0, z1;
+  imu_range_get(buf, rg, toff, t_start, t_end, 0, &z0);
+  for (int m = 1; m < n_meas; ++m) {
+    imu_range_get(buf, rg, toff, t_start, t_end, m, &z1);
+    w_step(L, &sx, z0, z1, b, sf, gw, sg2, sa2, lane);
+    z0 = z1;
+  }
+  // J = dLog_dSE3(T_pred T2^-1) dt1t2_dt1(T_pred, T2^-1), velocity identity appended (9 x 10)
+  const double qc[4] = {-T2[0], -T2[1], -T2[2], T2[3]}, nt[3] = {-T2[4], -T2[5], -T2[6]};
+  double t2w[7], rel[7], tr[3];
+  quat_rotate(qc, nt, t2w + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t2w[i] = qc[i];
+  quat_mul(sx.q, qc, rel);
+  const double nrm = sqrt(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2] + rel[3] * rel[3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rel[i] /= nrm;
+  quat_rotate(sx.q, t2w + 4, tr);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) rel[4 + i] = sx.p[i] + tr[i];
+  for (int e = lane; e < 90; e += 64) L.J[e] = 0.0;
+  wave_lds_sync();
+  if (lane == 0) {
+    double dl[42], dt12[49], J67[42], m34[12], m44[16];
+    w_dlog_dse3(rel, dl);
+#pragma unroll
+    for (int i = 0; i < 49; ++i) dt12[i] = 0.0;
+    dt12[0] = dt12[8] = dt12[16] = 1.0;
+    w_dqx_dq(sx.q, t2w + 4, m34);
+    w_dq1q2_dq1(t2w, m44);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) dt12[i * 7 + 3 + jj] = m34[i * 4 + jj];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) dt12[(3 + i) * 7 + 3 + jj] = m44[i * 4 + jj];
+    mm(dl, dt12, J67, 6, 7, 7);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 7; ++jj) L.J[i * 10 + jj] = J67[i * 7 + jj];
+    L.J[6 * 10 + 7] = L.J[7 * 10 + 8] = L.J[8 * 10 + 9] = 1.0;
+  }
+  wave_lds_sync();
+  wmm<9, 10, 10>(L.J, L.Sigma, L.tmp, lane);
+  wave_lds_sync();
+  for (int e = lane; e < 81; e += 64) {
+    const int i = e / 9, jj = e % 9;
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) acc += L.tmp[i * 10 + q] * L.J[jj * 10 + q];
+    L.P[e] = acc;
+  }
+  wave_lds_sync();
+  // Cholesky P = L L^T in place (lane 0; 9 columns), then X = L^-1 column per lane, W = X^T
+  if (lane == 0) {
+    for (int c = 0; c < 9; ++c) {
+      double d = L.P[c * 9 + c];
+      for (int k = 0; k < c; ++k) d -= L.P[c * 9 + k] * L.P[c * 9 + k];
+      const double id = (d > 0.0) ? fast_rsqrt(d) : 0.0;
+      L.P[c * 9 + c] = d * id;
+      L.tmp[c] = id;
+      for (int i = c + 1; i < 9; ++i) {
+        double a = L.P[i * 9 + c];
+        for (int k = 0; k < c; ++k) a -= L.P[i * 9 + k] * L.P[c * 9 + k];
+        L.P[i * 9 + c] = a * id;
+      }
+    }
+  }
+  wave_lds_sync();
+  bool ok = true;
+  for (int c = 0; c < 9; ++c) ok = ok && (L.tmp[c] > 0.0);
+  if (!ok) return;                              // singular projection: keep the previous weight
+  if (lane < 9) {
+    const int c = lane;                         // column c of X = L^-1
+    double x[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) x[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      double a = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) if (k < i) a -= L.P[i * 9 + k] * x[k];
+      x[i] = (i >= c) ? a * L.tmp[i] : 0.0;
+    }
+    double* w = v.wsqrt + (size_t)s * 81;       // W[a][b] = X[b][a]
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[c * 9 + i] = x[i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------ chain assembly
@@ -600,7 +853,7 @@ void launch_imu_res(const DevView& v, int sel, hipStream_t s) {
 }
 void launch_imu_weights(const DevView& v, hipStream_t s) {
   if (v.n_frames < 2) return;
-  hipLaunchKernelGGL(k_imu_weights, dim3((v.n_frames - 1 + 63) / 64), dim3(64), 0, s, v);
+  hipLaunchKernelGGL(k_imu_weights, dim3((v.n_frames - 1 + 3) / 4), dim3(256), 0, s, v);
 }
 void launch_chain_solve_a(const DevView& v, hipStream_t s) {
   const int N = v.n_frames;
