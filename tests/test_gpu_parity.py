@@ -236,6 +236,23 @@ def _compare_vi(p, cal, orc, rtol=1e-6):
     np.testing.assert_allclose(cal.GetCameraProjRMSE(), orc.rmse(), rtol=rtol)
 
 
+def test_visual_inertial_with_outlier_removal_matches_oracle():
+    """Stage machine with -remove_outliers under IMU calibration: the outliers leave the latest copy after stage D and
+    SetupProblem then re-adds every block (vicalibrator.h:641-649, :911-914, :995-1012), so they carry 4 copies against
+    the inliers' 5 in the final stage.  Per-corner multiplicity bit on the GPU vs per-observation deltas in the oracle."""
+    p = _vi_problem(48, seed=9)
+    rng = np.random.default_rng(3)
+    for k in rng.choice(len(p.tiles), 8, replace=False):
+        f, c, ids, pix = p.tiles[k]
+        pix[rng.integers(len(ids))] += rng.normal(size=2) * 10.0
+    cal = ViCalibrator(0).load_problem(p); cal.SetRemoveOutliers(True, 2.0); cal.SetMaxIters(100)
+    orc = ol.Oracle().load(p); orc.set_options(calibrate_imu=True, max_iters=100, remove_outliers=True, outlier_threshold=2.0, num_threads=8)
+    cal.Solve(); orc.solve()
+    tg = cal.trace()
+    assert tg[:, 9].max() >= 4          # a fifth stage ran after the removal
+    _compare_vi(p, cal, orc)
+
+
 def test_rotation_only_stage_matches_oracle():
     """Stages A (visual) + B (inertial, rotation only): 2x visual + 1x IMU multiplicities, block-tridiagonal chain."""
     p = _vi_problem(24)

@@ -80,7 +80,8 @@ struct vc_calibrator {
   std::vector<HostFrame> frames;
   std::vector<int> o_frame, o_cam;
   std::vector<double> o_pw, o_pc;
-  std::vector<signed char> o_removed;       // 1: removed from the latest copy by RemoveOutliers
+  std::vector<signed char> o_removed;       // RemoveOutliers: 1 = no copy left (dropped), 2 = one copy fewer than vis_mult (kObsOneLess)
+  long n_one_less = 0;
   std::vector<double> imu_w, imu_a, imu_t;
   double imu_end_time = -1.0;
   double g_dir[2] = {0, 0}, time_offset = 0, biases[6] = {0, 0, 0, 0, 0, 0}, scale[6] = {1, 1, 1, 1, 1, 1};
@@ -181,7 +182,7 @@ struct vc_calibrator {
     // ---- tiles: sort the active observations by (frame, camera) ------------------------------
     const size_t n_all = o_frame.size();
     std::vector<int> idx; idx.reserve(n_all);
-    for (size_t i = 0; i < n_all; ++i) if (!o_removed[i]) idx.push_back((int)i);
+    for (size_t i = 0; i < n_all; ++i) if (o_removed[i] != 1) idx.push_back((int)i);
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
       return o_frame[a] != o_frame[b] ? o_frame[a] < o_frame[b] : o_cam[a] < o_cam[b]; });
     h_obs_index = idx;
@@ -190,6 +191,7 @@ struct vc_calibrator {
     std::vector<double> points;
     std::vector<double2> uv(idx.size());
     std::vector<unsigned short> pt(idx.size());
+    n_one_less = 0;
     for (size_t k = 0; k < idx.size(); ++k) {
       const int i = idx[k];
       if (k == 0 || o_frame[i] != o_frame[idx[k - 1]] || o_cam[i] != o_cam[idx[k - 1]]) {
@@ -200,11 +202,12 @@ struct vc_calibrator {
       int id;
       if (it == pmap.end()) {
         id = (int)pmap.size();
-        if (id >= 65536) return VC_ERR_TOO_MANY_POINTS;
+        if (id >= kObsPointMask + 1) return VC_ERR_TOO_MANY_POINTS;
         pmap.emplace(key, id);
         points.push_back(key.x); points.push_back(key.y); points.push_back(key.z);
       } else id = it->second;
-      pt[k] = (unsigned short)id;
+      pt[k] = (unsigned short)(id | (o_removed[i] == 2 ? kObsOneLess : 0));
+      if (o_removed[i] == 2) ++n_one_less;
       uv[k] = make_double2(o_pc[2 * (size_t)i], o_pc[2 * (size_t)i + 1]);
     }
     h_tile_off.push_back((int)idx.size());
@@ -389,7 +392,7 @@ struct vc_calibrator {
   // on the device (lm_decide in vc_kernels.hip); the host enqueues passes in batches and polls Ctrl::done.
   int solve_once(Termination* term, double* final_cost, long* nres) {
     if (device_dirty) { int rc = upload(); if (rc) return rc; }
-    *nres = 2L * (long)dv.n_obs * vis_mult + (dv.imu_on ? 9L * imu_mult * std::max(0, dv.n_frames - 1) : 0L);
+    *nres = 2L * ((long)dv.n_obs * vis_mult - n_one_less) + (dv.imu_on ? 9L * imu_mult * std::max(0, dv.n_frames - 1) : 0L);
     if (trace_cap < max_iters + 8) { trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); dv.trace = d_trace.p; }
     if (!pin) HIP_OK(hipHostMalloc((void**)&pin, sizeof(Pinned), hipHostMallocDefault));
     init_ctrl(&pin->up);
@@ -470,7 +473,11 @@ struct vc_calibrator {
     if (!mask.empty()) HIP_OK(hipMemcpyAsync(mask.data(), d_mask.p, mask.size(), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
     int rc = download_state(); if (rc) return rc;
-    for (size_t k = 0; k < mask.size(); ++k) if (mask[k]) o_removed[h_obs_index[k]] = 1;
+    // The reference removes the blocks of the LATEST copy only (:911-914).  Vision-only: there is one copy, the
+    // corner is gone.  With the IMU the stage loop re-adds every block right after (SetupProblem :641-649), so
+    // an outlier ends up with one copy fewer than the inliers.
+    const signed char mark = calibrate_imu ? 2 : 1;
+    for (size_t k = 0; k < mask.size(); ++k) if (mask[k] && o_removed[h_obs_index[k]] == 0) o_removed[h_obs_index[k]] = mark;
     device_dirty = true;
     return VC_OK;
   }
@@ -507,7 +514,6 @@ struct vc_calibrator {
     while (should_run && !is_finished && guard++ < 64) {
       if (is_visual_active) vis_mult += 1;                      // SetupProblem re-adds every block (:641-649)
       if (calibrate_imu && is_inertial_active) imu_mult += 1;   // :651-655
-      if (calibrate_imu && remove_outliers) { status = VC_ERR_UNSUPPORTED; break; }   // per-copy outlier multiplicities: not built yet
       if (is_inertial_active && !rotation_only && !gravity_initialized) init_gravity();   // :927-949
       device_dirty = true;                                      // constancy flags may have changed
       bool stage_done = false;

@@ -13,6 +13,9 @@
 namespace vc {
 
 constexpr int kMaxCams = 8;
+// obs_pt[i]: bits 0..14 = index into points[], bit 15 = this corner has one residual-block copy fewer than Ctrl::mult
+// (an outlier removed from the latest copy before SetupProblem re-added every block, vicalibrator.h:641-649, :911-914)
+constexpr int kObsPointMask = 0x7fff, kObsOneLess = 0x8000;
 constexpr int kGStride = 256;      // 16x16 Gram block per tile
 constexpr int kYStride = 96;       // 6 x 16 per tile
 constexpr int kFrStride = 48;      // per frame: L(21) z(6) g(6) lam(6) 1/diag(L)(6) pad

@@ -45,22 +45,26 @@ __device__ __forceinline__ void jac_tile_body(const DevView& v, int cur, double 
   // software prefetch: the corner of the NEXT pass (detection + target point) is in flight while this pass computes
   double2 uv_n = make_double2(0.0, 0.0);
   double pw_n[3] = {0.0, 0.0, 0.0};
+  int id_n = 0;
   if (lane < cnt) {
     uv_n = v.obs_uv[off + lane];
-    const double* pp = v.points + 3 * (size_t)v.obs_pt[off + lane];
+    id_n = v.obs_pt[off + lane];
+    const double* pp = v.points + 3 * (size_t)(id_n & kObsPointMask);
     pw_n[0] = pp[0]; pw_n[1] = pp[1]; pw_n[2] = pp[2];
   }
   for (int base = 0; base < cnt; base += 64) {
     const int d = base + lane;
     const double2 uv = uv_n;
     const double pw[3] = {pw_n[0], pw_n[1], pw_n[2]};
+    const double mult_d = (id_n & kObsOneLess) ? mult - 1.0 : mult;
     if (d + 64 < cnt) {
       uv_n = v.obs_uv[off + d + 64];
-      const double* pp = v.points + 3 * (size_t)v.obs_pt[off + d + 64];
+      id_n = v.obs_pt[off + d + 64];
+      const double* pp = v.points + 3 * (size_t)(id_n & kObsPointMask);
       pw_n[0] = pp[0]; pw_n[1] = pp[1]; pw_n[2] = pp[2];
     }
     if (d < cnt) {
-      cost += corner_rows<MODEL>(x, K, pre, pw, uv.x, uv.y, mult, mine, mine + 16);
+      cost += corner_rows<MODEL>(x, K, pre, pw, uv.x, uv.y, mult_d, mine, mine + 16);
     } else {
 #pragma unroll
       for (int i = 0; i < 32; ++i) mine[i] = 0.0;
@@ -124,28 +128,29 @@ __global__ __launch_bounds__(256) void k_reproj_jac(DevView v) {
 // ------------------------------------------------------------------------------------------ residual sweeps
 template <int MODEL>
 __device__ __forceinline__ void res_tile_sweep(const DevView& v, const TileXf& x, const double* K, int off, int cnt, int lane,
-                                               double* cost_out, double* sq_out) {
+                                               double mult, double* cost_out, double* sq_out) {
   double cost = 0.0, sq = 0.0;
   ModelPre pre;
   model_precompute(MODEL, K, &pre);
   for (int d = lane; d < cnt; d += 64) {
     const double2 uv = v.obs_uv[off + d];
-    const double* pw = v.points + 3 * (size_t)v.obs_pt[off + d];
+    const int id = v.obs_pt[off + d];
+    const double* pw = v.points + 3 * (size_t)(id & kObsPointMask);
     double r[2];
-    cost += corner_residual<MODEL>(x, K, pre, pw, uv.x, uv.y, r);
+    cost += ((id & kObsOneLess) ? mult - 1.0 : mult) * corner_residual<MODEL>(x, K, pre, pw, uv.x, uv.y, r);
     sq += r[0] * r[0] + r[1] * r[1];
   }
   *cost_out = wave_sum(cost);
   *sq_out = wave_sum(sq);
 }
 __device__ __forceinline__ void res_tile_dispatch(const DevView& v, int model, const TileXf& x, const double* K, int off, int cnt,
-                                                  int lane, double* cost, double* sq) {
+                                                  int lane, double mult, double* cost, double* sq) {
   switch (model) {
-    case kFov: res_tile_sweep<kFov>(v, x, K, off, cnt, lane, cost, sq); break;
-    case kPoly2: res_tile_sweep<kPoly2>(v, x, K, off, cnt, lane, cost, sq); break;
-    case kPoly3: res_tile_sweep<kPoly3>(v, x, K, off, cnt, lane, cost, sq); break;
-    case kKb4: res_tile_sweep<kKb4>(v, x, K, off, cnt, lane, cost, sq); break;
-    default: res_tile_sweep<kLinear>(v, x, K, off, cnt, lane, cost, sq); break;
+    case kFov: res_tile_sweep<kFov>(v, x, K, off, cnt, lane, mult, cost, sq); break;
+    case kPoly2: res_tile_sweep<kPoly2>(v, x, K, off, cnt, lane, mult, cost, sq); break;
+    case kPoly3: res_tile_sweep<kPoly3>(v, x, K, off, cnt, lane, mult, cost, sq); break;
+    case kKb4: res_tile_sweep<kKb4>(v, x, K, off, cnt, lane, mult, cost, sq); break;
+    default: res_tile_sweep<kLinear>(v, x, K, off, cnt, lane, mult, cost, sq); break;
   }
 }
 // plain sweep of one state buffer (RMSE, vc_evaluate): tile_trial[t] = {mult * sum rho, sum |r|^2}
@@ -167,8 +172,8 @@ __global__ __launch_bounds__(256) void k_reproj_res(DevView v, int state, double
 #pragma unroll
   for (int i = 0; i < 8; ++i) K[i] = cam[kCamK + i];
   double cost, sq;
-  res_tile_dispatch(v, v.cd[c].model, x, K, v.tile_off[tile], v.tile_off[tile + 1] - v.tile_off[tile], lane, &cost, &sq);
-  if (lane == 0) { v.tile_trial[2 * tile] = mult * cost; v.tile_trial[2 * tile + 1] = sq; }
+  res_tile_dispatch(v, v.cd[c].model, x, K, v.tile_off[tile], v.tile_off[tile + 1] - v.tile_off[tile], lane, mult, &cost, &sq);
+  if (lane == 0) { v.tile_trial[2 * tile] = cost; v.tile_trial[2 * tile + 1] = sq; }
 }
 
 // per-corner outlier mask (RemoveOutliers, vicalibrator.h:859-916): |r| > thresh[cam]
@@ -180,7 +185,7 @@ __device__ __forceinline__ void mask_tile_body(const DevView& v, const TileXf& x
   for (int d = lane; d < cnt; d += 64) {
     const double2 uv = v.obs_uv[off + d];
     double r[2];
-    corner_residual<MODEL>(x, K, pre, v.points + 3 * (size_t)v.obs_pt[off + d], uv.x, uv.y, r);
+    corner_residual<MODEL>(x, K, pre, v.points + 3 * (size_t)(v.obs_pt[off + d] & kObsPointMask), uv.x, uv.y, r);
     mask[off + d] = sqrt(r[0] * r[0] + r[1] * r[1]) > th ? 1 : 0;
   }
 }
@@ -822,9 +827,9 @@ __global__ __launch_bounds__(256) void k_trial(DevView v) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) K[i] = camr[kCamK + i];
   double cost, sq;
-  res_tile_dispatch(v, v.cd[c].model, x, K, v.tile_off[tile], v.tile_off[tile + 1] - v.tile_off[tile], lane, &cost, &sq);
+  res_tile_dispatch(v, v.cd[c].model, x, K, v.tile_off[tile], v.tile_off[tile + 1] - v.tile_off[tile], lane, mult, &cost, &sq);
   if (lane == 0) {
-    v.tile_trial[2 * tile] = mult * cost;
+    v.tile_trial[2 * tile] = cost;
     v.tile_trial[2 * tile + 1] = sq;
     if (tile == t0) {
       double* pout = v.poses[1 - cur] + (size_t)f * kPoseStride;
