@@ -30,7 +30,7 @@ enum {
   VC_ERR_BAD_ARG = -2,        /* index out of range, null pointer, unsupported model */
   VC_ERR_RUNNING = -3,        /* setter called while the solver runs (reference: CHECK(!is_running_)) */
   VC_ERR_TIME_ORDER = -4,     /* IMU timestamps not strictly increasing (vicalibrator.h:373-378) */
-  VC_ERR_TOO_MANY_POINTS = -5,/* more than 65536 distinct target points */
+  VC_ERR_TOO_MANY_POINTS = -5,/* more than 32768 distinct target points */
   VC_ERR_NUMERIC = -6,        /* factorisation failed repeatedly */
   VC_ERR_UNSUPPORTED = -7     /* feature of the reference not available in this build */
 };
@@ -51,6 +51,13 @@ int vc_fix_camera_intrinsics(vc_calibrator* h, int should_fix);   /* FixCameraIn
 int vc_add_frame(vc_calibrator* h, const double T_wk[7], double time);
 /* GetFrame(id)->t_wp_ = ... (vicalib-task.cc:347-348) */
 int vc_set_frame_pose(vc_calibrator* h, int frame, const double T_wk[7]);
+/* Pose initialisation of the frames from their detections: replaces calibu::PosePnPRansac + the pose write at
+   vicalib-task.cc:335-348 (T_wk = T_cw^-1 * T_ck, camera 0 if it tracked the grid, otherwise the last camera that
+   did).  Deterministic planar homography + LM refinement on the current intrinsics; host code, runs once. */
+int vc_init_frame_poses_pnp(vc_calibrator* h, int* n_initialised);
+/* The same for one view, no handle: T_cw of a camera of `model`/`params` seeing n >= 4 corners of the planar grid. */
+int vc_pnp_planar(int model, const double* params, int nparams, int n, const double* p_w /* n x 3 */,
+                  const double* p_c /* n x 2 */, double T_cw[7], double* rms_px);
 /* AddObservation(frame, cam, p_w, p_c, time) :385-468, in bulk: n corners of one (frame, camera) */
 int vc_add_observations(vc_calibrator* h, int frame, int camera, int n, const double* p_w /* n x 3 */,
                         const double* p_c /* n x 2 */);

@@ -1,0 +1,113 @@
+// vicalib_amd.hpp -- C++ face of libvicalib_amd.so: the public surface of
+// visual_inertial_calibration::ViCalibrator (reference include/vicalib/vicalibrator.h:119-544) with the same
+// member names, argument order and meaning, over the C ABI of vicalib_amd.h.  Header-only, no dependencies
+// (the reference's Sophus/Calibu/Eigen types are replaced by plain aggregates with the same memory layout:
+// Se3 = Sophus::SE3d::data() = [qx qy qz qw tx ty tz]).  INTEGRATION.md shows the variant that keeps the
+// Calibu / Sophus types for a build inside the vicalib tree.
+#pragma once
+#include <vicalib_amd.h>
+
+#include <array>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace visual_inertial_calibration {
+
+struct Se3 {
+  std::array<double, 7> v{{0, 0, 0, 1, 0, 0, 0}};
+  double* data() { return v.data(); }
+  const double* data() const { return v.data(); }
+};
+
+// CameraAndPose (vicalibrator.h:65-73): the calibu camera becomes (model id, parameter vector, image size)
+struct CameraAndPose {
+  int model = VC_MODEL_POLY3;
+  std::vector<double> params;
+  int width = 0, height = 0;
+  Se3 T_ck;
+};
+struct VicalibFrame {          // vicalibrator.h:76-97
+  Se3 t_wp_;
+  std::array<double, 3> v_w_{{0, 0, 0}};
+  double time = 0;
+};
+
+class ViCalibrator {
+ public:
+  explicit ViCalibrator(int device = 0) {
+    const int rc = vc_create(&h_, device);
+    if (rc != VC_OK) throw std::runtime_error(rc == VC_ERR_NO_DEVICE ? "vicalib_amd: no HIP device (there is no CPU fallback)" : "vicalib_amd: vc_create failed");
+  }
+  ~ViCalibrator() { vc_destroy(h_); }
+  ViCalibrator(const ViCalibrator&) = delete;
+  ViCalibrator& operator=(const ViCalibrator&) = delete;
+
+  void Clear() { vc_clear(h_); }                                                         // :232
+  int AddCamera(const CameraAndPose& c) {                                               // :332
+    return vc_add_camera(h_, c.model, c.params.data(), (int)c.params.size(), c.width, c.height, c.T_ck.data());
+  }
+  void FixCameraIntrinsics(bool should_fix = true) { vc_fix_camera_intrinsics(h_, should_fix); }   // :346
+  int AddFrame(const Se3& t_wk, double time) { return vc_add_frame(h_, t_wk.data(), time); }        // :355
+  void SetFramePose(int frame, const Se3& t_wk) { vc_set_frame_pose(h_, frame, t_wk.data()); }      // GetFrame(id)->t_wp_ = ...
+  // AddObservation(frame, cam, p_w, p_c, time) :385 -- and its bulk form
+  void AddObservation(size_t frame, size_t cam, const double p_w[3], const double p_c[2], double /*time*/) {
+    vc_add_observations(h_, (int)frame, (int)cam, 1, p_w, p_c);
+  }
+  void AddObservations(size_t frame, size_t cam, int n, const double* p_w, const double* p_c) {
+    vc_add_observations(h_, (int)frame, (int)cam, n, p_w, p_c);
+  }
+  bool AddImuMeasurements(const double gyro[3], const double accel[3], double time) {    // :370
+    return vc_add_imu(h_, 1, gyro, accel, &time) == VC_OK;
+  }
+  int AddImuMeasurements(int n, const double* gyro, const double* accel, const double* time) { return vc_add_imu(h_, n, gyro, accel, time); }
+  int InitFramePosesPnP() { int n = 0; vc_init_frame_poses_pnp(h_, &n); return n; }      // vicalib-task.cc:335-348
+
+  void SetOptimizationFlags(bool bias_active, bool inertial_active, bool rotation_only, bool optimize_imu_time_offset) {   // :252
+    vc_set_optimization_flags(h_, bias_active, inertial_active, rotation_only, optimize_imu_time_offset);
+  }
+  void SetFunctionTolerance(double t) { vc_set_function_tolerance(h_, t); }              // :277
+  void SetSigmas(double gyro_sigma, double accel_sigma) { vc_set_sigmas(h_, gyro_sigma, accel_sigma); }   // :290
+  void SetTimeOffset(double t) { vc_set_time_offset(h_, t); }                            // :296
+  void SetBiases(const double b[6]) { vc_set_biases(h_, b); }                            // :301
+  void SetScaleFactor(const double s[6]) { vc_set_scale_factor(h_, s); }                 // :308
+  // gflags the reference reads inside the class
+  void SetMaxIters(int n) { vc_set_max_iters(h_, n); }
+  void SetCalibrateImu(bool b) { vc_set_calibrate_imu(h_, b); }
+  void SetRemoveOutliers(bool b, double threshold) { vc_set_remove_outliers(h_, b, threshold); }
+
+  void Start() { vc_start(h_); }                                                         // :263
+  bool IsRunning() { return vc_is_running(h_) > 0; }                                     // :314
+  void Stop() { vc_stop(h_); }                                                           // :317
+  int Solve() { return vc_solve(h_); }                                                   // Start() + join
+
+  size_t NumFrames() { return (size_t)vc_num_frames(h_); }                               // :471
+  size_t NumCameras() { return (size_t)vc_num_cameras(h_); }                             // :484
+  double time_offset() { return vc_time_offset(h_); }                                    // :474
+  double MeanSquaredError() { return vc_mean_squared_error(h_); }                        // :506
+  unsigned GetNumIterations() { return vc_get_num_iterations(h_); }                      // :283
+  std::vector<double> GetCameraProjRMSE() { std::vector<double> r(NumCameras()); vc_get_camera_proj_rmse(h_, r.data()); return r; }   // :160
+  std::array<double, 6> GetBiases() { std::array<double, 6> b; vc_get_biases(h_, b.data()); return b; }              // :286
+  std::array<double, 6> GetScaleFactor() { std::array<double, 6> s; vc_get_scale_factor(h_, s.data()); return s; }   // :306
+  std::array<double, 2> GetGravity() { std::array<double, 2> g; vc_get_gravity(h_, g.data()); return g; }
+  CameraAndPose GetCamera(size_t id) {                                                   // :492
+    CameraAndPose c;
+    c.params.resize(16);
+    int n = 0;
+    if (vc_get_camera(h_, (int)id, c.params.data(), &n, c.T_ck.data()) != VC_OK) throw std::out_of_range("GetCamera");
+    c.params.resize(n);
+    return c;
+  }
+  VicalibFrame GetFrame(size_t id) {                                                     // :477
+    VicalibFrame f;
+    if (vc_get_frame(h_, (int)id, f.t_wp_.data(), f.v_w_.data(), &f.time) != VC_OK) throw std::out_of_range("GetFrame");
+    return f;
+  }
+  void WriteCameraModels(const std::string& filename) { vc_write_camera_models(h_, filename.c_str()); }   // :208
+  vc_calibrator* handle() { return h_; }
+
+ private:
+  vc_calibrator* h_ = nullptr;
+};
+
+}  // namespace visual_inertial_calibration

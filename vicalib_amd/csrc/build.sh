@@ -7,3 +7,8 @@ OUT="$HERE/../libvicalib_amd.so"
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
   -o "$OUT" "$HERE/vc_kernels.hip" "$HERE/vc_imu_kernels.hip" "$HERE/vc_calibrator.cpp" "$@"
 echo "built $OUT"
+# the command-line tool (host C++ over the C ABI only): vicalib_amd/vicalib
+CXX=${CXX:-g++}
+$CXX -O2 -std=c++17 -Wall -I"$HERE/../../include" -o "$HERE/../vicalib" "$HERE/../../apps/vicalib.cpp" \
+  -L"$HERE/.." -lvicalib_amd -Wl,-rpath,'$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib -pthread
+echo "built $HERE/../vicalib"

@@ -25,6 +25,7 @@
 #include "../../include/vicalib_amd.h"
 #include "vc_device.h"
 #include "vc_math.hpp"
+#include "vc_pnp.hpp"
 
 using namespace vc;
 
@@ -598,6 +599,49 @@ int vc_set_frame_pose(vc_calibrator* h, int frame, const double T_wk[7]) {
   NOT_RUNNING(h);
   if (!T_wk || frame < 0 || frame >= (int)h->frames.size()) return VC_ERR_BAD_ARG;
   std::memcpy(h->frames[frame].T, T_wk, 56); h->device_dirty = true;
+  return VC_OK;
+}
+int vc_pnp_planar(int model, const double* params, int nparams, int n, const double* p_w, const double* p_c, double T_cw[7], double* rms) {
+  if (!params || !p_w || !p_c || !T_cw || model_nk(model) < 0 || nparams != model_nk(model)) return VC_ERR_BAD_ARG;
+  return pnp_planar(model, params, n, p_w, p_c, T_cw, rms) ? VC_OK : VC_ERR_BAD_ARG;
+}
+int vc_init_frame_poses_pnp(vc_calibrator* h, int* n_initialised) {
+  NOT_RUNNING(h);
+  const int N = (int)h->frames.size(), C = (int)h->cams.size();
+  // group the observation indices per (frame, camera)
+  std::vector<std::vector<int>> view((size_t)N * std::max(C, 1));
+  for (size_t i = 0; i < h->o_frame.size(); ++i) view[(size_t)h->o_frame[i] * C + h->o_cam[i]].push_back((int)i);
+  int done = 0;
+  std::vector<double> pw, pc;
+  for (int f = 0; f < N; ++f) {
+    bool cam0_good = false, any = false;
+    for (int c = 0; c < C; ++c) {
+      const std::vector<int>& ids = view[(size_t)f * C + c];
+      if (ids.size() < 4) continue;
+      if (c != 0 && cam0_good) break;           // `ii == 0 || !tracking_good_[0]` (vicalib-task.cc:341)
+      pw.resize(3 * ids.size()); pc.resize(2 * ids.size());
+      for (size_t k = 0; k < ids.size(); ++k) {
+        std::memcpy(&pw[3 * k], &h->o_pw[3 * (size_t)ids[k]], 24); std::memcpy(&pc[2 * k], &h->o_pc[2 * (size_t)ids[k]], 16);
+      }
+      const HostCam& cm = h->cams[c];
+      double T_cw[7], rms;
+      if (!pnp_planar(cm.model, cm.K, (int)ids.size(), pw.data(), pc.data(), T_cw, &rms)) continue;
+      // T_wk = T_cw^-1 * T_ck  (vicalib-task.cc:344-348)
+      const double qi[4] = {-T_cw[0], -T_cw[1], -T_cw[2], T_cw[3]};
+      double ti[3], tr[3], T[7];
+      const double nt[3] = {-T_cw[4], -T_cw[5], -T_cw[6]};
+      quat_rotate(qi, nt, ti);
+      quat_mul(qi, cm.T_ck, T);
+      quat_rotate(qi, cm.T_ck + 4, tr);
+      for (int k = 0; k < 3; ++k) T[4 + k] = ti[k] + tr[k];
+      std::memcpy(h->frames[f].T, T, 56);
+      any = true;
+      if (c == 0) cam0_good = true;
+    }
+    if (any) ++done;
+  }
+  if (n_initialised) *n_initialised = done;
+  h->device_dirty = true;
   return VC_OK;
 }
 int vc_add_observations(vc_calibrator* h, int frame, int camera, int n, const double* p_w, const double* p_c) {

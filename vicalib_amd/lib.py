@@ -29,11 +29,24 @@ SYMBOLS = [
     "vc_get_biases", "vc_get_scale_factor", "vc_get_gravity", "vc_time_offset", "vc_mean_squared_error", "vc_get_camera_proj_rmse",
     "vc_get_num_iterations", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
     "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
+    "vc_init_frame_poses_pnp", "vc_pnp_planar",
 ]
 
 
 class VicalibError(RuntimeError):
     pass
+
+
+def pnp_planar(model, params, p_w, p_c):
+    """T_cw and RMS reprojection error (pixels) of one view of the planar grid (vc_pnp_planar; host code, needs no GPU)."""
+    L = load()
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    p_w = np.ascontiguousarray(p_w, dtype=np.float64); p_c = np.ascontiguousarray(p_c, dtype=np.float64)
+    T = np.zeros(7); rms = C.c_double(0)
+    from .synth import MODEL_IDS
+    m = MODEL_IDS[model] if isinstance(model, str) else int(model)
+    _check(L.vc_pnp_planar(m, _d(params), len(params), len(p_w), _d(p_w), _d(p_c), _d(T), C.byref(rms)), "pnp_planar")
+    return T, rms.value
 
 
 def load():
@@ -93,6 +106,12 @@ class ViCalibrator:
 
     def SetFramePose(self, frame, T_wk):
         _check(self.L.vc_set_frame_pose(self.h, int(frame), _d(T_wk)), "SetFramePose")
+
+    def InitFramePosesPnP(self):
+        """calibu::PosePnPRansac + the pose write of vicalib-task.cc:335-348; returns the number of frames initialised."""
+        n = C.c_int(0)
+        _check(self.L.vc_init_frame_poses_pnp(self.h, C.byref(n)), "InitFramePosesPnP")
+        return n.value
 
     def AddObservations(self, frame, camera, p_w, p_c):
         p_w = np.ascontiguousarray(p_w, dtype=np.float64); p_c = np.ascontiguousarray(p_c, dtype=np.float64)

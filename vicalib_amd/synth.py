@@ -331,3 +331,29 @@ def flatten(prob: Problem):
     pw = prob.grid_points[ids]
     pc = np.concatenate([t[3] for t in prob.tiles]) if prob.tiles else np.zeros((0, 2))
     return tf, tc, off, np.ascontiguousarray(pw), np.ascontiguousarray(pc)
+
+
+def write_dataset(prob, directory):
+    """Write `prob` as the files the command-line tool reads: one detections CSV per camera
+    (`frame,dot_id,u,v,X,Y,Z,time` -- the -output_conics line of vicalib-task.cc:313-317 plus a time column) and,
+    with an IMU, HAL's csv:// layout (accel.txt, gyro.txt, timestamp.txt).  Returns (cam_files, imu_dir or None)."""
+    import os
+    os.makedirs(directory, exist_ok=True)
+    n_cam = len(prob.cam_model)
+    files = [os.path.join(directory, "cam%d.csv" % c) for c in range(n_cam)]
+    handles = [open(f, "w") for f in files]
+    for (f, c, ids, pix) in prob.tiles:
+        P = prob.grid_points[ids]
+        t = prob.frame_time[f]
+        for k in range(len(ids)):
+            handles[c].write("%d,%d,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g\n" % (f, ids[k], pix[k, 0], pix[k, 1], P[k, 0], P[k, 1], P[k, 2], t))
+    for h in handles:
+        h.close()
+    imu_dir = None
+    if prob.imu_t is not None:
+        imu_dir = os.path.join(directory, "imu")
+        os.makedirs(imu_dir, exist_ok=True)
+        np.savetxt(os.path.join(imu_dir, "accel.txt"), prob.imu_accel, fmt="%.17g", delimiter=",")
+        np.savetxt(os.path.join(imu_dir, "gyro.txt"), prob.imu_gyro, fmt="%.17g", delimiter=",")
+        np.savetxt(os.path.join(imu_dir, "timestamp.txt"), np.stack([prob.imu_t, prob.imu_t], axis=1), fmt="%.17g", delimiter=",")
+    return files, imu_dir
