@@ -72,5 +72,55 @@ def main(mode):
     print("rank", rank, "ok")
 
 
+def load_slice(cal, prob, lo, hi):
+    """Frames [lo, hi) of `prob` with their observations; the whole IMU stream (a shard needs the samples up to the next
+    shard's first frame)."""
+    for c, m in enumerate(prob.cam_model):
+        cal.AddCamera(m, prob.cam_K_init[c], prob.cam_T_ck_init[c], prob.cfg.width, prob.cfg.height)
+    for n in range(lo, hi):
+        cal.AddFrame(prob.frame_T_wk_init[n], prob.frame_time[n])
+    for (f, c, ids, pix) in prob.tiles:
+        if lo <= f < hi:
+            cal.AddObservations(f - lo, c, prob.grid_points[ids], pix)
+    cal.AddImuMeasurements(prob.imu_gyro, prob.imu_accel, prob.imu_t)
+    return cal
+
+
+def main_imu():
+    """Frame-sharded visual-inertial calibration: separators in the reduced system, interior chains per rank."""
+    from vicalib_amd.lib import ViCalibrator
+    rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_total = 80
+    full = synth.generate(synth.Config(models=("kb4",), n_frames=n_total, imu=True, seed=5))
+    lo, hi = frame_shard(n_total, rank, world)
+    cal = load_slice(ViCalibrator(0), full, lo, hi); cal.SetMaxIters(100)
+    comm = FrameShardComm(device="cuda:0", stream_ptr=cal.stream())
+    cal.set_shard(rank, world, comm)
+    cal.Solve()
+    ref = ViCalibrator(0).load_problem(full); ref.SetMaxIters(100); ref.Solve()
+    tg = cal.trace(); tr = ref.trace()
+    np.set_printoptions(linewidth=200)
+    assert len(tg) == len(tr), (tg[:, [0, 1, 8, 9]], tr[:, [0, 1, 8, 9]])
+    np.testing.assert_allclose(tg[:, 1], tr[:, 1], rtol=1e-7)
+    np.testing.assert_array_equal(tg[:, 8], tr[:, 8])
+    np.testing.assert_allclose(cal.GetCamera(0)[0], ref.GetCamera(0)[0], rtol=1e-7)
+    np.testing.assert_allclose(cal.GetCamera(0)[1], ref.GetCamera(0)[1], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(cal.GetFrames(), ref.GetFrames()[lo:hi], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(cal.GetVelocities(), ref.GetVelocities()[lo:hi], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(cal.GetBiases(), ref.GetBiases(), rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(cal.GetScaleFactor(), ref.GetScaleFactor(), rtol=1e-7)
+    np.testing.assert_allclose(cal.GetGravity(), ref.GetGravity(), rtol=1e-7, atol=1e-10)
+    assert abs(cal.time_offset() - ref.time_offset()) < 1e-9
+    np.testing.assert_allclose(cal.GetCameraProjRMSE(), ref.GetCameraProjRMSE(), rtol=1e-7)
+    assert abs(cal.MeanSquaredError() - ref.MeanSquaredError()) <= 1e-7 * abs(ref.MeanSquaredError())
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if sys.argv[1] == "gpu_imu":
+        main_imu()
+    else:
+        main(sys.argv[1])

@@ -110,6 +110,8 @@ struct vc_calibrator {
   std::mutex result_mutex;
   // ---- sharding ---------------------------------------------------------------------------
   int rank = 0, world = 1;
+  DBuf<double> d_halo, d_sep_strip;
+  long global_first = 0, global_total = 0;     // this rank's frame range in the sharded problem (known after gather_shard_info)
   vc_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
   // ---- device -----------------------------------------------------------------------------
@@ -176,10 +178,50 @@ struct vc_calibrator {
   bool imu_on() const { return calibrate_imu && is_inertial_active; }
   int imu_param_col[15];
 
+  // sum a small host vector over the ranks through the caller's device all-reduce
+  int host_allreduce_sum(std::vector<double>& v) {
+    if (world <= 1) return VC_OK;
+    HIP_OK(d_halo.upload(v, stream));
+    int rc = do_allreduce(d_halo.p, (int)v.size(), 0); if (rc) return rc;
+    HIP_OK(hipMemcpyAsync(v.data(), d_halo.p, v.size() * 8, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    return VC_OK;
+  }
+  // every rank's first frame (pose, velocity, time) and frame count: slot r of the gathered table
+  int gather_shard_info(std::vector<double>* table) {
+    table->assign((size_t)world * 12, 0.0);
+    if (!frames.empty()) {
+      double* o = table->data() + (size_t)rank * 12;
+      std::memcpy(o, frames[0].T, 56); std::memcpy(o + 7, frames[0].v, 24); o[10] = frames[0].time;
+    }
+    (*table)[(size_t)rank * 12 + 11] = (double)frames.size();
+    int rc = host_allreduce_sum(*table); if (rc) return rc;
+    global_first = 0; global_total = 0;
+    for (int r = 0; r < world; ++r) { if (r < rank) global_first += (long)(*table)[(size_t)r * 12 + 11]; global_total += (long)(*table)[(size_t)r * 12 + 11]; }
+    return VC_OK;
+  }
+
   int upload() {
     HIP_OK(hipSetDevice(device));
-    const int N = (int)frames.size(), C = (int)cams.size();
+    const int Nown = (int)frames.size(), C = (int)cams.size();
     if (C > kMaxCams) return VC_ERR_UNSUPPORTED;
+    // ---- frame-sharded IMU chain: this rank's first frame is a separator of the reduced system (rank > 0) and the
+    // next rank's separator is kept here as a ghost frame (the IMU block that ends in it is ours)
+    const bool shard_imu = world > 1 && imu_on();
+    bool ghost = false;
+    HostFrame ghost_frame{};
+    if (shard_imu) {
+      if (Nown < 2) return VC_ERR_BAD_ARG;
+      std::vector<double> table;
+      int rc = gather_shard_info(&table); if (rc) return rc;
+      if (rank + 1 < world) {
+        const double* o = table.data() + (size_t)(rank + 1) * 12;
+        std::memcpy(ghost_frame.T, o, 56); std::memcpy(ghost_frame.v, o + 7, 24); ghost_frame.time = o[10];
+        ghost = true;
+      }
+    }
+    const int N = Nown + (ghost ? 1 : 0);
+    auto frame_at = [&](int f) -> const HostFrame& { return f < Nown ? frames[f] : ghost_frame; };
     // ---- tiles: sort the active observations by (frame, camera) ------------------------------
     const size_t n_all = o_frame.size();
     std::vector<int> idx; idx.reserve(n_all);
@@ -220,7 +262,10 @@ struct vc_calibrator {
       for (int t2 = 0; t2 < T; ++t2) frame_cam_tile[(size_t)h_tile_frame[t2] * C + h_tile_cam[t2]] = t2;
     }
     std::vector<int> col_cam, col_local, cam_model(C);
-    const int D = build_layout(col_cam, col_local);
+    const int D0 = build_layout(col_cam, col_local);
+    const int D = D0 + (shard_imu ? 9 * (world - 1) : 0);          // + one 9-column separator per shard boundary
+    col_cam.resize(D, -1); col_local.resize(D, 0);
+    if (((size_t)(D + 1) * (D + 1) + 2 * (D + 1)) * sizeof(double) > 160 * 1024 || D + 1 > 12 * 16) return VC_ERR_UNSUPPORTED;   // reduced solve lives in LDS
     for (int c = 0; c < C; ++c) cam_model[c] = cams[c].model;
     // ---- upload ---------------------------------------------------------------------------------
     HIP_OK(d_uv.upload(uv, stream)); HIP_OK(d_pt.upload(pt, stream)); HIP_OK(d_points.upload(points, stream));
@@ -230,7 +275,7 @@ struct vc_calibrator {
     HIP_OK(d_cam_flags.upload(cam_flags, stream)); HIP_OK(d_cam_col0.upload(cam_col0, stream));
     HIP_OK(d_col_cam.upload(col_cam, stream)); HIP_OK(d_col_local.upload(col_local, stream));
     std::vector<double> poses((size_t)N * kPoseStride, 0.0), camrec((size_t)C * kCamStride, 0.0);
-    for (int f = 0; f < N; ++f) std::memcpy(&poses[(size_t)f * kPoseStride], frames[f].T, 56);
+    for (int f = 0; f < N; ++f) std::memcpy(&poses[(size_t)f * kPoseStride], frame_at(f).T, 56);
     for (int c = 0; c < C; ++c) {
       std::memcpy(&camrec[(size_t)c * kCamStride], cams[c].T_ck, 56);
       std::memcpy(&camrec[(size_t)c * kCamStride + kCamK], cams[c].K, cams[c].nk * 8);
@@ -273,7 +318,7 @@ struct vc_calibrator {
     HIP_OK(d_pose_init.upload(poses, stream)); HIP_OK(d_cam_init.upload(camrec, stream));
     // ---- inertial terms ------------------------------------------------------------------------------
     std::vector<double> vels((size_t)std::max(N, 1) * 4, 0.0), imus(16, 0.0), ftime(std::max(N, 1), 0.0);
-    for (int f = 0; f < N; ++f) { std::memcpy(&vels[(size_t)f * 4], frames[f].v, 24); ftime[f] = frames[f].time; }
+    for (int f = 0; f < N; ++f) { std::memcpy(&vels[(size_t)f * 4], frame_at(f).v, 24); ftime[f] = frame_at(f).time; }
     imus[0] = g_dir[0]; imus[1] = g_dir[1];
     for (int i = 0; i < 6; ++i) { imus[2 + i] = biases[i]; imus[8 + i] = scale[i]; }
     imus[14] = time_offset;
@@ -286,6 +331,9 @@ struct vc_calibrator {
     dv.gyro_sigma = gyro_sigma; dv.accel_sigma = accel_sigma;
     for (int a = 0; a < 15; ++a) dv.imu_param_col[a] = imu_param_col[a];
     dv.ldw = (((D + 1 + 15) / 16) * 16 % 32 == 0) ? ((D + 1 + 15) / 16) * 16 + 16 : ((D + 1 + 15) / 16) * 16;
+    dv.pin_first = (shard_imu && rank > 0) ? 1 : 0; dv.pin_last = ghost ? 1 : 0;
+    dv.sep_col0 = D0 + 9 * (rank - 1); dv.sep_col1 = D0 + 9 * rank;
+    HIP_OK(d_sep_strip.alloc((size_t)2 * 9 * dv.ldw)); dv.sep_strip = d_sep_strip.p;
     if (dv.imu_on) {
       HIP_OK(d_imu_t.upload(imu_t, stream)); HIP_OK(d_imu_w.upload(imu_w, stream)); HIP_OK(d_imu_a.upload(imu_a, stream));
       const size_t ns = (size_t)std::max(N - 1, 1);
@@ -346,17 +394,30 @@ struct vc_calibrator {
   int enqueue_pass() {
     const int D = dv.D;
     if (dv.imu_on) {
-      if (world > 1) return VC_ERR_UNSUPPORTED;      // frame-sharded IMU chain: separator handling not built yet
       launch_reproj_jac(dv, stream);
       launch_imu_jac(dv, stream);
       launch_imu_weights(dv, stream);                // iteration callback's UpdateImuWeights (vicalibrator.h:691)
       launch_chain_solve_a(dv, stream);
       launch_part_sum(dv, stream);
-      launch_reduced(dv, 0, stream);
+      int rc = VC_OK;
+      if (world > 1) {
+        launch_reduced(dv, 1, stream);
+        rc = do_allreduce(dv.Sbuf, D * D + 3 * D + 2, 0); if (rc) return rc;
+        launch_reduced(dv, 2, stream);
+      } else {
+        launch_reduced(dv, 0, stream);
+      }
       launch_chain_solve_b(dv, stream);
       launch_reproj_res(dv, 3, 0.0, stream);
       launch_imu_res(dv, 3, stream);
-      launch_final(dv, 0, stream);
+      if (world > 1) {
+        launch_final(dv, 1, stream);
+        rc = do_allreduce(dv.scal, 6, 0); if (rc) return rc;
+        rc = do_allreduce(dv.scal + kScGmax, 1, 1); if (rc) return rc;
+        launch_final(dv, 2, stream);
+      } else {
+        launch_final(dv, 0, stream);
+      }
       return VC_OK;
     }
     launch_reproj_jac(dv, stream);
@@ -394,6 +455,7 @@ struct vc_calibrator {
   int solve_once(Termination* term, double* final_cost, long* nres) {
     if (device_dirty) { int rc = upload(); if (rc) return rc; }
     *nres = 2L * ((long)dv.n_obs * vis_mult - n_one_less) + (dv.imu_on ? 9L * imu_mult * std::max(0, dv.n_frames - 1) : 0L);
+    if (world > 1) { std::vector<double> v = {(double)*nres}; int rc = host_allreduce_sum(v); if (rc) return rc; *nres = (long)v[0]; }
     if (trace_cap < max_iters + 8) { trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); dv.trace = d_trace.p; }
     if (!pin) HIP_OK(hipHostMalloc((void**)&pin, sizeof(Pinned), hipHostMallocDefault));
     init_ctrl(&pin->up);
@@ -484,28 +546,44 @@ struct vc_calibrator {
   }
 
   // Gravity initialisation, vicalibrator.h:927-949: accel at the middle frame's time (offset 0), rotated into the world
-  void init_gravity() {
+  int init_gravity() {
     const int N = (int)frames.size(), n = (int)imu_t.size();
     gravity_initialized = true;
-    if (N == 0 || n == 0) return;
-    const HostFrame& fr = frames[N / 2];
-    double a[3];
-    const double time = fr.time;
-    if (imu_t[0] > time) { for (int k = 0; k < 3; ++k) a[k] = imu_a[k]; }
-    else if (imu_t[n - 1] <= time || n < 2) { for (int k = 0; k < 3; ++k) a[k] = imu_a[3 * (size_t)(n - 1) + k]; }
-    else {
-      int lo = 0, hi = n - 1;
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (imu_t[mid] <= time) lo = mid; else hi = mid; }
-      const double f = (time - imu_t[lo]) / (imu_t[lo + 1] - imu_t[lo]);
-      for (int k = 0; k < 3; ++k) a[k] = imu_a[3 * (size_t)lo + k] * (1.0 - f) + imu_a[3 * (size_t)(lo + 1) + k] * f;
+    // the middle frame of the WHOLE problem; when the frames are sharded its owner computes, everybody receives
+    long mid = N / 2; bool mine = true;
+    if (world > 1) {
+      std::vector<double> table;
+      int rc = gather_shard_info(&table); if (rc) return rc;
+      mid = global_total / 2 - global_first;
+      mine = mid >= 0 && mid < N;
     }
-    const double nrm = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-    const double gb[3] = {a[0] / nrm, a[1] / nrm, a[2] / nrm};
-    double gw[3];
-    quat_rotate(fr.T, gb, gw);
-    const double p = std::asin(gw[1]);
-    const double q = std::asin(-gw[0] / std::cos(p));
-    g_dir[0] = p; g_dir[1] = q;
+    double g[2] = {0.0, 0.0};
+    if (mine && N > 0 && n > 0) {
+      const HostFrame& fr = frames[mid];
+      double a[3];
+      const double time = fr.time;
+      if (imu_t[0] > time) { for (int k = 0; k < 3; ++k) a[k] = imu_a[k]; }
+      else if (imu_t[n - 1] <= time || n < 2) { for (int k = 0; k < 3; ++k) a[k] = imu_a[3 * (size_t)(n - 1) + k]; }
+      else {
+        int lo = 0, hi = n - 1;
+        while (hi - lo > 1) { const int m2 = (lo + hi) >> 1; if (imu_t[m2] <= time) lo = m2; else hi = m2; }
+        const double f = (time - imu_t[lo]) / (imu_t[lo + 1] - imu_t[lo]);
+        for (int k = 0; k < 3; ++k) a[k] = imu_a[3 * (size_t)lo + k] * (1.0 - f) + imu_a[3 * (size_t)(lo + 1) + k] * f;
+      }
+      const double nrm = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+      const double gb[3] = {a[0] / nrm, a[1] / nrm, a[2] / nrm};
+      double gw[3];
+      quat_rotate(fr.T, gb, gw);
+      g[0] = std::asin(gw[1]);
+      g[1] = std::asin(-gw[0] / std::cos(g[0]));
+    }
+    if (world > 1) {
+      std::vector<double> v = {g[0], g[1]};
+      int rc = host_allreduce_sum(v); if (rc) return rc;
+      g[0] = v[0]; g[1] = v[1];
+    } else if (!(N > 0 && n > 0)) return VC_OK;
+    g_dir[0] = g[0]; g_dir[1] = g[1];
+    return VC_OK;
   }
 
   // SolveThread, vicalibrator.h:919-1040
@@ -515,7 +593,7 @@ struct vc_calibrator {
     while (should_run && !is_finished && guard++ < 64) {
       if (is_visual_active) vis_mult += 1;                      // SetupProblem re-adds every block (:641-649)
       if (calibrate_imu && is_inertial_active) imu_mult += 1;   // :651-655
-      if (is_inertial_active && !rotation_only && !gravity_initialized) init_gravity();   // :927-949
+      if (is_inertial_active && !rotation_only && !gravity_initialized) { status = init_gravity(); if (status) break; }   // :927-949
       device_dirty = true;                                      // constancy flags may have changed
       bool stage_done = false;
       int inner = 0;

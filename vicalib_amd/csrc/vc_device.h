@@ -114,6 +114,12 @@ struct DevView {
   double* cdiag;                   // n_frames x 9
   double* cscale2;                 // n_frames x 9
   int ldw;
+  // frame sharding of the IMU chain: the first frame of every rank but rank 0 is a *separator* -- its 9 unknowns live in
+  // the reduced system (columns sep_col0..+8) instead of the chain, so the interior chains of the ranks are independent.
+  // pin_first: local frame 0 is this rank's separator; pin_last: local frame n_frames-1 is a copy ("ghost") of the next
+  // rank's separator (columns sep_col1..+8), kept here because the IMU block that ends in it belongs to this rank.
+  int pin_first, pin_last, sep_col0, sep_col1;
+  double* sep_strip;               // 2 x 9 x ldw: rows of the reduced system contributed directly by the pinned frames
 };
 
 // launchers (vc_kernels.hip); all asynchronous on `s`

@@ -423,7 +423,12 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
     if (f >= f1) continue;
     const int t0 = v.frame_tile_off[f], nt = v.frame_tile_off[f + 1] - t0;
     double* Wf = v.cW + (size_t)f * 9 * ldw;
-    for (int i = lane; i < 9 * ldw; i += 64) Wf[i] = 0.0;
+    // pinned frames (separator / ghost, see DevView): their rows go to sep_strip, the chain sees an isolated identity block
+    const bool pin_f = (f == 0 && v.pin_first), pin_l = (f == N - 1 && v.pin_last), pin_self = pin_f || pin_l;
+    const bool pin_prev = (f == 1 && v.pin_first), pin_next = (f + 1 == N - 1 && v.pin_last);
+    double* Wt = pin_self ? v.sep_strip + (size_t)(pin_f ? 0 : 1) * 9 * ldw : Wf;
+    const int sep_self = pin_f ? v.sep_col0 : v.sep_col1;
+    for (int i = lane; i < 9 * ldw; i += 64) { Wf[i] = 0.0; if (pin_self) Wt[i] = 0.0; }
     if (lane < 42) Hs[lane] = 0.0;
     wave_lds_sync();
     if (nt > 0) {
@@ -487,8 +492,8 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
           const int col = v.cd[c].col0 + j;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            Wf[i * ldw + col] = -(Rm[i] * u[0] + Rm[3 + i] * u[1] + Rm[6 + i] * u[2]);
-            Wf[(3 + i) * ldw + col] = Rm[i] * u[3] + Rm[3 + i] * u[4] + Rm[6 + i] * u[5];
+            Wt[i * ldw + col] = -(Rm[i] * u[0] + Rm[3 + i] * u[1] + Rm[6 + i] * u[2]);
+            Wt[(3 + i) * ldw + col] = Rm[i] * u[3] + Rm[3 + i] * u[4] + Rm[6 + i] * u[5];
           }
         }
       }
@@ -508,7 +513,11 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
         if (Hc) a += Hc[i * 33 + j];
         if (Hp) a += Hp[(9 + i) * 33 + 9 + j];
         aval[q] = a;
-        v.cB[(size_t)f * 81 + e] = Hp ? Hp[(9 + i) * 33 + j] : 0.0;     // rows: this frame (prev of block f), cols: frame f+1 (cur)
+        // rows: this frame (prev of block f), cols: frame f+1 (cur); a pinned end cuts the chain and couples through
+        // the separator's columns of the border instead
+        v.cB[(size_t)f * 81 + e] = (Hp && !pin_self && !pin_next) ? Hp[(9 + i) * 33 + j] : 0.0;
+        if (pin_prev && Hc) Wf[i * ldw + v.sep_col0 + j] = Hc[i * 33 + 9 + j];
+        if (pin_next && Hp) Wf[i * ldw + v.sep_col1 + j] = Hp[(9 + i) * 33 + j];
       }
     }
     double gval = 0.0;
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
         double w = 0.0;
         if (Hc) w += Hc[i * 33 + 18 + a];
         if (Hp) w += Hp[(9 + i) * 33 + 18 + a];
-        Wf[i * ldw + col] = w;
+        Wt[i * ldw + col] = w;
       }
     }
     // IMU shared block of block f-1 (every block counted once, by its "cur" frame)
@@ -549,10 +558,10 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
       double sc2, dg;
       if (init_scale) { sc2 = jacobi_scale2(hd); v.cscale2[(size_t)f * 9 + lane] = sc2; } else sc2 = v.cscale2[(size_t)f * 9 + lane];
       if (!reuse) { dg = lm_clamped_diag(hd, sc2); v.cdiag[(size_t)f * 9 + lane] = dg; } else dg = v.cdiag[(size_t)f * 9 + lane];
-      lam = dg / (radius * sc2);
+      lam = pin_self ? 0.0 : dg / (radius * sc2);
       v.clam[(size_t)f * 9 + lane] = lam;
-      v.cg[(size_t)f * 9 + lane] = gval;
-      Wf[lane * ldw + D] = gval;                // right-hand side rides as column D
+      v.cg[(size_t)f * 9 + lane] = pin_self ? 0.0 : gval;
+      Wt[lane * ldw + D] = gval;                // right-hand side rides as column D
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -562,6 +571,7 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
         double a = aval[q];
         const double li = __shfl(lam, i, 64);
         if (i == j) a += li;
+        if (pin_self) { Wt[i * ldw + sep_self + j] = aval[q]; a = (i == j) ? 1.0 : 0.0; }
         v.cA[(size_t)f * 81 + e] = a;
       }
     }
@@ -767,49 +777,56 @@ __global__ __launch_bounds__(256) void k_chain_gram(DevView v) {
   const int nT = (D + 1 + 15) / 16, nPairs = nT * (nT + 1) / 2;
   const int chunk = blockIdx.x;
   const int f0 = chunk * v.chunk_frames, f1 = min(f0 + v.chunk_frames, N);
-  v4d acc[kMaxPairsPerWaveI];
+  double* part = v.part + (size_t)chunk * v.part_stride;
+  // column-tile pairs are processed in batches of 36 (9 accumulators per wavefront); more than 8 column tiles
+  // (D + 1 > 128) re-reads the chunk's rows once per batch
+  for (int pb = 0; pb < nPairs; pb += 4 * kMaxPairsPerWaveI) {
+    const int pe = min(nPairs, pb + 4 * kMaxPairsPerWaveI);
+    int Ib = 0, Jb = 0;
+    for (int p = 0; p < pb; ++p) if (++Jb == nT) { ++Ib; Jb = Ib; }
+    v4d acc[kMaxPairsPerWaveI];
 #pragma unroll
-  for (int i = 0; i < kMaxPairsPerWaveI; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
-  for (int fg = f0; fg < f1; fg += 4) {
-    const int nf = min(4, f1 - fg);
-    for (int i = tid; i < 36 * ld; i += 256) {
-      const int row = i / ld;
-      R[i] = (row < nf * 9) ? v.cW[(size_t)fg * 9 * ld + i] : 0.0;
+    for (int i = 0; i < kMaxPairsPerWaveI; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int fg = f0; fg < f1; fg += 4) {
+      const int nf = min(4, f1 - fg);
+      for (int i = tid; i < 36 * ld; i += 256) {
+        const int row = i / ld;
+        R[i] = (row < nf * 9) ? v.cW[(size_t)fg * 9 * ld + i] : 0.0;
+      }
+      __syncthreads();
+      int I = Ib, J = Jb, pi = 0;
+      for (int p = pb; p < pe; ++p) {
+        if ((p & 3) == wave) {
+          const double* ra = R + (lane >> 4) * ld + I * 16 + (lane & 15);
+          const double* rb = R + (lane >> 4) * ld + J * 16 + (lane & 15);
+          v4d a4 = acc[0];
+#pragma unroll
+          for (int q = 0; q < kMaxPairsPerWaveI; ++q) a4 = (q == pi) ? acc[q] : a4;
+#pragma unroll
+          for (int ks = 0; ks < 9; ++ks) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[ks * 4 * ld], rb[ks * 4 * ld], a4, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < kMaxPairsPerWaveI; ++q) acc[q] = (q == pi) ? a4 : acc[q];
+          ++pi;
+        }
+        if (++J == nT) { ++I; J = I; }
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    int I = 0, J = 0, pi = 0;
-    for (int p = 0; p < nPairs; ++p) {
+    int I = Ib, J = Jb, pi = 0;
+    for (int p = pb; p < pe; ++p) {
       if ((p & 3) == wave) {
-        const double* ra = R + (lane >> 4) * ld + I * 16 + (lane & 15);
-        const double* rb = R + (lane >> 4) * ld + J * 16 + (lane & 15);
         v4d a4 = acc[0];
 #pragma unroll
         for (int q = 0; q < kMaxPairsPerWaveI; ++q) a4 = (q == pi) ? acc[q] : a4;
 #pragma unroll
-        for (int ks = 0; ks < 9; ++ks) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[ks * 4 * ld], rb[ks * 4 * ld], a4, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < kMaxPairsPerWaveI; ++q) acc[q] = (q == pi) ? a4 : acc[q];
+        for (int g = 0; g < 4; ++g) {
+          const int row = I * 16 + (lane >> 4) + 4 * g, col = J * 16 + (lane & 15);
+          if (row < D) { if (col < D) part[row * D + col] = a4[g]; else if (col == D) part[D * D + row] = a4[g]; }
+        }
         ++pi;
       }
       if (++J == nT) { ++I; J = I; }
     }
-    __syncthreads();
-  }
-  double* part = v.part + (size_t)chunk * v.part_stride;
-  int I = 0, J = 0, pi = 0;
-  for (int p = 0; p < nPairs; ++p) {
-    if ((p & 3) == wave) {
-      v4d a4 = acc[0];
-#pragma unroll
-      for (int q = 0; q < kMaxPairsPerWaveI; ++q) a4 = (q == pi) ? acc[q] : a4;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int row = I * 16 + (lane >> 4) + 4 * g, col = J * 16 + (lane & 15);
-        if (row < D) { if (col < D) part[row * D + col] = a4[g]; else if (col == D) part[D * D + row] = a4[g]; }
-      }
-      ++pi;
-    }
-    if (++J == nT) { ++I; J = I; }
   }
 }
 
@@ -820,7 +837,10 @@ __global__ __launch_bounds__(64) void k_frame_update(DevView v) {
   const int f = blockIdx.x * 64 + threadIdx.x;
   if (f >= v.n_frames) return;
   const int cur = ct->cur;
-  const double* d = v.cdelta + (size_t)f * 9;
+  // pinned frames step with the reduced system's solution; their gradient / damping terms are counted there, and only the
+  // owner (not the rank that holds the ghost copy) counts the step and parameter norms
+  const bool pin_f = (f == 0 && v.pin_first), pin_l = (f == v.n_frames - 1 && v.pin_last);
+  const double* d = pin_f ? v.delta_s + v.sep_col0 : pin_l ? v.delta_s + v.sep_col1 : v.cdelta + (size_t)f * 9;
   const double* pin = v.poses[cur] + (size_t)f * kPoseStride;
   double* pout = v.poses[1 - cur] + (size_t)f * kPoseStride;
   double Tin[7], Tout[7], dd[6];
@@ -838,6 +858,8 @@ __global__ __launch_bounds__(64) void k_frame_update(DevView v) {
     const double gi = v.cg[(size_t)f * 9 + i];
     gd += gi * d[i]; dld += v.clam[(size_t)f * 9 + i] * d[i] * d[i]; g2 += gi * gi; gmax = fmax(gmax, fabs(gi));
   }
+  if (pin_f || pin_l) { gd = 0; dld = 0; g2 = 0; gmax = 0; }
+  if (pin_l) { step2 = 0; x2 = 0; }
   double* o = v.fpart + (size_t)f * kNumScal;
   o[kScGd] = gd; o[kScDld] = dld; o[kScStep2] = step2; o[kScX2] = x2; o[kScG2] = g2; o[kScCost] = 0.0; o[kScGmax] = gmax; o[kScSq] = 0.0;
 }

@@ -545,6 +545,20 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
       }
     }
     __syncthreads();
+    // rows of the pinned frames (separator of this rank, ghost of the next rank's): straight into the reduced system
+    for (int slot = 0; slot < 2; ++slot) {
+      if (!(slot ? v.pin_last : v.pin_first)) continue;
+      const int sc = slot ? v.sep_col1 : v.sep_col0;
+      const double* st = v.sep_strip + (size_t)slot * 9 * v.ldw;
+      for (int e = tid; e < 9 * (D + 1); e += 256) {
+        const int i = e / (D + 1), col = e % (D + 1);
+        const double val = st[i * v.ldw + col];
+        if (col == D) { gred[sc + i] += val; gs[sc + i] += val; }
+        else if (col < sc) S[col * D + sc + i] += val;                       // upper triangle: (col, sc + i)
+        else if (col >= sc + i) { S[(sc + i) * D + col] += val; if (col == sc + i) hd[sc + i] += val; }
+      }
+      __syncthreads();
+    }
   }
   for (int e = tid; e < D * D; e += 256) {
     const int i = e / D, j = e % D;
