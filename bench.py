@@ -21,6 +21,9 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+# HBM bytes per launch at the default workload, measured with rocprofv3 --pmc (profiles/r01_v5_pmc_traffic_cfg2.txt)
+PMC_TRAFFIC = {"k_trial": 6656655.0, "k_reproj_res": 3345152.0}
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -92,21 +95,29 @@ def main():
     rmse = [float(x) for x in cal2.GetCameraProjRMSE()]
 
     # ---- kernel-level roofline of the dominant kernel (HIP events on the calibrator's stream) --------
-    jac_ms, res_ms = cal.time_kernels(50)
+    # Vision-only passes evaluate the Jacobian sweep at the trial point inside k_trial (one projection sweep per LM
+    # iteration): k_trial<true> = back-substitution of the tile's frame + manifold update + Jacobian/Gram sweep of the tile.
+    stages = cal.time_stages(50)                 # us per launch, each stage launched 50x back to back
+    trial_ms = stages["trial"] * 1e-3
+    jac_ms, res_ms = cal.time_kernels(50)        # stand-alone sweeps: k_reproj_jac (first pass of a solve), k_reproj_res (RMSE)
     n_tiles = cal.num_tiles()
     kc = 5   # fov
-    # 18 B/corner + per tile [64 B in + 8*(21 + 6 + 6*S_c + 1) B out], S_c = 6 + K_c
+    # 18 B/corner + per tile [64 B in + 8*(21 + 6 + 6*S_c + 1) B out], S_c = 6 + K_c; the fused kernel also
+    # reads the frame factor (48 doubles / frame) and Y (6 x 16 doubles / tile) for the back-substitution
     bytes_jac = 18.0 * n_obs_local + n_tiles * (64 + 8 * (28 + 6 * (6 + kc)))
+    bytes_trial = bytes_jac + n_tiles * 8 * 96 + len(prob.frame_time) * 8 * 48
     bytes_res = 18.0 * n_obs_local + n_tiles * (64 + 8)
     flops_jac = 1050.0 * n_obs_local          # ~1.0-1.1 kflop per corner (fp64)
-    ach = flops_jac / (jac_ms * 1e-3) / 1e12
+    ach = flops_jac / (trial_ms * 1e-3) / 1e12
     # traffic: HBM bytes per launch from rocprofv3 PMC passes on this exact workload (FETCH_SIZE and WRITE_SIZE in
-    # separate runs, KB -> bytes, FETCH x2 per the gfx950 note in MI355X_MICROARCH.md): profiles/r01_pmc_traffic_cfg2.txt
-    traffic_jac = 5426190.0 if (args.frames == 500 and world == 1) else None
-    traffic_res = 3355397.0 if (args.frames == 500 and world == 1) else None
-    roofline = {"kernel": "k_reproj_jac", "bound": "mfma", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6,
-                "traffic": traffic_jac, "hbm_gbs": bytes_jac / (jac_ms * 1e-3) / 1e9, "hbm_frac": bytes_jac / (jac_ms * 1e-3) / 8e12,
-                "avg_ms": jac_ms, "algorithmic_bytes": bytes_jac, "algorithmic_flops": flops_jac}
+    # separate runs, KB -> bytes, FETCH x2 per the gfx950 note in MI355X_MICROARCH.md): profiles/r01_v5_pmc_traffic_cfg2.txt
+    base_cfg = (args.frames == 500 and world == 1)
+    traffic_trial = PMC_TRAFFIC.get("k_trial") if base_cfg else None
+    traffic_res = PMC_TRAFFIC.get("k_reproj_res") if base_cfg else None
+    roofline = {"kernel": "k_trial<fused Jacobian sweep>", "bound": "mfma", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6,
+                "traffic": traffic_trial, "hbm_gbs": bytes_trial / (trial_ms * 1e-3) / 1e9, "hbm_frac": bytes_trial / (trial_ms * 1e-3) / 8e12,
+                "avg_ms": trial_ms, "algorithmic_bytes": bytes_trial, "algorithmic_flops": flops_jac,
+                "standalone_jacobian_sweep_ms": jac_ms, "stage_us": stages}
     roofline_res = {"kernel": "k_reproj_res", "bound": "hbm", "achieved": bytes_res / (res_ms * 1e-3) / 1e9, "peak": 8000.0,
                     "unit": "GB/s", "frac": bytes_res / (res_ms * 1e-3) / 8e12, "traffic": traffic_res, "avg_ms": res_ms,
                     "algorithmic_bytes": bytes_res}

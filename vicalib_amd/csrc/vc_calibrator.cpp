@@ -110,7 +110,7 @@ struct vc_calibrator {
   std::mutex result_mutex;
   // ---- sharding ---------------------------------------------------------------------------
   int rank = 0, world = 1;
-  DBuf<double> d_halo, d_sep_strip;
+  DBuf<double> d_halo, d_sep_strip, d_gath;
   long global_first = 0, global_total = 0;     // this rank's frame range in the sharded problem (known after gather_shard_info)
   vc_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
@@ -121,7 +121,7 @@ struct vc_calibrator {
   DBuf<double2> d_uv; DBuf<unsigned short> d_pt; DBuf<double> d_points;
   DBuf<int> d_tile_frame, d_tile_cam, d_tile_off, d_frame_tile_off, d_frame_cam_tile, d_cam_model, d_cam_flags, d_cam_col0,
       d_col_cam, d_col_local, d_flags;
-  DBuf<double> d_pose[2], d_cam[2], d_G, d_tile_cost, d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_sdiag,
+  DBuf<double> d_pose[2], d_cam[2], d_G[2], d_tile_cost[2], d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_sdiag,
       d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total;
   DBuf<Ctrl> d_ctrl;
   DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt, d_segH, d_segg, d_seg_cost, d_seg_trial,
@@ -286,7 +286,7 @@ struct vc_calibrator {
     const int chunk_frames = std::max(4, (((N + 2047) / 2048) + 3) / 4 * 4);
     const int n_chunks = std::max(1, (N + chunk_frames - 1) / chunk_frames);
     const int part_stride = D * D + D + C * kGStride + (imu_on() ? kGStride : 0);
-    HIP_OK(d_G.alloc((size_t)std::max(T, 1) * kGStride)); HIP_OK(d_tile_cost.alloc(std::max(T, 1))); HIP_OK(d_tile_trial.alloc((size_t)std::max(T, 1) * 2));
+    for (int b = 0; b < 2; ++b) { HIP_OK(d_G[b].alloc((size_t)std::max(T, 1) * kGStride)); HIP_OK(d_tile_cost[b].alloc(std::max(T, 1))); } HIP_OK(d_tile_trial.alloc((size_t)std::max(T, 1) * 2));
     HIP_OK(d_Y.alloc((size_t)std::max(T, 1) * kYStride)); HIP_OK(d_fr.alloc((size_t)std::max(N, 1) * kFrStride));
     HIP_OK(d_fdiag.alloc((size_t)std::max(N, 1) * 6)); HIP_OK(d_fscale2.alloc((size_t)std::max(N, 1) * 6));
     HIP_OK(d_part.alloc((size_t)n_chunks * part_stride)); HIP_OK(d_part_total.alloc((size_t)part_stride * ((n_chunks + 63) / 64))); HIP_OK(d_Sbuf.alloc((size_t)D * D + 3 * D + 2));
@@ -310,7 +310,9 @@ struct vc_calibrator {
     dv.cam_model = d_cam_model.p; dv.cam_flags = d_cam_flags.p; dv.cam_col0 = d_cam_col0.p;
     dv.col_cam = d_col_cam.p; dv.col_local = d_col_local.p;
     dv.poses[0] = d_pose[0].p; dv.poses[1] = d_pose[1].p; dv.cams[0] = d_cam[0].p; dv.cams[1] = d_cam[1].p;
-    dv.G = d_G.p; dv.tile_cost = d_tile_cost.p; dv.tile_trial = d_tile_trial.p; dv.Y = d_Y.p; dv.fr = d_fr.p;
+    for (int b = 0; b < 2; ++b) { dv.Gb[b] = d_G[b].p; dv.tile_costb[b] = d_tile_cost[b].p; }
+    dv.fused = imu_on() ? 0 : 1;
+ dv.tile_trial = d_tile_trial.p; dv.Y = d_Y.p; dv.fr = d_fr.p;
     dv.fdiag = d_fdiag.p; dv.fscale2 = d_fscale2.p; dv.part = d_part.p; dv.part_total = d_part_total.p; dv.Sbuf = d_Sbuf.p;
     dv.sdiag = d_sdiag.p; dv.sscale2 = d_sscale2.p; dv.slam = d_slam.p; dv.delta_s = d_delta_s.p;
     dv.fpart = d_fpart.p; dv.scal = d_scal.p; dv.flags = d_flags.p;
@@ -334,6 +336,7 @@ struct vc_calibrator {
     dv.pin_first = (shard_imu && rank > 0) ? 1 : 0; dv.pin_last = ghost ? 1 : 0;
     dv.sep_col0 = D0 + 9 * (rank - 1); dv.sep_col1 = D0 + 9 * rank;
     HIP_OK(d_sep_strip.alloc((size_t)2 * 9 * dv.ldw)); dv.sep_strip = d_sep_strip.p;
+    HIP_OK(d_gath.alloc((size_t)world * kNumScal)); dv.gath = d_gath.p; dv.rank = rank; dv.world = world;
     if (dv.imu_on) {
       HIP_OK(d_imu_t.upload(imu_t, stream)); HIP_OK(d_imu_w.upload(imu_w, stream)); HIP_OK(d_imu_a.upload(imu_a, stream));
       const size_t ns = (size_t)std::max(N - 1, 1);
@@ -391,7 +394,8 @@ struct vc_calibrator {
     if (world > 1 && allreduce) { if (allreduce(allreduce_ctx, p, n, op) != 0) return VC_ERR_NO_DEVICE; }
     return VC_OK;
   }
-  int enqueue_pass() {
+  // first_pass: the pass right after init_ctrl (the only one that needs k_reproj_jac when k_trial carries the sweep)
+  int enqueue_pass(bool first_pass = true) {
     const int D = dv.D;
     if (dv.imu_on) {
       launch_reproj_jac(dv, stream);
@@ -412,15 +416,14 @@ struct vc_calibrator {
       launch_imu_res(dv, 3, stream);
       if (world > 1) {
         launch_final(dv, 1, stream);
-        rc = do_allreduce(dv.scal, 6, 0); if (rc) return rc;
-        rc = do_allreduce(dv.scal + kScGmax, 1, 1); if (rc) return rc;
+        rc = do_allreduce(dv.gath, world * kNumScal, 0); if (rc) return rc;
         launch_final(dv, 2, stream);
       } else {
         launch_final(dv, 0, stream);
       }
       return VC_OK;
     }
-    launch_reproj_jac(dv, stream);
+    if (first_pass || !dv.fused) launch_reproj_jac(dv, stream);
     launch_frame_schur(dv, stream);
     int rc = VC_OK;
     if (world > 1) {
@@ -433,8 +436,7 @@ struct vc_calibrator {
     launch_trial(dv, stream);
     if (world > 1) {
       launch_final(dv, 1, stream);
-      rc = do_allreduce(dv.scal, 6, 0); if (rc) return rc;
-      rc = do_allreduce(dv.scal + kScGmax, 1, 1); if (rc) return rc;
+      rc = do_allreduce(dv.gath, world * kNumScal, 0); if (rc) return rc;
       launch_final(dv, 2, stream);
     } else {
       launch_final(dv, 0, stream);
@@ -463,10 +465,10 @@ struct vc_calibrator {
     if (dv.imu_on) launch_imu_weights(dv, stream);     // UpdateImuWeights() before ceres::Solve (vicalibrator.h:955)
     // First batch = what the previous solve needed (repeated solves of similar problems: no wasted launches,
     // one host sync per solve); then small top-up batches until the device reports `done`.
-    int batch = std::max(1, std::min(expected_passes, max_iters + 1)), guard = 0;
+    int batch = std::max(1, std::min(expected_passes, max_iters + 1)), guard = 0, n_enq = 0;
     const size_t trace_bytes = (size_t)std::min(trace_cap, 64) * kTraceCols * 8;
     while (true) {
-      for (int b = 0; b < batch; ++b) { int rc = enqueue_pass(); if (rc) return rc; }
+      for (int b = 0; b < batch; ++b) { int rc = enqueue_pass(n_enq++ == 0); if (rc) return rc; }
       HIP_OK(hipMemcpyAsync(&pin->down, d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
       HIP_OK(hipMemcpyAsync(pin->trace, d_trace.p, trace_bytes, hipMemcpyDeviceToHost, stream));
       HIP_OK(hipStreamSynchronize(stream));

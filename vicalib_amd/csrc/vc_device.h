@@ -63,8 +63,12 @@ struct DevView {
   const int* col_local;            // D: column inside the camera's tile block
   double* poses[2];                // state double buffer
   double* cams[2];
-  double* G;                       // n_tiles x 256
-  double* tile_cost;               // n_tiles   (Jacobian sweep: cost at the linearisation point)
+  // Linearisation of the vision terms, double-buffered like the state: Gb[b] / tile_costb[b] belong to state buffer b.
+  // Vision-only passes evaluate the Jacobian sweep AT THE TRIAL POINT inside k_trial (one projection sweep per LM
+  // iteration instead of two); accepting the step flips `cur` and the linearisation is already there.
+  double* Gb[2];                   // n_tiles x 256
+  double* tile_costb[2];           // n_tiles   (Jacobian sweep: cost at the linearisation point)
+  int fused;                       // 1: k_trial produces Gb[1-cur] (vision-only passes); 0: k_reproj_jac at the start of a pass
   double* tile_trial;              // n_tiles x 2: trial cost, sum of squared residuals
   double* Y;                       // n_tiles x 96
   double* fr;                      // n_frames x 40
@@ -119,6 +123,8 @@ struct DevView {
   // pin_first: local frame 0 is this rank's separator; pin_last: local frame n_frames-1 is a copy ("ghost") of the next
   // rank's separator (columns sep_col1..+8), kept here because the IMU block that ends in it belongs to this rank.
   int pin_first, pin_last, sep_col0, sep_col1;
+  int rank, world;                 // frame sharding: this process's rank, number of ranks
+  double* gath;                    // world x kNumScal: every rank's step scalars (one all-reduce(SUM) of disjoint slots = all-gather)
   double* sep_strip;               // 2 x 9 x ldw: rows of the reduced system contributed directly by the pinned frames
 };
 

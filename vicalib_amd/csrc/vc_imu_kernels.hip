@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
     if (nt > 0) {
       for (int m = 0; m < nt * 4; ++m) {
         const int t = m >> 2, q = m & 3;
-        const double val = v.G[(size_t)(t0 + t) * kGStride + q * 64 + lane];
+        const double val = v.Gb[cur][(size_t)(t0 + t) * kGStride + q * 64 + lane];
         Gw[t * kGStride + q * 64 + lane] = val;
         const int c = v.tile_cam[t0 + t];
 #pragma unroll

@@ -27,11 +27,9 @@ namespace vc {
 
 // ------------------------------------------------------------------------------------------ Jacobian sweep
 template <int MODEL>
-__device__ __forceinline__ void jac_tile_body(const DevView& v, int cur, double mult, int tile, int lane, double* wl) {
-  const int f = v.tile_frame[tile], c = v.tile_cam[tile];
+__device__ __forceinline__ double jac_tile_body(const DevView& v, const double* pose, const double* cam, double mult, int tile, int lane,
+                                                double* wl, double* G) {
   const int off = v.tile_off[tile], cnt = v.tile_off[tile + 1] - off;
-  const double* pose = v.poses[cur] + (size_t)f * kPoseStride;
-  const double* cam = v.cams[cur] + (size_t)c * kCamStride;
   TileXf x;
   make_tile_xf(pose, cam, &x);
   double K[8];
@@ -99,11 +97,19 @@ __device__ __forceinline__ void jac_tile_body(const DevView& v, int cur, double 
     }
     wave_lds_sync();
   }
-  double* G = v.G + (size_t)tile * kGStride;
 #pragma unroll
   for (int i = 0; i < 4; ++i) G[((lane >> 4) + 4 * i) * 16 + (lane & 15)] = acc0[i] + acc1[i];
-  cost = wave_sum(cost);
-  if (lane == 0) v.tile_cost[tile] = cost;
+  return wave_sum(cost);          // valid in lane 0
+}
+__device__ __forceinline__ double jac_tile_dispatch(const DevView& v, int model, const double* pose, const double* cam, double mult, int tile,
+                                                    int lane, double* wl, double* G) {
+  switch (model) {   // wave-uniform
+    case kFov: return jac_tile_body<kFov>(v, pose, cam, mult, tile, lane, wl, G);
+    case kPoly2: return jac_tile_body<kPoly2>(v, pose, cam, mult, tile, lane, wl, G);
+    case kPoly3: return jac_tile_body<kPoly3>(v, pose, cam, mult, tile, lane, wl, G);
+    case kKb4: return jac_tile_body<kKb4>(v, pose, cam, mult, tile, lane, wl, G);
+    default: return jac_tile_body<kLinear>(v, pose, cam, mult, tile, lane, wl, G);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_reproj_jac(DevView v) {
@@ -115,14 +121,10 @@ __global__ __launch_bounds__(256) void k_reproj_jac(DevView v) {
   if (tile >= v.n_tiles) return;
   double* wl = lds + wave * 64 * kDotStride;
   const int cur = ct->cur;
-  const double mult = ct->mult;
-  switch (v.cd[v.tile_cam[tile]].model) {   // wave-uniform
-    case kFov: jac_tile_body<kFov>(v, cur, mult, tile, lane, wl); break;
-    case kPoly2: jac_tile_body<kPoly2>(v, cur, mult, tile, lane, wl); break;
-    case kPoly3: jac_tile_body<kPoly3>(v, cur, mult, tile, lane, wl); break;
-    case kKb4: jac_tile_body<kKb4>(v, cur, mult, tile, lane, wl); break;
-    default: jac_tile_body<kLinear>(v, cur, mult, tile, lane, wl); break;
-  }
+  const int f = v.tile_frame[tile], c = v.tile_cam[tile];
+  const double cost = jac_tile_dispatch(v, v.cd[c].model, v.poses[cur] + (size_t)f * kPoseStride, v.cams[cur] + (size_t)c * kCamStride, ct->mult,
+                                        tile, lane, wl, v.Gb[cur] + (size_t)tile * kGStride);
+  if (lane == 0) v.tile_costb[cur][tile] = cost;
 }
 
 // ------------------------------------------------------------------------------------------ residual sweeps
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
       for (int t = 0; t < nt; ++t) {           // full 16x16 Gram block of every tile of the frame
         double val[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) val[q] = v.G[(size_t)(t0 + t) * kGStride + q * 64 + lane];
+        for (int q = 0; q < 4; ++q) val[q] = v.Gb[cur][(size_t)(t0 + t) * kGStride + q * 64 + lane];
 #pragma unroll
         for (int q = 0; q < 4; ++q) Gw[t * kGStride + q * 64 + lane] = val[q];
         const int c = v.tile_cam[t0 + t];      // wave-uniform: scalar branch, one camera's accumulators touched
@@ -482,7 +484,7 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
   {
     double s = 0.0;
 #pragma unroll 4
-    for (int t = tid; t < v.n_tiles; t += 256) s += v.tile_cost[t];
+    for (int t = tid; t < v.n_tiles; t += 256) s += v.tile_costb[cur][t];
     if (v.imu_on) for (int t = tid; t < v.n_frames - 1; t += 256) s += v.seg_cost[t];
     L.red[tid] = s;
   }
@@ -597,24 +599,22 @@ __device__ void solve_small_wave(const DevView& v, const Ctrl* ct, int lane, dou
   }
 #pragma unroll
   for (int k = 0; k < DMAX; ++k) row[k] += (k == lane) ? lam : 0.0;
+  // Every loop below is fully unrolled (j, k compile-time): register indices are static, pivots and pivot columns travel
+  // as scalars through v_readlane -- no LDS round trip and no select chains inside the dependent chain.  Columns >= D
+  // only ever hold zeros (or, for column D, unused values), so the inner loop needs no bound on k.
   bool bad = false;
-  for (int j = 0; j < D; ++j) {
-    double mine = 0.0;
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) mine = (k == j) ? row[k] : mine;
-    double d = readlane_f64(mine, j);
-    if (!(d > 0.0)) { bad = true; d = 1.0; }
-    const double ipiv = fast_rsqrt(d);
-    const double lij = (lane == j) ? d * ipiv : mine * ipiv;
-    if (lane >= j && lane <= D) Lt[j * ldt + lane] = lij;          // column j of L, contiguous over the rows
-    wave_lds_sync();
-    double colv[DMAX];
+  for (int j = 0; j < DMAX; ++j) {
+    if (j < D) {
+      const double mine = row[j];
+      double d = readlane_f64(mine, j);
+      if (!(d > 0.0)) { bad = true; d = 1.0; }
+      const double ipiv = fast_rsqrt(d);
+      const double lij = (lane == j) ? d * ipiv : mine * ipiv;
+      row[j] = lij;
+      if (lane >= j && lane <= D) Lt[j * ldt + lane] = lij;          // column j of L, contiguous over the rows
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) colv[k] = Lt[j * ldt + k];
-#pragma unroll
-    for (int k = 0; k < DMAX; ++k) {
-      const bool upd = (k > j) && (k <= lane) && (k < D);
-      row[k] = upd ? row[k] - lij * colv[k] : ((k == j) ? lij : row[k]);
+      for (int k = j + 1; k < DMAX; ++k) row[k] -= lij * readlane_f64(lij, k);
     }
   }
   if (bad && lane == 0) v.flags[1] = 1;
@@ -624,17 +624,15 @@ __device__ void solve_small_wave(const DevView& v, const Ctrl* ct, int lane, dou
 #pragma unroll
   for (int j = 0; j < DMAX; ++j) c[j] = (j < D && lane < D && j >= lane) ? Lt[lane * ldt + j] : 0.0;
   double s = (lane < D) ? -Lt[lane * ldt + D] : 0.0;
-  double dinv = 1.0;
-#pragma unroll
-  for (int j = 0; j < DMAX; ++j) dinv = (j == lane && j < D) ? 1.0 / c[j] : dinv;
+  const double dinv = (lane < D) ? 1.0 / Lt[lane * ldt + lane] : 1.0;
   double mine = 0.0;
-  for (int j = D - 1; j >= 0; --j) {
-    const double xj = readlane_f64(s * dinv, j);
-    double cj = 0.0;
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) cj = (k == j) ? c[k] : cj;
-    if (lane == j) mine = xj;
-    if (lane < j) s -= cj * xj;
+  for (int j = DMAX - 1; j >= 0; --j) {
+    if (j < D) {
+      const double xj = readlane_f64(s * dinv, j);
+      if (lane == j) mine = xj;
+      s -= c[j] * xj;              // c[j] = 0 for j < lane; lane j's own s is not needed any more
+    }
   }
   if (lane < D) x[lane] = mine;
 }
@@ -781,15 +779,9 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
 // One wavefront per tile: delta_p = -L^-T (z + sum_tiles Y delta_s) (lanes = (tile, column), butterfly sum),
 // T_trial = T exp(delta_p), residual sweep of the tile at the trial state.  The first tile of a frame
 // also publishes the frame's trial pose and its step terms.
-__global__ __launch_bounds__(256) void k_trial(DevView v) {
-  __shared__ double ds_s[kMaxCams * 16 + 16];     // delta_s of the workgroup's cameras is read many times: keep it in LDS
-  const Ctrl* ct = v.ctrl;
-  if (ct->done) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + wave;
-  for (int i = threadIdx.x; i < v.D; i += 256) if (i < kMaxCams * 16 + 16) ds_s[i] = v.delta_s[i];
-  __syncthreads();
-  if (tile >= v.n_tiles) return;
+__device__ void final_phase(const DevView& v, int mode, double* red /* 7 x 256 */);
+template <bool FUSED>
+__device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int tile, int wave, int lane, const double* ds_s, double* lds_rows) {
   const int cur = ct->cur;
   const double mult = ct->mult;
   const int f = v.tile_frame[tile], c = v.tile_cam[tile];
@@ -835,13 +827,21 @@ __global__ __launch_bounds__(256) void k_trial(DevView v) {
   for (int i = 0; i < 6; ++i) d[i] = -y[i];
   double Tout[7];
   se3_plus(Tin, d, Tout);
-  TileXf x;
-  make_tile_xf(Tout, camr, &x);
-  double K[8];
+  double cost, sq = 0.0;
+  if (FUSED) {
+    // Jacobian sweep at the trial point: its cost is the trial cost, its Gram block is the next linearisation if the
+    // step is accepted (k_final flips `cur`); a rejected step leaves Gb[cur] untouched
+    cost = jac_tile_dispatch(v, v.cd[c].model, Tout, camr, mult, tile, lane, lds_rows + wave * 64 * kDotStride,
+                             v.Gb[1 - cur] + (size_t)tile * kGStride);
+    if (lane == 0) v.tile_costb[1 - cur][tile] = cost;
+  } else {
+    TileXf x;
+    make_tile_xf(Tout, camr, &x);
+    double K[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) K[i] = camr[kCamK + i];
-  double cost, sq;
-  res_tile_dispatch(v, v.cd[c].model, x, K, v.tile_off[tile], v.tile_off[tile + 1] - v.tile_off[tile], lane, mult, &cost, &sq);
+    for (int i = 0; i < 8; ++i) K[i] = camr[kCamK + i];
+    res_tile_dispatch(v, v.cd[c].model, x, K, v.tile_off[tile], v.tile_off[tile + 1] - v.tile_off[tile], lane, mult, &cost, &sq);
+  }
   if (lane == 0) {
     v.tile_trial[2 * tile] = cost;
     v.tile_trial[2 * tile + 1] = sq;
@@ -860,6 +860,21 @@ __global__ __launch_bounds__(256) void k_trial(DevView v) {
       o[kScGd] = gd; o[kScDld] = dld; o[kScStep2] = step2; o[kScX2] = x2; o[kScG2] = g2; o[kScCost] = 0.0; o[kScGmax] = gmax; o[kScSq] = 0.0;
     }
   }
+}
+// (Tried and dropped: letting the last workgroup to finish run the final phase.  Device-scope release/acquire fences are
+// expensive on this part -- every XCD has its own L2, so each fence writes back / invalidates L2 -- and cost 25 us at
+// 250 workgroups; the kernel boundary does the same flush once.)
+template <bool FUSED>
+__global__ __launch_bounds__(256, 2) void k_trial(DevView v) {
+  extern __shared__ __attribute__((aligned(16))) double lds_rows[];   // fused Jacobian sweep: 4 x 64 x kDotStride row images
+  __shared__ double ds_s[kMaxCams * 16 + 16];     // delta_s of the workgroup's cameras is read many times: keep it in LDS
+  const Ctrl* ct = v.ctrl;
+  if (ct->done) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + wave;
+  for (int i = threadIdx.x; i < v.D; i += 256) if (i < kMaxCams * 16 + 16) ds_s[i] = v.delta_s[i];
+  __syncthreads();
+  if (tile < v.n_tiles) trial_tile<FUSED>(v, ct, tile, wave, lane, ds_s, lds_rows);
 }
 
 // ------------------------------------------------------------------------------------------ decision
@@ -885,8 +900,8 @@ __device__ void lm_decide_local(const DevView& v, Ctrl* c) {
   const bool fail = (v.flags[0] != 0) || (v.flags[1] != 0);
   v.flags[0] = 0; v.flags[1] = 0;
   c->passes += 1;
-  c->res_sweeps += 1;
-  if (c->need_lin) c->jac_sweeps += 1;
+  c->res_sweeps += v.fused ? 0 : 1;
+  c->jac_sweeps += (c->need_lin ? 1 : 0) + (v.fused ? 1 : 0);
   if (c->hold) { c->cost = R_cost; c->gmax = R_gmax; c->gnorm = R_gnorm; return; }
   if (c->pending) {            // the pass linearised at the newly accepted point
     c->cost = R_cost; c->gmax = R_gmax; c->gnorm = R_gnorm;
@@ -931,7 +946,7 @@ __device__ void lm_decide_local(const DevView& v, Ctrl* c) {
     c->decrease_factor = 2.0;
     rec[7] = c->radius; rec[8] = 1.0;
     for (int i = 0; i < kTraceCols; ++i) c->pend[i] = rec[i];
-    c->pending = 1; c->need_lin = 1; c->reuse_diag = 0;
+    c->pending = 1; c->need_lin = v.fused ? 0 : 1; c->reuse_diag = 0;
   } else {
     c->radius = c->radius / c->decrease_factor; c->decrease_factor *= 2.0;
     rec[7] = c->radius;
@@ -947,9 +962,7 @@ __device__ void lm_decide(const DevView& v) {
   *v.ctrl = local;
 }
 // mode 0: reduce + decide, 1: reduce only (an all-reduce follows), 2: decide only
-__global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
-  __shared__ double red[256 * 7];
-  if (v.ctrl->done) return;
+__device__ void final_phase(const DevView& v, int mode, double* red) {
   const int tid = threadIdx.x;
   if (mode != 2) {
     double s[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -973,9 +986,27 @@ __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
       double* o = v.scal;
       o[kScGd] = red[0]; o[kScDld] = red[256]; o[kScStep2] = red[512]; o[kScX2] = red[768]; o[kScG2] = red[1024];
       o[kScCost] = 0.5 * red[1280]; o[kScGmax] = red[1536]; o[kScSq] = 0.0;
+      if (mode == 1) {       // sharded: publish this rank's terms (and its numeric-failure flags) in its slot of the gather table
+        for (int r = 0; r < v.world; ++r)
+          for (int k = 0; k < kNumScal; ++k) v.gath[r * kNumScal + k] = (r == v.rank) ? (k == kScSq ? (double)(v.flags[0] + v.flags[1]) : o[k]) : 0.0;
+      }
     }
   }
+  if (mode == 2 && tid == 0) {   // after the all-reduce: combine the ranks in fixed order, identically everywhere
+    double* o = v.scal;
+    for (int k = 0; k < kNumScal; ++k) {
+      double a = 0.0;
+      for (int r = 0; r < v.world; ++r) a = (k == kScGmax) ? fmax(a, v.gath[r * kNumScal + k]) : a + v.gath[r * kNumScal + k];
+      o[k] = a;
+    }
+    v.flags[0] = (o[kScSq] > 0.0) ? 1 : 0; v.flags[1] = 0;
+  }
   if (mode != 1 && tid == 0) lm_decide(v);
+}
+__global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
+  __shared__ double red[256 * 7];
+  if (v.ctrl->done) return;
+  final_phase(v, mode, red);
 }
 
 // both state buffers <- the uploaded initial state (benchmark restarts), one launch
@@ -1048,7 +1079,11 @@ void launch_reduced(const DevView& v, int mode, hipStream_t s) {
 }
 void launch_trial(const DevView& v, hipStream_t s) {
   if (v.n_tiles == 0) return;
-  hipLaunchKernelGGL(k_trial, dim3(tiles_grid(v)), dim3(256), 0, s, v);
+  const size_t lds = v.fused ? 4 * 64 * kDotStride * sizeof(double) : 0;
+  static bool granted = false;
+  if (lds > 0 && !granted) { (void)hipFuncSetAttribute((const void*)k_trial<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 4096)); granted = true; }
+  if (v.fused) hipLaunchKernelGGL(k_trial<true>, dim3(tiles_grid(v)), dim3(256), lds, s, v);
+  else hipLaunchKernelGGL(k_trial<false>, dim3(tiles_grid(v)), dim3(256), 0, s, v);
 }
 void launch_final(const DevView& v, int mode, hipStream_t s) {
   hipLaunchKernelGGL(k_final, dim3(1), dim3(256), 0, s, v, mode);
