@@ -26,79 +26,141 @@
 namespace vc {
 
 // ------------------------------------------------------------------------------------------ Jacobian sweep
+// One wavefront sweeps one tile.  Per pass of 64 corners: lane = corner computes its two unique-column rows into the
+// wave-private LDS image; the Gram block G += u^T u then accumulates on the matrix pipe, four rows (two corners) per step.
+//
+// The step uses v_mfma_f64_4x4x4_f64 (four independent 4x4x4 blocks per instruction), not the 16x16x4 shape.  Measured on
+// MI355X (tools/probe/mfma_f64_probe.hip): the 16x16x4 f64 MFMA has ~300 cycles latency and sustains 49 TF/s, the 4x4x4
+// one ~40 cycles and 75 TF/s; f64 MFMA and f64 VALU work do NOT overlap (one shared DP datapath), so what counts is the
+// total number of f64 operations -- and the symmetric 16x16 block only needs its upper 4x4 sub-blocks.
+// Lane layout of the 4x4x4 instruction (tools/probe/mfma_layout_probe.hip): lane = 16 k + 4 b + i for A_b[i][k],
+// 16 k + 4 b + j for B_b[k][j], 16 i + 4 b + j for D_b[i][j].  With k = row of the 4-row group and column
+// 4 X_b + (lane & 3) read from that row, block b of an instruction accumulates the sub-block (I_b, J_b) of G:
+//   all models : A = pattern (0,1,2,3) for every instruction (one LDS read, also the B operand of the diagonal blocks)
+//   <= 12 used columns (fov, linear; 3 block columns): 2 instructions -- diagonal (0,0)(1,1)(2,2)(3,3) and, with
+//                A = (0,0,1,3), B = (1,2,2,3): (0,1)(0,2)(1,2)(3,3)           [3 LDS reads per group]
+//   otherwise  : 3 instructions -- B = A rotated by 0, 1, 2 blocks: diagonal, (0,1)(1,2)(2,3)(3,0), (0,2)(1,3)(2,0)(3,1)
 template <int MODEL>
 __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* pose, const double* cam, double mult, int tile, int lane,
                                                 double* wl, double* G) {
-  const int off = v.tile_off[tile], cnt = v.tile_off[tile + 1] - off;
-  TileXf x;
-  make_tile_xf(pose, cam, &x);
-  double K[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) K[i] = cam[kCamK + i];
-  ModelPre pre;
-  model_precompute(MODEL, K, &pre);
-  v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+  constexpr int nk = MODEL == kFov ? 5 : MODEL == kPoly2 ? 6 : MODEL == kPoly3 ? 7 : MODEL == kKb4 ? 8 : 4;
+  constexpr bool kThreeCols = (7 + nk) <= 12;
+  const int off = __builtin_amdgcn_readfirstlane(v.tile_off[tile]);
+  const int cnt = __builtin_amdgcn_readfirstlane(v.tile_off[tile + 1]) - off;
+  const int b = (lane >> 2) & 3, i4 = lane & 3;
+  // column-block patterns of the three operand reads
+  const int xa = b;
+  const int xb = kThreeCols ? (b == 0 ? 0 : b == 1 ? 0 : b == 2 ? 1 : 3) : ((b + 1) & 3);
+  const int xc = kThreeCols ? (b == 0 ? 1 : b == 1 ? 2 : b == 2 ? 2 : 3) : ((b + 2) & 3);
+  double acc[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
   double cost = 0.0;
-  double* mine = wl + lane * kDotStride;
-  // software prefetch: the corner of the NEXT pass (detection + target point) is in flight while this pass computes
-  double2 uv_n = make_double2(0.0, 0.0);
-  double pw_n[3] = {0.0, 0.0, 0.0};
-  int id_n = 0;
-  if (lane < cnt) {
-    uv_n = v.obs_uv[off + lane];
-    id_n = v.obs_pt[off + lane];
-    const double* pp = v.points + 3 * (size_t)(id_n & kObsPointMask);
-    pw_n[0] = pp[0]; pw_n[1] = pp[1]; pw_n[2] = pp[2];
-  }
-  for (int base = 0; base < cnt; base += 64) {
-    const int d = base + lane;
-    const double2 uv = uv_n;
-    const double pw[3] = {pw_n[0], pw_n[1], pw_n[2]};
-    const double mult_d = (id_n & kObsOneLess) ? mult - 1.0 : mult;
-    if (d + 64 < cnt) {
-      uv_n = v.obs_uv[off + d + 64];
-      id_n = v.obs_pt[off + d + 64];
+#ifdef VC_JAC_STAMPS
+#define JSTAMP(i) do { if (tile == 0 && lane == 0) v.dbg[8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define JSTAMP(i) do {} while (0)
+#endif
+  JSTAMP(0);
+  if (cnt > 0) {
+    TileXf x;
+    make_tile_xf(pose, cam, &x);
+    double K[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) K[i] = cam[kCamK + i];
+    ModelPre pre;
+    model_precompute(MODEL, K, &pre);
+    double* mine = wl + lane * kDotStride;
+    // row (lane >> 4) of a 4-row group: corner (lane >> 5), residual row (lane >> 4) & 1
+    const double* rowp = wl + (lane >> 5) * kDotStride + ((lane >> 4) & 1) * 16 + i4;
+    const double* pa = rowp + 4 * xa;
+    const double* pb = rowp + 4 * xb;
+    const double* pc = rowp + 4 * xc;
+    // software prefetch: the corner of the NEXT pass (detection + target point) is in flight while this pass computes
+    double2 uv_n = make_double2(0.0, 0.0);
+    double pw_n[3] = {0.0, 0.0, 0.0};
+    int id_n = 0;
+    if (lane < cnt) {
+      uv_n = v.obs_uv[off + lane];
+      id_n = v.obs_pt[off + lane];
       const double* pp = v.points + 3 * (size_t)(id_n & kObsPointMask);
       pw_n[0] = pp[0]; pw_n[1] = pp[1]; pw_n[2] = pp[2];
     }
-    if (d < cnt) {
-      cost += corner_rows<MODEL>(x, K, pre, pw, uv.x, uv.y, mult_d, mine, mine + 16);
-    } else {
+    for (int base = 0; base < cnt; base += 64) {
+      const int d = base + lane;
+      const double2 uv = uv_n;
+      const double pw[3] = {pw_n[0], pw_n[1], pw_n[2]};
+      const double mult_d = (id_n & kObsOneLess) ? mult - 1.0 : mult;
+      if (d + 64 < cnt) {
+        uv_n = v.obs_uv[off + d + 64];
+        id_n = v.obs_pt[off + d + 64];
+        const double* pp = v.points + 3 * (size_t)(id_n & kObsPointMask);
+        pw_n[0] = pp[0]; pw_n[1] = pp[1]; pw_n[2] = pp[2];
+      }
+      if (base == 0) JSTAMP(1);
+      if (d < cnt) {
+        cost += corner_rows<MODEL>(x, K, pre, pw, uv.x, uv.y, mult_d, mine, mine + 16);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 32; ++i) mine[i] = 0.0;
+        for (int i = 0; i < 32; ++i) mine[i] = 0.0;
+      }
+      wave_lds_sync();
+      if (base == 0) JSTAMP(2);
+      const int ngroups = (min(64, cnt - base) + 1) >> 1;      // groups of 4 rows (2 corners) that hold data; the rest is zero
+      auto step = [&](int s, double a, double bb, double cc) {
+        acc[s][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, a, acc[s][0], 0, 0, 0);
+        if (kThreeCols) {
+          acc[s][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(bb, cc, acc[s][1], 0, 0, 0);     // A = (0,0,1,3), B = (1,2,2,3)
+        } else {
+          acc[s][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb, acc[s][1], 0, 0, 0);
+          acc[s][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, cc, acc[s][2], 0, 0, 0);
+        }
+      };
+      if (ngroups == 32) {
+        // full pass, straight-line: operands of 4 groups at a time, the next chunk's LDS reads in flight under the
+        // current chunk's MFMAs
+        double ua[2][4], ub[2][4], uc[2][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { ua[0][g] = pa[g * 2 * kDotStride]; ub[0][g] = pb[g * 2 * kDotStride]; uc[0][g] = pc[g * 2 * kDotStride]; }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (c < 7) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int gg = (c + 1) * 4 + g;
+              ua[(c + 1) & 1][g] = pa[gg * 2 * kDotStride]; ub[(c + 1) & 1][g] = pb[gg * 2 * kDotStride]; uc[(c + 1) & 1][g] = pc[gg * 2 * kDotStride];
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) step(g & 1, ua[c & 1][g], ub[c & 1][g], uc[c & 1][g]);
+        }
+      } else {
+        // ragged last pass: chunks of 8 groups (rows past the data are zero, so a chunk may run over the end)
+        for (int g0 = 0; g0 < ngroups; g0 += 8) {
+          double va[8], vb[8], vc8[8];
+#pragma unroll
+          for (int g = 0; g < 8; ++g) { va[g] = pa[(g0 + g) * 2 * kDotStride]; vb[g] = pb[(g0 + g) * 2 * kDotStride]; vc8[g] = pc[(g0 + g) * 2 * kDotStride]; }
+#pragma unroll
+          for (int g = 0; g < 8; ++g) step(g & 1, va[g], vb[g], vc8[g]);
+        }
+      }
+      wave_lds_sync();
+      if (base == 0) JSTAMP(3);
     }
-    wave_lds_sync();
-    const int nd = min(64, cnt - base);
-    const int nsteps = (nd + 1) >> 1;          // one MFMA covers 2 corners x 2 residual rows (K = 4)
-    const double* src = wl + (lane >> 5) * kDotStride + (lane & 31);
-    if (nsteps == 32) {
-      // full pass: fetch all 32 operands first (conflict-free ds_read_b64), then issue the MFMAs back to back on
-      // two independent accumulators -- the matrix pipe never waits on an LDS round trip
-      double u[32];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) u[k] = src[2 * k * kDotStride];
-#pragma unroll
-      for (int k = 0; k < 32; k += 2) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u[k], u[k], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(u[k + 1], u[k + 1], acc1, 0, 0, 0);
-      }
-    } else {
-      int k = 0;
-      for (; k + 1 < nsteps; k += 2) {
-        const double u0 = src[2 * k * kDotStride];
-        const double u1 = src[(2 * k + 2) * kDotStride];
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, u0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, u1, acc1, 0, 0, 0);
-      }
-      if (k < nsteps) {
-        const double u0 = src[2 * k * kDotStride];
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, u0, acc0, 0, 0, 0);
-      }
-    }
-    wave_lds_sync();
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) G[((lane >> 4) + 4 * i) * 16 + (lane & 15)] = acc0[i] + acc1[i];
+  JSTAMP(4);
+  // D lane = 16 i + 4 b + j holds G[4 I_b + i][4 J_b + j]; both triangles are written (unused blocks stay zero from upload)
+  {
+    const int i = lane >> 4, j = lane & 3;
+    const double d0 = acc[0][0] + acc[1][0], d1 = acc[0][1] + acc[1][1], d2 = acc[0][2] + acc[1][2];
+    const int r0 = 4 * b + i, c0 = 4 * b + j;
+    G[r0 * 16 + c0] = d0;
+    const int r1 = 4 * (kThreeCols ? xb : b) + i, c1 = 4 * (kThreeCols ? xc : ((b + 1) & 3)) + j;
+    G[r1 * 16 + c1] = d1; G[c1 * 16 + r1] = d1;
+    if (!kThreeCols) {
+      const int r2 = 4 * b + i, c2 = 4 * ((b + 2) & 3) + j;
+      G[r2 * 16 + c2] = d2; G[c2 * 16 + r2] = d2;
+    }
+  }
+  JSTAMP(5);
   return wave_sum(cost);          // valid in lane 0
 }
 __device__ __forceinline__ double jac_tile_dispatch(const DevView& v, int model, const double* pose, const double* cam, double mult, int tile,
@@ -115,6 +177,9 @@ __device__ __forceinline__ double jac_tile_dispatch(const DevView& v, int model,
 __global__ __launch_bounds__(256) void k_reproj_jac(DevView v) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const Ctrl* ct = v.ctrl;
+#ifdef VC_JAC_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) v.dbg[7] = (long long)__builtin_readcyclecounter();
+#endif
   if (ct->done || !ct->need_lin) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
@@ -827,6 +892,21 @@ __device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int
   for (int i = 0; i < 6; ++i) d[i] = -y[i];
   double Tout[7];
   se3_plus(Tin, d, Tout);
+  // the frame's trial pose and step terms go out first: nothing but the tile id has to live across the sweep
+  if (lane == 0 && tile == t0) {
+    double* pout = v.poses[1 - cur] + (size_t)f * kPoseStride;
+    double gd = 0, dld = 0, step2 = 0, x2 = 0, g2 = 0, gmax = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { pout[i] = Tout[i]; const double e = Tout[i] - Tin[i]; step2 += e * e; x2 += Tin[i] * Tin[i]; }
+    pout[7] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double gi = fr[kFrG + i];
+      gd += gi * d[i]; dld += fr[kFrLam + i] * d[i] * d[i]; g2 += gi * gi; gmax = fmax(gmax, fabs(gi));
+    }
+    double* o = v.fpart + (size_t)f * kNumScal;
+    o[kScGd] = gd; o[kScDld] = dld; o[kScStep2] = step2; o[kScX2] = x2; o[kScG2] = g2; o[kScCost] = 0.0; o[kScGmax] = gmax; o[kScSq] = 0.0;
+  }
   double cost, sq = 0.0;
   if (FUSED) {
     // Jacobian sweep at the trial point: its cost is the trial cost, its Gram block is the next linearisation if the
@@ -845,20 +925,6 @@ __device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int
   if (lane == 0) {
     v.tile_trial[2 * tile] = cost;
     v.tile_trial[2 * tile + 1] = sq;
-    if (tile == t0) {
-      double* pout = v.poses[1 - cur] + (size_t)f * kPoseStride;
-      double gd = 0, dld = 0, step2 = 0, x2 = 0, g2 = 0, gmax = 0;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) { pout[i] = Tout[i]; const double e = Tout[i] - Tin[i]; step2 += e * e; x2 += Tin[i] * Tin[i]; }
-      pout[7] = 0.0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const double gi = fr[kFrG + i];
-        gd += gi * d[i]; dld += fr[kFrLam + i] * d[i] * d[i]; g2 += gi * gi; gmax = fmax(gmax, fabs(gi));
-      }
-      double* o = v.fpart + (size_t)f * kNumScal;
-      o[kScGd] = gd; o[kScDld] = dld; o[kScStep2] = step2; o[kScX2] = x2; o[kScG2] = g2; o[kScCost] = 0.0; o[kScGmax] = gmax; o[kScSq] = 0.0;
-    }
   }
 }
 // (Tried and dropped: letting the last workgroup to finish run the final phase.  Device-scope release/acquire fences are

@@ -122,6 +122,29 @@ VC_HD void loss_cauchy100(double s, double* rho, double* rho1) {
   *rho1 = 1.0 / sum;
 }
 
+// Branch-free arctangent (Cephes atan.c scheme: two-step argument reduction + degree 4/5 rational, < 2 ulp): the math
+// library's atan carries a divergent branch, which on the GPU would cut the region that overlaps with the MFMAs.
+VC_HD double vc_atan(double x) {
+  const double ax = fabs(x);
+  const bool big = ax > 2.41421356237309504880, mid = ax > 0.66;
+  // one division with selected operands (two conditional divisions would be turned back into branches by the compiler)
+  const double t = (big ? -1.0 : (mid ? ax - 1.0 : ax)) / (big ? ax : (mid ? ax + 1.0 : 1.0));
+  const double y0 = big ? 1.57079632679489661923 : (mid ? 0.78539816339744830962 : 0.0);
+  const double more = big ? 6.123233995736765886130e-17 : (mid ? 3.061616997868382943065e-17 : 0.0);
+  const double z = t * t;
+  const double pn = (((-8.750608600031904122785e-1 * z - 1.615753718733365076637e1) * z - 7.500855792314704667340e1) * z
+                     - 1.228866684490136173410e2) * z - 6.485021904942025371773e1;
+  const double qd = ((((z + 2.485846490142306297962e1) * z + 1.650270098316988542046e2) * z + 4.328810604912902668951e2) * z
+                     + 4.853903996359136964868e2) * z + 1.945506571482613964425e2;
+  const double r = y0 + (t * (z * pn / qd) + t + more);
+  return x < 0.0 ? -r : r;
+}
+// atan2(y, x) for y >= 0
+VC_HD double vc_atan2_pos(double y, double x) {
+  const double a = vc_atan(y / x);
+  return x > 0.0 ? a : (x < 0.0 ? a + 3.14159265358979323846 : 1.57079632679489661923);
+}
+
 // per-camera constants that do not depend on the corner (fov: m = 2 tan(w/2), dm = dm/dw)
 struct ModelPre { double m, dm; };
 VC_HD void model_precompute(int model, const double* K, ModelPre* p) {
@@ -139,22 +162,22 @@ VC_HD void project_radial(int model, const double* pc, const double* K, const Mo
   double fac = 1.0, h = 0.0;           // h = fac'(r) / r
   double dk0 = 0.0, dk1 = 0.0, dk2 = 0.0;
   if (model == kFov) {
+    // Branch-free (selects, not jumps): on the GPU this arithmetic runs in the shadow of the previous pass's MFMAs and a
+    // jump would cut the scheduling region.  The discarded alternatives may hold inf/nan; they are never blended in.
     const double w = K[4];
-    if (w * w > 1e-5) {
-      const double m = pre.m, dm = pre.dm;
-      if (r2 < 1e-5) {
-        fac = m / w;
-        if (JAC) dk0 = dm / w - m / (w * w);
-      } else {
-        const double r = sqrt(r2);
-        const double at = atan(r * m);
-        const double den = 1.0 + r2 * m * m;
-        fac = at / (r * w);
-        if (JAC) {
-          h = (m * r / den - at) / (r2 * r * w);
-          dk0 = dm / (w * den) - fac / w;
-        }
-      }
+    const double m = pre.m, dm = pre.dm;
+    const bool w_big = w * w > 1e-5, r_small = r2 < 1e-5;
+    const double r = sqrt(r2);
+    const double at = vc_atan(r * m);
+    // every division is unconditional and on a safe operand; the alternatives differ only by cheap selects
+    const double iw = 1.0 / (w_big ? w : 1.0), ir = 1.0 / (r_small ? 1.0 : r), iden = 1.0 / (1.0 + r2 * m * m);
+    const double fac_g = at * ir * iw, fac_s = m * iw;
+    fac = w_big ? (r_small ? fac_s : fac_g) : 1.0;
+    if (JAC) {
+      const double h_g = (m * r * iden - at) * ir * ir * ir * iw;
+      const double dk_g = dm * iw * iden - fac_g * iw, dk_s = dm * iw - m * iw * iw;
+      h = (w_big && !r_small) ? h_g : 0.0;
+      dk0 = w_big ? (r_small ? dk_s : dk_g) : 0.0;
     }
   } else if (model == kPoly2) {
     fac = 1.0 + r2 * (K[4] + r2 * K[5]);
@@ -184,12 +207,13 @@ VC_HD void project_kb4(const double* pc, const double* K, double* pix, double* A
   const double X = pc[0], Y = pc[1], Z = pc[2];
   const double rho2 = X * X + Y * Y;
   const double rho = sqrt(rho2);
-  const double th = atan2(rho, Z);
+  const double th = vc_atan2_pos(rho, Z);
   const double t2 = th * th;
   const double poly = 1.0 + t2 * (K[4] + t2 * (K[5] + t2 * (K[6] + t2 * K[7])));
   const double Rr = th * poly;
-  double c = 1.0, s = 0.0, irho = 0.0;
-  if (rho > 0.0) { irho = 1.0 / rho; c = X * irho; s = Y * irho; }
+  const bool off_axis = rho > 0.0;            // selects, not jumps (see project_radial)
+  const double irho1 = 1.0 / (off_axis ? rho : 1.0);      // unconditional division on a safe operand
+  const double irho = off_axis ? irho1 : 0.0, c = X * irho1 + (off_axis ? 0.0 : 1.0), s = Y * irho1;   // on the axis X = Y = 0
   const double fu = K[0], fv = K[1];
   pix[0] = fu * Rr * c + K[2];
   pix[1] = fv * Rr * s + K[3];
@@ -199,7 +223,7 @@ VC_HD void project_kb4(const double* pc, const double* K, double* pix, double* A
     const double in2 = 1.0 / n2;
     const double thX = Z * c * in2, thY = Z * s * in2, thZ = -rho * in2;
     // R/rho -> 1/Z on the axis
-    const double Rq = (rho > 0.0) ? Rr * irho : 1.0 / Z;
+    const double Rq = (off_axis ? Rr : 1.0) / (off_axis ? rho : Z);
     const double cX = s * s * Rq, cY = -c * s * Rq, sX = cY, sY = c * c * Rq;   // R * dc/dX etc.
     A[0] = fu * (dR * thX * c + cX); A[1] = fu * (dR * thY * c + cY); A[2] = fu * dR * thZ * c;
     A[3] = fv * (dR * thX * s + sX); A[4] = fv * (dR * thY * s + sY); A[5] = fv * dR * thZ * s;

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvicalib_amd.so")
+LIB_PATH = os.environ.get("VICALIB_AMD_LIB") or os.path.join(_HERE, "libvicalib_amd.so")
 _lib = None
 
 VC_OK = 0
