@@ -45,8 +45,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # VICALIB_AMD_FORCE_SHARD_PATH=1 (test hook): one rank, but through the sharded code path (split kernels + RCCL callbacks)
+    force_shard = world == 1 and os.environ.get("VICALIB_AMD_FORCE_SHARD_PATH") == "1"
+    if world > 1 or force_shard:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # ---- this rank's frame shard of the N*frames problem ------------------------------------------
@@ -55,11 +57,21 @@ def main():
     cal = ViCalibrator(local_rank).load_problem(prob)
     cal.SetCalibrateImu(False)
 
-    comm = None
-    if world > 1:
+    # Per-iteration all-reduces: the library's own RCCL communicator, enqueued straight onto the calibrator's stream
+    # (VICALIB_AMD_SHARD_COMM=torch selects the torch.distributed callback instead; it is also the fallback).
+    def attach(c):
+        if world == 1 and not force_shard:
+            return "none"
+        if os.environ.get("VICALIB_AMD_SHARD_COMM", "rccl") == "rccl":
+            try:
+                c.set_shard_rccl(rank, world)
+                return "rccl"
+            except Exception as e:      # noqa: BLE001
+                print("bench: native RCCL path unavailable (%s); using the torch.distributed callback" % e, file=sys.stderr)
         from vicalib_amd.parallel import FrameShardComm
-        comm = FrameShardComm(device="cuda:%d" % local_rank, stream_ptr=cal.stream())
-        cal.set_shard(rank, world, comm)
+        c.set_shard(rank, world, FrameShardComm(device="cuda:%d" % local_rank, stream_ptr=c.stream()))
+        return "torch"
+    comm_kind = attach(cal)
 
     cal.prepare()
     n_obs_local = cal.num_observations()
@@ -89,8 +101,7 @@ def main():
     # ---- final accuracy of one complete solve (the metric's "final RMS reproj err") --------------------
     cal2 = ViCalibrator(local_rank).load_problem(prob)
     cal2.SetCalibrateImu(False)
-    if world > 1:
-        cal2.set_shard(rank, world, FrameShardComm(device="cuda:%d" % local_rank, stream_ptr=cal2.stream()))
+    attach(cal2)
     cal2.Solve()
     rmse = [float(x) for x in cal2.GetCameraProjRMSE()]
 
@@ -132,15 +143,23 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE cfg2: stereo fov,fov, small grid 19x10, %d frames/GPU, intrinsics+extrinsics, no IMU" % args.frames,
                        "frames_total": args.frames * world, "corners_total": n_obs_total, "tiles_per_gpu": n_tiles,
-                       "parallelism": "frames sharded x%d, all-reduce of reduced system per LM iteration" % world},
+                       "parallelism": "frames sharded x%d, all-reduce of reduced system per LM iteration (%s)" % (world, comm_kind)},
             "lm_iters_per_sec": iters_per_s, "jacobian_sweeps": jac_sweeps, "residual_sweeps": res_sweeps,
             "final_rmse_px": rmse, "roofline": roofline, "roofline_residual_sweep": roofline_res,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prob)
-        print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_shard:
         dist.destroy_process_group()
+    if rank == 0:
+        # the one JSON line comes last: RCCL writes a version banner to the C-level stdout, flush that first
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:      # noqa: BLE001
+            pass
+        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(prob):

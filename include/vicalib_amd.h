@@ -113,6 +113,12 @@ int vc_get_trace(vc_calibrator* h, double* rows, int max_rows);
 typedef int (*vc_allreduce_fn)(void* ctx, double* device_buf, int count, int op /*0 sum, 1 max*/);
 int vc_set_shard(vc_calibrator* h, int rank, int world_size, vc_allreduce_fn fn, void* ctx);
 void* vc_get_stream(vc_calibrator* h);    /* hipStream_t */
+/* The same sharding with the library's own RCCL communicator (librccl bound at run time): the per-iteration all-reduces
+ * are enqueued directly on the calibrator's stream, no callback.  Rank 0 creates the id (ncclGetUniqueId, 128 bytes),
+ * the host distributes it by whatever means it has, every rank calls vc_set_shard_rccl (collective: ncclCommInitRank). */
+int vc_rccl_unique_id(void* out128);
+int vc_set_shard_rccl(vc_calibrator* h, int rank, int world_size, const void* unique_id128);
+long long vc_allreduce_calls(vc_calibrator* h);    /* all-reduces issued through the library's own communicator */
 /* Upload the problem and linearise once at the current state (stage flags as set): fills the device
  * normal equations.  Used by the parity tests and the benchmark. */
 int vc_prepare(vc_calibrator* h);

@@ -52,3 +52,38 @@ def test_two_rank_sharded_visual_inertial_solve_on_one_gpu():
 def test_three_rank_sharded_visual_inertial_solve_on_one_gpu():
     """The middle rank holds a separator (its first frame) and a ghost (the last rank's first frame)."""
     _run("gpu_imu", 900, nproc=3)
+
+
+@pytest.mark.gpu
+def test_rccl_callback_path_single_rank():
+    """The sharded code path (split kernels, all-reduce callbacks on the calibrator's stream) through torch.distributed's
+    "nccl" backend (= RCCL) with one rank: the plumbing the multi-GPU bench uses, minus the peers."""
+    env = dict(os.environ, VICALIB_AMD_FORCE_SHARD_PATH="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from vicalib_amd import synth
+from vicalib_amd.lib import ViCalibrator
+from vicalib_amd.parallel import FrameShardComm
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+p = synth.generate(synth.Config(models=("fov", "poly3"), n_frames=40, seed=13))
+cal = ViCalibrator(0).load_problem(p); cal.SetCalibrateImu(False)
+comm = FrameShardComm(device="cuda:0", stream_ptr=cal.stream()); cal.set_shard(0, 1, comm)
+cal.Solve()
+assert comm.calls > 10, comm.calls
+nat = ViCalibrator(0).load_problem(p); nat.SetCalibrateImu(False); nat.set_shard_rccl(0, 1)     # the library's own communicator
+nat.Solve()
+assert nat.allreduce_calls() > 10
+np.testing.assert_allclose(nat.trace()[:, 1], cal.trace()[:, 1], rtol=1e-12)
+os.environ["VICALIB_AMD_FORCE_SHARD_PATH"] = "0"
+ref = ViCalibrator(0).load_problem(p); ref.SetCalibrateImu(False); ref.Solve()
+tg, tr = cal.trace(), ref.trace()
+assert len(tg) == len(tr)
+np.testing.assert_allclose(tg[:, 1], tr[:, 1], rtol=1e-12)
+np.testing.assert_allclose(cal.GetFrames(), ref.GetFrames(), rtol=1e-10, atol=1e-12)
+dist.destroy_process_group()
+print("ok")
+''' % os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -9,6 +9,7 @@
 // quality, radius update) whose every O(observations) and O(frames) step is a HIP kernel
 // (vc_kernels.hip).  The host only takes the accept/reject decision from a handful of scalars.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -72,6 +73,32 @@ struct PointHash {
 
 }  // namespace
 
+// ---- RCCL, bound at run time (the library is already in the process when the host is PyTorch; a plain C++ host gets
+// /opt/rocm/lib/librccl.so).  Only what the per-iteration all-reduce needs.
+struct RcclUniqueId { char internal[128]; };
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclUniqueId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  bool load() {
+    if (AllReduce) return true;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (lib) break; }
+    if (!lib) for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+    if (!lib) return false;
+    GetUniqueId = (int (*)(RcclUniqueId*))dlsym(lib, "ncclGetUniqueId");
+    CommInitRank = (int (*)(void**, int, RcclUniqueId, int))dlsym(lib, "ncclCommInitRank");
+    AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
+    CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) { AllReduce = nullptr; return false; }
+    return true;
+  }
+};
+static RcclApi g_rccl;
+constexpr int kNcclDouble = 8, kNcclSum = 0, kNcclMax = 2;     // ncclDataType_t / ncclRedOp_t values of nccl.h
+
 struct vc_calibrator {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -110,10 +137,14 @@ struct vc_calibrator {
   std::mutex result_mutex;
   // ---- sharding ---------------------------------------------------------------------------
   int rank = 0, world = 1;
+  bool force_shard_path = false;   // VICALIB_AMD_FORCE_SHARD_PATH=1: run the sharded code path (split kernels + callbacks) with one rank (test hook)
+  bool sharded() const { return world > 1 || (force_shard_path && (allreduce || rccl_comm)); }
   DBuf<double> d_halo, d_sep_strip, d_gath;
   long global_first = 0, global_total = 0;     // this rank's frame range in the sharded problem (known after gather_shard_info)
   vc_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
+  void* rccl_comm = nullptr;        // own communicator (vc_set_shard_rccl): all-reduces go straight onto `stream`
+  long rccl_calls = 0;
   // ---- device -----------------------------------------------------------------------------
   bool device_dirty = true;      // host problem changed since the last upload
   DevView dv{};
@@ -137,6 +168,7 @@ struct vc_calibrator {
 
   ~vc_calibrator() {
     stop();
+    if (rccl_comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(stream); (void)g_rccl.CommDestroy(rccl_comm); }
     if (stream) (void)hipStreamDestroy(stream);
     if (pin) (void)hipHostFree(pin);
   }
@@ -180,7 +212,7 @@ struct vc_calibrator {
 
   // sum a small host vector over the ranks through the caller's device all-reduce
   int host_allreduce_sum(std::vector<double>& v) {
-    if (world <= 1) return VC_OK;
+    if (!sharded()) return VC_OK;
     HIP_OK(d_halo.upload(v, stream));
     int rc = do_allreduce(d_halo.p, (int)v.size(), 0); if (rc) return rc;
     HIP_OK(hipMemcpyAsync(v.data(), d_halo.p, v.size() * 8, hipMemcpyDeviceToHost, stream));
@@ -394,7 +426,10 @@ struct vc_calibrator {
 
   // ---- one pass of the device pipeline (all asynchronous; the decision is taken on the device) ------
   int do_allreduce(double* p, int n, int op) {
-    if (world > 1 && allreduce) { if (allreduce(allreduce_ctx, p, n, op) != 0) return VC_ERR_NO_DEVICE; }
+    if (sharded() && rccl_comm) {
+      ++rccl_calls;
+      if (g_rccl.AllReduce(p, p, (size_t)n, kNcclDouble, op == 1 ? kNcclMax : kNcclSum, rccl_comm, stream) != 0) return VC_ERR_NO_DEVICE;
+    } else if (sharded() && allreduce) { if (allreduce(allreduce_ctx, p, n, op) != 0) return VC_ERR_NO_DEVICE; }
     return VC_OK;
   }
   // first_pass: the pass right after init_ctrl (the only one that needs k_reproj_jac when k_trial carries the sweep)
@@ -407,7 +442,7 @@ struct vc_calibrator {
       launch_chain_solve_a(dv, stream);
       launch_part_sum(dv, stream);
       int rc = VC_OK;
-      if (world > 1) {
+      if (sharded()) {
         launch_reduced(dv, 1, stream);
         rc = do_allreduce(dv.Sbuf, D * D + 3 * D + 2, 0); if (rc) return rc;
         launch_reduced(dv, 2, stream);
@@ -417,7 +452,7 @@ struct vc_calibrator {
       launch_chain_solve_b(dv, stream);
       launch_reproj_res(dv, 3, 0.0, stream);
       launch_imu_res(dv, 3, stream);
-      if (world > 1) {
+      if (sharded()) {
         launch_final(dv, 1, stream);
         rc = do_allreduce(dv.gath, world * kNumScal, 0); if (rc) return rc;
         launch_final(dv, 2, stream);
@@ -429,7 +464,7 @@ struct vc_calibrator {
     if (first_pass || !dv.fused) launch_reproj_jac(dv, stream);
     launch_frame_schur(dv, stream);
     int rc = VC_OK;
-    if (world > 1) {
+    if (sharded()) {
       launch_reduced(dv, 1, stream);
       rc = do_allreduce(dv.Sbuf, D * D + 3 * D + 2, 0); if (rc) return rc;
       launch_reduced(dv, 2, stream);
@@ -437,7 +472,7 @@ struct vc_calibrator {
       launch_reduced(dv, 0, stream);
     }
     launch_trial(dv, stream);
-    if (world > 1) {
+    if (sharded()) {
       launch_final(dv, 1, stream);
       rc = do_allreduce(dv.gath, world * kNumScal, 0); if (rc) return rc;
       launch_final(dv, 2, stream);
@@ -460,7 +495,7 @@ struct vc_calibrator {
   int solve_once(Termination* term, double* final_cost, long* nres) {
     if (device_dirty) { int rc = upload(); if (rc) return rc; }
     *nres = 2L * ((long)dv.n_obs * vis_mult - n_one_less) + (dv.imu_on ? 9L * imu_mult * std::max(0, dv.n_frames - 1) : 0L);
-    if (world > 1) { std::vector<double> v = {(double)*nres}; int rc = host_allreduce_sum(v); if (rc) return rc; *nres = (long)v[0]; }
+    if (sharded()) { std::vector<double> v = {(double)*nres}; int rc = host_allreduce_sum(v); if (rc) return rc; *nres = (long)v[0]; }
     if (trace_cap < max_iters + 8) { trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); dv.trace = d_trace.p; }
     if (!pin) HIP_OK(hipHostMalloc((void**)&pin, sizeof(Pinned), hipHostMallocDefault));
     init_ctrl(&pin->up);
@@ -862,8 +897,31 @@ int vc_set_shard(vc_calibrator* h, int rank, int world_size, vc_allreduce_fn fn,
   NOT_RUNNING(h);
   if (world_size < 1 || rank < 0 || rank >= world_size || (world_size > 1 && !fn)) return VC_ERR_BAD_ARG;
   h->rank = rank; h->world = world_size; h->allreduce = fn; h->allreduce_ctx = ctx;
+  { const char* e = std::getenv("VICALIB_AMD_FORCE_SHARD_PATH"); h->force_shard_path = e && e[0] == '1'; }
   return VC_OK;
 }
+int vc_rccl_unique_id(void* out128) {
+  if (!out128) return VC_ERR_BAD_ARG;
+  if (!g_rccl.load()) return VC_ERR_UNSUPPORTED;
+  RcclUniqueId id;
+  if (g_rccl.GetUniqueId(&id) != 0) return VC_ERR_NO_DEVICE;
+  std::memcpy(out128, &id, sizeof(id));
+  return VC_OK;
+}
+int vc_set_shard_rccl(vc_calibrator* h, int rank, int world_size, const void* unique_id128) {
+  NOT_RUNNING(h);
+  if (world_size < 1 || rank < 0 || rank >= world_size || !unique_id128) return VC_ERR_BAD_ARG;
+  if (!g_rccl.load()) return VC_ERR_UNSUPPORTED;
+  if (hipSetDevice(h->device) != hipSuccess) return VC_ERR_NO_DEVICE;
+  RcclUniqueId id;
+  std::memcpy(&id, unique_id128, sizeof(id));
+  if (h->rccl_comm) { (void)g_rccl.CommDestroy(h->rccl_comm); h->rccl_comm = nullptr; }
+  if (g_rccl.CommInitRank(&h->rccl_comm, world_size, id, rank) != 0) { h->rccl_comm = nullptr; return VC_ERR_NO_DEVICE; }
+  h->rank = rank; h->world = world_size; h->allreduce = nullptr; h->allreduce_ctx = nullptr;
+  { const char* e = std::getenv("VICALIB_AMD_FORCE_SHARD_PATH"); h->force_shard_path = e && e[0] == '1'; }
+  return VC_OK;
+}
+long long vc_allreduce_calls(vc_calibrator* h) { return h ? h->rccl_calls : 0; }
 void* vc_get_stream(vc_calibrator* h) { return h ? (void*)h->stream : nullptr; }
 int vc_prepare(vc_calibrator* h) {
   NOT_RUNNING(h);

@@ -29,7 +29,7 @@ SYMBOLS = [
     "vc_get_biases", "vc_get_scale_factor", "vc_get_gravity", "vc_time_offset", "vc_mean_squared_error", "vc_get_camera_proj_rmse",
     "vc_get_num_iterations", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
     "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
-    "vc_init_frame_poses_pnp", "vc_pnp_planar",
+    "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_allreduce_calls",
 ]
 
 
@@ -60,6 +60,7 @@ def load():
         L.vc_get_num_iterations.restype = C.c_uint
         L.vc_get_stream.restype = C.c_void_p
         L.vc_num_observations.restype = C.c_longlong
+        L.vc_allreduce_calls.restype = C.c_longlong
         for name in ("vc_destroy",):
             getattr(L, name).restype = None
         _lib = L
@@ -207,6 +208,19 @@ class ViCalibrator:
     def set_shard(self, rank, world, fn=None):
         self._cb = ALLREDUCE_FN(fn) if fn is not None else None
         _check(self.L.vc_set_shard(self.h, int(rank), int(world), self._cb, None), "set_shard")
+
+    def set_shard_rccl(self, rank, world, group=None):
+        """Frame sharding over the library's own RCCL communicator; the 128-byte id travels through torch.distributed."""
+        import torch.distributed as dist
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _check(self.L.vc_rccl_unique_id(buf), "rccl_unique_id")
+        box = [bytes(buf.raw)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        _check(self.L.vc_set_shard_rccl(self.h, int(rank), int(world), C.create_string_buffer(box[0], 128)), "set_shard_rccl")
+
+    def allreduce_calls(self): return int(self.L.vc_allreduce_calls(self.h))
 
     def stream(self): return self.L.vc_get_stream(self.h)
     def prepare(self): _check(self.L.vc_prepare(self.h), "prepare")
