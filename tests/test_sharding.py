@@ -55,6 +55,12 @@ def test_three_rank_sharded_visual_inertial_solve_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_four_rank_eight_camera_visual_inertial_solve_on_one_gpu():
+    """cfg5-like rig: reduced dimension 115 + 3 x 9 = 142 -> packed-triangle reduced solve, 10 column tiles in the chain Gram."""
+    _run("gpu_imu8", 1200, nproc=4)
+
+
+@pytest.mark.gpu
 def test_rccl_callback_path_single_rank():
     """The sharded code path (split kernels, all-reduce callbacks on the calibrator's stream) through torch.distributed's
     "nccl" backend (= RCCL) with one rank: the plumbing the multi-GPU bench uses, minus the peers."""

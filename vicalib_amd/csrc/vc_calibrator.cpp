@@ -297,7 +297,8 @@ struct vc_calibrator {
     const int D0 = build_layout(col_cam, col_local);
     const int D = D0 + (shard_imu ? 9 * (world - 1) : 0);          // + one 9-column separator per shard boundary
     col_cam.resize(D, -1); col_local.resize(D, 0);
-    if (((size_t)(D + 1) * (D + 1) + 2 * (D + 1)) * sizeof(double) > 160 * 1024 || D + 1 > 12 * 16) return VC_ERR_UNSUPPORTED;   // reduced solve lives in LDS
+    // the reduced solve lives in LDS (packed lower triangle + 12 KB of staging), the chain Gram handles 12 column tiles
+    if (((size_t)(D + 1) * (D + 2) / 2 + 2 * (D + 1)) * sizeof(double) + 13 * 1024 > 160 * 1024 || D + 1 > 12 * 16) return VC_ERR_UNSUPPORTED;
     for (int c = 0; c < C; ++c) cam_model[c] = cams[c].model;
     // ---- upload ---------------------------------------------------------------------------------
     HIP_OK(d_uv.upload(uv, stream)); HIP_OK(d_pt.upload(pt, stream)); HIP_OK(d_points.upload(points, stream));

@@ -702,14 +702,20 @@ __device__ void solve_small_wave(const DevView& v, const Ctrl* ct, int lane, dou
   if (lane < D) x[lane] = mine;
 }
 
+// Workgroup-wide factorisation for D > 32.  Only the lower triangle (plus the right-hand-side row D) is kept, packed:
+// row i starts at i (i + 1) / 2 -- 129 KB of LDS at D = 178 (8 cameras + IMU + 7 separators) instead of 256 KB.
+__device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 __device__ void solve_large_block(const DevView& v, const Ctrl* ct, double* M, double* x) {
-  const int tid = threadIdx.x, D = v.D, ld = D + 1;
-  double* col = M + (size_t)(D + 1) * ld;
+  const int tid = threadIdx.x, D = v.D;
+  double* col = M + tri(D + 1);
   const double* S = v.Sbuf;
   const double* gred = S + D * D;
   const double* hd = gred + D;
-  for (int e = tid; e < D * D; e += 256) M[(e / D) * ld + (e % D)] = S[e];
-  for (int i = tid; i < D; i += 256) M[D * ld + i] = gred[i];
+  for (int i = tid >> 4; i < D; i += 16) {            // 16 x 16 thread grid over (row, column)
+    const int ri = tri(i);
+    for (int k = tid & 15; k <= i; k += 16) M[ri + k] = S[i * D + k];
+  }
+  for (int i = tid; i < D; i += 256) M[tri(D) + i] = gred[i];
   __syncthreads();
   for (int i = tid; i < D; i += 256) {
     double sc2, dg;
@@ -717,34 +723,36 @@ __device__ void solve_large_block(const DevView& v, const Ctrl* ct, double* M, d
     if (!ct->reuse_diag) { dg = lm_clamped_diag(hd[i], sc2); v.sdiag[i] = dg; } else dg = v.sdiag[i];
     const double lam = dg / (ct->radius * sc2);
     v.slam[i] = lam;
-    M[i * ld + i] += lam;
+    M[tri(i) + i] += lam;
   }
   __syncthreads();
   for (int j = 0; j < D; ++j) {
-    double d = M[j * ld + j];
+    double d = M[tri(j) + j];
     const bool bad = !(d > 0.0);
     if (bad) d = 1.0;
     const double piv = sqrt(d);
-    for (int i = j + 1 + tid; i <= D; i += 256) col[i] = M[i * ld + j] / piv;
+    for (int i = j + 1 + tid; i <= D; i += 256) col[i] = M[tri(i) + j] / piv;
     __syncthreads();
-    if (tid == 0) { M[j * ld + j] = piv; if (bad) v.flags[1] = 1; }
+    if (tid == 0) { M[tri(j) + j] = piv; if (bad) v.flags[1] = 1; }
     {   // trailing update on a 16 x 16 thread grid (no integer divisions on the per-column path)
       const int ti = tid >> 4, tj = tid & 15;
       for (int i = j + 1 + ti; i <= D; i += 16) {
         const double ci = col[i];
-        for (int k = j + 1 + tj; k <= i && k < D; k += 16) M[i * ld + k] -= ci * col[k];
+        const int ri = tri(i);
+        for (int k = j + 1 + tj; k <= i && k < D; k += 16) M[ri + k] -= ci * col[k];
       }
     }
-    for (int i = j + 1 + tid; i <= D; i += 256) M[i * ld + j] = col[i];
+    for (int i = j + 1 + tid; i <= D; i += 256) M[tri(i) + j] = col[i];
     __syncthreads();
   }
-  for (int i = tid; i < D; i += 256) x[i] = -M[D * ld + i];
+  for (int i = tid; i < D; i += 256) x[i] = -M[tri(D) + i];
   __syncthreads();
   for (int j = D - 1; j >= 0; --j) {
-    if (tid == 0) x[j] /= M[j * ld + j];
+    if (tid == 0) x[j] /= M[tri(j) + j];
     __syncthreads();
     const double xj = x[j];
-    for (int i = tid; i < j; i += 256) x[i] -= M[j * ld + i] * xj;
+    const int rj = tri(j);
+    for (int i = tid; i < j; i += 256) x[i] -= M[rj + i] * xj;
     __syncthreads();
   }
 }
@@ -761,7 +769,7 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
     }
     __syncthreads();
   } else {
-    x = dyn + (size_t)(D + 1) * (D + 1) + (D + 1);
+    x = dyn + tri(D + 1) + (D + 1);
     solve_large_block(v, ct, dyn, x);
   }
   VC_STAMP(5);
@@ -831,12 +839,11 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
 // mode 0: phase A + phase B in one launch (single process); 1: phase A only (an all-reduce of Sbuf follows);
 // 2: phase B only
 __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
-  extern __shared__ __attribute__((aligned(16))) double dyn[];
-  __shared__ FinalLds fl;
+  extern __shared__ __attribute__((aligned(16))) double dyn[];   // phase A: FinalLds; phase B: the matrix (the phases do not overlap)
   __shared__ double red[6 * 256];
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
-  if (mode != 2) schur_final_phase(v, ct->cur, fl);
+  if (mode != 2) { schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn)); __syncthreads(); }
   if (mode != 1) reduced_solve_phase(v, ct, dyn, red);
 }
 
@@ -1134,8 +1141,9 @@ void launch_frame_schur(const DevView& v, hipStream_t s) {
   launch_part_sum(v, s);
 }
 static inline size_t reduced_lds(const DevView& v) {
-  return v.D <= kSmallD ? ((size_t)(kSmallD + 1) * (kSmallD + 2) + kSmallD + 1) * sizeof(double)
-                        : ((size_t)(v.D + 1) * (v.D + 1) + 2 * (v.D + 1)) * sizeof(double);
+  const size_t solve = v.D <= kSmallD ? ((size_t)(kSmallD + 1) * (kSmallD + 2) + kSmallD + 1) * sizeof(double)
+                                      : ((size_t)(v.D + 1) * (v.D + 2) / 2 + 2 * (v.D + 1)) * sizeof(double);
+  return std::max(solve, sizeof(FinalLds));
 }
 void launch_reduced(const DevView& v, int mode, hipStream_t s) {
   const size_t lds = reduced_lds(v);
