@@ -169,6 +169,44 @@ def test_full_size_properties_cfg2_scale():
     np.testing.assert_allclose(cal.GetCamera(0)[0], K0, rtol=1e-7)
 
 
+def test_full_size_cfg3_visual_inertial_recovers_ground_truth():
+    """BASELINE cfg3 at full size (mono kb4 + IMU, 2000 frames): the complete stage schedule; ground truth of the
+    generator (time offset, biases, scale factors, gravity, camera-to-IMU rotation) is recovered and the reprojection
+    RMSE sits at the noise floor."""
+    p = synth.generate(synth.BASELINE_CONFIGS["cfg3"])
+    cal = ViCalibrator(0).load_problem(p)
+    cal.Solve()
+    gt = p.imu_gt
+    tr = cal.trace()
+    assert int(tr[-1, 9]) == 3                                   # stages A, B, C, D
+    for st in range(4):
+        rows = tr[(tr[:, 9] == st) & (tr[:, 8] == 1)]
+        assert np.all(np.diff(rows[:, 1]) < 0)                   # accepted costs fall within each stage
+    assert abs(cal.time_offset() - gt["time_offset"]) < 5e-5
+    np.testing.assert_allclose(cal.GetBiases(), np.concatenate([gt["bg"], gt["ba"]]), atol=2e-4)
+    np.testing.assert_allclose(cal.GetScaleFactor(), np.concatenate([gt["sg"], gt["sa"]]), atol=2e-4)
+    np.testing.assert_allclose(cal.GetGravity(), gt["g_dir"], atol=1e-4)
+    q = cal.GetCamera(0)[1][:4]; qg = p.cam_T_ck_gt[0][:4]
+    assert abs(abs(q @ qg) - 1.0) < 1e-8
+    assert abs(cal.GetCameraProjRMSE()[0] - p.cfg.pixel_sigma) < 0.01
+
+
+def test_cfg4_rig_reduced_frame_count_visual_inertial():
+    """BASELINE cfg4's rig and grid (4 x poly3 + IMU, large 900-dot grid) at 1/25 of its frames: 4 tiles per frame, D = 67,
+    900-entry target-point table; properties as above."""
+    p = synth.generate(synth.Config(models=("poly3",) * 4, grid="large", n_frames=400, imu=True, seed=21))
+    cal = ViCalibrator(0).load_problem(p)
+    cal.Solve()
+    gt = p.imu_gt
+    assert cal.shared_dim() == 67
+    assert abs(cal.time_offset() - gt["time_offset"]) < 2e-4
+    np.testing.assert_allclose(cal.GetBiases()[:3], gt["bg"], atol=3e-4)
+    rm = cal.GetCameraProjRMSE()
+    assert np.all(np.abs(rm - p.cfg.pixel_sigma) < 0.01)
+    for c in range(4):
+        np.testing.assert_allclose(cal.GetCamera(c)[0][:4], p.cam_K_gt[c][:4], rtol=2e-3)
+
+
 def test_async_start_poll_stop():
     p = synth.generate(synth.BASELINE_CONFIGS["cfg1"])
     cal = ViCalibrator(0).load_problem(p); cal.SetCalibrateImu(False)
