@@ -102,6 +102,11 @@ constexpr int kNcclDouble = 8, kNcclSum = 0, kNcclMax = 2;     // ncclDataType_t
 struct vc_calibrator {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;        // the IMU weight update of a pass runs here, under the pass's Jacobian sweeps and chain solve
+  hipEvent_t ev_state = nullptr, ev_weights = nullptr;
+  int wcur = 0;                         // weight buffer holding the current weight_sqrt_
+  hipGraphExec_t pass_graph[2] = {nullptr, nullptr};   // one captured LM pass per weight-buffer parity (single process)
+  bool use_graphs = false;      // measured slower on ROCm 7.2 (cfg2: 65 vs 62 us / pass, instantiation ~10 ms per stage): opt-in via VICALIB_AMD_GRAPHS=1
   hipError_t last_hip_error = hipSuccess;
   // ---- problem (host copy) ---------------------------------------------------------------
   std::vector<HostCam> cams;
@@ -110,6 +115,8 @@ struct vc_calibrator {
   std::vector<double> o_pw, o_pc;
   std::vector<signed char> o_removed;       // RemoveOutliers: 1 = no copy left (dropped), 2 = one copy fewer than vis_mult (kObsOneLess)
   long n_one_less = 0;
+  bool obs_dirty = true;          // the observation set (or its multiplicity bits) changed since the tile layout was built
+  int n_points_dev = 0;
   std::vector<double> imu_w, imu_a, imu_t;
   double imu_end_time = -1.0;
   double g_dir[2] = {0, 0}, time_offset = 0, biases[6] = {0, 0, 0, 0, 0, 0}, scale[6] = {1, 1, 1, 1, 1, 1};
@@ -155,7 +162,7 @@ struct vc_calibrator {
   DBuf<double> d_pose[2], d_cam[2], d_G[2], d_tile_cost[2], d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_sdiag,
       d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total;
   DBuf<Ctrl> d_ctrl;
-  DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt, d_segH, d_segg, d_seg_cost, d_seg_trial,
+  DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_segH, d_segg, d_seg_cost, d_seg_trial,
       d_cA, d_cB, d_cP, d_cQ, d_cW, d_cdelta, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init;
   size_t wsqrt_frames = 0;       // number of frames the device weight_sqrt_ array was initialised for
   int trace_cap = 0;
@@ -169,6 +176,10 @@ struct vc_calibrator {
   ~vc_calibrator() {
     stop();
     if (rccl_comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(stream); (void)g_rccl.CommDestroy(rccl_comm); }
+    drop_graphs();
+    if (stream2) (void)hipStreamDestroy(stream2);
+    if (ev_state) (void)hipEventDestroy(ev_state);
+    if (ev_weights) (void)hipEventDestroy(ev_weights);
     if (stream) (void)hipStreamDestroy(stream);
     if (pin) (void)hipHostFree(pin);
   }
@@ -235,6 +246,7 @@ struct vc_calibrator {
 
   int upload() {
     HIP_OK(hipSetDevice(device));
+    drop_graphs();
     const int Nown = (int)frames.size(), C = (int)cams.size();
     if (C > kMaxCams) return VC_ERR_UNSUPPORTED;
     // ---- frame-sharded IMU chain: this rank's first frame is a separator of the reduced system (rank > 0) and the
@@ -254,38 +266,49 @@ struct vc_calibrator {
     }
     const int N = Nown + (ghost ? 1 : 0);
     auto frame_at = [&](int f) -> const HostFrame& { return f < Nown ? frames[f] : ghost_frame; };
-    // ---- tiles: sort the active observations by (frame, camera) ------------------------------
-    const size_t n_all = o_frame.size();
-    std::vector<int> idx; idx.reserve(n_all);
-    for (size_t i = 0; i < n_all; ++i) if (o_removed[i] != 1) idx.push_back((int)i);
-    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
-      return o_frame[a] != o_frame[b] ? o_frame[a] < o_frame[b] : o_cam[a] < o_cam[b]; });
-    h_obs_index = idx;
-    h_tile_frame.clear(); h_tile_cam.clear(); h_tile_off.clear();
-    std::unordered_map<PointKey, int, PointHash> pmap;
-    std::vector<double> points;
-    std::vector<double2> uv(idx.size());
-    std::vector<unsigned short> pt(idx.size());
-    n_one_less = 0;
-    for (size_t k = 0; k < idx.size(); ++k) {
-      const int i = idx[k];
-      if (k == 0 || o_frame[i] != o_frame[idx[k - 1]] || o_cam[i] != o_cam[idx[k - 1]]) {
-        h_tile_frame.push_back(o_frame[i]); h_tile_cam.push_back(o_cam[i]); h_tile_off.push_back((int)k);
+    // ---- tiles: sort the active observations by (frame, camera) -- only when the observation set changed (the stage
+    // machine re-uploads state and layout four times per calibration, the 10 ms sort / de-dup / 7 MB copy happen once)
+    if (obs_dirty) {
+      const size_t n_all = o_frame.size();
+      std::vector<int> idx; idx.reserve(n_all);
+      for (size_t i = 0; i < n_all; ++i) if (o_removed[i] != 1) idx.push_back((int)i);
+      std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+        return o_frame[a] != o_frame[b] ? o_frame[a] < o_frame[b] : o_cam[a] < o_cam[b]; });
+      h_obs_index = idx;
+      h_tile_frame.clear(); h_tile_cam.clear(); h_tile_off.clear();
+      std::unordered_map<PointKey, int, PointHash> pmap;
+      std::vector<double> points;
+      std::vector<double2> uv(idx.size());
+      std::vector<unsigned short> pt(idx.size());
+      n_one_less = 0;
+      for (size_t k = 0; k < idx.size(); ++k) {
+        const int i = idx[k];
+        if (k == 0 || o_frame[i] != o_frame[idx[k - 1]] || o_cam[i] != o_cam[idx[k - 1]]) {
+          h_tile_frame.push_back(o_frame[i]); h_tile_cam.push_back(o_cam[i]); h_tile_off.push_back((int)k);
+        }
+        PointKey key{o_pw[3 * (size_t)i], o_pw[3 * (size_t)i + 1], o_pw[3 * (size_t)i + 2]};
+        auto it = pmap.find(key);
+        int id;
+        if (it == pmap.end()) {
+          id = (int)pmap.size();
+          if (id >= kObsPointMask + 1) return VC_ERR_TOO_MANY_POINTS;
+          pmap.emplace(key, id);
+          points.push_back(key.x); points.push_back(key.y); points.push_back(key.z);
+        } else id = it->second;
+        pt[k] = (unsigned short)(id | (o_removed[i] == 2 ? kObsOneLess : 0));
+        if (o_removed[i] == 2) ++n_one_less;
+        uv[k] = make_double2(o_pc[2 * (size_t)i], o_pc[2 * (size_t)i + 1]);
       }
-      PointKey key{o_pw[3 * (size_t)i], o_pw[3 * (size_t)i + 1], o_pw[3 * (size_t)i + 2]};
-      auto it = pmap.find(key);
-      int id;
-      if (it == pmap.end()) {
-        id = (int)pmap.size();
-        if (id >= kObsPointMask + 1) return VC_ERR_TOO_MANY_POINTS;
-        pmap.emplace(key, id);
-        points.push_back(key.x); points.push_back(key.y); points.push_back(key.z);
-      } else id = it->second;
-      pt[k] = (unsigned short)(id | (o_removed[i] == 2 ? kObsOneLess : 0));
-      if (o_removed[i] == 2) ++n_one_less;
-      uv[k] = make_double2(o_pc[2 * (size_t)i], o_pc[2 * (size_t)i + 1]);
+      h_tile_off.push_back((int)idx.size());
+      n_points_dev = (int)pmap.size();
+      HIP_OK(d_uv.upload(uv, stream)); HIP_OK(d_pt.upload(pt, stream)); HIP_OK(d_points.upload(points, stream));
+      HIP_OK(d_tile_frame.upload(h_tile_frame, stream)); HIP_OK(d_tile_cam.upload(h_tile_cam, stream));
+      HIP_OK(d_tile_off.upload(h_tile_off, stream));
+      HIP_OK(d_mask.alloc(std::max<size_t>(idx.size(), 1)));
+      HIP_OK(hipStreamSynchronize(stream));        // the staging vectors go out of scope
+      obs_dirty = false;
     }
-    h_tile_off.push_back((int)idx.size());
+    const size_t n_active = h_obs_index.size();
     const int T = (int)h_tile_frame.size();
     std::vector<int> frame_tile_off(N + 1, T), frame_cam_tile((size_t)N * std::max(C, 1), -1);
     {
@@ -301,9 +324,7 @@ struct vc_calibrator {
     if (((size_t)(D + 1) * (D + 2) / 2 + 2 * (D + 1)) * sizeof(double) + 13 * 1024 > 160 * 1024 || D + 1 > 12 * 16) return VC_ERR_UNSUPPORTED;
     for (int c = 0; c < C; ++c) cam_model[c] = cams[c].model;
     // ---- upload ---------------------------------------------------------------------------------
-    HIP_OK(d_uv.upload(uv, stream)); HIP_OK(d_pt.upload(pt, stream)); HIP_OK(d_points.upload(points, stream));
-    HIP_OK(d_tile_frame.upload(h_tile_frame, stream)); HIP_OK(d_tile_cam.upload(h_tile_cam, stream));
-    HIP_OK(d_tile_off.upload(h_tile_off, stream)); HIP_OK(d_frame_tile_off.upload(frame_tile_off, stream));
+    HIP_OK(d_frame_tile_off.upload(frame_tile_off, stream));
     HIP_OK(d_frame_cam_tile.upload(frame_cam_tile, stream)); HIP_OK(d_cam_model.upload(cam_model, stream));
     HIP_OK(d_cam_flags.upload(cam_flags, stream)); HIP_OK(d_cam_col0.upload(cam_col0, stream));
     HIP_OK(d_col_cam.upload(col_cam, stream)); HIP_OK(d_col_local.upload(col_local, stream));
@@ -333,13 +354,13 @@ struct vc_calibrator {
     HIP_OK(hipMemsetAsync(d_fpart.p, 0, (size_t)std::max(N, 1) * kNumScal * sizeof(double), stream));
     HIP_OK(d_scal.alloc(2 * kNumScal)); HIP_OK(d_flags.alloc(4));
     HIP_OK(hipMemsetAsync(d_scal.p, 0, 2 * kNumScal * sizeof(double), stream));
-    HIP_OK(d_tmp.alloc(64)); HIP_OK(d_mask.alloc(std::max<size_t>(idx.size(), 1)));
+    HIP_OK(d_tmp.alloc(64));
     HIP_OK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(int), stream));
     HIP_OK(hipMemsetAsync(d_delta_s.p, 0, std::max(D, 1) * sizeof(double), stream));
     for (int c = 0; c < kMaxCams; ++c) { dv.cd[c].model = 0; dv.cd[c].flags = 0; dv.cd[c].col0 = 0; dv.cd[c].ncols = 0; }
     for (int c = 0; c < C; ++c) { dv.cd[c].model = cams[c].model; dv.cd[c].flags = cam_flags[c]; dv.cd[c].col0 = cam_col0[c]; dv.cd[c].ncols = cam_ncols(cam_flags[c], cams[c].nk); }
-    dv.n_frames = N; dv.n_cams = C; dv.n_tiles = T; dv.n_points = (int)pmap.size(); dv.D = D;
-    dv.n_chunks = n_chunks; dv.chunk_frames = chunk_frames; dv.n_obs = (long long)idx.size();
+    dv.n_frames = N; dv.n_cams = C; dv.n_tiles = T; dv.n_points = n_points_dev; dv.D = D;
+    dv.n_chunks = n_chunks; dv.chunk_frames = chunk_frames; dv.n_obs = (long long)n_active;
     dv.obs_uv = d_uv.p; dv.obs_pt = d_pt.p; dv.points = d_points.p;
     dv.tile_frame = d_tile_frame.p; dv.tile_cam = d_tile_cam.p; dv.tile_off = d_tile_off.p;
     dv.frame_tile_off = d_frame_tile_off.p; dv.frame_cam_tile = d_frame_cam_tile.p;
@@ -379,7 +400,7 @@ struct vc_calibrator {
       if (wsqrt_frames != (size_t)N) {          // initial weight 500 * I (vicalibrator.h:616); later stages keep the current weights
         std::vector<double> w(ns * 81, 0.0);
         for (size_t k = 0; k < ns; ++k) for (int i = 0; i < 9; ++i) w[k * 81 + i * 10] = 500.0;
-        HIP_OK(d_wsqrt.upload(w, stream)); wsqrt_frames = (size_t)N;
+        HIP_OK(d_wsqrt[0].upload(w, stream)); HIP_OK(d_wsqrt[1].upload(w, stream)); wsqrt_frames = (size_t)N; wcur = 0;
         HIP_OK(hipStreamSynchronize(stream));
       }
       HIP_OK(d_segH.alloc(ns * 33 * 33)); HIP_OK(d_segg.alloc(ns * 33)); HIP_OK(d_seg_cost.alloc(ns)); HIP_OK(d_seg_trial.alloc(ns));
@@ -390,7 +411,7 @@ struct vc_calibrator {
     }
     dv.imu_t = d_imu_t.p; dv.imu_w = d_imu_w.p; dv.imu_a = d_imu_a.p; dv.frame_time = d_frame_time.p;
     dv.vel[0] = d_vel[0].p; dv.vel[1] = d_vel[1].p; dv.imus[0] = d_imus[0].p; dv.imus[1] = d_imus[1].p;
-    dv.wsqrt = d_wsqrt.p; dv.segH = d_segH.p; dv.segg = d_segg.p; dv.seg_cost = d_seg_cost.p; dv.seg_trial = d_seg_trial.p;
+    dv.wsqrtb[0] = d_wsqrt[0].p; dv.wsqrtb[1] = d_wsqrt[1].p; dv.segH = d_segH.p; dv.segg = d_segg.p; dv.seg_cost = d_seg_cost.p; dv.seg_trial = d_seg_trial.p;
     dv.cA = d_cA.p; dv.cB = d_cB.p; dv.cP = d_cP.p; dv.cQ = d_cQ.p; dv.cW = d_cW.p; dv.cdelta = d_cdelta.p; dv.cg = d_cg.p;
     dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p;
     HIP_OK(hipStreamSynchronize(stream));   // the staging vectors above go out of scope
@@ -425,6 +446,34 @@ struct vc_calibrator {
     return VC_OK;
   }
 
+  void drop_graphs() {
+    for (int i = 0; i < 2; ++i) if (pass_graph[i]) { (void)hipGraphExecDestroy(pass_graph[i]); pass_graph[i] = nullptr; }
+  }
+  // A pass is a fixed sequence of launches (up to ~45 with the IMU chain): captured once per upload and replayed, the host
+  // pays one graph launch per pass instead of one call per kernel.  Sharded runs keep direct launches (host callbacks).
+  int launch_pass_graph() {
+    const bool flips = dv.imu_on && dv.weights_on;
+    const int par = flips ? wcur : 0;
+    if (!pass_graph[par]) {
+      hipGraph_t g = nullptr;
+      const int w0 = wcur;
+      if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { use_graphs = false; return enqueue_pass(false); }
+      const int rc = enqueue_pass(false);
+      const hipError_t e = hipStreamEndCapture(stream, &g);
+      wcur = w0;
+      if (rc != VC_OK || e != hipSuccess || !g || hipGraphInstantiate(&pass_graph[par], g, nullptr, nullptr, 0) != hipSuccess) {
+        if (g) (void)hipGraphDestroy(g);
+        pass_graph[par] = nullptr; use_graphs = false;
+        (void)hipGetLastError();
+        return enqueue_pass(false);
+      }
+      (void)hipGraphDestroy(g);
+    }
+    HIP_OK(hipGraphLaunch(pass_graph[par], stream));
+    if (flips) wcur = 1 - wcur;
+    return VC_OK;
+  }
+
   // ---- one pass of the device pipeline (all asynchronous; the decision is taken on the device) ------
   int do_allreduce(double* p, int n, int op) {
     if (sharded() && rccl_comm) {
@@ -437,9 +486,18 @@ struct vc_calibrator {
   int enqueue_pass(bool first_pass = true) {
     const int D = dv.D;
     if (dv.imu_on) {
+      // UpdateImuWeights of the iteration callback (vicalibrator.h:691): linearise with the current weights, evaluate the
+      // trial point with the updated ones.  The update only needs the accepted state, so it runs on a second stream under
+      // the Jacobian sweeps and the chain solve and writes the other weight buffer.
+      const bool upd = dv.weights_on != 0;
+      if (upd) {
+        HIP_OK(hipEventRecord(ev_state, stream));
+        HIP_OK(hipStreamWaitEvent(stream2, ev_state, 0));
+        launch_imu_weights(dv, wcur, stream2);
+        HIP_OK(hipEventRecord(ev_weights, stream2));
+      }
       launch_reproj_jac(dv, stream);
-      launch_imu_jac(dv, stream);
-      launch_imu_weights(dv, stream);                // iteration callback's UpdateImuWeights (vicalibrator.h:691)
+      launch_imu_jac(dv, wcur, stream);
       launch_chain_solve_a(dv, stream);
       launch_part_sum(dv, stream);
       int rc = VC_OK;
@@ -452,7 +510,8 @@ struct vc_calibrator {
       }
       launch_chain_solve_b(dv, stream);
       launch_reproj_res(dv, 3, 0.0, stream);
-      launch_imu_res(dv, 3, stream);
+      if (upd) { HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0)); wcur = 1 - wcur; }
+      launch_imu_res(dv, 3, wcur, stream);
       if (sharded()) {
         launch_final(dv, 1, stream);
         rc = do_allreduce(dv.gath, world * kNumScal, 0); if (rc) return rc;
@@ -501,13 +560,17 @@ struct vc_calibrator {
     if (!pin) HIP_OK(hipHostMalloc((void**)&pin, sizeof(Pinned), hipHostMallocDefault));
     init_ctrl(&pin->up);
     HIP_OK(hipMemcpyAsync(d_ctrl.p, &pin->up, sizeof(Ctrl), hipMemcpyHostToDevice, stream));
-    if (dv.imu_on) launch_imu_weights(dv, stream);     // UpdateImuWeights() before ceres::Solve (vicalibrator.h:955)
+    if (dv.imu_on && dv.weights_on) { launch_imu_weights(dv, wcur, stream); wcur = 1 - wcur; }     // UpdateImuWeights() before ceres::Solve (vicalibrator.h:955)
     // First batch = what the previous solve needed (repeated solves of similar problems: no wasted launches,
     // one host sync per solve); then small top-up batches until the device reports `done`.
     int batch = std::max(1, std::min(expected_passes, max_iters + 1)), guard = 0, n_enq = 0;
     const size_t trace_bytes = (size_t)std::min(trace_cap, 64) * kTraceCols * 8;
     while (true) {
-      for (int b = 0; b < batch; ++b) { int rc = enqueue_pass(n_enq++ == 0); if (rc) return rc; }
+      for (int b = 0; b < batch; ++b) {
+        const bool first = (n_enq++ == 0);
+        int rc = (first || sharded() || !use_graphs) ? enqueue_pass(first) : launch_pass_graph();
+        if (rc) return rc;
+      }
       HIP_OK(hipMemcpyAsync(&pin->down, d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
       HIP_OK(hipMemcpyAsync(pin->trace, d_trace.p, trace_bytes, hipMemcpyDeviceToHost, stream));
       HIP_OK(hipStreamSynchronize(stream));
@@ -582,7 +645,7 @@ struct vc_calibrator {
     // an outlier ends up with one copy fewer than the inliers.
     const signed char mark = calibrate_imu ? 2 : 1;
     for (size_t k = 0; k < mask.size(); ++k) if (mask[k] && o_removed[h_obs_index[k]] == 0) o_removed[h_obs_index[k]] = mark;
-    device_dirty = true;
+    device_dirty = true; obs_dirty = true;
     return VC_OK;
   }
 
@@ -677,7 +740,10 @@ int vc_create(vc_calibrator** out, int device) {
   if (hipSetDevice(device) != hipSuccess) return VC_ERR_NO_DEVICE;
   vc_calibrator* h = new vc_calibrator();
   h->device = device;
-  if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }
+  { const char* e = std::getenv("VICALIB_AMD_GRAPHS"); if (e && e[0] == '1') h->use_graphs = true; }
+  if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_weights, hipEventDisableTiming) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }
   *out = h;
   return VC_OK;
 }
@@ -689,7 +755,7 @@ int vc_clear(vc_calibrator* h) {
   h->cams.clear(); h->frames.clear(); h->o_frame.clear(); h->o_cam.clear(); h->o_pw.clear(); h->o_pc.clear(); h->o_removed.clear();
   h->mse = 0; h->num_iterations = 0; h->is_bias_active = false; h->is_scale_active = false; h->is_inertial_active = false;
   h->is_visual_active = true; h->rotation_only = true; h->is_finished = false; h->gravity_initialized = false;
-  h->outliers_removed = false; h->vis_mult = 0; h->imu_mult = 0; h->wsqrt_frames = 0; h->imu_w.clear(); h->imu_a.clear(); h->imu_t.clear(); h->imu_end_time = -1.0; h->trace.clear(); h->stage = 0; h->device_dirty = true;
+  h->outliers_removed = false; h->vis_mult = 0; h->imu_mult = 0; h->wsqrt_frames = 0; h->imu_w.clear(); h->imu_a.clear(); h->imu_t.clear(); h->imu_end_time = -1.0; h->trace.clear(); h->stage = 0; h->device_dirty = true; h->obs_dirty = true;
   return VC_OK;
 }
 
@@ -769,7 +835,7 @@ int vc_add_observations(vc_calibrator* h, int frame, int camera, int n, const do
   if (frame < 0 || frame >= (int)h->frames.size() || camera < 0 || camera >= (int)h->cams.size()) return VC_ERR_BAD_ARG;
   h->o_frame.insert(h->o_frame.end(), n, frame); h->o_cam.insert(h->o_cam.end(), n, camera);
   h->o_pw.insert(h->o_pw.end(), p_w, p_w + 3 * (size_t)n); h->o_pc.insert(h->o_pc.end(), p_c, p_c + 2 * (size_t)n);
-  h->o_removed.insert(h->o_removed.end(), n, 0); h->device_dirty = true;
+  h->o_removed.insert(h->o_removed.end(), n, 0); h->device_dirty = true; h->obs_dirty = true;
   return VC_OK;
 }
 int vc_add_imu(vc_calibrator* h, int n, const double* gyro, const double* accel, const double* time) {

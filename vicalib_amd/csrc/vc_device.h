@@ -101,7 +101,8 @@ struct DevView {
   double* imus[2];                 // 16: g(2) b(6) sf(6) toff(1) pad
   int imu_param_col[15];           // shared column of g0 g1 b0..5 sf0..5 toff, -1 = constant
   double gyro_sigma, accel_sigma;
-  double* wsqrt;                   // (n_frames-1) x 81  weight_sqrt_ of every IMU cost
+  double* wsqrtb[2];               // (n_frames-1) x 81  weight_sqrt_ of every IMU cost, double-buffered: the update of pass p
+                                   // (k_imu_weights on a second stream) writes the buffer the Jacobian sweep of pass p is not reading
   double* segH;                    // (n_frames-1) x 33 x 33  weighted J^T J, columns [frame j (9) | frame j-1 (9) | imu (15)]
   double* segg;                    // (n_frames-1) x 33       weighted J^T r
   double* seg_cost;                // (n_frames-1)  imu_mult * rho at the linearisation point
@@ -143,9 +144,9 @@ void launch_cam_sq(const DevView& v, double* out /*n_cams x 2: sum sq, count*/, 
 void launch_outlier_mask(const DevView& v, int state, const double* thresh /*device, n_cams*/, unsigned char* mask, hipStream_t s);
 
 // inertial path (vc_imu_kernels.hip)
-void launch_imu_jac(const DevView& v, hipStream_t s);
-void launch_imu_res(const DevView& v, int state_sel, hipStream_t s);        // 2: accepted -> seg_cost-like eval into seg_trial, 3: trial
-void launch_imu_weights(const DevView& v, hipStream_t s);                   // weight_sqrt_ from the accepted state
+void launch_imu_jac(const DevView& v, int wr, hipStream_t s);               // wr: weight buffer to read
+void launch_imu_res(const DevView& v, int state_sel, int wr, hipStream_t s);        // 2: accepted -> seg_cost-like eval into seg_trial, 3: trial
+void launch_imu_weights(const DevView& v, int wr, hipStream_t s);          // reads wsqrtb[wr], writes wsqrtb[1 - wr];                   // weight_sqrt_ from the accepted state
 void launch_chain_solve_a(const DevView& v, hipStream_t s);                 // assemble + cyclic-reduction elimination + Gram partials
 void launch_chain_solve_b(const DevView& v, hipStream_t s);                 // back-substitution + trial frame state
 

@@ -31,7 +31,7 @@ __device__ __forceinline__ ImuView imu_view(const DevView& v) { ImuView b = {v.i
 
 // ------------------------------------------------------------------------------------------ IMU Jacobian
 constexpr int kImuJacLds = 35 * 9 + 33 * 9 + 16;
-__global__ __launch_bounds__(256) void k_imu_jac(DevView v) {
+__global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr) {
   __shared__ double sh[4 * kImuJacLds];
   const Ctrl* ct = v.ctrl;
   if (ct->done || !ct->need_lin) return;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v) {
   const double* im = v.imus[cur];
   double r[9], dr[9];
   const ImuView buf = imu_view(v);
-  imu_block_direction(buf, v.frame_time[j - 1], v.frame_time[j], v.wsqrt + (size_t)s * 81, v.rotation_only, T2, T1, v2, v1, im, im + 2,
+  imu_block_direction(buf, v.frame_time[j - 1], v.frame_time[j], v.wsqrtb[wr] + (size_t)s * 81, v.rotation_only, T2, T1, v2, v1, im, im + 2,
                       im + 8, im[14], lane < 35 ? lane : -1, r, dr);
   if (lane < 35) {
 #pragma unroll
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v) {
 }
 
 // residual cost of every IMU block at a state: sel 2 = accepted buffer, 3 = trial buffer
-__global__ __launch_bounds__(64) void k_imu_res(DevView v, int sel) {
+__global__ __launch_bounds__(64) void k_imu_res(DevView v, int sel, int wr) {
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
   const int s = blockIdx.x * 64 + threadIdx.x;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64) void k_imu_res(DevView v, int sel) {
   const int st = (sel == 3) ? 1 - ct->cur : ct->cur, j = s + 1;
   const double* im = v.imus[st];
   double r[9];
-  imu_residual<double>(imu_view(v), v.frame_time[j - 1], v.frame_time[j], v.wsqrt + (size_t)s * 81, v.rotation_only,
+  imu_residual<double>(imu_view(v), v.frame_time[j - 1], v.frame_time[j], v.wsqrtb[wr] + (size_t)s * 81, v.rotation_only,
                        v.poses[st] + (size_t)j * kPoseStride, v.poses[st] + (size_t)(j - 1) * kPoseStride, v.vel[st] + (size_t)j * 4,
                        v.vel[st] + (size_t)(j - 1) * 4, im, im + 2, im + 8, im[14], r);
   double ss = 0.0;
@@ -270,13 +270,16 @@ __device__ void w_step(WLds& L, WState* st, const Meas<double>& z0, const Meas<d
   *st = y;
 }
 
-__global__ __launch_bounds__(256) void k_imu_weights(DevView v) {
+__global__ __launch_bounds__(256) void k_imu_weights(DevView v, int wr) {
   __shared__ WLds lds[4];
   const Ctrl* ct = v.ctrl;
-  if (ct->done || !v.weights_on) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int s = blockIdx.x * 4 + wave;
   if (s >= v.n_frames - 1) return;
+  // the buffer being written starts as a copy of the current weights: blocks that keep their weight (no samples, singular
+  // projection) and passes queued behind a finished solve leave a consistent buffer behind
+  for (int e = lane; e < 81; e += 64) v.wsqrtb[1 - wr][(size_t)s * 81 + e] = v.wsqrtb[wr][(size_t)s * 81 + e];
+  if (ct->done || !v.weights_on) return;
   WLds& L = lds[wave];
   const int st = ct->cur, j = s + 1;
   const double* im = v.imus[st];
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(256) void k_imu_weights(DevView v) {
       for (int k = 0; k < 9; ++k) if (k < i) a -= L.P[i * 9 + k] * x[k];
       x[i] = (i >= c) ? a * L.tmp[i] : 0.0;
     }
-    double* w = v.wsqrt + (size_t)s * 81;       // W[a][b] = X[b][a]
+    double* w = v.wsqrtb[1 - wr] + (size_t)s * 81;       // W[a][b] = X[b][a]
 #pragma unroll
     for (int i = 0; i < 9; ++i) w[c * 9 + i] = x[i];
   }
@@ -865,17 +868,17 @@ __global__ __launch_bounds__(64) void k_frame_update(DevView v) {
 }
 
 // ------------------------------------------------------------------------------------------ launchers
-void launch_imu_jac(const DevView& v, hipStream_t s) {
+void launch_imu_jac(const DevView& v, int wr, hipStream_t s) {
   if (v.n_frames < 2) return;
-  hipLaunchKernelGGL(k_imu_jac, dim3((v.n_frames - 1 + 3) / 4), dim3(256), 0, s, v);
+  hipLaunchKernelGGL(k_imu_jac, dim3((v.n_frames - 1 + 3) / 4), dim3(256), 0, s, v, wr);
 }
-void launch_imu_res(const DevView& v, int sel, hipStream_t s) {
+void launch_imu_res(const DevView& v, int sel, int wr, hipStream_t s) {
   if (v.n_frames < 2) return;
-  hipLaunchKernelGGL(k_imu_res, dim3((v.n_frames - 1 + 63) / 64), dim3(64), 0, s, v, sel);
+  hipLaunchKernelGGL(k_imu_res, dim3((v.n_frames - 1 + 63) / 64), dim3(64), 0, s, v, sel, wr);
 }
-void launch_imu_weights(const DevView& v, hipStream_t s) {
+void launch_imu_weights(const DevView& v, int wr, hipStream_t s) {
   if (v.n_frames < 2) return;
-  hipLaunchKernelGGL(k_imu_weights, dim3((v.n_frames - 1 + 3) / 4), dim3(256), 0, s, v);
+  hipLaunchKernelGGL(k_imu_weights, dim3((v.n_frames - 1 + 3) / 4), dim3(256), 0, s, v, wr);
 }
 void launch_chain_solve_a(const DevView& v, hipStream_t s) {
   const int N = v.n_frames;
