@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Per-iteration traces of the CPU oracle's LM loop on small seeded problems: cost, gradient max-norm,
+accepted flag, radius, stage for every iteration, and the converged shared parameters.  The fixture pins (a) the oracle
+against its own regressions (tests/test_oracle.py, no GPU) and (b) the GPU solver at iteration level
+(tests/test_gpu_parity.py).  Run from the repo root:  python tests/golden/make_golden_traces.py"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle_lib as ol  # noqa: E402
+from vicalib_amd import synth  # noqa: E402
+
+CASES = {
+    # name: (generator config, oracle options)
+    "cfg1_poly3_50": (dict(models=("poly3",), n_frames=50), dict(calibrate_imu=False)),
+    "stereo_fov_kb4_30": (dict(models=("fov", "kb4"), n_frames=30, seed=7), dict(calibrate_imu=False)),
+    "mono_kb4_imu_60": (dict(models=("kb4",), n_frames=60, imu=True, seed=5), dict(calibrate_imu=True, max_iters=100)),
+}
+
+
+def run(cfg_kw, opt):
+    p = synth.generate(synth.Config(**cfg_kw))
+    orc = ol.Oracle().load(p)
+    orc.set_options(num_threads=8, **opt)
+    orc.solve()
+    tr = orc.trace()
+    out = {"config": {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg_kw.items()}, "options": opt,
+           "trace_columns": ["iteration", "cost", "gradient_max_norm", "accepted", "radius", "stage"],
+           "trace": tr[:, [0, 1, 3, 8, 7, 9]].tolist(),
+           "cameras": [{"K": orc.camera(c)[0].tolist(), "T_ck": orc.camera(c)[1].tolist()} for c in range(len(p.cam_model))],
+           "rmse": np.asarray(orc.rmse()).tolist()}
+    if opt.get("calibrate_imu"):
+        b, s, g, toff = orc.imu_state()
+        out["imu"] = {"biases": np.asarray(b).tolist(), "scale": np.asarray(s).tolist(), "gravity": np.asarray(g).tolist(), "time_offset": float(toff)}
+    return out
+
+
+if __name__ == "__main__":
+    data = {name: run(*spec) for name, spec in CASES.items()}
+    with open(os.path.join(HERE, "lm_traces.json"), "w") as f:
+        json.dump(data, f, indent=0)
+    for k, v in data.items():
+        print(k, len(v["trace"]), "trace rows, final cost", v["trace"][-1][1])

@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on identical
 seeded inputs.  Floating point (f64) -> tolerance, stated per test; north_star asks <= 1e-6 relative on
 recovered parameters and per-iteration residual costs."""
+import os
 import numpy as np
 import pytest
 
@@ -205,6 +206,37 @@ def test_cfg4_rig_reduced_frame_count_visual_inertial():
     assert np.all(np.abs(rm - p.cfg.pixel_sigma) < 0.01)
     for c in range(4):
         np.testing.assert_allclose(cal.GetCamera(c)[0][:4], p.cam_K_gt[c][:4], rtol=2e-3)
+
+
+@pytest.mark.parametrize("name", ["cfg1_poly3_50", "stereo_fov_kb4_30", "mono_kb4_imu_60"])
+def test_solver_matches_committed_lm_traces(name):
+    """Iteration-level agreement with the fixture tests/golden/lm_traces.json (the oracle's LM loop, generated by
+    tests/golden/make_golden_traces.py): cost of every iteration, accept/reject sequence, radius, final parameters."""
+    import json
+    e = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lm_traces.json")))[name]
+    cfg = dict(e["config"]); cfg["models"] = tuple(cfg["models"])
+    p = synth.generate(synth.Config(**cfg))
+    cal = ViCalibrator(0).load_problem(p)
+    cal.SetCalibrateImu(bool(e["options"].get("calibrate_imu", False)))
+    if "max_iters" in e["options"]:
+        cal.SetMaxIters(e["options"]["max_iters"])
+    cal.Solve()
+    tr = cal.trace()[:, [0, 1, 3, 8, 7, 9]]
+    want = np.array(e["trace"])
+    assert tr.shape == want.shape
+    np.testing.assert_allclose(tr[:, 1], want[:, 1], rtol=1e-6)
+    np.testing.assert_array_equal(tr[:, 3], want[:, 3])
+    np.testing.assert_allclose(tr[:, 4], want[:, 4], rtol=1e-6)
+    np.testing.assert_array_equal(tr[:, 5], want[:, 5])
+    for c, cam in enumerate(e["cameras"]):
+        np.testing.assert_allclose(cal.GetCamera(c)[0], cam["K"], rtol=1e-6)
+        np.testing.assert_allclose(cal.GetCamera(c)[1], cam["T_ck"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(cal.GetCameraProjRMSE(), e["rmse"], rtol=1e-6)
+    if "imu" in e:
+        np.testing.assert_allclose(cal.GetBiases(), e["imu"]["biases"], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(cal.GetScaleFactor(), e["imu"]["scale"], rtol=1e-6)
+        np.testing.assert_allclose(cal.GetGravity(), e["imu"]["gravity"], rtol=1e-6, atol=1e-9)
+        assert abs(cal.time_offset() - e["imu"]["time_offset"]) < 1e-9
 
 
 def test_async_start_poll_stop():

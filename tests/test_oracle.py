@@ -179,3 +179,23 @@ def test_cfg1_optimum_matches_scipy():
     np.testing.assert_allclose(K_lm[4:], K_sp[4:], rtol=2e-4, atol=1e-7)
     # and it recovers ground truth to the accuracy the noise allows
     np.testing.assert_allclose(K_lm[:4], p.cam_K_gt[0][:4], rtol=2e-3)
+
+
+TRACES = json.load(open(os.path.join(HERE, "golden", "lm_traces.json")))
+
+
+@pytest.mark.parametrize("name", ["cfg1_poly3_50", "stereo_fov_kb4_30"])
+def test_oracle_reproduces_committed_lm_trace(name):
+    """tests/golden/lm_traces.json (make_golden_traces.py): the oracle's per-iteration record is stable."""
+    e = TRACES[name]
+    cfg = dict(e["config"]); cfg["models"] = tuple(cfg["models"])
+    p = synth.generate(synth.Config(**cfg))
+    orc = ol.Oracle().load(p); orc.set_options(num_threads=4, **e["options"]); orc.solve()
+    tr = orc.trace()[:, [0, 1, 3, 8, 7, 9]]
+    want = np.array(e["trace"])
+    assert tr.shape == want.shape
+    np.testing.assert_allclose(tr[:, 1], want[:, 1], rtol=1e-9)          # costs
+    np.testing.assert_array_equal(tr[:, 3], want[:, 3])                   # accept / reject
+    np.testing.assert_allclose(tr[:, 4], want[:, 4], rtol=1e-9)          # trust-region radius
+    for c, cam in enumerate(e["cameras"]):
+        np.testing.assert_allclose(orc.camera(c)[0], cam["K"], rtol=1e-9)
