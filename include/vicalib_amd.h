@@ -141,6 +141,9 @@ int vc_time_stages(vc_calibrator* h, int reps, double out[6]);
 /* After vc_linearize with inertial terms active: weighted J^T J (33 x 33), J^T r (33), cost of each IMU block,
  * columns [frame j: pose 6, vel 3 | frame j-1: pose 6, vel 3 | g 2, b 6, sf 6, time offset 1] */
 int vc_get_imu_blocks(vc_calibrator* h, double* H, double* g, double* cost);
+/* Current weight_sqrt_ factors W (9 x 9 per IMU block, row-major) with W W^T = (J Sigma J^T)^-1, after vc_linearize
+ * with the weight update active (UpdateImuWeights, vicalibrator.h:723-799). */
+int vc_get_imu_weights(vc_calibrator* h, double* W);
 int vc_get_debug_stamps(vc_calibrator* h, long long out[32]);   /* shader-clock stamps of the last k_reduced (profiling aid) */
 long long vc_num_observations(vc_calibrator* h);
 int vc_num_tiles(vc_calibrator* h);

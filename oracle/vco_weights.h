@@ -332,6 +332,25 @@ inline void imu_weight_sqrt(const std::vector<ImuMeas<double>>& meas, const doub
   set_block(J, 0, 0, J67);
   J(6, 7) = J(7, 8) = J(8, 9) = 1.0;
   const Mat P = mul(mul(J, sigma), tr(J));
+  // Where the reference is undefined (Eigen's inverse() / sqrt() of a matrix that is not positive definite -- seen only for
+  // the one block that straddles the end of a truncated IMU stream, itself a read past the buffer end in the reference,
+  // interpolation-buffer.h:195-199) the block keeps its weight.  Test: symmetric Cholesky of J Sigma J^T.
+  {
+    double Lc[81];
+    for (int i = 0; i < 81; ++i) Lc[i] = P.d[i];
+    for (int c = 0; c < 9; ++c) {
+      double d = Lc[c * 9 + c];
+      for (int k = 0; k < c; ++k) d -= Lc[c * 9 + k] * Lc[c * 9 + k];
+      if (!(d > 0.0)) return;
+      const double piv = std::sqrt(d);
+      Lc[c * 9 + c] = piv;
+      for (int i = c + 1; i < 9; ++i) {
+        double a = Lc[i * 9 + c];
+        for (int k = 0; k < c; ++k) a -= Lc[i * 9 + k] * Lc[c * 9 + k];
+        Lc[i * 9 + c] = a / piv;
+      }
+    }
+  }
   double cov[81];
   inverse9(P.d, cov);
   if (cov_out) std::memcpy(cov_out, cov, sizeof(cov));

@@ -285,6 +285,27 @@ def test_imu_blocks_match_oracle(rot_only):
         np.testing.assert_allclose(g[j - 1], go, rtol=1e-7, atol=1e-9 * np.abs(go).max())
 
 
+def test_imu_weight_update_matches_oracle():
+    """UpdateImuWeights (vicalibrator.h:723-799) on the GPU: covariance propagation with the reference's hand Jacobians,
+    information matrix W W^T = (J Sigma J^T)^-1.  The GPU keeps the Cholesky-form factor, the oracle the symmetric square
+    root: the products agree."""
+    p = _vi_problem(24)
+    gt = p.imu_gt
+    cal = ViCalibrator(0).load_problem(p, init=False)
+    orc = ol.Oracle().load(p, init=False); orc.set_options(calibrate_imu=True)
+    b0 = np.concatenate([gt["bg"], gt["ba"]]) * 0.9; s0 = np.concatenate([gt["sg"], gt["sa"]])
+    orc.set_flags(True, True, False, True); orc.set_imu_state(b0, s0, np.zeros(2), 0.0025)
+    cal.SetOptimizationFlags(True, True, False, True); cal.SetBiases(b0); cal.SetScaleFactor(s0); cal.SetTimeOffset(0.0025)
+    orc.prepare(vis_mult=1, imu_mult=1)
+    cal.linearize()                       # one pass on hold: the weight update runs, the state does not move
+    Wg = cal.imu_weights()
+    orc.update_imu_weights(); Wo = orc.imu_weights().reshape(-1, 9, 9)
+    for j in range(len(Wg)):
+        Cg = Wg[j] @ Wg[j].T; Co = Wo[j] @ Wo[j].T
+        np.testing.assert_allclose(Cg, Co, rtol=1e-7, atol=1e-9 * np.abs(Co).max())
+        assert np.allclose(np.tril(Wg[j], -1), 0.0)          # W = L^-T is upper triangular
+
+
 def _compare_vi(p, cal, orc, rtol=1e-6):
     tg = cal.trace(); to = orc.trace()
     np.set_printoptions(linewidth=220, precision=6)
@@ -321,6 +342,54 @@ def test_visual_inertial_with_outlier_removal_matches_oracle():
     tg = cal.trace()
     assert tg[:, 9].max() >= 4          # a fifth stage ran after the removal
     _compare_vi(p, cal, orc)
+
+
+def _load_both(p, drop_frames=(), imu_until=None, **opt):
+    """The same (possibly mutilated) problem into the GPU calibrator and the oracle."""
+    cal = ViCalibrator(0); orc = ol.Oracle()
+    for c, m in enumerate(p.cam_model):
+        cal.AddCamera(m, p.cam_K_init[c], p.cam_T_ck_init[c], p.cfg.width, p.cfg.height)
+        orc.add_camera(m, p.cam_K_init[c], p.cam_T_ck_init[c], p.cfg.width, p.cfg.height)
+    for n in range(len(p.frame_time)):
+        cal.AddFrame(p.frame_T_wk_init[n], p.frame_time[n]); orc.add_frame(p.frame_T_wk_init[n], p.frame_time[n])
+    for (f, c, ids, pix) in p.tiles:
+        if f in drop_frames:
+            continue
+        cal.AddObservations(f, c, p.grid_points[ids], pix); orc.add_observations(f, c, p.grid_points[ids], pix)
+    k = len(p.imu_t) if imu_until is None else int(np.searchsorted(p.imu_t, imu_until))
+    cal.AddImuMeasurements(p.imu_gyro[:k], p.imu_accel[:k], p.imu_t[:k]); orc.add_imu(p.imu_gyro[:k], p.imu_accel[:k], p.imu_t[:k])
+    orc.set_options(calibrate_imu=True, max_iters=60, num_threads=8, **opt)
+    cal.SetMaxIters(60)
+    return cal, orc
+
+
+def test_visual_inertial_with_frames_that_have_no_detections():
+    """Frames the grid tracker lost (no observations) stay in the IMU chain: their pose / velocity are carried by the
+    inertial blocks alone (6 x 6 vision block = 0, the 9 x 9 chain block comes from the two IMU blocks)."""
+    p = _vi_problem(60, seed=11)
+    cal, orc = _load_both(p, drop_frames=(7, 8, 31))
+    cal.Solve(); orc.solve()
+    _compare_vi(p, cal, orc)
+
+
+def test_visual_inertial_with_imu_stream_ending_early():
+    """IMU samples stop before the last frames: those blocks see an empty sample range and contribute r = 0
+    (ceres-cost-functions.h:452-455; interpolation-buffer.h:208-226), their weights stay at the previous value
+    (vicalibrator.h:731-733)."""
+    p = _vi_problem(60, seed=12)
+    cal, orc = _load_both(p, imu_until=p.frame_time[50])
+    cal.Solve(); orc.solve()
+    _compare_vi(p, cal, orc)
+
+
+def test_visual_inertial_without_time_offset_estimation():
+    """-nofind_time_offset: the offset column leaves the reduced system (vicalibrator.h:673-676)."""
+    p = _vi_problem(60, seed=13)
+    cal, orc = _load_both(p)
+    cal.SetOptimizationFlags(False, False, True, False); orc.set_flags(False, False, True, False)
+    cal.Solve(); orc.solve()
+    _compare_vi(p, cal, orc)
+    assert cal.time_offset() == 0.0
 
 
 def test_rotation_only_stage_matches_oracle():

@@ -1123,6 +1123,14 @@ int vc_get_imu_blocks(vc_calibrator* h, double* H, double* g, double* cost) {
   if (cost && hipMemcpy(cost, h->dv.seg_cost, ns * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
   return VC_OK;
 }
+int vc_get_imu_weights(vc_calibrator* h, double* out) {
+  NOT_RUNNING(h);
+  if (!out || !h->dv.imu_on) return VC_ERR_BAD_ARG;
+  const size_t n = (size_t)std::max(0, h->dv.n_frames - 1) * 81;
+  if (n == 0) return VC_OK;
+  if (hipMemcpyAsync(out, h->dv.wsqrtb[h->wcur], n * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return VC_ERR_NO_DEVICE;
+  return VC_OK;
+}
 int vc_get_debug_stamps(vc_calibrator* h, long long* out) {
   if (!h || !out) return VC_ERR_BAD_ARG;
   return hipMemcpy(out, h->dv.dbg, 32 * 8, hipMemcpyDeviceToHost) == hipSuccess ? VC_OK : VC_ERR_NO_DEVICE;

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void k_imu_weights(DevView v, int wr) {
   wave_lds_sync();
   bool ok = true;
   for (int c = 0; c < 9; ++c) ok = ok && (L.tmp[c] > 0.0);
-  if (!ok) return;                              // singular projection: keep the previous weight
+  if (!ok) { if (lane == 0) atomicAdd((unsigned long long*)&v.dbg[20], 1ull); return; }   // singular projection: keep the previous weight (counted in dbg[20])
   if (lane < 9) {
     const int c = lane;                         // column c of X = L^-1
     double x[9];

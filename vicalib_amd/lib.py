@@ -29,7 +29,7 @@ SYMBOLS = [
     "vc_get_biases", "vc_get_scale_factor", "vc_get_gravity", "vc_time_offset", "vc_mean_squared_error", "vc_get_camera_proj_rmse",
     "vc_get_num_iterations", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
     "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
-    "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_allreduce_calls",
+    "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_allreduce_calls", "vc_get_imu_weights",
 ]
 
 
@@ -252,6 +252,12 @@ class ViCalibrator:
         out = np.zeros(6)
         _check(self.L.vc_time_stages(self.h, int(reps), _d(out)), "time_stages")
         return dict(zip(["jac", "frame_schur", "-", "reduced", "trial", "final"], (out * 1e3).tolist()))
+
+    def imu_weights(self):
+        ns = max(self.NumFrames() - 1, 0)
+        W = np.zeros((ns, 9, 9))
+        _check(self.L.vc_get_imu_weights(self.h, _d(W)), "imu_weights")
+        return W
 
     def imu_blocks(self):
         ns = max(self.NumFrames() - 1, 0)
