@@ -891,8 +891,12 @@ __device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int
 #pragma unroll
       for (int j = 0; j < 6; ++j) L[i * 6 + j] = (j <= i) ? Lr[k++] : 0.0;
   }
+  {
+    double ys[6];
+    wave_sum6(y, ys, lane);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) y[k] = wave_allsum(y[k]) + zr[k];
+    for (int k = 0; k < 6; ++k) y[k] = ys[k] + zr[k];
+  }
   bwd_solve_inv<6>(L, di, y);
   double d[6];
 #pragma unroll

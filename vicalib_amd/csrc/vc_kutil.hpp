@@ -22,6 +22,30 @@ __device__ __forceinline__ double wave_sum(double x) {      // result valid in l
   for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
   return x;
 }
+// Sums of six per-lane values over the wavefront, all six results in every lane.  Instead of six butterflies (36 exchanges)
+// the lanes first split the six values among themselves: after the xor-1, xor-2 and xor-4 exchanges (3 + 2 + 1 values
+// travel) every lane owns ONE of the sums, partially reduced; three more exchanges finish it and six v_readlane pick the
+// owners.  The summation order is fixed.
+__device__ __forceinline__ void wave_sum6(const double* a, double* out, int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  double b[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double r = __shfl_xor(b0 ? a[i] : a[3 + i], 1, 64);       // even lanes keep sums 0..2, odd lanes 3..5
+    b[i] = (b0 ? a[3 + i] : a[i]) + r;
+  }
+  const double r0 = __shfl_xor(b1 ? b[0] : b[2], 2, 64);            // bit1 = 0 keeps the first two, bit1 = 1 the third
+  const double r1 = __shfl_xor(b1 ? b[1] : 0.0, 2, 64);
+  const double c0 = (b1 ? b[2] : b[0]) + r0, c1 = b1 ? 0.0 : b[1] + r1;
+  const double r2 = __shfl_xor(b2 ? c0 : c1, 4, 64);                // bit2 picks between the two
+  double d = (b2 ? c1 : c0) + r2;
+  d += __shfl_xor(d, 8, 64);
+  d += __shfl_xor(d, 16, 64);
+  d += __shfl_xor(d, 32, 64);
+  // owner lanes: sum 0 -> lane 0, 1 -> lane 4, 2 -> lane 2, 3 -> lane 1, 4 -> lane 5, 5 -> lane 3
+  out[0] = readlane_f64(d, 0); out[1] = readlane_f64(d, 4); out[2] = readlane_f64(d, 2);
+  out[3] = readlane_f64(d, 1); out[4] = readlane_f64(d, 5); out[5] = readlane_f64(d, 3);
+}
 __device__ __forceinline__ double wave_allsum(double x) {   // result in every lane, fixed order
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
