@@ -105,6 +105,9 @@ struct vc_calibrator {
   hipStream_t stream2 = nullptr;        // the IMU weight update of a pass runs here, under the pass's Jacobian sweeps and chain solve
   hipEvent_t ev_state = nullptr, ev_weights = nullptr;
   int wcur = 0;                         // weight buffer holding the current weight_sqrt_
+  bool serial_weights = true;           // weight update in line on the main stream; VICALIB_AMD_OVERLAP_WEIGHTS=1 moves it to a second
+                                        // stream under the Jacobian sweeps / chain solve (measured: the two latency-bound kernels then
+                                        // share the CUs and the pass gets 4 % slower on cfg3)
   hipGraphExec_t pass_graph[2] = {nullptr, nullptr};   // one captured LM pass per weight-buffer parity (single process)
   bool use_graphs = false;      // measured slower on ROCm 7.2 (cfg2: 65 vs 62 us / pass, instantiation ~10 ms per stage): opt-in via VICALIB_AMD_GRAPHS=1
   hipError_t last_hip_error = hipSuccess;
@@ -490,7 +493,9 @@ struct vc_calibrator {
       // trial point with the updated ones.  The update only needs the accepted state, so it runs on a second stream under
       // the Jacobian sweeps and the chain solve and writes the other weight buffer.
       const bool upd = dv.weights_on != 0;
-      if (upd) {
+      if (upd && serial_weights) {
+        launch_imu_weights(dv, wcur, stream);
+      } else if (upd) {
         HIP_OK(hipEventRecord(ev_state, stream));
         HIP_OK(hipStreamWaitEvent(stream2, ev_state, 0));
         launch_imu_weights(dv, wcur, stream2);
@@ -510,7 +515,7 @@ struct vc_calibrator {
       }
       launch_chain_solve_b(dv, stream);
       launch_reproj_res(dv, 3, 0.0, stream);
-      if (upd) { HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0)); wcur = 1 - wcur; }
+      if (upd) { if (!serial_weights) HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0)); wcur = 1 - wcur; }
       launch_imu_res(dv, 3, wcur, stream);
       if (sharded()) {
         launch_final(dv, 1, stream);
@@ -741,6 +746,7 @@ int vc_create(vc_calibrator** out, int device) {
   vc_calibrator* h = new vc_calibrator();
   h->device = device;
   { const char* e = std::getenv("VICALIB_AMD_GRAPHS"); if (e && e[0] == '1') h->use_graphs = true; }
+  { const char* e = std::getenv("VICALIB_AMD_OVERLAP_WEIGHTS"); if (e && e[0] == '1') h->serial_weights = false; }
   if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_weights, hipEventDisableTiming) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }

@@ -149,124 +149,141 @@ __device__ __forceinline__ void wmm_add(const double* Add, const double* A, cons
     C[e] = s;
   }
 }
-struct WLds { double dy_db[60], dy_dy0[100], dk_db[54], dk_dy[90], dy_dk[90], dy_dy[100], kt_db[54], kt_dy[90], kc_db[54], kc_dy[90], tmp[100], Sigma[100], J[90], P[81]; };
+// Wave-private LDS of the weight update: M / T are the 10 x 16 images used to transpose / broadcast the step's
+// sensitivity matrices (two round trips per IMU step), the rest serves the final 9 x 10 projection.
+struct WLds { double M[160], T[160], tmp[100], Sigma[100], J[90], P[81]; };
 
-__device__ void w_fill_pose_derivative(WLds& L, const WState& s, const double* zg, const double* za, const double* b, int lane) {
-  // dk_db (9x6): rows 3..5 <- R (gyro bias), rows 6..8 <- R (accel bias); dk_dy (9x10): dv/dv, d(Rw)/dq, d(Ra)/dq
-  for (int i = lane; i < 54; i += 64) L.dk_db[i] = 0.0;
-  for (int i = lane; i < 90; i += 64) L.dk_dy[i] = 0.0;
-  wave_lds_sync();
-  if (lane == 0) {
-    double R[9], m1[12], m2[12];
-    quat_to_R(s.q, R);
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) { L.dk_db[(3 + i) * 6 + j] = R[3 * i + j]; L.dk_db[(6 + i) * 6 + 3 + j] = R[3 * i + j]; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) L.dk_dy[i * 10 + 7 + i] = 1.0;
-    w_dqx_dq(s.q, zg, m1); w_dqx_dq(s.q, b, m2);
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) L.dk_dy[(3 + i) * 10 + 3 + j] = m1[i * 4 + j] + m2[i * 4 + j];
-    w_dqx_dq(s.q, za, m1); w_dqx_dq(s.q, b + 3, m2);
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) L.dk_dy[(6 + i) * 10 + 3 + j] = m1[i * 4 + j] + m2[i * 4 + j];
-  }
-  wave_lds_sync();
-}
-__device__ void w_fill_integrate_pose(WLds& L, const WState& s, const double* k, double dt, WState* y, int lane) {
-  const double wdt[3] = {k[3] * dt, k[4] * dt, k[5] * dt};
-  double rq[4];
-  so3_exp(wdt, rq);
-  for (int i = 0; i < 3; ++i) { y->p[i] = s.p[i] + k[i] * dt; y->v[i] = s.v[i] + k[6 + i] * dt; }
-  quat_mul(rq, s.q, y->q);
-  for (int i = lane; i < 90; i += 64) L.dy_dk[i] = 0.0;
-  for (int i = lane; i < 100; i += 64) L.dy_dy[i] = 0.0;
-  wave_lds_sync();
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { L.dy_dk[i * 9 + i] = dt; L.dy_dk[(7 + i) * 9 + 6 + i] = dt; L.dy_dy[i * 10 + i] = 1.0; L.dy_dy[(7 + i) * 10 + 7 + i] = 1.0; }
-    double a[16], e[12], ae[12], d2[16];
-    w_dq1q2_dq1(s.q, a); w_dqexp_dw(wdt, e);
-    mm(a, e, ae, 4, 4, 3);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) L.dy_dk[(3 + i) * 9 + 3 + j] = ae[i * 3 + j] * dt;
-    w_dq1q2_dq2(rq, d2);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) L.dy_dy[(3 + i) * 10 + 3 + j] = d2[i * 4 + j];
-  }
-  wave_lds_sync();
-}
-__device__ void w_step(WLds& L, WState* st, const Meas<double>& z0, const Meas<double>& z1, const double* b, const double* sf,
-                       const double* g, double sg2, double sa2, int lane) {
+// One RK4 step of the covariance propagation (types.h:427-595) with lane = column: lane c (< 16) carries column c of
+// [dy_dy0 (10) | dy_db (6)] through the four stages in registers.  The stage matrices of the reference's hand-derived
+// chain (dk_dx 9 x 10, dk_db 9 x 6, dy_dk 10 x 9, dy_dy 10 x 10) are sparse with a handful of small dense blocks; every
+// lane forms those blocks from the (replicated) state and applies them to its own column, so the whole step needs no
+// communication until Sigma <- F Sigma F^T + G R G^T, which goes through two LDS images.  Sc: column c of Sigma (c < 10).
+__device__ void w_step_cols(WLds& L, WState* st, const Meas<double>& z0, const Meas<double>& z1, const double* b, const double* sf,
+                            const double* g, double sg2, double sa2, int c, double* Sc) {
   const double dt = z1.time - z0.time;
   if (dt == 0) return;
-  for (int i = lane; i < 60; i += 64) L.dy_db[i] = 0.0;
-  for (int i = lane; i < 100; i += 64) L.dy_dy0[i] = (i % 11 == 0) ? 1.0 : 0.0;
-  for (int i = lane; i < 54; i += 64) L.kt_db[i] = 0.0;
-  for (int i = lane; i < 90; i += 64) L.kt_dy[i] = 0.0;
-  wave_lds_sync();
-  const double tau[4] = {0.0, dt / 2, dt / 2, dt}, hh[3] = {dt * 0.5, dt * 0.5, dt}, wgt[4] = {1.0, 2.0, 2.0, 1.0};
-  WState cur = *st, y;
-  double ksum[9];
+  const double tau[4] = {0.0, dt / 2, dt / 2, dt}, hh[4] = {dt * 0.5, dt * 0.5, dt, dt / 6.0}, wgt[4] = {1.0, 2.0, 2.0, 1.0};
+  double Y0[10], Yc[10], kt[9], ksum[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) ksum[i] = 0.0;
+  for (int i = 0; i < 10; ++i) { Y0[i] = (i == c) ? 1.0 : 0.0; Yc[i] = Y0[i]; }     // dy_dy0 = I, dy_db = 0 at the step start
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { kt[i] = 0.0; ksum[i] = 0.0; }
+  WState cur = *st, y = *st;
 #pragma unroll 1
-  for (int stage = 0; stage < 4; ++stage) {
-    // k = f(cur) and its partials
-    const double alpha = (z1.time - (z0.time + tau[stage])) / (z1.time - z0.time);
-    double zg[3], za[3], u[3], o[3], R[9], kc[9];
-    for (int i = 0; i < 3; ++i) { zg[i] = z0.w[i] * alpha + z1.w[i] * (1.0 - alpha); za[i] = z0.a[i] * alpha + z1.a[i] * (1.0 - alpha); }
-    for (int i = 0; i < 3; ++i) kc[i] = cur.v[i];
-    quat_to_R(cur.q, R);
-    for (int i = 0; i < 3; ++i) u[i] = zg[i] * sf[i] + b[i];
-    for (int i = 0; i < 3; ++i) kc[3 + i] = R[3 * i] * u[0] + R[3 * i + 1] * u[1] + R[3 * i + 2] * u[2];
-    for (int i = 0; i < 3; ++i) u[i] = za[i] * sf[3 + i] + b[3 + i];
-    quat_rotate(cur.q, u, o);
-    for (int i = 0; i < 3; ++i) kc[6 + i] = o[i] - g[i];
-    w_fill_pose_derivative(L, cur, zg, za, b, lane);
-    wmm_add<9, 10, 6>(L.dk_db, L.dk_dy, L.dy_db, L.kc_db, lane);      // dk/db  = dk_db + dk_dy dy_db
-    wmm<9, 10, 10>(L.dk_dy, L.dy_dy0, L.kc_dy, lane);                  // dk/dy0 = dk_dy dy_dy0
-    wave_lds_sync();
-    const double wg = wgt[stage];
-    for (int i = lane; i < 54; i += 64) L.kt_db[i] += wg * L.kc_db[i];
-    for (int i = lane; i < 90; i += 64) L.kt_dy[i] += wg * L.kc_dy[i];
+  for (int stage = 0; stage < 5; ++stage) {
+    double kcol[9], kv[9];
+    if (stage < 4) {
+      // k = f(cur) (GetPoseDerivative, types.h:380-425) and this lane's column of dk/d[y0 | b]
+      const double alpha = (z1.time - (z0.time + tau[stage])) / (z1.time - z0.time);
+      double zg[3], za[3], u[3], o[3], R[9], m1[12], m2[12];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) ksum[i] += wg * kc[i];
-    if (stage < 3) {
-      w_fill_integrate_pose(L, *st, kc, hh[stage], &y, lane);
-      wmm<10, 9, 6>(L.dy_dk, L.kc_db, L.dy_db, lane);
-      wmm_add<10, 9, 10>(L.dy_dy, L.dy_dk, L.kc_dy, L.dy_dy0, lane);
-      wave_lds_sync();
-      cur = y;
+      for (int i = 0; i < 3; ++i) { zg[i] = z0.w[i] * alpha + z1.w[i] * (1.0 - alpha); za[i] = z0.a[i] * alpha + z1.a[i] * (1.0 - alpha); }
+      quat_to_R(cur.q, R);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { kv[i] = cur.v[i]; u[i] = zg[i] * sf[i] + b[i]; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) kv[3 + i] = R[3 * i] * u[0] + R[3 * i + 1] * u[1] + R[3 * i + 2] * u[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) u[i] = za[i] * sf[3 + i] + b[3 + i];
+      quat_rotate(cur.q, u, o);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) kv[6 + i] = o[i] - g[i];
+      // dk_dx: rows 0-2 = d/dv, rows 3-5 = (dqx_dq(q, zg) + dqx_dq(q, bg)) on the quaternion, rows 6-8 likewise with za, ba
+#pragma unroll
+      for (int i = 0; i < 3; ++i) kcol[i] = Yc[7 + i];
+      w_dqx_dq(cur.q, zg, m1); w_dqx_dq(cur.q, b, m2);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a += (m1[i * 4 + q] + m2[i * 4 + q]) * Yc[3 + q];
+        kcol[3 + i] = a;
+      }
+      w_dqx_dq(cur.q, za, m1); w_dqx_dq(cur.q, b + 3, m2);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a += (m1[i * 4 + q] + m2[i * 4 + q]) * Yc[3 + q];
+        kcol[6 + i] = a;
+      }
+      // dk_db: R in rows 3-5 for the gyro bias columns (10..12), in rows 6-8 for the accelerometer bias columns (13..15)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          kcol[3 + i] += (c == 10 + q) ? R[3 * i + q] : 0.0;
+          kcol[6 + i] += (c == 13 + q) ? R[3 * i + q] : 0.0;
+        }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { kt[i] += wgt[stage] * kcol[i]; ksum[i] += wgt[stage] * kv[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { kcol[i] = kt[i]; kv[i] = ksum[i]; }      // final combination: k1 + 2 k2 + 2 k3 + k4, h = dt / 6
     }
-  }
-  w_fill_integrate_pose(L, *st, ksum, dt / 6.0, &y, lane);
-  wmm<10, 9, 6>(L.dy_dk, L.kt_db, L.dy_db, lane);
-  wmm_add<10, 9, 10>(L.dy_dy, L.dy_dk, L.kt_dy, L.dy_dy0, lane);
-  wave_lds_sync();
-  wmm<10, 10, 10>(L.dy_dy0, L.Sigma, L.tmp, lane);
-  wave_lds_sync();
-  for (int e = lane; e < 100; e += 64) {     // Sigma <- F Sigma F^T + G R G^T
-    const int i = e / 10, j = e % 10;
-    double s = 0.0;
+    if (stage == 3) continue;                     // k4 only enters the sum
+    // y = IntegratePose(st, k, h) (types.h:330-378) and this lane's column of dy/d[y0 | b] = dy_dk kcol + dy_dy Y0
+    const double h = hh[stage == 4 ? 3 : stage];
+    const double wdt[3] = {kv[3] * h, kv[4] * h, kv[5] * h};
+    double rq[4], A[16], E[12], AE[12], D2[16];
+    so3_exp(wdt, rq);
 #pragma unroll
-    for (int q = 0; q < 10; ++q) s += L.tmp[i * 10 + q] * L.dy_dy0[j * 10 + q];
+    for (int i = 0; i < 3; ++i) { y.p[i] = st->p[i] + kv[i] * h; y.v[i] = st->v[i] + kv[6 + i] * h; }
+    quat_mul(rq, st->q, y.q);
+    w_dq1q2_dq1(st->q, A); w_dqexp_dw(wdt, E);
+    mm(A, E, AE, 4, 4, 3);
+    w_dq1q2_dq2(rq, D2);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) s += L.dy_db[i * 6 + q] * (q < 3 ? sg2 : sa2) * L.dy_db[j * 6 + q];
-    L.dy_dy[e] = s;
+    for (int i = 0; i < 3; ++i) { Yc[i] = h * kcol[i] + Y0[i]; Yc[7 + i] = h * kcol[6 + i] + Y0[7 + i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double a = 0.0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a += AE[i * 3 + q] * kcol[3 + q];
+      a *= h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a += D2[i * 4 + q] * Y0[3 + q];
+      Yc[3 + i] = a;
+    }
+    cur = y;
+  }
+  // ---- Sigma <- F Sigma F^T + G R G^T:  F = columns 0..9, G = columns 10..15 of the lanes ------------------------------
+#pragma unroll
+  for (int i = 0; i < 10; ++i) L.M[i * 16 + c] = Yc[i];
+  wave_lds_sync();
+  double T[10], Frow[16];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) T[i] = 0.0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Frow[r] = (c < 10) ? L.M[c * 16 + r] : 0.0;          // row c of [F | G]
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) T[i] += L.M[i * 16 + q] * Sc[q];                  // column c of F Sigma (broadcast reads)
+    __builtin_amdgcn_sched_barrier(0);          // ten loads in flight at a time, not a hundred (register pressure)
+  }
+#pragma unroll
+  for (int i = 0; i < 10; ++i) L.T[i * 16 + c] = T[i];
+  wave_lds_sync();
+  double Sn[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) Sn[i] = 0.0;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) Sn[i] += L.T[i * 16 + r] * Frow[r];                // (F Sigma) F^T, column c
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const double rw = (q < 3 ? sg2 : sa2) * Frow[10 + q];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) Sn[i] += L.M[i * 16 + 10 + q] * rw;                // G R G^T, column c
+    __builtin_amdgcn_sched_barrier(0);
   }
   wave_lds_sync();
-  for (int e = lane; e < 100; e += 64) L.Sigma[e] = L.dy_dy[e];
-  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < 10; ++i) Sc[i] = (c < 10) ? Sn[i] : 0.0;
   *st = y;
 }
 
@@ -300,17 +317,24 @@ __global__ __launch_bounds__(256) void k_imu_weights(DevView v, int wr) {
   for (int i = 0; i < 4; ++i) sx.q[i] = T1[i];
 #pragma unroll
   for (int i = 0; i < 3; ++i) { sx.p[i] = T1[4 + i]; sx.v[i] = v.vel[st][(size_t)(j - 1) * 4 + i]; }
-  for (int e = lane; e < 100; e += 64) L.Sigma[e] = 0.0;
-  wave_lds_sync();
   const double sg2 = v.gyro_sigma * v.gyro_sigma, sa2 = v.accel_sigma * v.accel_sigma;
   const int n_meas = (rg.k1 - rg.k0 + 1) + 2;
+  const int c = lane & 15;                      // column of [dy_dy0 | dy_db] this lane carries (lanes >= 16 mirror lanes 0..15)
+  double Sc[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) Sc[i] = 0.0;
   Meas<double> z0, z1;
   imu_range_get(buf, rg, toff, t_start, t_end, 0, &z0);
   for (int m = 1; m < n_meas; ++m) {
     imu_range_get(buf, rg, toff, t_start, t_end, m, &z1);
-    w_step(L, &sx, z0, z1, b, sf, gw, sg2, sa2, lane);
+    w_step_cols(L, &sx, z0, z1, b, sf, gw, sg2, sa2, c, Sc);
     z0 = z1;
   }
+  if (lane < 10) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) L.Sigma[i * 10 + lane] = Sc[i];
+  }
+  wave_lds_sync();
   // J = dLog_dSE3(T_pred T2^-1) dt1t2_dt1(T_pred, T2^-1), velocity identity appended (9 x 10)
   const double qc[4] = {-T2[0], -T2[1], -T2[2], T2[3]}, nt[3] = {-T2[4], -T2[5], -T2[6]};
   double t2w[7], rel[7], tr[3];
@@ -326,28 +350,36 @@ __global__ __launch_bounds__(256) void k_imu_weights(DevView v, int wr) {
   for (int i = 0; i < 3; ++i) rel[4 + i] = sx.p[i] + tr[i];
   for (int e = lane; e < 90; e += 64) L.J[e] = 0.0;
   wave_lds_sync();
-  if (lane == 0) {
-    double dl[42], dt12[49], J67[42], m34[12], m44[16];
+  {
+    // J67 = dLog_dSE3 * dt1t2_dt1 with dt1t2_dt1 = [I3, dqx_dq(q, t); 0, dq1q2_dq1] (sparse): row i of J67 in lane i
+    double dl[42], m34[12], m44[16];
     w_dlog_dse3(rel, dl);
-#pragma unroll
-    for (int i = 0; i < 49; ++i) dt12[i] = 0.0;
-    dt12[0] = dt12[8] = dt12[16] = 1.0;
     w_dqx_dq(sx.q, t2w + 4, m34);
     w_dq1q2_dq1(t2w, m44);
+    if (lane < 6) {
+      double row[7];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+      for (int jj = 0; jj < 7; ++jj) row[jj] = 0.0;
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) dt12[i * 7 + 3 + jj] = m34[i * 4 + jj];
+      for (int i = 0; i < 6; ++i) {
+        if (i == lane) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+          for (int jj = 0; jj < 3; ++jj) row[jj] = dl[i * 7 + jj];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) dt12[(3 + i) * 7 + 3 + jj] = m44[i * 4 + jj];
-    mm(dl, dt12, J67, 6, 7, 7);
+          for (int jj = 0; jj < 4; ++jj) {
+            double a = 0.0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+            for (int k = 0; k < 3; ++k) a += dl[i * 7 + k] * m34[k * 4 + jj];
 #pragma unroll
-      for (int jj = 0; jj < 7; ++jj) L.J[i * 10 + jj] = J67[i * 7 + jj];
-    L.J[6 * 10 + 7] = L.J[7 * 10 + 8] = L.J[8 * 10 + 9] = 1.0;
+            for (int k = 0; k < 4; ++k) a += dl[i * 7 + 3 + k] * m44[k * 4 + jj];
+            row[3 + jj] = a;
+          }
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 7; ++jj) L.J[lane * 10 + jj] = row[jj];
+    }
+    if (lane == 0) L.J[6 * 10 + 7] = L.J[7 * 10 + 8] = L.J[8 * 10 + 9] = 1.0;
   }
   wave_lds_sync();
   wmm<9, 10, 10>(L.J, L.Sigma, L.tmp, lane);
