@@ -1157,11 +1157,10 @@ void launch_reduced(const DevView& v, int mode, hipStream_t s) {
 }
 void launch_trial(const DevView& v, hipStream_t s) {
   if (v.n_tiles == 0) return;
-  const size_t lds = v.fused ? 4 * 64 * kDotStride * sizeof(double) : 0;
+  const size_t lds = 4 * 64 * kDotStride * sizeof(double);
   static bool granted = false;
   if (lds > 0 && !granted) { (void)hipFuncSetAttribute((const void*)k_trial<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 4096)); granted = true; }
-  if (v.fused) hipLaunchKernelGGL(k_trial<true>, dim3(tiles_grid(v)), dim3(256), lds, s, v);
-  else hipLaunchKernelGGL(k_trial<false>, dim3(tiles_grid(v)), dim3(256), 0, s, v);
+  hipLaunchKernelGGL(k_trial<true>, dim3(tiles_grid(v)), dim3(256), lds, s, v);      // vision-only passes are always fused
 }
 void launch_final(const DevView& v, int mode, hipStream_t s) {
   hipLaunchKernelGGL(k_final, dim3(1), dim3(256), 0, s, v, mode);
