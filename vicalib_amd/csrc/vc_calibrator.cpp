@@ -342,7 +342,7 @@ struct vc_calibrator {
     // one wavefront per frame, 4 frames per group: up to 2048 chunks (= partial sums) before chunks grow
     const int chunk_frames = std::max(4, (((N + 2047) / 2048) + 3) / 4 * 4);
     const int n_chunks = std::max(1, (N + chunk_frames - 1) / chunk_frames);
-    const int part_stride = D * D + D + C * kGStride + (imu_on() ? kGStride : 0);
+    const int part_stride = D * D + D + C * kGStride + (imu_on() ? kGStride : 0) + 1;     // ... + the chunk's cost (vision path)
     for (int b = 0; b < 2; ++b) {
       HIP_OK(d_G[b].alloc((size_t)std::max(T, 1) * kGStride)); HIP_OK(d_tile_cost[b].alloc(std::max(T, 1)));
       HIP_OK(hipMemsetAsync(d_G[b].p, 0, (size_t)std::max(T, 1) * kGStride * sizeof(double), stream));   // sub-blocks a model never writes stay 0

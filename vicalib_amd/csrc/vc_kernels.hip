@@ -315,12 +315,14 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
   for (int c = 0; c < MAXC; ++c)
 #pragma unroll
     for (int q = 0; q < 4; ++q) gsum[c][q] = 0.0;
+  double csum = 0.0;      // lane t: cost of tile t of this wave's frames (the chunk's cost rides in the partials)
 
   for (int fg = f0; fg < f1; fg += 4) {
     const int f = fg + wave;
     for (int i = lane; i < 6 * ld; i += 64) R[(wave * 6) * ld + i] = 0.0;
     const int t0 = (f < f1) ? v.frame_tile_off[f] : 0;
     const int nt = (f < f1) ? v.frame_tile_off[f + 1] - t0 : 0;
+    if (lane < nt) csum += v.tile_costb[cur][t0 + lane];
     if (f < f1 && nt == 0 && lane == 0) {     // frame without observations: nothing to eliminate, keeps its pose
       const double* p = v.poses[cur] + (size_t)f * kPoseStride;
       double x2 = 0;
@@ -495,6 +497,12 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
   __syncthreads();
   for (int e = tid; e < C * kGStride; e += 256)
     part[D * D + D + e] = (sh[e] + sh[C * kGStride + e]) + (sh[2 * C * kGStride + e] + sh[3 * C * kGStride + e]);
+  // chunk cost (sum of the tiles' robustified costs at the linearisation point), last slot of the partial record
+  __syncthreads();
+  csum = wave_sum(csum);
+  if (lane == 0) sh[wave] = csum;
+  __syncthreads();
+  if (tid == 0) part[v.part_stride - 1] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 // Fixed-order sum of the chunk partials, spread over many CUs (one CU can only pull ~20-50 GB/s):
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(256) void k_part_sum(DevView v) {
 
 // Phase A of the reduced system (one workgroup):
 // Sbuf = [ S = H_ss - sum Y^T Y (full symmetric, undamped) | g_red | diag(H_ss) | g_s | cost, 0 ]
-struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[256]; double T1[256]; double red[256]; };
+struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[256]; double T1[256]; double red[256]; double camq[kMaxCams * 4]; };
 #define VC_STAMP(i) do { if (threadIdx.x == 0) v.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
 __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
   VC_STAMP(0);
@@ -537,28 +545,36 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
   double* sc = gs + D;
   const int stride = v.part_stride;
   const int nslab = (v.n_chunks + kSlab - 1) / kSlab;
+  // camera rotations: fetched now, under the partial sums' latency, instead of one dependent global load per camera later
+  if (tid < C * 4) L.camq[tid] = v.cams[cur][(size_t)(tid >> 2) * kCamStride + (tid & 3)];
   for (int e = tid; e < stride; e += 256) {
     double t = 0.0;
 #pragma unroll 8
     for (int k = 0; k < nslab; ++k) t += v.part_total[(size_t)k * stride + e];
     if (e < D * D) S[e] = -t;
     else if (e < D * D + D) gred[e - D * D] = -t;
-    else L.gsum[e - D * D - D] = t;
+    else if (e < stride - 1) L.gsum[e - D * D - D] = t;      // (the last slot is the chunk cost, read below)
   }
   VC_STAMP(1);
-  {
+  for (int i = tid; i < D; i += 256) { hd[i] = 0.0; gs[i] = 0.0; }
+  if (v.imu_on) {        // chain path: tile and IMU-block costs summed here (its partial records carry no cost slot)
     double s = 0.0;
 #pragma unroll 4
     for (int t = tid; t < v.n_tiles; t += 256) s += v.tile_costb[cur][t];
-    if (v.imu_on) for (int t = tid; t < v.n_frames - 1; t += 256) s += v.seg_cost[t];
+    for (int t = tid; t < v.n_frames - 1; t += 256) s += v.seg_cost[t];
     L.red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) L.red[tid] += L.red[tid + o]; __syncthreads(); }
+    if (tid == 0) { sc[0] = 0.5 * L.red[0]; sc[1] = 0.0; }
+  } else if (tid == 0) {
+    double t = 0.0;
+    for (int k = 0; k < nslab; ++k) t += v.part_total[(size_t)k * stride + stride - 1];
+    sc[0] = 0.5 * t; sc[1] = 0.0;
   }
-  for (int i = tid; i < D; i += 256) { hd[i] = 0.0; gs[i] = 0.0; }
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (tid < o) L.red[tid] += L.red[tid + o]; __syncthreads(); }
-  if (tid == 0) { sc[0] = 0.5 * L.red[0]; sc[1] = 0.0; }
   VC_STAMP(2);
-  // camera blocks H_cc = P^T G P, g_c = P^T G[:, r]   (P: u-columns -> shared columns of the camera)
+  // camera blocks H_cc = P^T G P, g_c = P^T G[:, r]   (P: u-columns -> shared columns of the camera).  The inner products
+  // run over all 16 columns (the padding of G and P is zero): fully unrolled, all LDS loads of a thread issue together.
   for (int c = 0; c < C; ++c) {
     const int flags = v.cd[c].flags, nk = model_nk(v.cd[c].model);
     const int nu = 6 + nk, nc = cam_ncols(flags, nk), c0 = v.cd[c].col0;
@@ -568,7 +584,7 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
     {
       const int i = tid >> 4, a = tid & 15;     // P[i][a]
       double R[9];
-      quat_to_R(v.cams[cur] + (size_t)c * kCamStride, R);
+      quat_to_R(L.camq + 4 * c, R);
       double pv = 0.0;
       if (i < nu && a < nc) {
         if (a < nrot) { if (i >= 3 && i < 6) pv = -R[3 * (i - 3) + a]; }
@@ -579,18 +595,25 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
     }
     __syncthreads();
     {
-      const int i = tid >> 4, a = tid & 15;     // T1[i][a] = sum_k G[i][k] P[k][a]; row 15 := g_c
+      const int i = tid >> 4, a = tid & 15;     // T1[i][a] = sum_k G[i][k] P[k][a]; row 15 := g_c = sum_k P[k][a] G[k][nu]
       double s = 0.0;
-      if (i < nu && a < nc) for (int k = 0; k < nu; ++k) s += G[i * 16 + k] * L.P[k * 16 + a];
-      if (i == 15 && a < nc) { s = 0.0; for (int k = 0; k < nu; ++k) s += L.P[k * 16 + a] * G[k * 16 + nu]; }
+      if (i == 15) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += L.P[k * 16 + a] * G[k * 16 + nu];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += G[i * 16 + k] * L.P[k * 16 + a];
+        if (i >= nu) s = 0.0;
+      }
       L.T1[tid] = s;
     }
     __syncthreads();
     {
-      const int b = tid >> 4, a = tid & 15;     // Hcc[b][a] = sum_i P[i][b] T1[i][a]
+      const int b = tid >> 4, a = tid & 15;     // Hcc[b][a] = sum_i P[i][b] T1[i][a]  (rows i >= nu of P are zero; row 15 of T1 is g_c)
       if (a < nc && b < nc && a >= b) {
         double s = 0.0;
-        for (int i = 0; i < nu; ++i) s += L.P[i * 16 + b] * L.T1[i * 16 + a];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) s += L.P[i * 16 + b] * L.T1[i * 16 + a];
         S[(c0 + b) * D + c0 + a] += s;
         if (a == b) hd[c0 + a] = s;
       }
