@@ -97,6 +97,9 @@ class ViCalibrator:
     def AddCamera(self, model, params, T_ck, width=640, height=480):
         params = np.ascontiguousarray(params, dtype=np.float64)
         self.nk.append(len(params))
+        if isinstance(model, str):               # the -models strings of vicalib-engine.cc:203-253
+            from .synth import MODEL_IDS
+            model = MODEL_IDS[model]
         return _check(self.L.vc_add_camera(self.h, int(model), _d(params), len(params), int(width), int(height), _d(T_ck)), "AddCamera")
 
     def FixCameraIntrinsics(self, should_fix=True):
