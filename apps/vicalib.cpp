@@ -87,7 +87,8 @@ static void DefineFlags() {
   Define("image_width", "int32", "640", "Image width of every channel (HAL reports it in the reference).");
   Define("image_height", "int32", "480", "Image height of every channel.");
   Define("frame_rate", "double", "30", "Frame rate used for timestamps when the detections carry no time column.");
-  Define("device", "int32", "0", "HIP device ordinal.");
+  Define("device", "int32", "0", "HIP device ordinal (first device with -gpus N).");
+  Define("gpus", "int32", "1", "Number of GPUs: frames are sharded, one calibrator per device, RCCL all-reduce per iteration.");
 }
 
 static int Usage(int code) {
@@ -348,32 +349,45 @@ int main(int argc, char** argv) {
   }
   if (frame_ids.empty()) { std::fprintf(stderr, "F no usable frames in the detections\n"); return 1; }
 
-  std::unique_ptr<vic::ViCalibrator> calp;
-  try { calp.reset(new vic::ViCalibrator((int)FlagInt("device"))); }
-  catch (const std::exception& e) { std::fprintf(stderr, "F %s\n", e.what()); return 3; }
-  vic::ViCalibrator& cal = *calp;
-  cal.SetSigmas(FlagDouble("gyro_sigma"), FlagDouble("accel_sigma"));                       // vicalib-engine.cc:301-303
-  const double zeros[6] = {0, 0, 0, 0, 0, 0}, ones[6] = {1, 1, 1, 1, 1, 1};
-  cal.SetBiases(zeros); cal.SetScaleFactor(ones);
-  cal.FixCameraIntrinsics(!FlagBool("calibrate_intrinsics"));                              // vicalib-task.cc:128
-  for (const vic::CameraAndPose& c : input_cameras)
-    if (cal.AddCamera(c) < 0) { std::fprintf(stderr, "F AddCamera failed (model %s, %zu parameters)\n", ModelName(c.model), c.params.size()); return 1; }
-  if (have_imu && !imu.time.empty() && cal.AddImuMeasurements((int)imu.time.size(), imu.gyro.data(), imu.accel.data(), imu.time.data()) != VC_OK) {
-    std::fprintf(stderr, "F IMU measurements rejected\n"); return 1;
+  // ---- one calibrator per GPU; frames sharded contiguously, the library's own RCCL communicator does the per-iteration
+  // all-reduces (-gpus 1: plain single-device run, no communicator) -----------------------------------------------------
+  const int n_gpus = std::max(1, (int)FlagInt("gpus"));
+  if ((size_t)n_gpus * 2 > frame_ids.size()) { std::fprintf(stderr, "F -gpus %d needs at least %d frames\n", n_gpus, 2 * n_gpus); return 1; }
+  std::vector<std::unique_ptr<vic::ViCalibrator>> cals((size_t)n_gpus);
+  for (int r = 0; r < n_gpus; ++r) {
+    try { cals[r].reset(new vic::ViCalibrator((int)FlagInt("device") + r)); }
+    catch (const std::exception& e) { std::fprintf(stderr, "F %s (device %d)\n", e.what(), (int)FlagInt("device") + r); return 3; }
   }
+  const bool guess = FlagBool("has_initial_guess");
   // initial time offset (vicalib-task.cc:638-662): with system time the clocks are already aligned
   double image_time_offset = 0.0;
-  std::map<long, int> frame_index;
-  vic::Se3 placeholder; placeholder.v = {{0, 0, 0, 1, 0, 0, 1000}};                         // vicalib-task.cc:241-244
-  for (long id : frame_ids) {
-    double t = (double)id / FlagDouble("frame_rate");
-    for (const Channel& ch : channels) { auto it = ch.frame_time.find(id); if (it != ch.frame_time.end()) { t = it->second; break; } }
-    if (calibrate_imu && FlagBool("find_time_offset") && !FlagBool("use_system_time") && frame_index.empty() && !imu.time.empty())
-      image_time_offset = imu.time[0] - t;
-    frame_index[id] = cal.AddFrame(placeholder, t + image_time_offset);
-  }
-  long n_obs = 0;
   {
+    double t0f = (double)frame_ids[0] / FlagDouble("frame_rate");
+    for (const Channel& ch : channels) { auto it = ch.frame_time.find(frame_ids[0]); if (it != ch.frame_time.end()) { t0f = it->second; break; } }
+    if (calibrate_imu && FlagBool("find_time_offset") && !FlagBool("use_system_time") && !imu.time.empty()) image_time_offset = imu.time[0] - t0f;
+  }
+  long n_obs = 0; int seeded = 0;
+  for (int r = 0; r < n_gpus; ++r) {
+    vic::ViCalibrator& cal = *cals[r];
+    cal.SetSigmas(FlagDouble("gyro_sigma"), FlagDouble("accel_sigma"));                     // vicalib-engine.cc:301-303
+    const double zeros[6] = {0, 0, 0, 0, 0, 0}, ones[6] = {1, 1, 1, 1, 1, 1};
+    cal.SetBiases(zeros); cal.SetScaleFactor(ones);
+    cal.FixCameraIntrinsics(!FlagBool("calibrate_intrinsics"));                            // vicalib-task.cc:128
+    for (const vic::CameraAndPose& c : input_cameras)
+      if (cal.AddCamera(c) < 0) { std::fprintf(stderr, "F AddCamera failed (model %s, %zu parameters)\n", ModelName(c.model), c.params.size()); return 1; }
+    // every shard gets the whole IMU stream: its last block reaches into the next shard's first frame
+    if (have_imu && !imu.time.empty() && cal.AddImuMeasurements((int)imu.time.size(), imu.gyro.data(), imu.accel.data(), imu.time.data()) != VC_OK) {
+      std::fprintf(stderr, "F IMU measurements rejected\n"); return 1;
+    }
+    const size_t lo = frame_ids.size() * (size_t)r / (size_t)n_gpus, hi = frame_ids.size() * (size_t)(r + 1) / (size_t)n_gpus;
+    std::map<long, int> frame_index;
+    vic::Se3 placeholder; placeholder.v = {{0, 0, 0, 1, 0, 0, 1000}};                       // vicalib-task.cc:241-244
+    for (size_t k = lo; k < hi; ++k) {
+      const long id = frame_ids[k];
+      double t = (double)id / FlagDouble("frame_rate");
+      for (const Channel& ch : channels) { auto it = ch.frame_time.find(id); if (it != ch.frame_time.end()) { t = it->second; break; } }
+      frame_index[id] = cal.AddFrame(placeholder, t + image_time_offset);
+    }
     std::vector<double> pw, pc;
     for (size_t c = 0; c < n_cam; ++c) {
       std::map<int, std::vector<const Detection*>> per_frame;
@@ -387,33 +401,45 @@ int main(int argc, char** argv) {
         pw.clear(); pc.clear();
         for (const Detection* d : kv.second) {
           pw.insert(pw.end(), {d->X, d->Y, d->Z}); pc.insert(pc.end(), {d->u, d->v});
-          if (FlagBool("output_conics")) std::printf("%d,%d,%.10g,%.10g,%.10g,%.10g,%.10g\n", kv.first, d->dot, d->u, d->v, d->X, d->Y, d->Z);
+          if (FlagBool("output_conics")) std::printf("%ld,%d,%.10g,%.10g,%.10g,%.10g,%.10g\n", d->frame, d->dot, d->u, d->v, d->X, d->Y, d->Z);
         }
         cal.AddObservations(kv.first, c, (int)kv.second.size(), pw.data(), pc.data());
         n_obs += (long)kv.second.size();
       }
     }
+    seeded += cal.InitFramePosesPnP();
+    // ---- VicalibTask::Start(has_initial_guess) (vicalib-task.cc:226-234) + flags read inside the calibrator ---------
+    cal.SetOptimizationFlags(guess, guess && calibrate_imu, !guess, FlagBool("find_time_offset"));
+    cal.SetFunctionTolerance(FlagDouble("function_tolerance"));
+    cal.SetMaxIters((int)FlagInt("max_iters"));
+    cal.SetCalibrateImu(calibrate_imu);
+    cal.SetRemoveOutliers(FlagBool("remove_outliers"), FlagDouble("outlier_threshold"));
   }
-  const int seeded = cal.InitFramePosesPnP();
-  std::fprintf(stderr, "I %zu cameras, %zu frames (%d with a PnP seed), %ld corner observations, %zu IMU samples\n", n_cam, frame_ids.size(), seeded, n_obs, imu.time.size());
-
-  // ---- VicalibTask::Start(has_initial_guess) (vicalib-task.cc:226-234) + flags read inside the calibrator -----------
-  const bool guess = FlagBool("has_initial_guess");
-  cal.SetOptimizationFlags(guess, guess && calibrate_imu, !guess, FlagBool("find_time_offset"));
-  cal.SetFunctionTolerance(FlagDouble("function_tolerance"));
-  cal.SetMaxIters((int)FlagInt("max_iters"));
-  cal.SetCalibrateImu(calibrate_imu);
-  cal.SetRemoveOutliers(FlagBool("remove_outliers"), FlagDouble("outlier_threshold"));
+  std::fprintf(stderr, "I %zu cameras, %zu frames on %d GPU(s) (%d with a PnP seed), %ld corner observations, %zu IMU samples\n", n_cam, frame_ids.size(), n_gpus, seeded, n_obs, imu.time.size());
+  if (n_gpus > 1) {
+    char id[128];
+    if (vc_rccl_unique_id(id) != VC_OK) { std::fprintf(stderr, "F RCCL is not available (librccl.so)\n"); return 3; }
+    std::vector<int> rc((size_t)n_gpus, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < n_gpus; ++r) th.emplace_back([&, r] { rc[r] = vc_set_shard_rccl(cals[r]->handle(), r, n_gpus, id); });   // ncclCommInitRank: collective
+    for (std::thread& t : th) t.join();
+    for (int r = 0; r < n_gpus; ++r) if (rc[r] != VC_OK) { std::fprintf(stderr, "F RCCL communicator setup failed on rank %d (%d)\n", r, rc[r]); return 3; }
+  }
+  vic::ViCalibrator& cal = *cals[0];              // shared parameters and statistics are identical on every rank
   const auto t0 = std::chrono::steady_clock::now();
-  cal.Start();
+  for (auto& c : cals) c->Start();
   unsigned last_iters = ~0u;
-  while (cal.IsRunning()) {                                       // vicalib-engine.cc:376-431, 30 ms
+  auto any_running = [&] { for (auto& c : cals) if (c->IsRunning()) return true; return false; };
+  while (any_running()) {                                         // vicalib-engine.cc:376-431, 30 ms
     const unsigned it = cal.GetNumIterations();
     if (it != last_iters) { std::fprintf(stderr, "I iteration %u  mse %.6g\n", it, cal.MeanSquaredError()); last_iters = it; }
     std::this_thread::sleep_for(std::chrono::milliseconds(30));
   }
-  cal.Stop();
+  for (auto& c : cals) c->Stop();
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  // frames of all shards, in order
+  std::vector<vic::VicalibFrame> all_frames;
+  for (auto& c : cals) for (size_t i = 0; i < c->NumFrames(); ++i) all_frames.push_back(c->GetFrame(i));
 
   // ---- Finish + PrintResults (vicalibrator.h:536-544) ------------------------------------------------------------------
   const std::vector<double> rmse = cal.GetCameraProjRMSE();
@@ -438,15 +464,15 @@ int main(int argc, char** argv) {
   cal.WriteCameraModels(FlagString("output"));
   if (FlagBool("print_poses")) {
     if (FILE* f = std::fopen("poses.txt", "w")) {
-      for (size_t i = 0; i < cal.NumFrames(); ++i) { double c[6]; T2Cart(cal.GetFrame(i).t_wp_.data(), c); std::fprintf(f, "%f\t%f\t%f\t%f\t%f\t%f\n", c[0], c[1], c[2], c[3], c[4], c[5]); }
+      for (size_t i = 0; i < all_frames.size(); ++i) { double c[6]; T2Cart(all_frames[i].t_wp_.data(), c); std::fprintf(f, "%f\t%f\t%f\t%f\t%f\t%f\n", c[0], c[1], c[2], c[3], c[4], c[5]); }
       std::fclose(f);
     }
   }
   if (FlagBool("save_poses")) {
     if (FILE* f = std::fopen("poses.csv", "w")) {
       std::fprintf(f, "%% Pose file generated with vicalib.\n%% Each line is the 12 elements from the top 3 rows of a 4x4transformation matrix, printed row major.\n");
-      for (size_t i = 0; i < cal.NumFrames(); ++i) {
-        const vic::VicalibFrame fr = cal.GetFrame(i);
+      for (size_t i = 0; i < all_frames.size(); ++i) {
+        const vic::VicalibFrame& fr = all_frames[i];
         double R[9]; RotationMatrix(fr.t_wp_.data(), R);
         std::fprintf(f, "%.10g %.10g %.10g %.10g     %.10g %.10g %.10g %.10g     %.10g %.10g %.10g %.10g\n", R[0], R[1], R[2], fr.t_wp_.v[4], R[3], R[4], R[5], fr.t_wp_.v[5], R[6], R[7], R[8], fr.t_wp_.v[6]);
       }

@@ -33,7 +33,7 @@ def test_help_and_flag_errors():
     for flag in ("-models", "-cam", "-imu", "-grid_preset", "-output", "-calibrate_imu", "-calibrate_intrinsics", "-find_time_offset",
                  "-has_initial_guess", "-model_files", "-max_iters", "-function_tolerance", "-gyro_sigma", "-accel_sigma",
                  "-remove_outliers", "-outlier_threshold", "-max_reprojection_error", "-num_vicalib_frames", "-frame_skip",
-                 "-save_poses", "-print_poses", "-grid_height", "-grid_width", "-grid_spacing", "-grid_seed"):
+                 "-save_poses", "-print_poses", "-grid_height", "-grid_width", "-grid_spacing", "-grid_seed", "-gpus"):
         assert flag + " " in r.stdout, flag          # the CLI contract of SURVEY 8(b)
     assert _run([]).returncode == 1                   # "No camera URI given" (vicalib-engine.cc:445)
     r = _run(["-bogus", "1"]); assert r.returncode == 1 and "unknown command line flag" in r.stderr

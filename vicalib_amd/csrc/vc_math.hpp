@@ -213,7 +213,7 @@ VC_HD void project_kb4(const double* pc, const double* K, double* pix, double* A
   const double Rr = th * poly;
   const bool off_axis = rho > 0.0;            // selects, not jumps (see project_radial)
   const double irho1 = 1.0 / (off_axis ? rho : 1.0);      // unconditional division on a safe operand
-  const double irho = off_axis ? irho1 : 0.0, c = X * irho1 + (off_axis ? 0.0 : 1.0), s = Y * irho1;   // on the axis X = Y = 0
+  const double c = X * irho1 + (off_axis ? 0.0 : 1.0), s = Y * irho1;   // on the axis X = Y = 0
   const double fu = K[0], fv = K[1];
   pix[0] = fu * Rr * c + K[2];
   pix[1] = fv * Rr * s + K[3];
