@@ -162,6 +162,8 @@ struct vc_calibrator {
   DBuf<double2> d_uv; DBuf<unsigned short> d_pt; DBuf<double> d_points;
   DBuf<int> d_tile_frame, d_tile_cam, d_tile_off, d_frame_tile_off, d_frame_cam_tile, d_cam_model, d_cam_flags, d_cam_col0,
       d_col_cam, d_col_local, d_flags;
+  DBuf<double> d_wgpart;
+  int kpass = 0;                  // passes enqueued since init_ctrl (merged mode: selects the control record and flag parity)
   DBuf<double> d_pose[2], d_cam[2], d_G[2], d_tile_cost[2], d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_sdiag,
       d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total;
   DBuf<Ctrl> d_ctrl;
@@ -342,7 +344,7 @@ struct vc_calibrator {
     // one wavefront per frame, 4 frames per group: up to 2048 chunks (= partial sums) before chunks grow
     const int chunk_frames = std::max(4, (((N + 2047) / 2048) + 3) / 4 * 4);
     const int n_chunks = std::max(1, (N + chunk_frames - 1) / chunk_frames);
-    const int part_stride = D * D + D + C * kGStride + (imu_on() ? kGStride : 0) + 1;     // ... + the chunk's cost (vision path)
+    const int part_stride = D * D + D + C * kGStride + (imu_on() ? kGStride : 0) + 2;     // ... + [x2 of observation-less frames, chunk cost] (vision path)
     for (int b = 0; b < 2; ++b) {
       HIP_OK(d_G[b].alloc((size_t)std::max(T, 1) * kGStride)); HIP_OK(d_tile_cost[b].alloc(std::max(T, 1)));
       HIP_OK(hipMemsetAsync(d_G[b].p, 0, (size_t)std::max(T, 1) * kGStride * sizeof(double), stream));   // sub-blocks a model never writes stay 0
@@ -352,13 +354,15 @@ struct vc_calibrator {
     HIP_OK(d_part.alloc((size_t)n_chunks * part_stride)); HIP_OK(d_part_total.alloc((size_t)part_stride * ((n_chunks + 63) / 64))); HIP_OK(d_Sbuf.alloc((size_t)D * D + 3 * D + 2));
     HIP_OK(d_sdiag.alloc(D)); HIP_OK(d_sscale2.alloc(D)); HIP_OK(d_slam.alloc(D)); HIP_OK(d_delta_s.alloc(D));
     HIP_OK(d_fpart.alloc((size_t)std::max(N, 1) * kNumScal));
-    trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); HIP_OK(d_ctrl.alloc(1));
+    trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); HIP_OK(d_ctrl.alloc(2));
     HIP_OK(hipMemsetAsync(d_part.p, 0, (size_t)n_chunks * part_stride * sizeof(double), stream));
     HIP_OK(hipMemsetAsync(d_fpart.p, 0, (size_t)std::max(N, 1) * kNumScal * sizeof(double), stream));
-    HIP_OK(d_scal.alloc(2 * kNumScal)); HIP_OK(d_flags.alloc(4));
+    HIP_OK(d_scal.alloc(2 * kNumScal)); HIP_OK(d_flags.alloc(8));
+    HIP_OK(d_wgpart.alloc((size_t)std::max(1, (T + 3) / 4) * kNumScal));
     HIP_OK(hipMemsetAsync(d_scal.p, 0, 2 * kNumScal * sizeof(double), stream));
     HIP_OK(d_tmp.alloc(64));
-    HIP_OK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(int), stream));
+    HIP_OK(hipMemsetAsync(d_flags.p, 0, 8 * sizeof(int), stream));
+    HIP_OK(hipMemsetAsync(d_ctrl.p, 0, 2 * sizeof(Ctrl), stream));
     HIP_OK(hipMemsetAsync(d_delta_s.p, 0, std::max(D, 1) * sizeof(double), stream));
     for (int c = 0; c < kMaxCams; ++c) { dv.cd[c].model = 0; dv.cd[c].flags = 0; dv.cd[c].col0 = 0; dv.cd[c].ncols = 0; }
     for (int c = 0; c < C; ++c) { dv.cd[c].model = cams[c].model; dv.cd[c].flags = cam_flags[c]; dv.cd[c].col0 = cam_col0[c]; dv.cd[c].ncols = cam_ncols(cam_flags[c], cams[c].nk); }
@@ -376,6 +380,7 @@ struct vc_calibrator {
     dv.fdiag = d_fdiag.p; dv.fscale2 = d_fscale2.p; dv.part = d_part.p; dv.part_total = d_part_total.p; dv.Sbuf = d_Sbuf.p;
     dv.sdiag = d_sdiag.p; dv.sscale2 = d_sscale2.p; dv.slam = d_slam.p; dv.delta_s = d_delta_s.p;
     dv.fpart = d_fpart.p; dv.scal = d_scal.p; dv.flags = d_flags.p;
+    dv.wgpart = d_wgpart.p; dv.merged = 0; dv.par = 0; dv.ctrl_prev = d_ctrl.p + 1;
     dv.part_stride = part_stride; dv.ctrl = d_ctrl.p; dv.trace = d_trace.p; dv.dbg = (long long*)(d_tmp.p + 24);
     HIP_OK(d_pose_init.upload(poses, stream)); HIP_OK(d_cam_init.upload(camrec, stream));
     // ---- inertial terms ------------------------------------------------------------------------------
@@ -488,6 +493,7 @@ struct vc_calibrator {
   // first_pass: the pass right after init_ctrl (the only one that needs k_reproj_jac when k_trial carries the sweep)
   int enqueue_pass(bool first_pass = true) {
     const int D = dv.D;
+    dv.merged = 0; dv.par = 0; dv.ctrl = d_ctrl.p; dv.ctrl_prev = d_ctrl.p + 1;
     if (dv.imu_on) {
       // UpdateImuWeights of the iteration callback (vicalibrator.h:691): linearise with the current weights, evaluate the
       // trial point with the updated ones.  The update only needs the accepted state, so it runs on a second stream under
@@ -526,6 +532,13 @@ struct vc_calibrator {
       }
       return VC_OK;
     }
+    // merged decision (single process): control records alternate, pass k judges pass k-1 at the head of k_frame_schur
+    const bool merged = !sharded() && merged_enabled && !use_graphs;      // (a captured graph has fixed kernel arguments)
+    if (merged) {
+      if (first_pass) kpass = 0;
+      dv.merged = 1; dv.par = kpass & 1; dv.ctrl = d_ctrl.p + (kpass & 1); dv.ctrl_prev = d_ctrl.p + ((kpass + 1) & 1);
+      ++kpass;
+    }
     if (first_pass || !dv.fused) launch_reproj_jac(dv, stream);
     launch_frame_schur(dv, stream);
     int rc = VC_OK;
@@ -541,9 +554,24 @@ struct vc_calibrator {
       launch_final(dv, 1, stream);
       rc = do_allreduce(dv.gath, world * kNumScal, 0); if (rc) return rc;
       launch_final(dv, 2, stream);
-    } else {
+    } else if (!merged) {
       launch_final(dv, 0, stream);
     }
+    return VC_OK;
+  }
+  // merged mode: judge the last enqueued pass; afterwards `ctrl_result()` is the record to read back
+  void finish_batch() {
+    if (!dv.merged) return;
+    dv.par = kpass & 1; dv.ctrl = d_ctrl.p + (kpass & 1); dv.ctrl_prev = d_ctrl.p + ((kpass + 1) & 1);
+    launch_final_merged(dv, stream);
+  }
+  const Ctrl* ctrl_result() const { return dv.merged ? d_ctrl.p + (kpass & 1) : d_ctrl.p; }
+  bool merged_enabled = true;
+  // a fresh control record goes to buffer 0; buffer 1 (the "previous pass" of the first pass in merged mode) is blanked
+  int upload_ctrl(const Ctrl* c) {
+    HIP_OK(hipMemcpyAsync(d_ctrl.p, c, sizeof(Ctrl), hipMemcpyHostToDevice, stream));
+    HIP_OK(hipMemsetAsync(d_ctrl.p + 1, 0, sizeof(Ctrl), stream));
+    kpass = 0;
     return VC_OK;
   }
   void init_ctrl(Ctrl* c) {
@@ -564,7 +592,7 @@ struct vc_calibrator {
     if (trace_cap < max_iters + 8) { trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); dv.trace = d_trace.p; }
     if (!pin) HIP_OK(hipHostMalloc((void**)&pin, sizeof(Pinned), hipHostMallocDefault));
     init_ctrl(&pin->up);
-    HIP_OK(hipMemcpyAsync(d_ctrl.p, &pin->up, sizeof(Ctrl), hipMemcpyHostToDevice, stream));
+    { int rcu = upload_ctrl(&pin->up); if (rcu) return rcu; }
     if (dv.imu_on && dv.weights_on) { launch_imu_weights(dv, wcur, stream); wcur = 1 - wcur; }     // UpdateImuWeights() before ceres::Solve (vicalibrator.h:955)
     // First batch = what the previous solve needed (repeated solves of similar problems: no wasted launches,
     // one host sync per solve); then small top-up batches until the device reports `done`.
@@ -576,7 +604,8 @@ struct vc_calibrator {
         int rc = (first || sharded() || !use_graphs) ? enqueue_pass(first) : launch_pass_graph();
         if (rc) return rc;
       }
-      HIP_OK(hipMemcpyAsync(&pin->down, d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+      finish_batch();
+      HIP_OK(hipMemcpyAsync(&pin->down, ctrl_result(), sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
       HIP_OK(hipMemcpyAsync(pin->trace, d_trace.p, trace_bytes, hipMemcpyDeviceToHost, stream));
       HIP_OK(hipStreamSynchronize(stream));
       if (pin->down.done || !should_run || ++guard > max_iters + 8) break;
@@ -612,9 +641,10 @@ struct vc_calibrator {
     Ctrl c;
     init_ctrl(&c);
     c.hold = 1; c.radius = radius; c.first = 0;
-    HIP_OK(hipMemcpyAsync(d_ctrl.p, &c, sizeof(Ctrl), hipMemcpyHostToDevice, stream));
+    { int rcu = upload_ctrl(&c); if (rcu) return rcu; }
     int rc = enqueue_pass(); if (rc) return rc;
-    HIP_OK(hipMemcpyAsync(&c, d_ctrl.p, sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+    finish_batch();
+    HIP_OK(hipMemcpyAsync(&c, ctrl_result(), sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
     if (cost) *cost = c.cost;
     return VC_OK;
@@ -746,6 +776,7 @@ int vc_create(vc_calibrator** out, int device) {
   vc_calibrator* h = new vc_calibrator();
   h->device = device;
   { const char* e = std::getenv("VICALIB_AMD_GRAPHS"); if (e && e[0] == '1') h->use_graphs = true; }
+  { const char* e = std::getenv("VICALIB_AMD_NO_MERGED_DECISION"); if (e && e[0] == '1') h->merged_enabled = false; }
   { const char* e = std::getenv("VICALIB_AMD_OVERLAP_WEIGHTS"); if (e && e[0] == '1') h->serial_weights = false; }
   if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming) != hipSuccess ||
@@ -1077,6 +1108,7 @@ int vc_time_kernels(vc_calibrator* h, int reps, double* jac_ms, double* res_ms) 
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) return VC_ERR_NO_DEVICE;
   Ctrl c; h->init_ctrl(&c); c.hold = 1; if (c.mult < 1) c.mult = 1;
   if (hipMemcpy(h->d_ctrl.p, &c, sizeof(Ctrl), hipMemcpyHostToDevice) != hipSuccess) return VC_ERR_NO_DEVICE;
+  h->dv.merged = 0; h->dv.par = 0; h->dv.ctrl = h->d_ctrl.p; h->dv.ctrl_prev = h->d_ctrl.p + 1;
   const double mult = c.mult;
   launch_reproj_jac(h->dv, h->stream); launch_reproj_res(h->dv, h->cur, mult, h->stream);   // warm
   (void)hipEventRecord(e0, h->stream);
@@ -1100,7 +1132,12 @@ int vc_time_stages(vc_calibrator* h, int reps, double* out) {
   if (h->device_dirty) { int rc = vc_prepare(h); if (rc) return rc; }
   Ctrl c; h->init_ctrl(&c); c.hold = 1; c.first = 0; if (c.mult < 1) c.mult = 1;
   if (hipMemcpy(h->d_ctrl.p, &c, sizeof(Ctrl), hipMemcpyHostToDevice) != hipSuccess) return VC_ERR_NO_DEVICE;
-  if (h->enqueue_pass()) return VC_ERR_NO_DEVICE;
+  // stage timing uses the stand-alone kernels of the unmerged pipeline (k_final as its own launch)
+  const bool was_merged = h->merged_enabled;
+  h->merged_enabled = false;
+  const int rc_pass = h->enqueue_pass();
+  h->merged_enabled = was_merged;
+  if (rc_pass) return VC_ERR_NO_DEVICE;
   hipEvent_t ev[7];
   for (int i = 0; i < 7; ++i) if (hipEventCreate(&ev[i]) != hipSuccess) return VC_ERR_NO_DEVICE;
   hipStream_t s = h->stream;

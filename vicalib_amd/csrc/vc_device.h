@@ -38,7 +38,9 @@ struct Ctrl {
   int iter, invalid, done, max_iters;
   int first, pending, trace_len, trace_cap;
   int stage, hold, num_callbacks, jac_sweeps;
-  int res_sweeps, passes, pad0, pad1;
+  int res_sweeps, passes;
+  int needs_decision;   // merged mode: the pass that used this record has produced a trial point nobody has judged yet
+  int pad1;
 };
 
 // per-camera descriptor, carried in the kernel arguments (scalar loads, no dependent global look-ups)
@@ -125,6 +127,12 @@ struct DevView {
   // rank's separator (columns sep_col1..+8), kept here because the IMU block that ends in it belongs to this rank.
   int pin_first, pin_last, sep_col0, sep_col1;
   int rank, world;                 // frame sharding: this process's rank, number of ranks
+  // Merged decision (vision-only, single process): the accept/reject decision on pass k's trial point is taken at the head
+  // of pass k+1's k_frame_schur -- by every workgroup, redundantly and identically -- instead of a k_final launch per pass.
+  // Control records alternate between two buffers: `ctrl` is the record of the current pass, `ctrl_prev` the previous one.
+  int merged, par;                 // par = pass parity (selects the numeric-failure flag pair)
+  const Ctrl* ctrl_prev;
+  double* wgpart;                  // k_trial: per-workgroup sums of the step scalars [n_workgroups][kNumScal]
   double* gath;                    // world x kNumScal: every rank's step scalars (one all-reduce(SUM) of disjoint slots = all-gather)
   double* sep_strip;               // 2 x 9 x ldw: rows of the reduced system contributed directly by the pinned frames
 };
@@ -136,7 +144,8 @@ void launch_frame_schur(const DevView& v, hipStream_t s);      // frame eliminat
 // mode 0: packed reduced system (Sbuf) + damped solve + trial shared parameters; 1: Sbuf only; 2: solve only
 void launch_reduced(const DevView& v, int mode, hipStream_t s);
 void launch_trial(const DevView& v, hipStream_t s);            // back-substitution + manifold update + trial residual sweep
-void launch_final(const DevView& v, int mode, hipStream_t s);  // mode 0: reduce + decide, 1: reduce only, 2: decide only
+void launch_final(const DevView& v, int mode, hipStream_t s);
+void launch_final_merged(const DevView& v, hipStream_t s);   // merged mode, batch end: judges the last pass (ctrl = next record, ctrl_prev = last pass's)  // mode 0: reduce + decide, 1: reduce only, 2: decide only
 void launch_reproj_res(const DevView& v, int state, double mult, hipStream_t s);   // residual sweep; state 0/1 buffer, 2 accepted, 3 trial (mult from Ctrl)
 void launch_reset_state(const DevView& v, const double* pose0, const double* cam0, const double* vel0, const double* imu0, hipStream_t s);
 void launch_sum_tile_cost(const DevView& v, double* out_cost_sq /*2*/, hipStream_t s);

@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void k_cr_elim(DevView v, int s) {
   for (int i = 0; i < 81; ++i) L[i] = A[i];
   double dinv[9];
   if (!chol_small<9>(L, dinv)) {
-    if (lane == 0) atomicAdd(&v.flags[0], 1);
+    if (lane == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
 #pragma unroll
     for (int i = 0; i < 81; ++i) L[i] = (i % 10 == 0) ? 1.0 : 0.0;
 #pragma unroll

@@ -25,6 +25,8 @@
 
 namespace vc {
 
+__device__ void merged_control(const DevView& v, Ctrl* out, double* red, bool writer);
+
 // ------------------------------------------------------------------------------------------ Jacobian sweep
 // One wavefront sweeps one tile.  Per pass of 64 corners: lane = corner computes its two unique-column rows into the
 // wave-private LDS image; the Gram block G += u^T u then accumulates on the matrix pipe, four rows (two corners) per step.
@@ -293,7 +295,9 @@ __device__ __forceinline__ int schur_ld(int D) { const int Dp = ((D + 1 + 15) / 
 template <int MAXC, int MAXP, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
+  __shared__ Ctrl s_ctrl;
   const Ctrl* ct = v.ctrl;
+  if (v.merged) { merged_control(v, &s_ctrl, sh, blockIdx.x == 0); ct = &s_ctrl; }
   if (ct->done) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int C = v.n_cams, D = v.D;
@@ -316,6 +320,7 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) gsum[c][q] = 0.0;
   double csum = 0.0;      // lane t: cost of tile t of this wave's frames (the chunk's cost rides in the partials)
+  double x2_noobs = 0.0;  // lane 0: parameter norm of this wave's frames that have no observations
 
   for (int fg = f0; fg < f1; fg += 4) {
     const int f = fg + wave;
@@ -330,6 +335,7 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
       double* o = v.fpart + (size_t)f * kNumScal;
       for (int i = 0; i < kNumScal; ++i) o[i] = 0.0;
       o[kScX2] = x2;
+      x2_noobs += x2;
     }
     if (nt > 0) {
       for (int t = 0; t < nt; ++t) {           // full 16x16 Gram block of every tile of the frame
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
       }
       double dinv[6];
       if (!chol_small<6>(H, dinv)) {
-        if (lane == 0) atomicAdd(&v.flags[0], 1);
+        if (lane == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
 #pragma unroll
         for (int i = 0; i < 36; ++i) H[i] = (i % 7 == 0) ? 1.0 : 0.0;
 #pragma unroll
@@ -500,9 +506,9 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
   // chunk cost (sum of the tiles' robustified costs at the linearisation point), last slot of the partial record
   __syncthreads();
   csum = wave_sum(csum);
-  if (lane == 0) sh[wave] = csum;
+  if (lane == 0) { sh[wave] = csum; sh[4 + wave] = x2_noobs; }
   __syncthreads();
-  if (tid == 0) part[v.part_stride - 1] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  if (tid == 0) { part[v.part_stride - 1] = (sh[0] + sh[1]) + (sh[2] + sh[3]); part[v.part_stride - 2] = (sh[4] + sh[5]) + (sh[6] + sh[7]); }
 }
 
 // Fixed-order sum of the chunk partials, spread over many CUs (one CU can only pull ~20-50 GB/s):
@@ -553,7 +559,7 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
     for (int k = 0; k < nslab; ++k) t += v.part_total[(size_t)k * stride + e];
     if (e < D * D) S[e] = -t;
     else if (e < D * D + D) gred[e - D * D] = -t;
-    else if (e < stride - 1) L.gsum[e - D * D - D] = t;      // (the last slot is the chunk cost, read below)
+    else if (e < stride - 2) L.gsum[e - D * D - D] = t;      // (the last two slots: x2 of observation-less frames, chunk cost)
   }
   VC_STAMP(1);
   for (int i = tid; i < D; i += 256) { hd[i] = 0.0; gs[i] = 0.0; }
@@ -705,7 +711,7 @@ __device__ void solve_small_wave(const DevView& v, const Ctrl* ct, int lane, dou
       for (int k = j + 1; k < DMAX; ++k) row[k] -= lij * readlane_f64(lij, k);
     }
   }
-  if (bad && lane == 0) v.flags[1] = 1;
+  if (bad && lane == 0) v.flags[5 + 2 * v.par] = 1;
   // delta_s = -L^-T y.  Lt row i is column i of L: L[j][i] for j >= i, and y_i = L[D][i] at index D.
   wave_lds_sync();
   double c[DMAX];
@@ -756,7 +762,7 @@ __device__ void solve_large_block(const DevView& v, const Ctrl* ct, double* M, d
     const double piv = sqrt(d);
     for (int i = j + 1 + tid; i <= D; i += 256) col[i] = M[tri(i) + j] / piv;
     __syncthreads();
-    if (tid == 0) { M[tri(j) + j] = piv; if (bad) v.flags[1] = 1; }
+    if (tid == 0) { M[tri(j) + j] = piv; if (bad) v.flags[5 + 2 * v.par] = 1; }
     {   // trailing update on a 16 x 16 thread grid (no integer divisions on the per-column path)
       const int ti = tid >> 4, tj = tid & 15;
       for (int i = j + 1 + ti; i <= D; i += 16) {
@@ -856,6 +862,16 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
     double* h = v.scal + kNumScal;
     h[kScGd] = red[0]; h[kScDld] = red[256]; h[kScStep2] = red[512]; h[kScX2] = red[768]; h[kScG2] = red[1024];
     h[kScCost] = 0.0; h[kScGmax] = red[1280]; h[kScSq] = 0.0;
+    if (v.merged) {
+      // frames without observations take no part in k_trial: their parameter norm (chunk sums in the Schur partials) is
+      // added here; then flag the record (a trial point is about to exist) and clear the failure flags of the next pass
+      const int stride = v.part_stride, nslab = (v.n_chunks + kSlab - 1) / kSlab;
+      double x2 = 0.0;
+      for (int k = 0; k < nslab; ++k) x2 += v.part_total[(size_t)k * stride + stride - 2];
+      h[kScX2] += x2;
+      v.ctrl->needs_decision = 1;
+      v.flags[4 + 2 * (1 - v.par)] = 0; v.flags[5 + 2 * (1 - v.par)] = 0;
+    }
   }
 }
 
@@ -876,7 +892,8 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
 // also publishes the frame's trial pose and its step terms.
 __device__ void final_phase(const DevView& v, int mode, double* red /* 7 x 256 */);
 template <bool FUSED>
-__device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int tile, int wave, int lane, const double* ds_s, double* lds_rows) {
+__device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int tile, int wave, int lane, const double* ds_s, double* lds_rows,
+                                           double* wsum /* kNumScal, lane 0: this wave's step scalars */) {
   const int cur = ct->cur;
   const double mult = ct->mult;
   const int f = v.tile_frame[tile], c = v.tile_cam[tile];
@@ -940,6 +957,7 @@ __device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int
     }
     double* o = v.fpart + (size_t)f * kNumScal;
     o[kScGd] = gd; o[kScDld] = dld; o[kScStep2] = step2; o[kScX2] = x2; o[kScG2] = g2; o[kScCost] = 0.0; o[kScGmax] = gmax; o[kScSq] = 0.0;
+    wsum[kScGd] = gd; wsum[kScDld] = dld; wsum[kScStep2] = step2; wsum[kScX2] = x2; wsum[kScG2] = g2; wsum[kScGmax] = gmax;
   }
   double cost, sq = 0.0;
   if (FUSED) {
@@ -959,6 +977,7 @@ __device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int
   if (lane == 0) {
     v.tile_trial[2 * tile] = cost;
     v.tile_trial[2 * tile + 1] = sq;
+    wsum[kScCost] = cost;
   }
 }
 // (Tried and dropped: letting the last workgroup to finish run the final phase.  Device-scope release/acquire fences are
@@ -974,31 +993,48 @@ __global__ __launch_bounds__(256, 2) void k_trial(DevView v) {
   const int tile = blockIdx.x * 4 + wave;
   for (int i = threadIdx.x; i < v.D; i += 256) if (i < kMaxCams * 16 + 16) ds_s[i] = v.delta_s[i];
   __syncthreads();
-  if (tile < v.n_tiles) trial_tile<FUSED>(v, ct, tile, wave, lane, ds_s, lds_rows);
+  double wsum[kNumScal];
+#pragma unroll
+  for (int k = 0; k < kNumScal; ++k) wsum[k] = 0.0;
+  if (tile < v.n_tiles) trial_tile<FUSED>(v, ct, tile, wave, lane, ds_s, lds_rows, wsum);
+  if (v.merged) {      // the workgroup's step scalars in one record: the next pass's decision reads n_tiles / 4 of these
+    __shared__ double s_w[4 * kNumScal];
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < kNumScal; ++k) s_w[wave * kNumScal + k] = wsum[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumScal) {
+      const int k = threadIdx.x;
+      const double a = s_w[k], b = s_w[kNumScal + k], c = s_w[2 * kNumScal + k], d = s_w[3 * kNumScal + k];
+      v.wgpart[(size_t)blockIdx.x * kNumScal + k] = (k == kScGmax) ? fmax(fmax(a, b), fmax(c, d)) : (a + b) + (c + d);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------ decision
 // The Ceres trust-region bookkeeping (TrustRegionMinimizer + LevenbergMarquardtStrategy) and the
 // reference's iteration callback (vicalibrator.h:690-721), run by one thread after every pass.
-__device__ void trace_push(const DevView& v, Ctrl* c, const double* rec) {
-  if (c->trace_len < c->trace_cap) {
+__device__ void trace_push(const DevView& v, Ctrl* c, const double* rec, bool writer = true) {
+  if (writer && c->trace_len < c->trace_cap) {
     double* o = v.trace + (size_t)c->trace_len * kTraceCols;
     for (int i = 0; i < kTraceCols; ++i) o[i] = rec[i];
   }
   c->trace_len += 1;
   c->last_gnorm = rec[4];
 }
-__device__ void lm_decide_local(const DevView& v, Ctrl* c) {
+// s: the frame-side step scalars of the judged pass, fpar: parity of its failure flags, writer: this caller owns the global
+// side effects (trace rows, flag reset)
+__device__ void lm_decide_local(const DevView& v, Ctrl* c, const double* s, int fpar, bool writer) {
   const int D = v.D;
-  const double* s = v.scal;
   const double* t = v.scal + kNumScal;
   const double R_cost = v.Sbuf[(size_t)D * D + 3 * D];
   const double R_gd = s[kScGd] + t[kScGd], R_dld = s[kScDld] + t[kScDld];
   const double R_step2 = s[kScStep2] + t[kScStep2], R_x2 = s[kScX2] + t[kScX2];
   const double R_gnorm = sqrt(s[kScG2] + t[kScG2]), R_gmax = fmax(s[kScGmax], t[kScGmax]);
   const double R_new_cost = s[kScCost];
-  const bool fail = (v.flags[0] != 0) || (v.flags[1] != 0);
-  v.flags[0] = 0; v.flags[1] = 0;
+  const bool fail = (v.flags[4 + 2 * fpar] != 0) || (v.flags[5 + 2 * fpar] != 0);
+  if (writer && !v.merged) { v.flags[4 + 2 * fpar] = 0; v.flags[5 + 2 * fpar] = 0; }      // merged: k_reduced clears the other parity
   c->passes += 1;
   c->res_sweeps += v.fused ? 0 : 1;
   c->jac_sweeps += (c->need_lin ? 1 : 0) + (v.fused ? 1 : 0);
@@ -1006,13 +1042,13 @@ __device__ void lm_decide_local(const DevView& v, Ctrl* c) {
   if (c->pending) {            // the pass linearised at the newly accepted point
     c->cost = R_cost; c->gmax = R_gmax; c->gnorm = R_gnorm;
     c->pend[1] = R_cost; c->pend[3] = R_gmax; c->pend[4] = R_gnorm;
-    trace_push(v, c, c->pend);
+    trace_push(v, c, c->pend, writer);
     c->pending = 0;
     if (R_gmax <= c->gtol) { c->done = kDoneConvergence; return; }
   } else if (c->first) {
     c->cost = R_cost; c->gmax = R_gmax; c->gnorm = R_gnorm;
     const double rec[kTraceCols] = {0.0, R_cost, 0.0, R_gmax, R_gnorm, 0.0, 0.0, c->radius, 1.0, (double)c->stage};
-    trace_push(v, c, rec);
+    trace_push(v, c, rec, writer);
     c->first = 0; c->init_scale = 0;
     if (R_gmax <= c->gtol) { c->done = kDoneConvergence; return; }
   }
@@ -1026,18 +1062,18 @@ __device__ void lm_decide_local(const DevView& v, Ctrl* c) {
   const double model_change = -0.5 * R_gd + 0.5 * R_dld;
   if (fail || !(model_change > 0.0)) {
     c->invalid += 1;
-    if (c->invalid >= 5) { trace_push(v, c, rec); c->done = kDoneFailure; return; }
+    if (c->invalid >= 5) { trace_push(v, c, rec, writer); c->done = kDoneFailure; return; }
     c->radius *= 0.5; rec[7] = c->radius;
-    trace_push(v, c, rec);
+    trace_push(v, c, rec, writer);
     c->need_lin = 0; c->reuse_diag = 1;
     return;
   }
   c->invalid = 0;
   rec[5] = sqrt(R_step2);
   const double xnorm = sqrt(R_x2);
-  if (rec[5] <= c->ptol * (xnorm + c->ptol)) { trace_push(v, c, rec); c->done = kDoneConvergence; return; }
+  if (rec[5] <= c->ptol * (xnorm + c->ptol)) { trace_push(v, c, rec, writer); c->done = kDoneConvergence; return; }
   rec[2] = c->cost - R_new_cost;
-  if (fabs(rec[2]) < c->ftol * c->cost) { trace_push(v, c, rec); c->done = kDoneConvergence; return; }
+  if (fabs(rec[2]) < c->ftol * c->cost) { trace_push(v, c, rec, writer); c->done = kDoneConvergence; return; }
   rec[6] = rec[2] / model_change;
   if (rec[6] > 1e-3) {
     c->cur = 1 - c->cur;
@@ -1050,7 +1086,7 @@ __device__ void lm_decide_local(const DevView& v, Ctrl* c) {
   } else {
     c->radius = c->radius / c->decrease_factor; c->decrease_factor *= 2.0;
     rec[7] = c->radius;
-    trace_push(v, c, rec);
+    trace_push(v, c, rec, writer);
     if (c->radius < 1e-32) { c->done = kDoneConvergence; return; }
     c->need_lin = 0; c->reuse_diag = 1;
   }
@@ -1058,8 +1094,69 @@ __device__ void lm_decide_local(const DevView& v, Ctrl* c) {
 
 __device__ void lm_decide(const DevView& v) {
   Ctrl local = *v.ctrl;          // one burst of loads, one burst of stores
-  lm_decide_local(v, &local);
+  lm_decide_local(v, &local, v.scal, v.par, true);
   *v.ctrl = local;
+}
+// ---- merged decision --------------------------------------------------------------------------------------------
+// The control record of the current pass from the previous pass's record: judge the pending trial point, or carry a finished
+// state forward, or (first pass / after k_final_merged) take the record that is already in place.  All threads call it;
+// `out` (LDS) holds the result after the trailing barrier; red: 8 x 4 doubles of LDS.  writer: this workgroup stores the
+// record and the trace rows.
+__device__ void merged_control(const DevView& v, Ctrl* out, double* red, bool writer) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const Ctrl* cp = v.ctrl_prev;
+  // everything the decision may need is requested up front (the per-workgroup scalars, the previous record): one memory
+  // latency instead of a chain of dependent ones
+  const int nwg = (v.n_tiles + 3) / 4;
+  double a[kNumScal];
+#pragma unroll
+  for (int k = 0; k < kNumScal; ++k) a[k] = 0.0;
+  for (int i = tid; i < nwg; i += 256) {
+#pragma unroll
+    for (int k = 0; k < kNumScal; ++k) {
+      const double x = v.wgpart[(size_t)i * kNumScal + k];
+      a[k] = (k == kScGmax) ? fmax(a[k], x) : a[k] + x;
+    }
+  }
+  Ctrl c;
+  if (tid == 0) c = *cp;
+  const int nd = cp->needs_decision, pdone = cp->done;       // wave-uniform
+  if (nd) {
+    // fixed-order sum of k_trial's per-workgroup scalars: every caller (each workgroup of k_frame_schur, k_final_merged)
+    // gets bit-identical sums
+#pragma unroll
+    for (int k = 0; k < kNumScal; ++k) {
+      double x = a[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_down(x, o, 64); x = (k == kScGmax) ? fmax(x, y) : x + y; }
+      if (lane == 0) red[k * 4 + wave] = x;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double s[kNumScal];
+#pragma unroll
+      for (int k = 0; k < kNumScal; ++k)
+        s[k] = (k == kScGmax) ? fmax(fmax(red[k * 4], red[k * 4 + 1]), fmax(red[k * 4 + 2], red[k * 4 + 3]))
+                              : (red[k * 4] + red[k * 4 + 1]) + (red[k * 4 + 2] + red[k * 4 + 3]);
+      s[kScCost] *= 0.5;
+      lm_decide_local(v, &c, s, 1 - v.par, writer);           // the judged pass ran with the other parity
+      c.needs_decision = 0;
+      *out = c;
+      if (writer) *v.ctrl = c;
+    }
+  } else if (tid == 0) {
+    if (pdone) { *out = c; if (writer) *v.ctrl = c; }
+    else *out = *v.ctrl;
+  }
+  __syncthreads();
+}
+// batch end in merged mode: the last pass's trial point is judged here (the host reads the record this writes)
+__global__ __launch_bounds__(256) void k_final_merged(DevView v) {
+  __shared__ Ctrl c;
+  __shared__ double red[kNumScal * 4];
+  // here `ctrl` = record of the NEXT pass (to be written), `ctrl_prev` = record of the pass just run
+  merged_control(v, &c, red, true);
+  if (threadIdx.x == 0 && v.ctrl_prev->needs_decision) const_cast<Ctrl*>(v.ctrl_prev)->needs_decision = 0;
 }
 // mode 0: reduce + decide, 1: reduce only (an all-reduce follows), 2: decide only
 __device__ void final_phase(const DevView& v, int mode, double* red) {
@@ -1088,7 +1185,7 @@ __device__ void final_phase(const DevView& v, int mode, double* red) {
       o[kScCost] = 0.5 * red[1280]; o[kScGmax] = red[1536]; o[kScSq] = 0.0;
       if (mode == 1) {       // sharded: publish this rank's terms (and its numeric-failure flags) in its slot of the gather table
         for (int r = 0; r < v.world; ++r)
-          for (int k = 0; k < kNumScal; ++k) v.gath[r * kNumScal + k] = (r == v.rank) ? (k == kScSq ? (double)(v.flags[0] + v.flags[1]) : o[k]) : 0.0;
+          for (int k = 0; k < kNumScal; ++k) v.gath[r * kNumScal + k] = (r == v.rank) ? (k == kScSq ? (double)(v.flags[4 + 2 * v.par] + v.flags[5 + 2 * v.par]) : o[k]) : 0.0;
       }
     }
   }
@@ -1099,7 +1196,7 @@ __device__ void final_phase(const DevView& v, int mode, double* red) {
       for (int r = 0; r < v.world; ++r) a = (k == kScGmax) ? fmax(a, v.gath[r * kNumScal + k]) : a + v.gath[r * kNumScal + k];
       o[k] = a;
     }
-    v.flags[0] = (o[kScSq] > 0.0) ? 1 : 0; v.flags[1] = 0;
+    v.flags[4 + 2 * v.par] = (o[kScSq] > 0.0) ? 1 : 0; v.flags[5 + 2 * v.par] = 0;
   }
   if (mode != 1 && tid == 0) lm_decide(v);
 }
@@ -1185,6 +1282,7 @@ void launch_trial(const DevView& v, hipStream_t s) {
   if (lds > 0 && !granted) { (void)hipFuncSetAttribute((const void*)k_trial<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 4096)); granted = true; }
   hipLaunchKernelGGL(k_trial<true>, dim3(tiles_grid(v)), dim3(256), lds, s, v);      // vision-only passes are always fused
 }
+void launch_final_merged(const DevView& v, hipStream_t s) { hipLaunchKernelGGL(k_final_merged, dim3(1), dim3(256), 0, s, v); }
 void launch_final(const DevView& v, int mode, hipStream_t s) {
   hipLaunchKernelGGL(k_final, dim3(1), dim3(256), 0, s, v, mode);
 }
