@@ -287,17 +287,24 @@ __device__ void w_step_cols(WLds& L, WState* st, const Meas<double>& z0, const M
   *st = y;
 }
 
+// Four IMU blocks per wavefront: the propagation only uses 16 lanes (one per column of [dy_dy0 | dy_db]), and the kernel is
+// bound by per-lane instruction latency at one wave per SIMD (it needs the whole register file), so packing four 16-lane
+// groups into a wave quarters the number of waves.  Everything below is per group: its own LDS record, 16-lane loops,
+// stores predicated on the group's state; no early return (the groups of a wave finish together).
 __global__ __launch_bounds__(256) void k_imu_weights(DevView v, int wr) {
-  __shared__ WLds lds[4];
+  extern __shared__ __attribute__((aligned(16))) double w_lds[];
   const Ctrl* ct = v.ctrl;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int s = blockIdx.x * 4 + wave;
-  if (s >= v.n_frames - 1) return;
+  const int grp = lane >> 4, c = lane & 15;      // c: column of [dy_dy0 | dy_db] this lane carries within its group
+  const int n_blocks = v.n_frames - 1;
+  const int s_raw = (blockIdx.x * 4 + wave) * 4 + grp;
+  const bool exists = s_raw < n_blocks;
+  const int s = exists ? s_raw : n_blocks - 1;   // groups past the end shadow the last block and store nothing
+  WLds& L = *reinterpret_cast<WLds*>(w_lds + (size_t)(wave * 4 + grp) * (sizeof(WLds) / sizeof(double)));
   // the buffer being written starts as a copy of the current weights: blocks that keep their weight (no samples, singular
   // projection) and passes queued behind a finished solve leave a consistent buffer behind
-  for (int e = lane; e < 81; e += 64) v.wsqrtb[1 - wr][(size_t)s * 81 + e] = v.wsqrtb[wr][(size_t)s * 81 + e];
-  if (ct->done || !v.weights_on) return;
-  WLds& L = lds[wave];
+  if (exists) for (int e = c; e < 81; e += 16) v.wsqrtb[1 - wr][(size_t)s * 81 + e] = v.wsqrtb[wr][(size_t)s * 81 + e];
+  if (ct->done || !v.weights_on) return;        // wave-uniform
   const int st = ct->cur, j = s + 1;
   const double* im = v.imus[st];
   double T1[7], T2[7], b[6], sf[6], g2[2], gw[3];
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(256) void k_imu_weights(DevView v, int wr) {
   const double t_start = v.frame_time[j - 1], t_end = v.frame_time[j];
   const ImuView buf = imu_view(v);
   const ImuRange rg = imu_range(buf, t_start, t_end, toff);
-  if (!rg.valid) return;                       // keeps its current weight (vicalibrator.h:731-733)
+  bool live = exists && rg.valid;                // an empty range keeps its current weight (vicalibrator.h:731-733)
   imu_gravity(g2, gw);
   WState sx;
 #pragma unroll
@@ -318,23 +325,26 @@ __global__ __launch_bounds__(256) void k_imu_weights(DevView v, int wr) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) { sx.p[i] = T1[4 + i]; sx.v[i] = v.vel[st][(size_t)(j - 1) * 4 + i]; }
   const double sg2 = v.gyro_sigma * v.gyro_sigma, sa2 = v.accel_sigma * v.accel_sigma;
-  const int n_meas = (rg.k1 - rg.k0 + 1) + 2;
-  const int c = lane & 15;                      // column of [dy_dy0 | dy_db] this lane carries (lanes >= 16 mirror lanes 0..15)
+  const int n_meas = live ? (rg.k1 - rg.k0 + 1) + 2 : 0;
+  int n_max = n_meas;                            // the wave runs to its longest group
+#pragma unroll
+  for (int o = 32; o >= 16; o >>= 1) n_max = max(n_max, __shfl_xor(n_max, o, 64));
   double Sc[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) Sc[i] = 0.0;
   Meas<double> z0, z1;
-  imu_range_get(buf, rg, toff, t_start, t_end, 0, &z0);
-  for (int m = 1; m < n_meas; ++m) {
-    imu_range_get(buf, rg, toff, t_start, t_end, m, &z1);
-    w_step_cols(L, &sx, z0, z1, b, sf, gw, sg2, sa2, c, Sc);
-    z0 = z1;
+  if (live) imu_range_get(buf, rg, toff, t_start, t_end, 0, &z0);
+  for (int m = 1; m < n_max; ++m) {
+    if (m < n_meas) {
+      imu_range_get(buf, rg, toff, t_start, t_end, m, &z1);
+      w_step_cols(L, &sx, z0, z1, b, sf, gw, sg2, sa2, c, Sc);
+      z0 = z1;
+    }
   }
-  if (lane < 10) {
+  if (c < 10) {
 #pragma unroll
-    for (int i = 0; i < 10; ++i) L.Sigma[i * 10 + lane] = Sc[i];
+    for (int i = 0; i < 10; ++i) L.Sigma[i * 10 + c] = Sc[i];
   }
-  wave_lds_sync();
   // J = dLog_dSE3(T_pred T2^-1) dt1t2_dt1(T_pred, T2^-1), velocity identity appended (9 x 10)
   const double qc[4] = {-T2[0], -T2[1], -T2[2], T2[3]}, nt[3] = {-T2[4], -T2[5], -T2[6]};
   double t2w[7], rel[7], tr[3];
@@ -348,21 +358,21 @@ __global__ __launch_bounds__(256) void k_imu_weights(DevView v, int wr) {
   quat_rotate(sx.q, t2w + 4, tr);
 #pragma unroll
   for (int i = 0; i < 3; ++i) rel[4 + i] = sx.p[i] + tr[i];
-  for (int e = lane; e < 90; e += 64) L.J[e] = 0.0;
+  for (int e = c; e < 90; e += 16) L.J[e] = 0.0;
   wave_lds_sync();
   {
-    // J67 = dLog_dSE3 * dt1t2_dt1 with dt1t2_dt1 = [I3, dqx_dq(q, t); 0, dq1q2_dq1] (sparse): row i of J67 in lane i
+    // J67 = dLog_dSE3 * dt1t2_dt1 with dt1t2_dt1 = [I3, dqx_dq(q, t); 0, dq1q2_dq1] (sparse): row i of J67 in lane i of the group
     double dl[42], m34[12], m44[16];
     w_dlog_dse3(rel, dl);
     w_dqx_dq(sx.q, t2w + 4, m34);
     w_dq1q2_dq1(t2w, m44);
-    if (lane < 6) {
+    if (c < 6) {
       double row[7];
 #pragma unroll
       for (int jj = 0; jj < 7; ++jj) row[jj] = 0.0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        if (i == lane) {
+        if (i == c) {
 #pragma unroll
           for (int jj = 0; jj < 3; ++jj) row[jj] = dl[i * 7 + jj];
 #pragma unroll
@@ -377,14 +387,20 @@ __global__ __launch_bounds__(256) void k_imu_weights(DevView v, int wr) {
         }
       }
 #pragma unroll
-      for (int jj = 0; jj < 7; ++jj) L.J[lane * 10 + jj] = row[jj];
+      for (int jj = 0; jj < 7; ++jj) L.J[c * 10 + jj] = row[jj];
     }
-    if (lane == 0) L.J[6 * 10 + 7] = L.J[7 * 10 + 8] = L.J[8 * 10 + 9] = 1.0;
+    if (c == 0) L.J[6 * 10 + 7] = L.J[7 * 10 + 8] = L.J[8 * 10 + 9] = 1.0;
   }
   wave_lds_sync();
-  wmm<9, 10, 10>(L.J, L.Sigma, L.tmp, lane);
+  for (int e = c; e < 90; e += 16) {             // tmp = J Sigma (9 x 10)
+    const int i = e / 10, jj = e % 10;
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) acc += L.J[i * 10 + q] * L.Sigma[q * 10 + jj];
+    L.tmp[e] = acc;
+  }
   wave_lds_sync();
-  for (int e = lane; e < 81; e += 64) {
+  for (int e = c; e < 81; e += 16) {             // P = (J Sigma) J^T
     const int i = e / 9, jj = e % 9;
     double acc = 0.0;
 #pragma unroll
@@ -392,27 +408,26 @@ __global__ __launch_bounds__(256) void k_imu_weights(DevView v, int wr) {
     L.P[e] = acc;
   }
   wave_lds_sync();
-  // Cholesky P = L L^T in place (lane 0; 9 columns), then X = L^-1 column per lane, W = X^T
-  if (lane == 0) {
-    for (int c = 0; c < 9; ++c) {
-      double d = L.P[c * 9 + c];
-      for (int k = 0; k < c; ++k) d -= L.P[c * 9 + k] * L.P[c * 9 + k];
+  // Cholesky P = L L^T in place (lane 0 of the group; 9 columns), then X = L^-1 column per lane, W = X^T
+  if (c == 0) {
+    for (int cc = 0; cc < 9; ++cc) {
+      double d = L.P[cc * 9 + cc];
+      for (int k = 0; k < cc; ++k) d -= L.P[cc * 9 + k] * L.P[cc * 9 + k];
       const double id = (d > 0.0) ? fast_rsqrt(d) : 0.0;
-      L.P[c * 9 + c] = d * id;
-      L.tmp[c] = id;
-      for (int i = c + 1; i < 9; ++i) {
-        double a = L.P[i * 9 + c];
-        for (int k = 0; k < c; ++k) a -= L.P[i * 9 + k] * L.P[c * 9 + k];
-        L.P[i * 9 + c] = a * id;
+      L.P[cc * 9 + cc] = d * id;
+      L.tmp[cc] = id;
+      for (int i = cc + 1; i < 9; ++i) {
+        double a = L.P[i * 9 + cc];
+        for (int k = 0; k < cc; ++k) a -= L.P[i * 9 + k] * L.P[cc * 9 + k];
+        L.P[i * 9 + cc] = a * id;
       }
     }
   }
   wave_lds_sync();
   bool ok = true;
-  for (int c = 0; c < 9; ++c) ok = ok && (L.tmp[c] > 0.0);
-  if (!ok) { if (lane == 0) atomicAdd((unsigned long long*)&v.dbg[20], 1ull); return; }   // singular projection: keep the previous weight (counted in dbg[20])
-  if (lane < 9) {
-    const int c = lane;                         // column c of X = L^-1
+  for (int cc = 0; cc < 9; ++cc) ok = ok && (L.tmp[cc] > 0.0);
+  if (live && !ok && c == 0) atomicAdd((unsigned long long*)&v.dbg[20], 1ull);     // singular projection: keeps the previous weight (counted)
+  if (live && ok && c < 9) {                     // column c of X = L^-1
     double x[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) x[i] = 0.0;
@@ -910,7 +925,10 @@ void launch_imu_res(const DevView& v, int sel, int wr, hipStream_t s) {
 }
 void launch_imu_weights(const DevView& v, int wr, hipStream_t s) {
   if (v.n_frames < 2) return;
-  hipLaunchKernelGGL(k_imu_weights, dim3((v.n_frames - 1 + 3) / 4), dim3(256), 0, s, v, wr);
+  const size_t lds = 16 * sizeof(WLds);        // 16 blocks per workgroup (4 per wavefront)
+  static bool granted = false;
+  if (!granted) { (void)hipFuncSetAttribute((const void*)k_imu_weights, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = true; }
+  hipLaunchKernelGGL(k_imu_weights, dim3((v.n_frames - 1 + 15) / 16), dim3(256), lds, s, v, wr);
 }
 void launch_chain_solve_a(const DevView& v, hipStream_t s) {
   const int N = v.n_frames;
