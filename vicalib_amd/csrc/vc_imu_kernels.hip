@@ -31,35 +31,49 @@ __device__ __forceinline__ ImuView imu_view(const DevView& v) { ImuView b = {v.i
 
 // ------------------------------------------------------------------------------------------ IMU Jacobian
 constexpr int kImuJacLds = 35 * 9 + 33 * 9 + 16;
+// Two IMU blocks per wavefront: 32 lanes carry the 32 derivative directions that need the dual propagation (the three
+// directions of the later frame's velocity do not -- d r / d v2 = -W^T rows 6..8, written directly), so a block fits a
+// half wave and the kernel, bound by per-lane latency at one wave per SIMD, needs half the waves.
 __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr) {
-  __shared__ double sh[4 * kImuJacLds];
+  __shared__ double sh[8 * kImuJacLds];
   const Ctrl* ct = v.ctrl;
   if (ct->done || !ct->need_lin) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int s = blockIdx.x * 4 + wave;         // block s couples frames s -> s+1
-  if (s >= v.n_frames - 1) return;
+  const int half = lane >> 5, l = lane & 31;
+  const int n_blocks = v.n_frames - 1;
+  const int s_raw = (blockIdx.x * 4 + wave) * 2 + half;       // block s couples frames s -> s+1
+  const bool exists = s_raw < n_blocks;
+  const int s = exists ? s_raw : n_blocks - 1;                 // a half past the end shadows the last block and stores nothing
   const int cur = ct->cur, j = s + 1;
-  double* Jg = sh + wave * kImuJacLds;         // [35][9] global-parameter partials
-  double* Jl = Jg + 35 * 9;                    // [33][9] local columns: cur9 | prev9 | imu15
+  double* Jg = sh + (wave * 2 + half) * kImuJacLds;            // [35][9] global-parameter partials
+  double* Jl = Jg + 35 * 9;                                    // [33][9] local columns: cur9 | prev9 | imu15
   const double* T2 = v.poses[cur] + (size_t)j * kPoseStride;
   const double* T1 = v.poses[cur] + (size_t)(j - 1) * kPoseStride;
   const double* v2 = v.vel[cur] + (size_t)j * 4;
   const double* v1 = v.vel[cur] + (size_t)(j - 1) * 4;
   const double* im = v.imus[cur];
+  const double* wq = v.wsqrtb[wr] + (size_t)s * 81;
   double r[9], dr[9];
   const ImuView buf = imu_view(v);
-  imu_block_direction(buf, v.frame_time[j - 1], v.frame_time[j], v.wsqrtb[wr] + (size_t)s * 81, v.rotation_only, T2, T1, v2, v1, im, im + 2,
-                      im + 8, im[14], lane < 35 ? lane : -1, r, dr);
-  if (lane < 35) {
+  const int dir = (l < 14) ? l : l + 3;                        // global directions 0..13 and 17..34
+  imu_block_direction(buf, v.frame_time[j - 1], v.frame_time[j], wq, v.rotation_only, T2, T1, v2, v1, im, im + 2,
+                      im + 8, im[14], dir, r, dr);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Jg[lane * 9 + k] = dr[k];
+  for (int k = 0; k < 9; ++k) Jg[dir * 9 + k] = dr[k];
+  if (l < 3) {                                                 // later frame's velocity: r = W^T raw, raw[6 + l] = v_pred - v2
+    const bool valid = imu_range(buf, v.frame_time[j - 1], v.frame_time[j], im[14]).valid;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const bool zeroed = v.rotation_only && (k < 3 || k >= 6);
+      Jg[(14 + l) * 9 + k] = (valid && !zeroed) ? -wq[(6 + l) * 9 + k] : 0.0;
+    }
   }
   wave_lds_sync();
-  if (lane < 33) {
-    double col[9];
-    if (lane < 6 || (lane >= 9 && lane < 15)) {
-      const bool is_cur = lane < 6;
-      const int c = is_cur ? lane : lane - 9;
+  for (int col = l; col < 33; col += 32) {
+    double cv[9];
+    if (col < 6 || (col >= 9 && col < 15)) {
+      const bool is_cur = col < 6;
+      const int c = is_cur ? col : col - 9;
       double P[42];
       local_jac_se3(is_cur ? T2 : T1, P);
       const double* src = Jg + (is_cur ? 0 : 7) * 9;
@@ -68,16 +82,16 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr) {
         double a = 0.0;
 #pragma unroll
         for (int i = 0; i < 7; ++i) a += src[i * 9 + k] * P[i * 6 + c];
-        col[k] = a;
+        cv[k] = a;
       }
     } else {
       // cur velocity 6..8 <- global 14..16 ; prev velocity 15..17 <- global 17..19 ; imu 18..32 <- global 20..34
-      const int gidx = (lane < 9) ? 14 + (lane - 6) : (lane < 18) ? 17 + (lane - 15) : 20 + (lane - 18);
+      const int gidx = (col < 9) ? 14 + (col - 6) : (col < 18) ? 17 + (col - 15) : 20 + (col - 18);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) col[k] = Jg[gidx * 9 + k];
+      for (int k = 0; k < 9; ++k) cv[k] = Jg[gidx * 9 + k];
     }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Jl[lane * 9 + k] = col[k];
+    for (int k = 0; k < 9; ++k) Jl[col * 9 + k] = cv[k];
   }
   wave_lds_sync();
   double ss = 0.0;
@@ -86,21 +100,22 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr) {
   double rho, rho1;
   loss_cauchy100(ss, &rho, &rho1);
   const double w = ct->imu_mult * rho1;
+  if (!exists) return;
   double* H = v.segH + (size_t)s * (33 * 33);
-  for (int e = lane; e < 33 * 33; e += 64) {
-    const int a = e / 33, b = e % 33;
+  for (int e = l; e < 33 * 33; e += 32) {
+    const int a = e / 33, bb = e % 33;
     double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc += Jl[a * 9 + k] * Jl[b * 9 + k];
+    for (int k = 0; k < 9; ++k) acc += Jl[a * 9 + k] * Jl[bb * 9 + k];
     H[e] = w * acc;
   }
-  if (lane < 33) {
+  for (int col = l; col < 33; col += 32) {
     double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc += Jl[lane * 9 + k] * r[k];
-    v.segg[(size_t)s * 33 + lane] = w * acc;
+    for (int k = 0; k < 9; ++k) acc += Jl[col * 9 + k] * r[k];
+    v.segg[(size_t)s * 33 + col] = w * acc;
   }
-  if (lane == 0) v.seg_cost[s] = ct->imu_mult * rho;
+  if (l == 0) v.seg_cost[s] = ct->imu_mult * rho;
 }
 
 // residual cost of every IMU block at a state: sel 2 = accepted buffer, 3 = trial buffer
@@ -917,7 +932,7 @@ __global__ __launch_bounds__(64) void k_frame_update(DevView v) {
 // ------------------------------------------------------------------------------------------ launchers
 void launch_imu_jac(const DevView& v, int wr, hipStream_t s) {
   if (v.n_frames < 2) return;
-  hipLaunchKernelGGL(k_imu_jac, dim3((v.n_frames - 1 + 3) / 4), dim3(256), 0, s, v, wr);
+  hipLaunchKernelGGL(k_imu_jac, dim3((v.n_frames - 1 + 7) / 8), dim3(256), 0, s, v, wr);      // 8 blocks per workgroup
 }
 void launch_imu_res(const DevView& v, int sel, int wr, hipStream_t s) {
   if (v.n_frames < 2) return;
