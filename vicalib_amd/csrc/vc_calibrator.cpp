@@ -326,7 +326,7 @@ struct vc_calibrator {
     const int D = D0 + (shard_imu ? 9 * (world - 1) : 0);          // + one 9-column separator per shard boundary
     col_cam.resize(D, -1); col_local.resize(D, 0);
     // the reduced solve lives in LDS (packed lower triangle + 12 KB of staging), the chain Gram handles 12 column tiles
-    if (((size_t)(D + 1) * (D + 2) / 2 + 2 * (D + 1)) * sizeof(double) + 13 * 1024 > 160 * 1024 || D + 1 > 12 * 16) return VC_ERR_UNSUPPORTED;
+    if (((size_t)(D + 1) * (D + 2) / 2 + 3 * (D + 1) + 528) * sizeof(double) + 13 * 1024 > 160 * 1024 || D + 1 > 12 * 16) return VC_ERR_UNSUPPORTED;
     for (int c = 0; c < C; ++c) cam_model[c] = cams[c].model;
     // ---- upload ---------------------------------------------------------------------------------
     HIP_OK(d_frame_tile_off.upload(frame_tile_off, stream));

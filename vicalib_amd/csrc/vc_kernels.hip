@@ -786,6 +786,141 @@ __device__ void solve_large_block(const DevView& v, const Ctrl* ct, double* M, d
   }
 }
 
+// Blocked variant of the workgroup-wide factorisation (panels of 16 columns): per panel the 16 x 16 diagonal block is
+// factorised by one wavefront in registers (pivots through v_readlane), the rows below are solved one per thread, the
+// trailing matrix is updated on the 16 x 16 thread grid -- a handful of barriers per panel instead of three per column
+// (D = 67: 30 instead of ~330 barriers).  Same packed storage; extra LDS after x: Lp (16 x 16 padded diagonal factor),
+// dinvp (16), red (16 x 16), dinv (D).
+__device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M, double* x) {
+  const int tid = threadIdx.x, lane = tid & 63, D = v.D;
+  double* Lp = x + (D + 1);
+  double* dinvp = Lp + 256;
+  double* red = dinvp + 16;
+  double* dinv = red + 256;
+  const double* S = v.Sbuf;
+  const double* gred = S + D * D;
+  const double* hd = gred + D;
+  for (int i = tid >> 4; i < D; i += 16) {            // 16 x 16 thread grid over (row, column)
+    const int ri = tri(i);
+    for (int k = tid & 15; k <= i; k += 16) M[ri + k] = S[i * D + k];
+  }
+  for (int i = tid; i < D; i += 256) M[tri(D) + i] = gred[i];
+  __syncthreads();
+  for (int i = tid; i < D; i += 256) {
+    double sc2, dg;
+    if (ct->init_scale) { sc2 = jacobi_scale2(hd[i]); v.sscale2[i] = sc2; } else sc2 = v.sscale2[i];
+    if (!ct->reuse_diag) { dg = lm_clamped_diag(hd[i], sc2); v.sdiag[i] = dg; } else dg = v.sdiag[i];
+    const double lam = dg / (ct->radius * sc2);
+    v.slam[i] = lam;
+    M[tri(i) + i] += lam;
+  }
+  __syncthreads();
+  for (int p0 = 0; p0 < D; p0 += 16) {
+    const int nb = min(16, D - p0);
+    // (1) diagonal block -> L11 (wavefront 0; lane = row, identity padding beyond nb)
+    if (tid < 64) {
+      double row[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) row[k] = (lane < nb && k <= lane) ? M[tri(p0 + lane) + p0 + k] : ((k == lane) ? 1.0 : 0.0);
+      bool bad = false;
+      double my_dinv = 1.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double d = readlane_f64(row[j], j);
+        if (!(d > 0.0)) { bad = true; d = 1.0; }
+        const double ipiv = fast_rsqrt(d);
+        const double lij = (lane == j) ? d * ipiv : row[j] * ipiv;
+        row[j] = lij;
+        if (lane == j) my_dinv = ipiv;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) row[k] -= lij * readlane_f64(lij, k);
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Lp[lane * 16 + k] = (k <= lane) ? row[k] : 0.0;
+        dinvp[lane] = my_dinv;
+        if (lane < nb) {
+          dinv[p0 + lane] = my_dinv;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) if (k <= lane) M[tri(p0 + lane) + p0 + k] = row[k];
+        }
+      }
+      if (bad && lane == 0) v.flags[5 + 2 * v.par] = 1;
+    }
+    __syncthreads();
+    // (2) rows below the panel (and the right-hand-side row D): X_i = A[i, panel] L11^-T, one row per thread
+    const int r0 = p0 + nb;
+    for (int i = r0 + tid; i <= D; i += 256) {
+      const int ri = tri(i) + p0;
+      double a[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a[k] = (k < nb) ? M[ri + k] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        double t = a[k];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) if (m < k) t -= a[m] * Lp[k * 16 + m];
+        a[k] = t * dinvp[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) if (k < nb) M[ri + k] = a[k];
+    }
+    __syncthreads();
+    // (3) trailing update A[i][k] -= X_i . X_k for r0 <= k <= i (k < D), i <= D
+    {
+      const int ti = tid >> 4, tj = tid & 15;
+      for (int i = r0 + ti; i <= D; i += 16) {
+        const int ri = tri(i);
+        double xi[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) xi[m] = (m < nb) ? M[ri + p0 + m] : 0.0;
+        for (int k = r0 + tj; k <= i && k < D; k += 16) {
+          const int rk = tri(k) + p0;
+          double acc = 0.0;
+#pragma unroll
+          for (int m = 0; m < 16; ++m) acc += xi[m] * ((m < nb) ? M[rk + m] : 0.0);
+          M[ri + k] -= acc;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- delta_s = -L^-T y (y = row D), panels from the bottom ----------------------------------------------------------
+  for (int i = tid; i < D; i += 256) x[i] = -M[tri(D) + i];
+  __syncthreads();
+  const int last = ((D - 1) / 16) * 16;
+  for (int p0 = last; p0 >= 0; p0 -= 16) {
+    const int nb = min(16, D - p0), r0 = p0 + nb;
+    {   // t_j = x_j - sum_{i >= r0} L[i][p0 + j] x_i : 16 columns x 16 partial sums
+      const int jcol = tid & 15, part = tid >> 4;
+      double acc = 0.0;
+      if (jcol < nb) for (int i = r0 + part; i < D; i += 16) acc += M[tri(i) + p0 + jcol] * x[i];
+      red[part * 16 + jcol] = acc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      double t = 0.0;
+      if (lane < nb) {
+        t = x[p0 + lane];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t -= red[q * 16 + lane];
+      }
+      const double di = (lane < nb) ? dinv[p0 + lane] : 1.0;
+      double z = 0.0;
+#pragma unroll
+      for (int j = 15; j >= 0; --j) {
+        if (j < nb) {                                  // wave-uniform
+          const double zj = readlane_f64(t * di, j);
+          if (lane == j) z = zj;
+          if (lane < j) t -= M[tri(p0 + j) + p0 + lane] * zj;
+        }
+      }
+      if (lane < nb) x[p0 + lane] = z;
+    }
+    __syncthreads();
+  }
+}
+
 __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dyn, double* red /* 6 x 256 */) {
   const int tid = threadIdx.x, D = v.D, cur = ct->cur;
   double* x;
@@ -799,7 +934,7 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
     __syncthreads();
   } else {
     x = dyn + tri(D + 1) + (D + 1);
-    solve_large_block(v, ct, dyn, x);
+    solve_large_blocked(v, ct, dyn, x);
   }
   VC_STAMP(5);
   const double* gs = v.Sbuf + (size_t)D * D + 2 * D;
@@ -1266,7 +1401,7 @@ void launch_frame_schur(const DevView& v, hipStream_t s) {
 }
 static inline size_t reduced_lds(const DevView& v) {
   const size_t solve = v.D <= kSmallD ? ((size_t)(kSmallD + 1) * (kSmallD + 2) + kSmallD + 1) * sizeof(double)
-                                      : ((size_t)(v.D + 1) * (v.D + 2) / 2 + 2 * (v.D + 1)) * sizeof(double);
+                                      : ((size_t)(v.D + 1) * (v.D + 2) / 2 + 3 * (v.D + 1) + 256 + 16 + 256) * sizeof(double);
   return std::max(solve, sizeof(FinalLds));
 }
 void launch_reduced(const DevView& v, int mode, hipStream_t s) {
