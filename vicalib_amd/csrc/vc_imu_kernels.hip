@@ -137,34 +137,12 @@ __global__ __launch_bounds__(64) void k_imu_res(DevView v, int sel, int wr) {
   v.seg_trial[s] = ct->imu_mult * rho;
 }
 
-// UpdateImuWeights from the accepted state (vicalibrator.h:723-799), one wavefront per IMU block.
-// The 10x10 / 10x9 / 9x10 / 9x6 Jacobian chains of the covariance propagation (types.h:427-595) live in
-// wave-private LDS; every product is computed lane-per-entry.  The state itself (and the small quaternion
-// Jacobian blocks) is propagated redundantly in every lane, which keeps all branches wave-uniform.
+// UpdateImuWeights from the accepted state (vicalibrator.h:723-799): covariance propagation along the block's samples
+// (w_step_cols below), projection through the residual's Jacobian, factorisation.
 // The weight is stored as W = L^-T with  J Sigma J^T = L L^T  (Cholesky): W W^T = (J Sigma J^T)^-1 exactly as
 // for the reference's symmetric square root (vicalibrator.h:783-796), and cost, gradient and Gauss-Newton
 // Hessian of the block depend on W only through W W^T -- same optimisation, no 9x9 eigen-decomposition.
-template <int M, int K, int N>
-__device__ __forceinline__ void wmm(const double* A, const double* B, double* C, int lane) {   // C = A B
-  for (int e = lane; e < M * N; e += 64) {
-    const int i = e / N, j = e % N;
-    double s = 0.0;
-#pragma unroll
-    for (int q = 0; q < K; ++q) s += A[i * K + q] * B[q * N + j];
-    C[e] = s;
-  }
-}
-template <int M, int K, int N>
-__device__ __forceinline__ void wmm_add(const double* Add, const double* A, const double* B, double* C, int lane) {   // C = Add + A B
-  for (int e = lane; e < M * N; e += 64) {
-    const int i = e / N, j = e % N;
-    double s = Add[e];
-#pragma unroll
-    for (int q = 0; q < K; ++q) s += A[i * K + q] * B[q * N + j];
-    C[e] = s;
-  }
-}
-// Wave-private LDS of the weight update: M / T are the 10 x 16 images used to transpose / broadcast the step's
+// Per-block LDS of the weight update: M / T are the 10 x 16 images used to transpose / broadcast the step's
 // sensitivity matrices (two round trips per IMU step), the rest serves the final 9 x 10 projection.
 struct WLds { double M[160], T[160], tmp[100], Sigma[100], J[90], P[81]; };
 

@@ -734,59 +734,7 @@ __device__ void solve_small_wave(const DevView& v, const Ctrl* ct, int lane, dou
 // Workgroup-wide factorisation for D > 32.  Only the lower triangle (plus the right-hand-side row D) is kept, packed:
 // row i starts at i (i + 1) / 2 -- 129 KB of LDS at D = 178 (8 cameras + IMU + 7 separators) instead of 256 KB.
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
-__device__ void solve_large_block(const DevView& v, const Ctrl* ct, double* M, double* x) {
-  const int tid = threadIdx.x, D = v.D;
-  double* col = M + tri(D + 1);
-  const double* S = v.Sbuf;
-  const double* gred = S + D * D;
-  const double* hd = gred + D;
-  for (int i = tid >> 4; i < D; i += 16) {            // 16 x 16 thread grid over (row, column)
-    const int ri = tri(i);
-    for (int k = tid & 15; k <= i; k += 16) M[ri + k] = S[i * D + k];
-  }
-  for (int i = tid; i < D; i += 256) M[tri(D) + i] = gred[i];
-  __syncthreads();
-  for (int i = tid; i < D; i += 256) {
-    double sc2, dg;
-    if (ct->init_scale) { sc2 = jacobi_scale2(hd[i]); v.sscale2[i] = sc2; } else sc2 = v.sscale2[i];
-    if (!ct->reuse_diag) { dg = lm_clamped_diag(hd[i], sc2); v.sdiag[i] = dg; } else dg = v.sdiag[i];
-    const double lam = dg / (ct->radius * sc2);
-    v.slam[i] = lam;
-    M[tri(i) + i] += lam;
-  }
-  __syncthreads();
-  for (int j = 0; j < D; ++j) {
-    double d = M[tri(j) + j];
-    const bool bad = !(d > 0.0);
-    if (bad) d = 1.0;
-    const double piv = sqrt(d);
-    for (int i = j + 1 + tid; i <= D; i += 256) col[i] = M[tri(i) + j] / piv;
-    __syncthreads();
-    if (tid == 0) { M[tri(j) + j] = piv; if (bad) v.flags[5 + 2 * v.par] = 1; }
-    {   // trailing update on a 16 x 16 thread grid (no integer divisions on the per-column path)
-      const int ti = tid >> 4, tj = tid & 15;
-      for (int i = j + 1 + ti; i <= D; i += 16) {
-        const double ci = col[i];
-        const int ri = tri(i);
-        for (int k = j + 1 + tj; k <= i && k < D; k += 16) M[ri + k] -= ci * col[k];
-      }
-    }
-    for (int i = j + 1 + tid; i <= D; i += 256) M[tri(i) + j] = col[i];
-    __syncthreads();
-  }
-  for (int i = tid; i < D; i += 256) x[i] = -M[tri(D) + i];
-  __syncthreads();
-  for (int j = D - 1; j >= 0; --j) {
-    if (tid == 0) x[j] /= M[tri(j) + j];
-    __syncthreads();
-    const double xj = x[j];
-    const int rj = tri(j);
-    for (int i = tid; i < j; i += 256) x[i] -= M[rj + i] * xj;
-    __syncthreads();
-  }
-}
-
-// Blocked variant of the workgroup-wide factorisation (panels of 16 columns): per panel the 16 x 16 diagonal block is
+// Blocked (panels of 16 columns): per panel the 16 x 16 diagonal block is
 // factorised by one wavefront in registers (pivots through v_readlane), the rows below are solved one per thread, the
 // trailing matrix is updated on the 16 x 16 thread grid -- a handful of barriers per panel instead of three per column
 // (D = 67: 30 instead of ~330 barriers).  Same packed storage; extra LDS after x: Lp (16 x 16 padded diagonal factor),
