@@ -360,7 +360,8 @@ struct vc_calibrator {
     HIP_OK(d_scal.alloc(2 * kNumScal)); HIP_OK(d_flags.alloc(8));
     HIP_OK(d_wgpart.alloc((size_t)std::max(1, (T + 3) / 4) * kNumScal));
     HIP_OK(hipMemsetAsync(d_scal.p, 0, 2 * kNumScal * sizeof(double), stream));
-    HIP_OK(d_tmp.alloc(64));
+    HIP_OK(d_tmp.alloc(128));       // [0,16) per-camera sums, [32,40) outlier thresholds, [64,96) profiling stamps
+    HIP_OK(hipMemsetAsync(d_tmp.p, 0, 128 * sizeof(double), stream));
     HIP_OK(hipMemsetAsync(d_flags.p, 0, 8 * sizeof(int), stream));
     HIP_OK(hipMemsetAsync(d_ctrl.p, 0, 2 * sizeof(Ctrl), stream));
     HIP_OK(hipMemsetAsync(d_delta_s.p, 0, std::max(D, 1) * sizeof(double), stream));
@@ -381,7 +382,7 @@ struct vc_calibrator {
     dv.sdiag = d_sdiag.p; dv.sscale2 = d_sscale2.p; dv.slam = d_slam.p; dv.delta_s = d_delta_s.p;
     dv.fpart = d_fpart.p; dv.scal = d_scal.p; dv.flags = d_flags.p;
     dv.wgpart = d_wgpart.p; dv.merged = 0; dv.par = 0; dv.ctrl_prev = d_ctrl.p + 1;
-    dv.part_stride = part_stride; dv.ctrl = d_ctrl.p; dv.trace = d_trace.p; dv.dbg = (long long*)(d_tmp.p + 24);
+    dv.part_stride = part_stride; dv.ctrl = d_ctrl.p; dv.trace = d_trace.p; dv.dbg = (long long*)(d_tmp.p + 64);
     HIP_OK(d_pose_init.upload(poses, stream)); HIP_OK(d_cam_init.upload(camrec, stream));
     // ---- inertial terms ------------------------------------------------------------------------------
     std::vector<double> vels((size_t)std::max(N, 1) * 4, 0.0), imus(16, 0.0), ftime(std::max(N, 1), 0.0);
