@@ -152,8 +152,6 @@ def main():
             out["roofline_at_scale"] = roofline_at_scale(local_rank, args.frames * 10)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prob)
-    if world > 1 or force_shard:
-        dist.destroy_process_group()
     if rank == 0:
         # the one JSON line comes last: RCCL writes a version banner to the C-level stdout, flush that first
         sys.stdout.flush()
@@ -163,6 +161,15 @@ def main():
         except Exception:      # noqa: BLE001
             pass
         print(json.dumps(out), flush=True)
+    if world > 1 or force_shard:
+        # leave together, and without the interpreter's teardown order deciding which of the two RCCL users (torch's process
+        # group, the library's own communicators) is torn down first
+        try:
+            dist.barrier()
+        except Exception:      # noqa: BLE001
+            pass
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 def roofline_at_scale(device, n_frames):
