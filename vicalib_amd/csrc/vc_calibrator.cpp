@@ -534,7 +534,8 @@ struct vc_calibrator {
       return VC_OK;
     }
     // merged decision (single process): control records alternate, pass k judges pass k-1 at the head of k_frame_schur
-    const bool merged = !sharded() && merged_enabled && !use_graphs;      // (a captured graph has fixed kernel arguments)
+    const bool merged = merged_enabled && !use_graphs;      // (a captured graph has fixed kernel arguments)
+    dv.shard_src = sharded() ? 1 : 0;
     if (merged) {
       if (first_pass) kpass = 0;
       dv.merged = 1; dv.par = kpass & 1; dv.ctrl = d_ctrl.p + (kpass & 1); dv.ctrl_prev = d_ctrl.p + ((kpass + 1) & 1);
@@ -554,7 +555,7 @@ struct vc_calibrator {
     if (sharded()) {
       launch_final(dv, 1, stream);
       rc = do_allreduce(dv.gath, world * kNumScal, 0); if (rc) return rc;
-      launch_final(dv, 2, stream);
+      if (!merged) launch_final(dv, 2, stream);      // merged: the next pass's frame elimination combines the ranks and decides
     } else if (!merged) {
       launch_final(dv, 0, stream);
     }

@@ -1106,9 +1106,9 @@ __device__ void trace_push(const DevView& v, Ctrl* c, const double* rec, bool wr
   c->trace_len += 1;
   c->last_gnorm = rec[4];
 }
-// s: the frame-side step scalars of the judged pass, fpar: parity of its failure flags, writer: this caller owns the global
-// side effects (trace rows, flag reset)
-__device__ void lm_decide_local(const DevView& v, Ctrl* c, const double* s, int fpar, bool writer) {
+// s: the frame-side step scalars of the judged pass, fail: a factorisation of that pass broke down, writer: this caller owns
+// the global side effects (trace rows)
+__device__ void lm_decide_local(const DevView& v, Ctrl* c, const double* s, bool fail, bool writer) {
   const int D = v.D;
   const double* t = v.scal + kNumScal;
   const double R_cost = v.Sbuf[(size_t)D * D + 3 * D];
@@ -1116,8 +1116,6 @@ __device__ void lm_decide_local(const DevView& v, Ctrl* c, const double* s, int 
   const double R_step2 = s[kScStep2] + t[kScStep2], R_x2 = s[kScX2] + t[kScX2];
   const double R_gnorm = sqrt(s[kScG2] + t[kScG2]), R_gmax = fmax(s[kScGmax], t[kScGmax]);
   const double R_new_cost = s[kScCost];
-  const bool fail = (v.flags[4 + 2 * fpar] != 0) || (v.flags[5 + 2 * fpar] != 0);
-  if (writer && !v.merged) { v.flags[4 + 2 * fpar] = 0; v.flags[5 + 2 * fpar] = 0; }      // merged: k_reduced clears the other parity
   c->passes += 1;
   c->res_sweeps += v.fused ? 0 : 1;
   c->jac_sweeps += (c->need_lin ? 1 : 0) + (v.fused ? 1 : 0);
@@ -1177,7 +1175,9 @@ __device__ void lm_decide_local(const DevView& v, Ctrl* c, const double* s, int 
 
 __device__ void lm_decide(const DevView& v) {
   Ctrl local = *v.ctrl;          // one burst of loads, one burst of stores
-  lm_decide_local(v, &local, v.scal, v.par, true);
+  const bool fail = (v.flags[4 + 2 * v.par] != 0) || (v.flags[5 + 2 * v.par] != 0);
+  v.flags[4 + 2 * v.par] = 0; v.flags[5 + 2 * v.par] = 0;
+  lm_decide_local(v, &local, v.scal, fail, true);
   *v.ctrl = local;
 }
 // ---- merged decision --------------------------------------------------------------------------------------------
@@ -1221,8 +1221,21 @@ __device__ void merged_control(const DevView& v, Ctrl* out, double* red, bool wr
       for (int k = 0; k < kNumScal; ++k)
         s[k] = (k == kScGmax) ? fmax(fmax(red[k * 4], red[k * 4 + 1]), fmax(red[k * 4 + 2], red[k * 4 + 3]))
                               : (red[k * 4] + red[k * 4 + 1]) + (red[k * 4 + 2] + red[k * 4 + 3]);
-      s[kScCost] *= 0.5;
-      lm_decide_local(v, &c, s, 1 - v.par, writer);           // the judged pass ran with the other parity
+      bool fail;
+      if (v.world > 1 || v.shard_src) {
+        // sharded: the ranks' scalars (already halved costs, failure flags in slot kScSq) were gathered by the all-reduce
+        for (int k = 0; k < kNumScal; ++k) {
+          double a2 = 0.0;
+          for (int r = 0; r < v.world; ++r) a2 = (k == kScGmax) ? fmax(a2, v.gath[r * kNumScal + k]) : a2 + v.gath[r * kNumScal + k];
+          s[k] = a2;
+        }
+        fail = s[kScSq] > 0.0;
+      } else {
+        s[kScCost] *= 0.5;
+        const int fp = 1 - v.par;                               // the judged pass ran with the other parity
+        fail = (v.flags[4 + 2 * fp] != 0) || (v.flags[5 + 2 * fp] != 0);
+      }
+      lm_decide_local(v, &c, s, fail, writer);
       c.needs_decision = 0;
       *out = c;
       if (writer) *v.ctrl = c;
