@@ -239,6 +239,19 @@ def test_solver_matches_committed_lm_traces(name):
         assert abs(cal.time_offset() - e["imu"]["time_offset"]) < 1e-9
 
 
+def test_per_frame_backsubstitution_kernel_gives_the_same_solve(monkeypatch):
+    """Above 2048 tiles the back-substitution moves from k_trial (once per tile) to k_backsub (once per frame); forced on
+    for a small problem it must reproduce the default path bit for bit."""
+    p = synth.generate(synth.Config(models=("fov", "kb4", "poly3"), n_frames=40, seed=17))
+    ref = ViCalibrator(0).load_problem(p); ref.SetCalibrateImu(False); ref.Solve()
+    monkeypatch.setenv("VICALIB_AMD_PRE_BACKSUB", "1")
+    cal = ViCalibrator(0).load_problem(p); cal.SetCalibrateImu(False); cal.Solve()
+    np.testing.assert_array_equal(cal.trace(), ref.trace())
+    np.testing.assert_array_equal(cal.GetFrames(), ref.GetFrames())
+    for c in range(3):
+        np.testing.assert_array_equal(cal.GetCamera(c)[0], ref.GetCamera(c)[0])
+
+
 def test_async_start_poll_stop():
     p = synth.generate(synth.BASELINE_CONFIGS["cfg1"])
     cal = ViCalibrator(0).load_problem(p); cal.SetCalibrateImu(False)

@@ -381,6 +381,8 @@ struct vc_calibrator {
     dv.fdiag = d_fdiag.p; dv.fscale2 = d_fscale2.p; dv.part = d_part.p; dv.part_total = d_part_total.p; dv.Sbuf = d_Sbuf.p;
     dv.sdiag = d_sdiag.p; dv.sscale2 = d_sscale2.p; dv.slam = d_slam.p; dv.delta_s = d_delta_s.p;
     dv.fpart = d_fpart.p; dv.scal = d_scal.p; dv.flags = d_flags.p;
+    dv.pre_backsub = (T > 2048) ? 1 : 0;
+    { const char* e = std::getenv("VICALIB_AMD_PRE_BACKSUB"); if (e && (e[0] == '0' || e[0] == '1')) dv.pre_backsub = e[0] - '0'; }   // test hook     // 1024 SIMDs x 2 resident waves: beyond that the per-tile repeat of the back-substitution is pure cost
     dv.wgpart = d_wgpart.p; dv.merged = 0; dv.par = 0; dv.ctrl_prev = d_ctrl.p + 1;
     dv.part_stride = part_stride; dv.ctrl = d_ctrl.p; dv.trace = d_trace.p; dv.dbg = (long long*)(d_tmp.p + 64);
     HIP_OK(d_pose_init.upload(poses, stream)); HIP_OK(d_cam_init.upload(camrec, stream));

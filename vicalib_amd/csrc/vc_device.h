@@ -131,6 +131,7 @@ struct DevView {
   // of pass k+1's k_frame_schur -- by every workgroup, redundantly and identically -- instead of a k_final launch per pass.
   // Control records alternate between two buffers: `ctrl` is the record of the current pass, `ctrl_prev` the previous one.
   int merged, par;                 // par = pass parity (selects the numeric-failure flag pair)
+  int pre_backsub;                 // 1: k_backsub computes the frames' trial poses before k_trial (more tiles than resident waves)
   int shard_src;                   // merged decision reads the gathered per-rank scalars (`gath`) instead of k_trial's workgroup sums
   const Ctrl* ctrl_prev;
   double* wgpart;                  // k_trial: per-workgroup sums of the step scalars [n_workgroups][kNumScal]

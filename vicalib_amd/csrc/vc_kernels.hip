@@ -974,26 +974,20 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
 // T_trial = T exp(delta_p), residual sweep of the tile at the trial state.  The first tile of a frame
 // also publishes the frame's trial pose and its step terms.
 __device__ void final_phase(const DevView& v, int mode, double* red /* 7 x 256 */);
-template <bool FUSED>
-__device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int tile, int wave, int lane, const double* ds_s, double* lds_rows,
-                                           double* wsum /* kNumScal, lane 0: this wave's step scalars */) {
-  const int cur = ct->cur;
-  const double mult = ct->mult;
-  const int f = v.tile_frame[tile], c = v.tile_cam[tile];
+// Back-substitution of one frame: delta_p = -L^-T (z + sum_tiles Y delta_s) (lanes = (tile, column), six-value butterfly),
+// T_trial = T exp(delta_p).  With `publish` lane 0 stores the trial pose and the frame's step terms (fpart).
+__device__ __forceinline__ void backsub_frame(const DevView& v, int cur, int f, int lane, const double* ds_s, double* Tout, bool publish,
+                                              double* wsum) {
   const int t0 = v.frame_tile_off[f], nt = v.frame_tile_off[f + 1] - t0;
   const double* fr = v.fr + (size_t)f * kFrStride;
   const double* pin = v.poses[cur] + (size_t)f * kPoseStride;
-  const double* cam = v.cams[1 - cur] + (size_t)c * kCamStride;
-  // issue everything whose address is known now: factor, pose, trial camera
-  double Lr[21], zr[6], di[6], Tin[7], camr[16];
+  double Lr[21], zr[6], di[6], Tin[7];
 #pragma unroll
   for (int i = 0; i < 21; ++i) Lr[i] = fr[kFrL + i];
 #pragma unroll
   for (int i = 0; i < 6; ++i) { zr[i] = fr[kFrZ + i]; di[i] = fr[kFrDinv + i]; }
 #pragma unroll
   for (int i = 0; i < 7; ++i) Tin[i] = pin[i];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) camr[i] = cam[i];
   double y[6] = {0, 0, 0, 0, 0, 0};
   const bool small_d = v.D <= kMaxCams * 16 + 16;
   for (int idx = lane; idx < nt * 16; idx += 64) {
@@ -1024,10 +1018,8 @@ __device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int
   double d[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) d[i] = -y[i];
-  double Tout[7];
   se3_plus(Tin, d, Tout);
-  // the frame's trial pose and step terms go out first: nothing but the tile id has to live across the sweep
-  if (lane == 0 && tile == t0) {
+  if (publish && lane == 0) {
     double* pout = v.poses[1 - cur] + (size_t)f * kPoseStride;
     double gd = 0, dld = 0, step2 = 0, x2 = 0, g2 = 0, gmax = 0;
 #pragma unroll
@@ -1040,7 +1032,46 @@ __device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int
     }
     double* o = v.fpart + (size_t)f * kNumScal;
     o[kScGd] = gd; o[kScDld] = dld; o[kScStep2] = step2; o[kScX2] = x2; o[kScG2] = g2; o[kScCost] = 0.0; o[kScGmax] = gmax; o[kScSq] = 0.0;
-    wsum[kScGd] = gd; wsum[kScDld] = dld; wsum[kScStep2] = step2; wsum[kScX2] = x2; wsum[kScG2] = g2; wsum[kScGmax] = gmax;
+    if (wsum) { wsum[kScGd] = gd; wsum[kScDld] = dld; wsum[kScStep2] = step2; wsum[kScX2] = x2; wsum[kScG2] = g2; wsum[kScGmax] = gmax; }
+  }
+}
+// Large problems (more tiles than the chip holds waves): the back-substitution runs once per frame here instead of once
+// per tile inside k_trial.
+__global__ __launch_bounds__(256) void k_backsub(DevView v) {
+  __shared__ double ds_s[kMaxCams * 16 + 16];
+  const Ctrl* ct = v.ctrl;
+  if (ct->done) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < v.D; i += 256) if (i < kMaxCams * 16 + 16) ds_s[i] = v.delta_s[i];
+  __syncthreads();
+  const int f = blockIdx.x * 4 + wave;
+  if (f >= v.n_frames || v.frame_tile_off[f + 1] == v.frame_tile_off[f]) return;
+  double Tout[7];
+  backsub_frame(v, ct->cur, f, lane, ds_s, Tout, true, nullptr);
+}
+template <bool FUSED>
+__device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int tile, int wave, int lane, const double* ds_s, double* lds_rows,
+                                           double* wsum /* kNumScal, lane 0: this wave's step scalars */) {
+  const int cur = ct->cur;
+  const double mult = ct->mult;
+  const int f = v.tile_frame[tile], c = v.tile_cam[tile];
+  const int t0 = v.frame_tile_off[f];
+  const double* cam = v.cams[1 - cur] + (size_t)c * kCamStride;
+  double camr[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) camr[i] = cam[i];
+  double Tout[7];
+  if (v.pre_backsub) {            // k_backsub has been here: take the frame's trial pose and (first tile) its step terms
+    const double* pt = v.poses[1 - cur] + (size_t)f * kPoseStride;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) Tout[i] = pt[i];
+    if (lane == 0 && tile == t0) {
+      const double* o = v.fpart + (size_t)f * kNumScal;
+      wsum[kScGd] = o[kScGd]; wsum[kScDld] = o[kScDld]; wsum[kScStep2] = o[kScStep2]; wsum[kScX2] = o[kScX2]; wsum[kScG2] = o[kScG2];
+      wsum[kScGmax] = o[kScGmax];
+    }
+  } else {
+    backsub_frame(v, cur, f, lane, ds_s, Tout, tile == t0, wsum);
   }
   double cost, sq = 0.0;
   if (FUSED) {
@@ -1373,6 +1404,7 @@ void launch_reduced(const DevView& v, int mode, hipStream_t s) {
 }
 void launch_trial(const DevView& v, hipStream_t s) {
   if (v.n_tiles == 0) return;
+  if (v.pre_backsub) hipLaunchKernelGGL(k_backsub, dim3((v.n_frames + 3) / 4), dim3(256), 0, s, v);
   const size_t lds = 4 * 64 * kDotStride * sizeof(double);
   static bool granted = false;
   if (lds > 0 && !granted) { (void)hipFuncSetAttribute((const void*)k_trial<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 4096)); granted = true; }
