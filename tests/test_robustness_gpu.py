@@ -90,3 +90,35 @@ def test_imu_time_order_and_missing_imu():
     c2 = ViCalibrator(0).load_problem(p); c2.SetMaxIters(30)
     c2.Solve()
     assert np.all(np.isfinite(c2.GetCamera(0)[0])) and c2.GetCameraProjRMSE()[0] < 0.2
+
+
+def test_handle_reuse_clear_and_reconfigure():
+    """One handle over several problems and settings: Clear() (vicalibrator.h:232-249), a different rig, fixed intrinsics,
+    a second solve after changing the tolerance -- state from the previous use must not leak."""
+    import oracle_lib as ol
+    p1 = synth.generate(synth.Config(models=("fov", "fov"), n_frames=20, seed=31))
+    p2 = synth.generate(synth.Config(models=("kb4",), n_frames=15, seed=32))
+    cal = ViCalibrator(0).load_problem(p1); cal.SetCalibrateImu(False)
+    cal.Solve()
+    k1 = cal.GetCamera(0)[0].copy()
+    cal.Clear()
+    assert cal.NumFrames() == 0 and cal.NumCameras() == 0
+    cal.load_problem(p2); cal.SetCalibrateImu(False)
+    cal.Solve()
+    orc = ol.Oracle().load(p2); orc.set_options(calibrate_imu=False); orc.solve()
+    np.testing.assert_allclose(cal.GetCamera(0)[0], orc.camera(0)[0], rtol=1e-6)
+    np.testing.assert_allclose(cal.trace()[:, 1], orc.trace()[:, 1], rtol=1e-6)
+    # same handle, back to the first rig with the intrinsics held fixed at the earlier result
+    cal.Clear()
+    for c, m in enumerate(p1.cam_model):
+        cal.AddCamera(m, k1 if c == 0 else p1.cam_K_gt[c], p1.cam_T_ck_init[c], 640, 480)
+    for n in range(len(p1.frame_time)):
+        cal.AddFrame(p1.frame_T_wk_init[n], p1.frame_time[n])
+    for (f, c, ids, pix) in p1.tiles:
+        cal.AddObservations(f, c, p1.grid_points[ids], pix)
+    cal.SetCalibrateImu(False); cal.FixCameraIntrinsics(True)
+    cal.Solve()
+    np.testing.assert_array_equal(cal.GetCamera(0)[0], k1)                 # untouched
+    assert cal.GetCameraProjRMSE()[0] < 0.15
+    cal.SetFunctionTolerance(1e-12); cal.Solve()                           # tighter tolerance: a few more iterations, same optimum
+    assert cal.GetCameraProjRMSE()[0] < 0.15

@@ -102,6 +102,10 @@ class ViCalibrator:
             model = MODEL_IDS[model]
         return _check(self.L.vc_add_camera(self.h, int(model), _d(params), len(params), int(width), int(height), _d(T_ck)), "AddCamera")
 
+    def Clear(self):
+        _check(self.L.vc_clear(self.h), "Clear")
+        self.nk = []
+
     def FixCameraIntrinsics(self, should_fix=True):
         _check(self.L.vc_fix_camera_intrinsics(self.h, int(should_fix)), "FixCameraIntrinsics")
 
