@@ -869,7 +869,7 @@ __device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M,
   }
 }
 
-__device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dyn, double* red /* 6 x 256 */) {
+__device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dyn, double* red /* 6 x 256 */, const double* s_cam) {
   const int tid = threadIdx.x, D = v.D, cur = ct->cur;
   double* x;
   VC_STAMP(4);
@@ -892,11 +892,11 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
     v.delta_s[i] = d;
     gd += g * d; dld += v.slam[i] * d * d; g2 += g * g; gmax = fmax(gmax, fabs(g));
   }
-  for (int i = tid; i < v.n_cams * kCamStride; i += 256) v.cams[1 - cur][i] = v.cams[cur][i];
+  for (int i = tid; i < v.n_cams * kCamStride; i += 256) v.cams[1 - cur][i] = s_cam[i];
   __syncthreads();
   if (tid < v.n_cams) {
     const int c = tid;
-    const double* cin = v.cams[cur] + (size_t)c * kCamStride;
+    const double* cin = s_cam + (size_t)c * kCamStride;
     double* cout = v.cams[1 - cur] + (size_t)c * kCamStride;
     const int flags = v.cd[c].flags, nk = model_nk(v.cd[c].model);
     int cc = v.cd[c].col0;
@@ -963,10 +963,12 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
 __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   extern __shared__ __attribute__((aligned(16))) double dyn[];   // phase A: FinalLds; phase B: the matrix (the phases do not overlap)
   __shared__ double red[6 * 256];
+  __shared__ double s_cam[kMaxCams * kCamStride];     // accepted camera records: requested at kernel entry, used by the tail
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
+  if (mode != 1) for (int i = threadIdx.x; i < v.n_cams * kCamStride; i += 256) s_cam[i] = v.cams[ct->cur][i];
   if (mode != 2) { schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn)); __syncthreads(); }
-  if (mode != 1) reduced_solve_phase(v, ct, dyn, red);
+  if (mode != 1) reduced_solve_phase(v, ct, dyn, red, s_cam);
 }
 
 // ------------------------------------------------------------------------------------------ trial point
