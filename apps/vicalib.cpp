@@ -56,6 +56,7 @@ static void DefineFlags() {
   Define("max_reprojection_error", "double", "0.15", "Maximum allowed reprojection error (pixels).");
   Define("num_vicalib_frames", "int64", "-1", "Number of frames to process before calibration begins (-1: all).");
   Define("print_poses", "bool", "false", "Output poses to poses.txt");
+  Define("print_covariance", "bool", "false", "Print the solution covariance of q_ck / p_ck / params (the reference compiles this in with COMPUTE_VICALIB_COVARIANCE).");
   Define("output", "string", "cameras.xml", "Output XML file to write camera models to.");
   Define("output_log_file", "string", "vicalibrator.log", "Calibration result output log file.");
   Define("cam", "string", "", "Camera URI: detections://cam0.csv[,cam1.csv...]");
@@ -459,6 +460,20 @@ int main(int argc, char** argv) {
     std::printf("gravity direction: %.8g %.8g   time offset: %.9g s\n", g[0], g[1], cal.time_offset());
   }
   std::printf("iterations: %u  mse: %.8g  solve time: %.3f s\n", cal.GetNumIterations(), cal.MeanSquaredError(), secs);
+  if (FlagBool("print_covariance")) {       // GetSolutionCovariance + its log lines (vicalibrator.h:802-857, :1004-1013)
+    std::vector<std::vector<double>> covs((size_t)n_gpus);
+    std::vector<int> dims((size_t)n_gpus, 0);
+    std::vector<std::thread> th;            // collective when the frames are sharded: every rank linearises
+    for (int r = 0; r < n_gpus; ++r) th.emplace_back([&, r] { covs[r] = cals[r]->GetSolutionCovariance(&dims[r]); });
+    for (auto& t : th) t.join();
+    if (dims[0] > 0) {
+      std::printf("Covariance calculated for blocks: %s\nSolution covariance:\n", cal.covariance_names().c_str());
+      for (int i = 0; i < dims[0]; ++i) {
+        for (int j = 0; j < dims[0]; ++j) std::printf(" %.6e", covs[0][(size_t)i * dims[0] + j]);
+        std::printf("\n");
+      }
+    } else std::printf("Failed to compute covariance...\n");
+  }
 
   // ---- WriteCalibration (vicalib-engine.cc:353-372) + poses.csv (:407-421) ----------------------------------------------
   cal.WriteCameraModels(FlagString("output"));

@@ -100,6 +100,15 @@ unsigned vc_get_num_iterations(vc_calibrator* h);                               
 /* WriteCameraModels(filename) :208-229 (calibu rig XML) */
 int vc_write_camera_models(vc_calibrator* h, const char* filename);
 
+/* GetSolutionCovariance(problem) :802-857 (compiled in the reference only with COMPUTE_VICALIB_COVARIANCE, :1004-1013):
+ * covariance of the blocks of covariance_params_ (:561, :567, :594) at the current state -- per camera q_ck (4, lifted
+ * through the SO3 local parameterisation), p_ck (3) and, unless the intrinsics are fixed, the model parameters; frames
+ * and IMU states marginalised; constant blocks are zero.  n x n row-major, n = vc_solution_covariance_dim().
+ * The names string is the reference's column header ("c[0].q_ck:(4) c[0].p_ck:(3) c[0].params:(5) ..."). */
+int vc_solution_covariance_dim(vc_calibrator* h);
+int vc_get_solution_covariance(vc_calibrator* h, double* cov, int max_n, int* n);
+int vc_get_solution_covariance_names(vc_calibrator* h, char* buf, int len);
+
 /* ---- engine-level entry points (no counterpart in the reference: it has no GPU, no sharding) ---- */
 /* Per-iteration record of the trust-region loop = the columns of the reference's log line (:698-707).
  * rows of 10 doubles: iteration, cost, cost_change, gradient_max_norm, gradient_norm, step_norm,

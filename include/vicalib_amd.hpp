@@ -104,6 +104,21 @@ class ViCalibrator {
     return f;
   }
   void WriteCameraModels(const std::string& filename) { vc_write_camera_models(h_, filename.c_str()); }   // :208
+  // GetSolutionCovariance(problem) :802-857: row-major n x n over the blocks named by covariance_names
+  std::vector<double> GetSolutionCovariance(int* n_out = nullptr) {
+    const int n = vc_solution_covariance_dim(h_);
+    std::vector<double> cov(n > 0 ? (size_t)n * n : 0);
+    int m = 0;
+    if (n <= 0 || vc_get_solution_covariance(h_, cov.data(), n, &m) != VC_OK) cov.clear();
+    if (n_out) *n_out = cov.empty() ? 0 : n;
+    return cov;
+  }
+  std::string covariance_names() {
+    std::string s(64 * 8 + 64, '\0');
+    if (vc_get_solution_covariance_names(h_, &s[0], (int)s.size()) != VC_OK) return std::string();
+    s.resize(s.find('\0'));
+    return s;
+  }
   vc_calibrator* handle() { return h_; }
 
  private:

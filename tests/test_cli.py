@@ -33,7 +33,7 @@ def test_help_and_flag_errors():
     for flag in ("-models", "-cam", "-imu", "-grid_preset", "-output", "-calibrate_imu", "-calibrate_intrinsics", "-find_time_offset",
                  "-has_initial_guess", "-model_files", "-max_iters", "-function_tolerance", "-gyro_sigma", "-accel_sigma",
                  "-remove_outliers", "-outlier_threshold", "-max_reprojection_error", "-num_vicalib_frames", "-frame_skip",
-                 "-save_poses", "-print_poses", "-grid_height", "-grid_width", "-grid_spacing", "-grid_seed", "-gpus"):
+                 "-save_poses", "-print_poses", "-print_covariance", "-grid_height", "-grid_width", "-grid_spacing", "-grid_seed", "-gpus"):
         assert flag + " " in r.stdout, flag          # the CLI contract of SURVEY 8(b)
     assert _run([]).returncode == 1                   # "No camera URI given" (vicalib-engine.cc:445)
     r = _run(["-bogus", "1"]); assert r.returncode == 1 and "unknown command line flag" in r.stderr
@@ -58,8 +58,17 @@ def test_cli_stereo_calibration_from_detection_files(tmp_path):
     files, _ = synth.write_dataset(p, str(tmp_path))
     out = tmp_path / "cameras.xml"
     r = _run(["-cam", "detections://" + ",".join(files), "-models", "fov,poly3", "-nocalibrate_imu", "-grid_preset", "small",
-              "-output", str(out), "-save_poses", "-print_poses"], cwd=str(tmp_path))
+              "-output", str(out), "-save_poses", "-print_poses", "-print_covariance"], cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout + r.stderr
+    # GetSolutionCovariance's log lines (vicalibrator.h:839-850): block names, then the matrix
+    assert "Covariance calculated for blocks: c[0].q_ck:(4) c[0].p_ck:(3) c[0].params:(5) c[1].q_ck:(4) c[1].p_ck:(3) c[1].params:(7)" in r.stdout
+    rows = r.stdout.split("Solution covariance:\n")[1].split("\n")[:26]
+    cov = np.array([[float(x) for x in row.split()] for row in rows])
+    assert cov.shape == (26, 26) and np.allclose(cov, cov.T, rtol=1e-5, atol=1e-300)
+    assert np.all(cov[:7] == 0.0) and np.all(np.diag(cov)[7:] > 0)
+    # residuals are in pixels (sigma 0.1 px): the focal length error is within a few predicted standard deviations
+    sig_fu = p.cfg.pixel_sigma * np.sqrt(cov[7, 7])
+    assert 0 < sig_fu < 1.0
     cams = _read_xml(str(out))
     assert [c[0] for c in cams] == ["calibu_fu_fv_u0_v0_w", "calibu_fu_fv_u0_v0_k1_k2_k3"]
     for c in range(2):

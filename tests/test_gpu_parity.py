@@ -467,3 +467,129 @@ def test_full_visual_inertial_calibration_matches_oracle():
     gt = p.imu_gt
     assert abs(cal.time_offset() - gt["time_offset"]) < 5e-4
     np.testing.assert_allclose(cal.GetBiases()[:3], gt["bg"], atol=3e-4)
+
+
+# ---------------------------------------------------------------------------- solution covariance
+def _quat_mul(a, b):      # [x y z w]
+    av, aw, bv, bw = a[:3], a[3], b[:3], b[3]
+    return np.concatenate([aw * bv + bw * av + np.cross(av, bv), [aw * bw - av @ bv]])
+
+
+def _so3_lift(q, h=1e-6):
+    """d(q * exp(w))/dw at w = 0 by central differences: what LocalParamSo3::ComputeJacobian (local-param-se3.h:121-157)
+    returns in closed form."""
+    J = np.zeros((4, 3))
+    for a in range(3):
+        w = np.zeros(3); w[a] = h
+        ep = np.concatenate([np.sin(h / 2) * w / h, [np.cos(h / 2)]])
+        em = np.concatenate([-np.sin(h / 2) * w / h, [np.cos(h / 2)]])
+        J[:, a] = (_quat_mul(q, ep) - _quat_mul(q, em)) / (2 * h)
+    return J
+
+
+def _lift_matrix(cal, layout, D):
+    """layout: per camera (rot_free, trans_free, k_free); columns in the order rot, trans, K per camera (build_layout)."""
+    rows = []; col = 0
+    for c, (rf, tf, kf) in enumerate(layout):
+        K, T_ck = cal.GetCamera(c)
+        P = np.zeros((4, D))
+        if rf:
+            P[:, col:col + 3] = _so3_lift(np.asarray(T_ck[:4])); col += 3
+        rows.append(P)
+        P = np.zeros((3, D))
+        if tf:
+            P[:, col:col + 3] = np.eye(3); col += 3
+        rows.append(P)
+        if kf:
+            P = np.zeros((len(K), D)); P[:, col:col + len(K)] = np.eye(len(K)); col += len(K)
+            rows.append(P)
+    return np.vstack(rows)
+
+
+def _dense_hessian(lin, df):
+    A = lin["A"]; Cc = lin["C"]; W = lin["W"]; Hss = lin["Hss"]; n = A.shape[0]; D = Hss.shape[0]
+    H = np.zeros((n * df + D, n * df + D))
+    for f in range(n):
+        s = slice(f * df, (f + 1) * df)
+        H[s, s] = A[f, :df, :df]
+        if f + 1 < n:
+            s1 = slice((f + 1) * df, (f + 2) * df)
+            H[s, s1] = Cc[f, :df, :df]; H[s1, s] = Cc[f, :df, :df].T
+        H[s, n * df:] = W[f, :df]; H[n * df:, s] = W[f, :df].T
+    H[n * df:, n * df:] = Hss
+    return H
+
+
+def test_solution_covariance_vision_matches_dense_inverse_of_the_oracle_hessian():
+    """GetSolutionCovariance (vicalibrator.h:802-857): blocks q_ck(4) p_ck(3) params per camera.  Reference value: the
+    shared-parameter block of the inverse of the oracle's complete (frames + shared) Gauss-Newton Hessian -- no Schur
+    complement on that side -- lifted with a finite-difference SO3 Jacobian.  cond(S) ~ 6e11 at this (initial) state:
+    1e-13 relative differences in S move the normalised covariance by ~3e-9, so the oracle comparison uses 1e-5 of
+    sqrt(C_ii C_jj); the host inverse + lift is pinned to 1e-8 against numpy on the device's own S."""
+    models = ("fov", "poly3")
+    p, cal, orc = _pair(synth.Config(models=models, n_frames=12, seed=21))
+    orc.prepare(vis_mult=1)
+    lin = orc.linearize()
+    D = lin["Hss"].shape[0]
+    cov, names = cal.GetSolutionCovariance()
+    assert names == ["c[0].q_ck:(4)", "c[0].p_ck:(3)", "c[0].params:(5)", "c[1].q_ck:(4)", "c[1].p_ck:(3)", "c[1].params:(7)"]
+    assert cov.shape == (26, 26)
+    P = _lift_matrix(cal, [(False, False, True), (True, True, True)], D)
+    n = lin["A"].shape[0]
+    ref = P @ np.linalg.inv(_dense_hessian(lin, 6))[n * 6:, n * 6:] @ P.T
+    own = P @ np.linalg.inv(cal.linearize()["S"]) @ P.T
+    np.testing.assert_array_equal(cov[:7], 0.0)             # camera 0's T_ck is constant without the IMU (:572-576)
+    np.testing.assert_allclose(cov, cov.T, rtol=1e-12, atol=1e-300)
+    d = np.sqrt(np.maximum(np.diag(ref), 1e-300))
+    assert np.abs((cov - own) / np.outer(d, d)).max() < 1e-8
+    assert np.abs((cov - ref) / np.outer(d, d)).max() < 1e-5
+    assert np.linalg.eigvalsh(cov).min() > -1e-12 * np.abs(cov).max()
+    # the quaternion block is rank 3: its null direction is q itself (P_q^T q = 0)
+    q = np.asarray(cal.GetCamera(1)[1][:4])
+    assert np.abs(cov[12:16, 12:16] @ q).max() < 1e-9 * np.abs(cov[12:16, 12:16]).max()
+
+
+def test_solution_covariance_visual_inertial_and_fixed_intrinsics():
+    """With the IMU the frames carry velocities and the reduced system also holds g, biases, scale factors and the time
+    offset; they are marginalised (not listed in covariance_params_).  The complete Hessian has cond ~ 5e15 here, so the
+    oracle comparison goes through the oracle's Schur complement and is loose; the tight check is on the device's S."""
+    p = _vi_problem(16)
+    gt = p.imu_gt
+    cal = ViCalibrator(0).load_problem(p, init=False)
+    orc = ol.Oracle().load(p, init=False)
+    orc.set_options(calibrate_imu=True)
+    b0 = np.concatenate([gt["bg"], gt["ba"]]) * 0.8; s0 = np.concatenate([gt["sg"], gt["sa"]])
+    orc.set_flags(True, True, False, True); orc.set_imu_state(b0, s0, np.zeros(2), 0.002)
+    cal.SetOptimizationFlags(True, True, False, True)
+    cal.SetBiases(b0); cal.SetScaleFactor(s0); cal.SetTimeOffset(0.002)
+    orc.prepare(vis_mult=1, imu_mult=1)
+    # every linearisation pass also runs UpdateImuWeights (the weights it leaves are the ones of the held state): one pass
+    # first, so that the covariance call and the pass that fetches S see the same weight_sqrt_; same on the oracle side
+    cal.linearize()
+    cov, names = cal.GetSolutionCovariance()
+    g = cal.linearize()
+    orc.update_imu_weights()
+    lin = orc.linearize()
+    D = g["S"].shape[0]
+    assert D == lin["Hss"].shape[0]
+    assert names == ["c[0].q_ck:(4)", "c[0].p_ck:(3)", "c[0].params:(8)"] and cov.shape == (15, 15)
+    P = _lift_matrix(cal, [(True, True, True)], D)
+    own = P @ np.linalg.inv(g["S"]) @ P.T
+    d = np.sqrt(np.diag(own))
+    assert np.all(d[4:] > 0)
+    assert np.abs((cov - own) / np.outer(np.maximum(d, 1e-300), np.maximum(d, 1e-300)))[4:, 4:].max() < 1e-7
+    np.testing.assert_allclose(cov[:4, :4], own[:4, :4], rtol=1e-6, atol=1e-7 * np.abs(own[:4, :4]).max())
+    n = lin["A"].shape[0]
+    H = _dense_hessian(lin, 9)
+    S = lin["Hss"] - H[:n * 9, n * 9:].T @ np.linalg.solve(H[:n * 9, :n * 9], H[:n * 9, n * 9:])
+    ref = P @ np.linalg.inv(S) @ P.T
+    np.testing.assert_allclose(np.sqrt(np.diag(cov)[4:]), np.sqrt(np.diag(ref)[4:]), rtol=2e-2)
+    # fixed intrinsics: the params blocks are not registered (:591-594)
+    cal2 = ViCalibrator(0).load_problem(p, init=False)
+    cal2.FixCameraIntrinsics(True); cal2.SetOptimizationFlags(True, True, False, True)
+    cal2.SetBiases(b0); cal2.SetScaleFactor(s0); cal2.SetTimeOffset(0.002)      # same linearisation point
+    cal2.linearize()                                                            # ... and the same weights
+    cov2, names2 = cal2.GetSolutionCovariance()
+    assert names2 == ["c[0].q_ck:(4)", "c[0].p_ck:(3)"] and cov2.shape == (7, 7)
+    assert np.all(np.diag(cov2)[4:] > 0)
+    assert np.all(np.diag(cov2)[4:] < np.diag(cov)[4:7])     # fewer free parameters: tighter extrinsics

@@ -1178,6 +1178,108 @@ int vc_get_imu_weights(vc_calibrator* h, double* out) {
   if (hipMemcpyAsync(out, h->dv.wsqrtb[h->wcur], n * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return VC_ERR_NO_DEVICE;
   return VC_OK;
 }
+// GetSolutionCovariance, vicalibrator.h:802-857.  The blocks are the ones SetupProblem files in covariance_params_
+// (:561, :567, :594): per camera q_ck (4), p_ck (3) and, unless the intrinsics are fixed, the model parameters.
+// The covariance of the shared parameters with the frames (and, with the IMU, velocities and the other IMU
+// parameters) marginalised is the inverse of the undamped reduced system S that every LM pass assembles on the device;
+// the D x D inverse is host code and runs once.  As Ceres does, the tangent-space covariance of q_ck is lifted with
+// the local parameterisation's Jacobian (local-param-se3.h:121-157) and constant blocks get zeros.
+static int covariance_layout(vc_calibrator* h, std::vector<int>* first, std::vector<int>* size) {
+  int n = 0;
+  for (const HostCam& cm : h->cams) {
+    first->push_back(n); size->push_back(4); n += 4;
+    first->push_back(n); size->push_back(3); n += 3;
+    if (!h->fix_intrinsics) { first->push_back(n); size->push_back(cm.nk); n += cm.nk; }
+  }
+  return n;
+}
+int vc_solution_covariance_dim(vc_calibrator* h) {
+  if (!h) return VC_ERR_BAD_ARG;
+  std::vector<int> first, size;
+  return covariance_layout(h, &first, &size);
+}
+int vc_get_solution_covariance_names(vc_calibrator* h, char* buf, int len) {
+  if (!h || !buf || len <= 0) return VC_ERR_BAD_ARG;
+  std::string out;
+  for (size_t c = 0; c < h->cams.size(); ++c) {       // the strings of vicalibrator.h:563, :569, :596-598
+    out += "c[" + std::to_string(c) + "].q_ck:(4) c[" + std::to_string(c) + "].p_ck:(3) ";
+    if (!h->fix_intrinsics) out += "c[" + std::to_string(c) + "].params:(" + std::to_string(h->cams[c].nk) + ") ";
+  }
+  if ((int)out.size() + 1 > len) return VC_ERR_BAD_ARG;
+  std::memcpy(buf, out.c_str(), out.size() + 1);
+  return VC_OK;
+}
+int vc_get_solution_covariance(vc_calibrator* h, double* cov, int max_n, int* n_out) {
+  NOT_RUNNING(h);
+  if (!cov) return VC_ERR_BAD_ARG;
+  std::vector<int> first, size;
+  const int n = covariance_layout(h, &first, &size);
+  if (n_out) *n_out = n;
+  if (n > max_n) return VC_ERR_BAD_ARG;
+  if (h->device_dirty) { int rc = vc_prepare(h); if (rc) return rc; }
+  { int rc = h->linearize_hold(1e300, nullptr); if (rc) return rc; }
+  const int D = h->dv.D;
+  std::vector<double> M((size_t)D * D);
+  if (D && hipMemcpy(M.data(), h->dv.Sbuf, M.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
+  // S = L L^T, then S^-1 = L^-T L^-1 (lower triangle of M holds L, then L^-1)
+  for (int j = 0; j < D; ++j) {
+    double d = M[(size_t)j * D + j];
+    for (int k = 0; k < j; ++k) d -= M[(size_t)j * D + k] * M[(size_t)j * D + k];
+    if (!(d > 0.0)) return VC_ERR_NUMERIC;            // rank deficient: Ceres reports "Failed to compute covariance" (:853)
+    d = std::sqrt(d); M[(size_t)j * D + j] = d;
+    for (int i = j + 1; i < D; ++i) {
+      double t = M[(size_t)i * D + j];
+      for (int k = 0; k < j; ++k) t -= M[(size_t)i * D + k] * M[(size_t)j * D + k];
+      M[(size_t)i * D + j] = t / d;
+    }
+  }
+  std::vector<double> Li((size_t)D * D, 0.0), Ct((size_t)D * D, 0.0);
+  for (int j = 0; j < D; ++j) {
+    Li[(size_t)j * D + j] = 1.0 / M[(size_t)j * D + j];
+    for (int i = j + 1; i < D; ++i) {
+      double t = 0.0;
+      for (int k = j; k < i; ++k) t -= M[(size_t)i * D + k] * Li[(size_t)k * D + j];
+      Li[(size_t)i * D + j] = t / M[(size_t)i * D + i];
+    }
+  }
+  for (int i = 0; i < D; ++i) for (int j = 0; j <= i; ++j) {
+    double t = 0.0;
+    for (int k = i; k < D; ++k) t += Li[(size_t)k * D + i] * Li[(size_t)k * D + j];
+    Ct[(size_t)i * D + j] = t; Ct[(size_t)j * D + i] = t;
+  }
+  // lift: ambient row r of block b = sum_a P_b[r][a] * tangent column (col_b + a);  P = local Jacobian (q_ck) or identity
+  std::vector<double> P((size_t)n * D, 0.0);
+  {
+    std::lock_guard<std::mutex> lk(h->result_mutex);
+    int b = 0;
+    for (size_t c = 0; c < h->cams.size(); ++c) {
+      const HostCam& cm = h->cams[c];
+      const int fl = h->cam_flags[c];
+      int col = h->cam_col0[c];
+      const double* q = cm.T_ck;       // [x y z w]: d(q * exp(w))/dw at 0 = 1/2 [ w I + [v]x ; -v^T ]
+      if (fl & kCamRotFree) {
+        const double J[12] = {q[3], -q[2], q[1], q[2], q[3], -q[0], -q[1], q[0], q[3], -q[0], -q[1], -q[2]};
+        for (int r = 0; r < 4; ++r) for (int a = 0; a < 3; ++a) P[(size_t)(first[b] + r) * D + col + a] = 0.5 * J[3 * r + a];
+        col += 3;
+      }
+      ++b;
+      if (fl & kCamTransFree) { for (int r = 0; r < 3; ++r) P[(size_t)(first[b] + r) * D + col + r] = 1.0; col += 3; }
+      ++b;
+      if (!h->fix_intrinsics) { for (int r = 0; r < cm.nk; ++r) P[(size_t)(first[b] + r) * D + col + r] = 1.0; ++b; }
+    }
+  }
+  std::vector<double> PC((size_t)n * D, 0.0);
+  for (int i = 0; i < n; ++i) for (int k = 0; k < D; ++k) {
+    const double p = P[(size_t)i * D + k];
+    if (p != 0.0) for (int j = 0; j < D; ++j) PC[(size_t)i * D + j] += p * Ct[(size_t)k * D + j];
+  }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+    double t = 0.0;
+    for (int k = 0; k < D; ++k) t += PC[(size_t)i * D + k] * P[(size_t)j * D + k];
+    cov[(size_t)i * n + j] = t;
+  }
+  return VC_OK;
+}
 int vc_get_debug_stamps(vc_calibrator* h, long long* out) {
   if (!h || !out) return VC_ERR_BAD_ARG;
   return hipMemcpy(out, h->dv.dbg, 32 * 8, hipMemcpyDeviceToHost) == hipSuccess ? VC_OK : VC_ERR_NO_DEVICE;

@@ -30,6 +30,7 @@ SYMBOLS = [
     "vc_get_num_iterations", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
     "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
     "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_allreduce_calls", "vc_get_imu_weights",
+    "vc_solution_covariance_dim", "vc_get_solution_covariance", "vc_get_solution_covariance_names",
 ]
 
 
@@ -265,6 +266,16 @@ class ViCalibrator:
         W = np.zeros((ns, 9, 9))
         _check(self.L.vc_get_imu_weights(self.h, _d(W)), "imu_weights")
         return W
+
+    def GetSolutionCovariance(self):
+        """(covariance n x n, block names) of q_ck / p_ck / params of every camera at the current state
+        (GetSolutionCovariance, vicalibrator.h:802-857; names as in :563, :569, :596)."""
+        n = _check(self.L.vc_solution_covariance_dim(self.h), "solution_covariance_dim")
+        cov = np.zeros((n, n)); m = C.c_int(0)
+        _check(self.L.vc_get_solution_covariance(self.h, _d(cov), n, C.byref(m)), "solution_covariance")
+        buf = C.create_string_buffer(64 * max(1, self.NumCameras()))
+        _check(self.L.vc_get_solution_covariance_names(self.h, buf, len(buf)), "solution_covariance_names")
+        return cov, buf.value.decode().split()
 
     def imu_blocks(self):
         ns = max(self.NumFrames() - 1, 0)
