@@ -1,0 +1,329 @@
+"""Pins the inertial half of the CPU oracle (oracle/vco_imu.h, vco_weights.h) without the GPU.
+
+The reference cannot be built here, so the oracle's C++ restatement of the IMU path is checked
+against a second, independent restatement written in numpy / scipy straight from the reference's text:
+
+  * InterpolationBufferT::GetRange / GetElement / GetNext      interpolation-buffer.h:100-226
+  * GetPoseDerivativeJet / IntegratePoseJet / IntegrateImuJet    ceres-cost-functions.h:39-177
+  * SwitchedFullImuCostFunction::operator()                      ceres-cost-functions.h:402-484
+  * GetGravityVector                                             types.h:94-104
+
+and against things that do not depend on either restatement: the analytic trajectory of the generator (the residual has
+to vanish at ground truth up to sensor noise and RK4 truncation), central differences (the Dual<35> Jacobian the oracle
+uses in place of ceres::AutoDiffCostFunction), and a covariance propagated with numerically differentiated step maps
+(structure / sign / ordering check of the reference's hand-written, deliberately approximate Jacobians of
+UpdateImuWeights, vicalibrator.h:723-799 + types.h:330-687)."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+import oracle_lib as ol
+from vicalib_amd import synth
+
+GRAVITY = 9.8007           # types.h:40-42
+
+
+# ----------------------------------------------------------------------------- independent restatement (numpy)
+def quat_mul(a, b):
+    """Hamilton product, coefficients [x y z w] (Eigen::Quaternion::coeffs order)."""
+    av, aw, bv, bw = a[:3], a[3], b[:3], b[3]
+    return np.concatenate([aw * bv + bw * av + np.cross(av, bv), [aw * bw - av @ bv]])
+
+
+def quat_exp(w):
+    th = np.linalg.norm(w)
+    if th < 1e-10:
+        return np.concatenate([0.5 * w, [1.0]])
+    return np.concatenate([np.sin(0.5 * th) * w / th, [np.cos(0.5 * th)]])
+
+
+def quat_rot(q, v):
+    return Rotation.from_quat(q).apply(v)
+
+
+def gravity_vector(g):
+    sp, cp, sq, cq = np.sin(g[0]), np.cos(g[0]), np.sin(g[1]), np.cos(g[1])
+    return -GRAVITY * np.array([cp * sq, -sp, cp * cq])
+
+
+def get_range(t, w, a, t0, t1, off):
+    """GetRange for generic times (no sample exactly on t0 / t1, range inside the buffer): first = interpolation at t0,
+    interior = stored samples stamped time + offset, last = interpolation at t1.  Rows (w, a, time)."""
+    ts = t + off
+    if not (ts[0] <= t0 <= ts[-1]):
+        return np.zeros((0, 7))
+
+    def interp(i, time):
+        f = (time - ts[i]) / (ts[i + 1] - ts[i])
+        return np.concatenate([w[i] * (1 - f) + w[i + 1] * f, a[i] * (1 - f) + a[i + 1] * f, [time]])
+
+    i = int(np.searchsorted(ts, t0, side="left")) - 1
+    rows = [interp(i, t0)]
+    while i + 1 < len(ts) and not (ts[i + 1] > t1):
+        i += 1
+        rows.append(np.concatenate([w[i], a[i], [ts[i]]]))
+    rows.append(interp(min(i, len(ts) - 2), t1))
+    return np.array(rows)
+
+
+def pose_derivative(p, q, v, g_w, z0, z1, bg, ba, sf, dt):
+    alpha = (z1[6] - (z0[6] + dt)) / (z1[6] - z0[6])
+    zg = z0[:3] * alpha + z1[:3] * (1 - alpha)
+    za = z0[3:6] * alpha + z1[3:6] * (1 - alpha)
+    return np.concatenate([v, quat_rot(q, zg * sf[:3] + bg), quat_rot(q, za * sf[3:] + ba) - g_w])
+
+
+def euler_step(p, q, v, k, dt):
+    return p + k[:3] * dt, quat_mul(quat_exp(k[3:6] * dt), q), v + k[6:] * dt      # left-multiplied, not renormalised
+
+
+def rk4_step(p, q, v, z0, z1, bg, ba, sf, g_w):
+    if z1[6] == z0[6]:
+        return p, q, v
+    dt = z1[6] - z0[6]
+    k1 = pose_derivative(p, q, v, g_w, z0, z1, bg, ba, sf, 0.0)
+    y1 = euler_step(p, q, v, k1, 0.5 * dt)
+    k2 = pose_derivative(*y1, g_w, z0, z1, bg, ba, sf, 0.5 * dt)
+    y2 = euler_step(p, q, v, k2, 0.5 * dt)
+    k3 = pose_derivative(*y2, g_w, z0, z1, bg, ba, sf, 0.5 * dt)
+    y3 = euler_step(p, q, v, k3, dt)
+    k4 = pose_derivative(*y3, g_w, z0, z1, bg, ba, sf, dt)
+    return euler_step(p, q, v, k1 + 2 * k2 + 2 * k3 + k4, dt / 6.0)
+
+
+def integrate(T1, v1, meas, b, sf, g_dir):
+    p, q, v = T1[4:].copy(), T1[:4].copy(), v1.copy()
+    g_w = gravity_vector(g_dir)
+    for i in range(1, len(meas)):
+        p, q, v = rk4_step(p, q, v, meas[i - 1], meas[i], b[:3], b[3:], sf, g_w)
+    return p, q, v
+
+
+def se3_log(q, t):
+    """Sophus SE3::log -> [upsilon, omega], upsilon = V^-1 t."""
+    om = Rotation.from_quat(q).as_rotvec()
+    th = np.linalg.norm(om)
+    Om = np.array([[0, -om[2], om[1]], [om[2], 0, -om[0]], [-om[1], om[0], 0]])
+    # coefficient (1 - (th/2) cot(th/2)) / th^2: series below 0.05 rad (the closed form cancels catastrophically there)
+    c = 1 / 12 + th ** 2 / 720 + th ** 4 / 30240 if th < 0.05 else (1 - 0.5 * th / np.tan(0.5 * th)) / (th * th)
+    Vinv = np.eye(3) - 0.5 * Om + c * Om @ Om
+    return np.concatenate([Vinv @ t, om])
+
+
+def residual_from_prediction(p, q, v, T2, v2):
+    """(T_pred * T_2^-1).log() and v_pred - v_2 (ceres-cost-functions.h:468-472)."""
+    q2i = np.concatenate([-T2[:3], [T2[3]]])
+    qe = quat_mul(q, q2i)
+    te = p - quat_rot(qe, T2[4:])
+    return np.concatenate([se3_log(qe / np.linalg.norm(qe), te), v - v2])
+
+
+def imu_residual(T2, T1, v2, v1, g_dir, b, sf, toff, t1, t2, imu):
+    meas = get_range(imu[0], imu[1], imu[2], t1, t2, toff)
+    if len(meas) == 0:
+        return np.zeros(9)
+    return residual_from_prediction(*integrate(T1, v1, meas, b, sf, g_dir), T2, v2)
+
+
+# ----------------------------------------------------------------------------- fixtures
+def _problem(n=12, seed=5):
+    return synth.generate(synth.Config(models=("kb4",), n_frames=n, imu=True, seed=seed))
+
+
+def _oracle(p, init, rot_only=False):
+    o = ol.Oracle().load(p, init=init)
+    o.set_options(calibrate_imu=True)
+    o.set_flags(True, True, rot_only, True)
+    return o
+
+
+def _state(p, gt=True):
+    g = p.imu_gt
+    if gt:
+        return np.concatenate([g["bg"], g["ba"]]), np.concatenate([g["sg"], g["sa"]]), np.asarray(g["g_dir"], float), g["time_offset"]
+    return (np.concatenate([g["bg"], g["ba"]]) * 0.7, np.concatenate([g["sg"], g["sa"]]) * 1.003, np.array([0.01, 0.015]), 0.0021)
+
+
+# ----------------------------------------------------------------------------- tests
+@pytest.mark.parametrize("off", [0.0, 0.003, -0.0017])
+def test_interpolation_buffer_range_matches_numpy_restatement(off):
+    p = _problem()
+    o = _oracle(p, init=True)
+    imu = (p.imu_t, p.imu_gyro, p.imu_accel)
+    for j in range(1, len(p.frame_time)):
+        t1, t2 = p.frame_time[j - 1] + 1.3e-4, p.frame_time[j] + 0.7e-4       # generic: never on a sample stamp
+        want = get_range(*imu, t1, t2, off)
+        got = o.imu_range(t1, t2, off)
+        assert got.shape == want.shape and len(got) >= 10
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13)
+        assert got[0, 6] == t1 and got[-1, 6] == t2                           # end points are stamped with the query times
+        assert np.all(np.diff(got[:, 6]) > 0)
+    # a range starting before the first (shifted) sample has no element: empty (HasElement, :122-125, :217)
+    assert len(o.imu_range(p.imu_t[0] + off - 0.01, p.frame_time[1], off)) == 0
+    assert len(get_range(*imu, p.imu_t[0] + off - 0.01, p.frame_time[1], off)) == 0
+
+
+def test_gravity_vector_convention():
+    np.testing.assert_allclose(gravity_vector([0.0, 0.0]), [0, 0, -GRAVITY])          # g(0,0) = (0,0,-9.8007)
+    np.testing.assert_allclose(synth.gravity_vector([0.03, -0.02]), gravity_vector([0.03, -0.02]), rtol=1e-15)
+
+
+@pytest.mark.parametrize("gt_state", [True, False])
+def test_imu_residual_matches_numpy_restatement(gt_state):
+    """Oracle residual (weight_sqrt_ = 500 I, vicalibrator.h:616) == 500 x the numpy RK4 restatement, at ground truth
+    and at a perturbed state (initial frame poses, wrong biases / scale / gravity / offset, non-zero velocities)."""
+    p = _problem()
+    o = _oracle(p, init=not gt_state)
+    b, s, g, toff = _state(p, gt_state)
+    o.set_imu_state(b, s, g, toff)
+    T = p.frame_T_wk_gt if gt_state else p.frame_T_wk_init
+    V = p.frame_v_gt if gt_state else p.frame_v_gt * 0.9 + 0.01
+    for f in range(len(T)):
+        o.set_frame(f, T[f], V[f])
+    o.prepare(vis_mult=1, imu_mult=1)
+    imu = (p.imu_t, p.imu_gyro, p.imu_accel)
+    for j in range(1, len(T)):
+        want = 500.0 * imu_residual(T[j], T[j - 1], V[j], V[j - 1], g, b, s, toff, p.frame_time[j - 1], p.frame_time[j], imu)
+        got = o.imu_value(j)
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(want).max()))
+
+
+def test_imu_residual_vanishes_on_the_analytic_trajectory():
+    """Independent of both restatements: the generator differentiates an analytic trajectory and inverts the sensor model;
+    integrating those samples from frame j-1's true state must land on frame j's true state.  What is left is the sensor
+    noise (default sigmas) and the RK4 truncation: position < 2e-5 m, rotation < 1e-5 rad, velocity < 5e-4 m/s over a
+    50 ms segment -- a wrong gravity sign alone would leave ~1 m/s."""
+    p = _problem(n=20)
+    b, s, g, toff = _state(p, True)
+    o = _oracle(p, init=False)
+    o.set_imu_state(b, s, g, toff)
+    for f in range(len(p.frame_time)):
+        o.set_frame(f, p.frame_T_wk_gt[f], p.frame_v_gt[f])
+    o.prepare(vis_mult=1, imu_mult=1)
+    for j in range(1, len(p.frame_time)):
+        r = o.imu_value(j) / 500.0
+        assert np.abs(r[:3]).max() < 2e-5 and np.abs(r[3:6]).max() < 1e-5 and np.abs(r[6:]).max() < 5e-4, (j, r)
+    # and each wrong convention is visible: flipped time offset, no gravity tilt, unit scale factors
+    o.set_imu_state(b, s, g, -toff)
+    assert max(np.abs(o.imu_value(j)[3:6] / 500.0).max() for j in range(1, 20)) > 1e-4
+    o.set_imu_state(b, s, np.zeros(2), toff)
+    assert max(np.abs(o.imu_value(j)[6:] / 500.0).max() for j in range(1, 20)) > 5e-3
+    o.set_imu_state(b, np.ones(6), g, toff)
+    assert max(np.abs(o.imu_value(j)[6:] / 500.0).max() for j in range(1, 20)) > 1e-3
+
+
+def test_rotation_only_switch_and_empty_range():
+    p = _problem()
+    b, s, g, toff = _state(p, False)
+    o = _oracle(p, init=True, rot_only=True)
+    o.set_imu_state(b, s, g, toff)
+    o.prepare(vis_mult=1, imu_mult=1)
+    full = _oracle(p, init=True, rot_only=False)
+    full.set_imu_state(b, s, g, toff)
+    full.prepare(vis_mult=1, imu_mult=1)
+    for j in range(1, o.n_frames):
+        r, rf = o.imu_value(j), full.imu_value(j)
+        assert np.all(r[:3] == 0) and np.all(r[6:] == 0)               # ceres-cost-functions.h:479-482
+        np.testing.assert_array_equal(r[3:6], rf[3:6])
+    # offset so large that the segment starts before the buffer: no measurements -> zero residual (:452-455)
+    full.set_imu_state(b, s, g, 10.0)
+    assert np.all(full.imu_value(1) == 0)
+
+
+def _plus_se3(T, d):
+    out = np.zeros(7)
+    ol.lib().vco_plus_se3(ol._d(np.ascontiguousarray(T)), ol._d(np.ascontiguousarray(d)), ol._d(out))
+    return out
+
+
+def test_imu_dual_jacobian_matches_central_differences():
+    """The oracle's Dual<35> Jacobian x local parameterisation (what AutoDiffCostFunction + LocalParamSe3 give the
+    reference, vicalibrator.h:620-632) against central differences of the oracle's own residual."""
+    p = _problem(n=8)
+    b, s, g, toff = _state(p, False)
+    o = _oracle(p, init=True)
+    o.set_imu_state(b, s, g, toff)
+    T = p.frame_T_wk_init.copy(); V = p.frame_v_gt * 0.9 + 0.01
+    for f in range(len(T)):
+        o.set_frame(f, T[f], V[f])
+    o.prepare(vis_mult=1, imu_mult=1)
+    j = 4
+    r0, J = o.imu_block(j)
+    np.testing.assert_allclose(r0, o.imu_value(j), rtol=1e-12)
+
+    def value(dT2=None, dT1=None, dv2=None, dv1=None, dg=None, db=None, ds=None, dt=0.0):
+        o.set_frame(j, _plus_se3(T[j], dT2) if dT2 is not None else T[j], V[j] + (dv2 if dv2 is not None else 0))
+        o.set_frame(j - 1, _plus_se3(T[j - 1], dT1) if dT1 is not None else T[j - 1], V[j - 1] + (dv1 if dv1 is not None else 0))
+        o.set_imu_state(b + (db if db is not None else 0), s + (ds if ds is not None else 0), g + (dg if dg is not None else 0), toff + dt)
+        return o.imu_value(j)
+
+    def fd(make, n, h):
+        cols = []
+        for a in range(n):
+            e = np.zeros(n); e[a] = h
+            cols.append((value(**make(e)) - value(**make(-e))) / (2 * h))
+        value()
+        return np.array(cols).T
+
+    # column order of vco_imu_block: J2(6) J1(6) v2(3) v1(3) g(2) b(6) sf(6) t(1)
+    blocks = [(0, 6, lambda e: dict(dT2=e), 1e-6), (6, 6, lambda e: dict(dT1=e), 1e-6), (12, 3, lambda e: dict(dv2=e), 1e-6),
+              (15, 3, lambda e: dict(dv1=e), 1e-6), (18, 2, lambda e: dict(dg=e), 1e-6), (20, 6, lambda e: dict(db=e), 1e-6),
+              (26, 6, lambda e: dict(ds=e), 1e-6)]
+    scale = np.abs(J).max()
+    for c0, n, make, h in blocks:
+        np.testing.assert_allclose(J[:, c0:c0 + n], fd(make, n, h), rtol=2e-6, atol=2e-8 * scale, err_msg=str(c0))
+    # time offset: the residual is piecewise smooth in the offset (samples enter / leave the range); step well inside a piece
+    h = 1e-7
+    Jt = (value(dt=h) - value(dt=-h)) / (2 * h); value()
+    np.testing.assert_allclose(J[:, 32], Jt, rtol=1e-4, atol=1e-6 * scale)
+
+
+def test_imu_weights_against_numerically_propagated_covariance():
+    """UpdateImuWeights: W W^T = (Jr Sigma Jr^T)^-1 with Sigma <- F Sigma F^T + G R G^T per sample interval.  Reference:
+    hand-written F = dy_dy0 (10x10), G = dy_db (10x6), Jr (9x10), with a low-order dqExp_dw and scale factors ignored in
+    dk_dx (types.h:417-422) -- approximations that are part of the reference result and that the oracle restates as
+    they are.  Here F, G, Jr come from central differences of the numpy integrator above, so the two information
+    matrices agree only to the size of those approximations.  Measured on these 50 ms segments: 1e-5 on the standard
+    deviations, 3e-5 on the correlations; the bounds are 2e-4 / 3e-4 (a transposed block or a sign error shows at
+    order one)."""
+    p = _problem(n=10)
+    b, s, g, toff = _state(p, True)
+    o = _oracle(p, init=False)
+    o.set_imu_state(b, s, g, toff)
+    for f in range(len(p.frame_time)):
+        o.set_frame(f, p.frame_T_wk_gt[f], p.frame_v_gt[f])
+    o.prepare(vis_mult=1, imu_mult=1)
+    o.update_imu_weights()
+    W = o.imu_weights()
+    Rn = np.diag([5.3088444e-5 ** 2] * 3 + [0.001883649 ** 2] * 3)
+    g_w = gravity_vector(g)
+    imu = (p.imu_t, p.imu_gyro, p.imu_accel)
+
+    def step(y, z0, z1, bias):
+        pn, qn, vn = rk4_step(y[:3], y[3:7], y[7:], z0, z1, bias[:3], bias[3:], s, g_w)
+        return np.concatenate([pn, qn, vn])
+
+    def jac(fun, x, h=1e-6):
+        cols = []
+        for a in range(len(x)):
+            e = np.zeros(len(x)); e[a] = h
+            cols.append((fun(x + e) - fun(x - e)) / (2 * h))
+        return np.array(cols).T
+
+    for j in (1, 4, 8):
+        meas = get_range(*imu, p.frame_time[j - 1], p.frame_time[j], toff)
+        T1, T2 = p.frame_T_wk_gt[j - 1], p.frame_T_wk_gt[j]
+        y = np.concatenate([T1[4:], T1[:4], p.frame_v_gt[j - 1]])           # state order [p, q(x y z w), v] (types.h:188-194)
+        Sigma = np.zeros((10, 10))
+        for i in range(1, len(meas)):
+            F = jac(lambda x: step(x, meas[i - 1], meas[i], b), y)
+            G = jac(lambda bb: step(y, meas[i - 1], meas[i], bb), b)
+            Sigma = F @ Sigma @ F.T + G @ Rn @ G.T
+            y = step(y, meas[i - 1], meas[i], b)
+        Jr = jac(lambda x: residual_from_prediction(x[:3], x[3:7], x[7:], T2, p.frame_v_gt[j]), y)
+        info_num = np.linalg.inv(Jr @ Sigma @ Jr.T)
+        info_orc = W[j - 1] @ W[j - 1].T
+        np.testing.assert_allclose(info_orc, info_orc.T, rtol=1e-9, atol=1e-9 * np.abs(info_orc).max())
+        sd_n, sd_o = np.sqrt(np.diag(info_num)), np.sqrt(np.diag(info_orc))
+        np.testing.assert_allclose(sd_o, sd_n, rtol=2e-4)
+        assert np.abs(info_orc / np.outer(sd_o, sd_o) - info_num / np.outer(sd_n, sd_n)).max() < 3e-4
