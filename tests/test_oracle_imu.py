@@ -327,3 +327,64 @@ def test_imu_weights_against_numerically_propagated_covariance():
         sd_n, sd_o = np.sqrt(np.diag(info_num)), np.sqrt(np.diag(info_orc))
         np.testing.assert_allclose(sd_o, sd_n, rtol=2e-4)
         assert np.abs(info_orc / np.outer(sd_o, sd_o) - info_num / np.outer(sd_n, sd_n)).max() < 3e-4
+
+
+def test_visual_inertial_optimum_is_a_scipy_fixed_point():
+    """SURVEY 8c-3 for the inertial problem (60 frames = 3 s; shorter toys are too ill-conditioned to converge): the state the oracle's stage machine converges to is a
+    stationary point of the final stage's objective -- k copies of every robustified reprojection block + (k-1) copies of
+    every Cauchy-robustified, weighted IMU block (vicalibrator.h:641-655) with weight_sqrt_ as the last callback left it --
+    as judged by an independent optimiser (scipy TRF, finite-difference Jacobian) started there."""
+    scipy_opt = pytest.importorskip("scipy.optimize")
+    p = _problem(n=60, seed=5)
+    o = ol.Oracle().load(p)
+    o.set_options(calibrate_imu=True, function_tolerance=1e-12, max_iters=200)
+    o.solve()
+    tr = o.trace()
+    k = int(tr[:, 9].max()) + 1                       # stages 0..k-1 ran: k visual copies, k-1 inertial copies
+    assert k == 4
+    L = ol.lib()
+    n = o.n_frames
+    T0, V0 = o.frames()
+    K0, Tck0 = o.camera(0)
+    b0, s0, g0, t0 = o.imu_state()
+    assert abs(t0 - p.imu_gt["time_offset"]) < 1e-3 and o.rmse()[0] < 0.15
+    o.prepare(vis_mult=k, imu_mult=k - 1)
+    nx = 9 * n + 6 + len(K0) + 2 + 6 + 6 + 1
+    # parameter scales: metres / radians / (m/s) ~ 1e-3 matters, pixels ~ 1e-2, biases 1e-4 ...
+    scale = np.concatenate([np.full(9 * n, 1e-3), np.full(6, 1e-3), np.full(len(K0), 1e-2), np.full(2, 1e-3), np.full(6, 1e-4),
+                            np.full(6, 1e-3), [1e-4]])
+
+    def apply(x):
+        x = x * scale
+        for f in range(n):
+            o.set_frame(f, _plus_se3(T0[f], x[9 * f:9 * f + 6]), V0[f] + x[9 * f + 6:9 * f + 9])
+        c = 9 * n
+        q = quat_mul(Tck0[:4], quat_exp(x[c:c + 3]))                    # LocalParamSo3::Plus: R * exp(w)
+        o.set_camera(0, K0 + x[c + 6:c + 6 + len(K0)], np.concatenate([q, Tck0[4:] + x[c + 3:c + 6]]))
+        c += 6 + len(K0)
+        o.set_imu_state(b0 + x[c + 2:c + 8], s0 + x[c + 8:c + 14], g0 + x[c:c + 2], t0 + x[c + 14])
+
+    def fun(x):
+        apply(x)
+        r = o.residuals()[0]
+        s = (r * r).sum(axis=1)
+        rho = 2 * 0.25 * (np.sqrt(1 + s / 0.25) - 1)                    # SoftLOneLoss(0.5)
+        rv = (r * np.sqrt(k * rho / np.maximum(s, 1e-300))[:, None]).ravel()
+        ri = []
+        for j in range(1, n):
+            e = o.imu_value(j)
+            si = e @ e
+            ri.append(e * np.sqrt((k - 1) * 1e4 * np.log1p(si / 1e4) / max(si, 1e-300)))      # CauchyLoss(100)
+        return np.concatenate([rv, np.concatenate(ri)])
+
+    x0 = np.zeros(nx)
+    f0 = fun(x0)
+    cost0 = 0.5 * f0 @ f0
+    assert abs(cost0 - o.evaluate_cost()) <= 1e-9 * cost0              # the objective above is the oracle's
+    assert abs(cost0 - tr[-1, 1]) <= 1e-6 * cost0                       # ... and the one its last iteration reported
+    sol = scipy_opt.least_squares(fun, x0, method="trf", x_scale=1.0, xtol=1e-12, ftol=1e-14, gtol=1e-12, max_nfev=15)
+    apply(x0)
+    assert sol.cost <= cost0 * (1 + 1e-12)
+    assert cost0 - sol.cost < 1e-9 * cost0, (cost0, sol.cost)          # measured: 1.6e-12
+    # scipy's move from the oracle's optimum, in the scaled units above (1 = a millimetre / milliradian / 0.01 px ...)
+    assert np.abs(sol.x).max() < 1e-3, np.abs(sol.x).max()             # measured: 1.5e-6
