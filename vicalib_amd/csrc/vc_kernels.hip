@@ -539,9 +539,9 @@ __global__ __launch_bounds__(256) void k_part_sum(DevView v) {
 
 // Phase A of the reduced system (one workgroup):
 // Sbuf = [ S = H_ss - sum Y^T Y (full symmetric, undamped) | g_red | diag(H_ss) | g_s | cost, 0 ]
-struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[256]; double T1[256]; double red[256]; double camq[kMaxCams * 4]; };
+struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[kMaxCams * 256]; double T1[kMaxCams * 256]; double red[256]; double camq[kMaxCams * 4]; };
 #define VC_STAMP(i) do { if (threadIdx.x == 0) v.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
-__device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
+__device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double* x2_noobs) {
   VC_STAMP(0);
   const int tid = threadIdx.x, D = v.D, C = v.n_cams;
   double* S = v.Sbuf;
@@ -560,6 +560,7 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
     if (e < D * D) S[e] = -t;
     else if (e < D * D + D) gred[e - D * D] = -t;
     else if (e < stride - 2) L.gsum[e - D * D - D] = t;      // (the last two slots: x2 of observation-less frames, chunk cost)
+    else if (e == stride - 2) *x2_noobs = t;                 // same summation order as the tail's own loop
   }
   VC_STAMP(1);
   for (int i = tid; i < D; i += 256) { hd[i] = 0.0; gs[i] = 0.0; }
@@ -581,50 +582,54 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L) {
   VC_STAMP(2);
   // camera blocks H_cc = P^T G P, g_c = P^T G[:, r]   (P: u-columns -> shared columns of the camera).  The inner products
   // run over all 16 columns (the padding of G and P is zero): fully unrolled, all LDS loads of a thread issue together.
+  // Every phase runs over all cameras before the barrier (own P / T1 per camera): two barriers, not three per camera.
   for (int c = 0; c < C; ++c) {
     const int flags = v.cd[c].flags, nk = model_nk(v.cd[c].model);
-    const int nu = 6 + nk, nc = cam_ncols(flags, nk), c0 = v.cd[c].col0;
+    const int nu = 6 + nk, nc = cam_ncols(flags, nk);
     const int nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
+    const int i = tid >> 4, a = tid & 15;     // P[i][a]
+    double R[9];
+    quat_to_R(L.camq + 4 * c, R);
+    double pv = 0.0;
+    if (i < nu && a < nc) {
+      if (a < nrot) { if (i >= 3 && i < 6) pv = -R[3 * (i - 3) + a]; }
+      else if (a < nrot + ntr) { if (i == a - nrot) pv = 1.0; }
+      else { if (i == 6 + (a - nrot - ntr)) pv = 1.0; }
+    }
+    L.P[c * 256 + tid] = pv;
+  }
+  __syncthreads();
+  for (int c = 0; c < C; ++c) {
+    const int nu = 6 + model_nk(v.cd[c].model);
     const double* G = L.gsum + c * kGStride;
-    __syncthreads();
-    {
-      const int i = tid >> 4, a = tid & 15;     // P[i][a]
-      double R[9];
-      quat_to_R(L.camq + 4 * c, R);
-      double pv = 0.0;
-      if (i < nu && a < nc) {
-        if (a < nrot) { if (i >= 3 && i < 6) pv = -R[3 * (i - 3) + a]; }
-        else if (a < nrot + ntr) { if (i == a - nrot) pv = 1.0; }
-        else { if (i == 6 + (a - nrot - ntr)) pv = 1.0; }
-      }
-      L.P[tid] = pv;
+    const double* P = L.P + c * 256;
+    const int i = tid >> 4, a = tid & 15;     // T1[i][a] = sum_k G[i][k] P[k][a]; row 15 := g_c = sum_k P[k][a] G[k][nu]
+    double s = 0.0;
+    if (i == 15) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += P[k * 16 + a] * G[k * 16 + nu];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += G[i * 16 + k] * P[k * 16 + a];
+      if (i >= nu) s = 0.0;
     }
-    __syncthreads();
-    {
-      const int i = tid >> 4, a = tid & 15;     // T1[i][a] = sum_k G[i][k] P[k][a]; row 15 := g_c = sum_k P[k][a] G[k][nu]
+    L.T1[c * 256 + tid] = s;
+  }
+  __syncthreads();
+  for (int c = 0; c < C; ++c) {
+    const int flags = v.cd[c].flags, nk = model_nk(v.cd[c].model);
+    const int nc = cam_ncols(flags, nk), c0 = v.cd[c].col0;
+    const double* P = L.P + c * 256;
+    const double* T1 = L.T1 + c * 256;
+    const int b = tid >> 4, a = tid & 15;     // Hcc[b][a] = sum_i P[i][b] T1[i][a]  (rows i >= nu of P are zero; row 15 of T1 is g_c)
+    if (a < nc && b < nc && a >= b) {
       double s = 0.0;
-      if (i == 15) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s += L.P[k * 16 + a] * G[k * 16 + nu];
-      } else {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += G[i * 16 + k] * L.P[k * 16 + a];
-        if (i >= nu) s = 0.0;
-      }
-      L.T1[tid] = s;
+      for (int i = 0; i < 15; ++i) s += P[i * 16 + b] * T1[i * 16 + a];
+      S[(c0 + b) * D + c0 + a] += s;
+      if (a == b) hd[c0 + a] = s;
     }
-    __syncthreads();
-    {
-      const int b = tid >> 4, a = tid & 15;     // Hcc[b][a] = sum_i P[i][b] T1[i][a]  (rows i >= nu of P are zero; row 15 of T1 is g_c)
-      if (a < nc && b < nc && a >= b) {
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < 15; ++i) s += L.P[i * 16 + b] * L.T1[i * 16 + a];
-        S[(c0 + b) * D + c0 + a] += s;
-        if (a == b) hd[c0 + a] = s;
-      }
-      if (b == 15 && a < nc) { gred[c0 + a] += L.T1[15 * 16 + a]; gs[c0 + a] = L.T1[15 * 16 + a]; }
-    }
+    if (b == 15 && a < nc) { gred[c0 + a] += T1[15 * 16 + a]; gs[c0 + a] = T1[15 * 16 + a]; }
   }
   __syncthreads();
   VC_STAMP(3);
@@ -674,7 +679,7 @@ constexpr int kSmallD = 32;   // above this the workgroup-wide LDS factorisation
 // unrolled to DMAX); the freshly scaled pivot column is exchanged through LDS as one contiguous vector
 // (broadcast reads, no dependent read-modify-write chains).  Lt: DMAX x ldt, x: D.
 template <int DMAX>
-__device__ void solve_small_wave(const DevView& v, const Ctrl* ct, int lane, double* Lt, double* x) {
+__device__ void solve_small_wave(const DevView& v, const Ctrl* ct, int lane, double* Lt, double* x, double pre_sc2, double pre_dg) {
   const int D = v.D;
   constexpr int ldt = DMAX + 2;
   const double* S = v.Sbuf;
@@ -686,32 +691,44 @@ __device__ void solve_small_wave(const DevView& v, const Ctrl* ct, int lane, dou
   double lam = 0.0;
   if (lane < D) {
     double sc2, dg;
-    if (ct->init_scale) { sc2 = jacobi_scale2(hd[lane]); v.sscale2[lane] = sc2; } else sc2 = v.sscale2[lane];
-    if (!ct->reuse_diag) { dg = lm_clamped_diag(hd[lane], sc2); v.sdiag[lane] = dg; } else dg = v.sdiag[lane];
+    // pre_sc2 / pre_dg: v.sscale2[lane] / v.sdiag[lane], requested at kernel entry (only read when they are valid)
+    if (ct->init_scale) { sc2 = jacobi_scale2(hd[lane]); v.sscale2[lane] = sc2; } else sc2 = pre_sc2;
+    if (!ct->reuse_diag) { dg = lm_clamped_diag(hd[lane], sc2); v.sdiag[lane] = dg; } else dg = pre_dg;
     lam = dg / (ct->radius * sc2);
     v.slam[lane] = lam;
+    // the tail's inputs ride along in LDS behind x: damping and g_s of this column
+    x[kSmallD + 1 + lane] = lam;
+    x[2 * (kSmallD + 1) + lane] = hd[D + lane];
   }
 #pragma unroll
   for (int k = 0; k < DMAX; ++k) row[k] += (k == lane) ? lam : 0.0;
   // Every loop below is fully unrolled (j, k compile-time): register indices are static, pivots and pivot columns travel
-  // as scalars through v_readlane -- no LDS round trip and no select chains inside the dependent chain.  Columns >= D
-  // only ever hold zeros (or, for column D, unused values), so the inner loop needs no bound on k.
+  // as scalars through v_readlane -- no LDS round trip and no select chains inside the dependent chain.  The column loop
+  // has no branch and no store (one scheduling region): the trailing updates of column j fill the latency of column
+  // j + 1's reciprocal square root.  Columns >= D only ever hold zeros (or, for column D, unused values): their steps run
+  // on harmless operands (pivot forced to 1) and are not checked, so the loop needs no bound on j or k.
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < DMAX; ++j) {
-    if (j < D) {
-      const double mine = row[j];
-      double d = readlane_f64(mine, j);
-      if (!(d > 0.0)) { bad = true; d = 1.0; }
-      const double ipiv = fast_rsqrt(d);
-      const double lij = (lane == j) ? d * ipiv : mine * ipiv;
-      row[j] = lij;
-      if (lane >= j && lane <= D) Lt[j * ldt + lane] = lij;          // column j of L, contiguous over the rows
+    const double mine = row[j];
+    double d = readlane_f64(mine, j);
+    const bool ok = d > 0.0;
+    bad |= (j < D) & !ok;
+    d = ok ? d : 1.0;
+    const double ipiv = fast_rsqrt(d);
+    const double lij = (lane == j) ? d * ipiv : mine * ipiv;
+    row[j] = lij;
 #pragma unroll
-      for (int k = j + 1; k < DMAX; ++k) row[k] -= lij * readlane_f64(lij, k);
-    }
+    for (int k = j + 1; k < DMAX; ++k) row[k] -= lij * readlane_f64(lij, k);
   }
   if (bad && lane == 0) v.flags[5 + 2 * v.par] = 1;
+  // column j of L, contiguous over the rows (entries above the diagonal / beyond row D are never read; lanes past the
+  // padded row length all write the last padding slot)
+  {
+    const int slot = lane < ldt - 1 ? lane : ldt - 1;
+#pragma unroll
+    for (int j = 0; j < DMAX; ++j) Lt[j * ldt + slot] = row[j];
+  }
   // delta_s = -L^-T y.  Lt row i is column i of L: L[j][i] for j >= i, and y_i = L[D][i] at index D.
   wave_lds_sync();
   double c[DMAX];
@@ -869,15 +886,16 @@ __device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M,
   }
 }
 
-__device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dyn, double* red /* 6 x 256 */, const double* s_cam) {
+__device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dyn, double* red /* 6 x 256 */, const double* s_cam,
+                                    double pre_sc2, double pre_dg, const double* x2_noobs) {
   const int tid = threadIdx.x, D = v.D, cur = ct->cur;
   double* x;
   VC_STAMP(4);
   if (D <= kSmallD) {
     x = dyn + (kSmallD + 1) * (kSmallD + 2);
     if (tid < 64 && D > 0) {
-      if (D <= 16) solve_small_wave<16>(v, ct, tid, dyn, x);
-      else solve_small_wave<32>(v, ct, tid, dyn, x);
+      if (D <= 16) solve_small_wave<16>(v, ct, tid, dyn, x, pre_sc2, pre_dg);
+      else solve_small_wave<32>(v, ct, tid, dyn, x, pre_sc2, pre_dg);
     }
     __syncthreads();
   } else {
@@ -885,15 +903,22 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
     solve_large_blocked(v, ct, dyn, x);
   }
   VC_STAMP(5);
-  const double* gs = v.Sbuf + (size_t)D * D + 2 * D;
+  const bool small = D <= kSmallD;      // the one-wavefront solve left damping and g_s in LDS behind x
+  const double* gs = small ? x + 2 * (kSmallD + 1) : v.Sbuf + (size_t)D * D + 2 * D;
+  const double* lamv = small ? x + (kSmallD + 1) : v.slam;
   double gd = 0, dld = 0, step2 = 0, x2 = 0, g2 = 0, gmax = 0;
   for (int i = tid; i < D; i += 256) {
     const double d = x[i], g = gs[i];
     v.delta_s[i] = d;
-    gd += g * d; dld += v.slam[i] * d * d; g2 += g * g; gmax = fmax(gmax, fabs(g));
+    gd += g * d; dld += lamv[i] * d * d; g2 += g * g; gmax = fmax(gmax, fabs(g));
   }
-  for (int i = tid; i < v.n_cams * kCamStride; i += 256) v.cams[1 - cur][i] = s_cam[i];
-  __syncthreads();
+  // D <= 64: every term lives in wavefront 0 (the IMU parameters move to its lane 63) -- no staging through LDS, no barriers
+  const bool one_wave = D <= 64;
+  if (one_wave) { if (tid < 64) for (int i = tid; i < v.n_cams * kCamStride; i += 64) v.cams[1 - cur][i] = s_cam[i]; }
+  else {
+    for (int i = tid; i < v.n_cams * kCamStride; i += 256) v.cams[1 - cur][i] = s_cam[i];
+    __syncthreads();
+  }
   if (tid < v.n_cams) {
     const int c = tid;
     const double* cin = s_cam + (size_t)c * kCamStride;
@@ -915,7 +940,7 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
       for (int i = 0; i < nk; ++i) { const double d = x[cc + i], o = cin[kCamK + i]; step2 += d * d; x2 += o * o; cout[kCamK + i] = o + d; }
     }
   }
-  if (v.imu_on && tid == 64) {     // g(2) b(6) sf(6) toff(1): plain additive parameters
+  if (v.imu_on && tid == (one_wave ? 63 : 64)) {     // g(2) b(6) sf(6) toff(1): plain additive parameters
     const double* iin = v.imus[cur];
     double* iout = v.imus[1 - cur];
     for (int a = 0; a < 16; ++a) iout[a] = iin[a];
@@ -924,33 +949,47 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
       if (col >= 0) { const double d = x[col], o = iin[a]; step2 += d * d; x2 += o * o; iout[a] = o + d; }
     }
   }
-  // only threads < max(D, 65) hold terms: stage them, one wavefront adds them in fixed order
-  red[tid] = gd; red[256 + tid] = dld; red[512 + tid] = step2; red[768 + tid] = x2; red[1024 + tid] = g2; red[1280 + tid] = gmax;
-  __syncthreads();
-  if (tid < 64) {
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+  double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;      // totals, valid in thread 0
+  if (one_wave) {
+    if (tid < 64) {
+      const double in6[6] = {gd, dld, step2, x2, g2, 0.0};
+      double out6[6];
+      wave_sum6(in6, out6, tid);
+      t0 = out6[0]; t1 = out6[1]; t2 = out6[2]; t3 = out6[3]; t4 = out6[4]; t5 = gmax;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = tid + 64 * q;
-      a0 += red[i]; a1 += red[256 + i]; a2 += red[512 + i]; a3 += red[768 + i]; a4 += red[1024 + i]; a5 = fmax(a5, red[1280 + i]);
+      for (int o = 32; o > 0; o >>= 1) t5 = fmax(t5, __shfl_down(t5, o, 64));
     }
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3); a4 = wave_sum(a4);
+  } else {
+    // only threads < max(D, 65) hold terms: stage them, one wavefront adds them in fixed order
+    red[tid] = gd; red[256 + tid] = dld; red[512 + tid] = step2; red[768 + tid] = x2; red[1024 + tid] = g2; red[1280 + tid] = gmax;
+    __syncthreads();
+    if (tid < 64) {
+      double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a5 = fmax(a5, __shfl_down(a5, o, 64));
-    if (tid == 0) { red[0] = a0; red[256] = a1; red[512] = a2; red[768] = a3; red[1024] = a4; red[1280] = a5; }
+      for (int q = 0; q < 4; ++q) {
+        const int i = tid + 64 * q;
+        a0 += red[i]; a1 += red[256 + i]; a2 += red[512 + i]; a3 += red[768 + i]; a4 += red[1024 + i]; a5 = fmax(a5, red[1280 + i]);
+      }
+      t0 = wave_sum(a0); t1 = wave_sum(a1); t2 = wave_sum(a2); t3 = wave_sum(a3); t4 = wave_sum(a4); t5 = a5;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t5 = fmax(t5, __shfl_down(t5, o, 64));
+    }
   }
-  __syncthreads();
   VC_STAMP(6);
   if (tid == 0) {
     double* h = v.scal + kNumScal;
-    h[kScGd] = red[0]; h[kScDld] = red[256]; h[kScStep2] = red[512]; h[kScX2] = red[768]; h[kScG2] = red[1024];
-    h[kScCost] = 0.0; h[kScGmax] = red[1280]; h[kScSq] = 0.0;
+    h[kScGd] = t0; h[kScDld] = t1; h[kScStep2] = t2; h[kScX2] = t3; h[kScG2] = t4;
+    h[kScCost] = 0.0; h[kScGmax] = t5; h[kScSq] = 0.0;
     if (v.merged) {
       // frames without observations take no part in k_trial: their parameter norm (chunk sums in the Schur partials) is
       // added here; then flag the record (a trial point is about to exist) and clear the failure flags of the next pass
-      const int stride = v.part_stride, nslab = (v.n_chunks + kSlab - 1) / kSlab;
+      // (x2_noobs: that sum, left in LDS by phase A when it ran in this launch)
       double x2 = 0.0;
-      for (int k = 0; k < nslab; ++k) x2 += v.part_total[(size_t)k * stride + stride - 2];
+      if (x2_noobs) x2 = *x2_noobs;
+      else {
+        const int stride = v.part_stride, nslab = (v.n_chunks + kSlab - 1) / kSlab;
+        for (int k = 0; k < nslab; ++k) x2 += v.part_total[(size_t)k * stride + stride - 2];
+      }
       h[kScX2] += x2;
       v.ctrl->needs_decision = 1;
       v.flags[4 + 2 * (1 - v.par)] = 0; v.flags[5 + 2 * (1 - v.par)] = 0;
@@ -964,11 +1003,16 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   extern __shared__ __attribute__((aligned(16))) double dyn[];   // phase A: FinalLds; phase B: the matrix (the phases do not overlap)
   __shared__ double red[6 * 256];
   __shared__ double s_cam[kMaxCams * kCamStride];     // accepted camera records: requested at kernel entry, used by the tail
+  __shared__ double s_x2;
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
-  if (mode != 1) for (int i = threadIdx.x; i < v.n_cams * kCamStride; i += 256) s_cam[i] = v.cams[ct->cur][i];
-  if (mode != 2) { schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn)); __syncthreads(); }
-  if (mode != 1) reduced_solve_phase(v, ct, dyn, red, s_cam);
+  double pre_sc2 = 1.0, pre_dg = 1.0;      // damping inputs of the small solve: requested now, consumed after phase A
+  if (mode != 1) {
+    for (int i = threadIdx.x; i < v.n_cams * kCamStride; i += 256) s_cam[i] = v.cams[ct->cur][i];
+    if (v.D <= kSmallD && (int)threadIdx.x < v.D) { pre_sc2 = v.sscale2[threadIdx.x]; pre_dg = v.sdiag[threadIdx.x]; }
+  }
+  if (mode != 2) { schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2); __syncthreads(); }
+  if (mode != 1) reduced_solve_phase(v, ct, dyn, red, s_cam, pre_sc2, pre_dg, mode == 0 ? &s_x2 : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------ trial point
@@ -1394,7 +1438,7 @@ void launch_frame_schur(const DevView& v, hipStream_t s) {
   launch_part_sum(v, s);
 }
 static inline size_t reduced_lds(const DevView& v) {
-  const size_t solve = v.D <= kSmallD ? ((size_t)(kSmallD + 1) * (kSmallD + 2) + kSmallD + 1) * sizeof(double)
+  const size_t solve = v.D <= kSmallD ? ((size_t)(kSmallD + 1) * (kSmallD + 2) + 3 * (kSmallD + 1)) * sizeof(double)
                                       : ((size_t)(v.D + 1) * (v.D + 2) / 2 + 3 * (v.D + 1) + 256 + 16 + 256) * sizeof(double);
   return std::max(solve, sizeof(FinalLds));
 }
