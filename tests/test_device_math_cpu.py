@@ -101,7 +101,9 @@ def test_tile_gram_algebra_matches_oracle_normal_equations(models, fix_k):
 def test_manifold_updates_match_oracle_plus():
     H = hh(); L = ol.lib()
     rng = np.random.default_rng(3)
-    for sc in [1e-12, 1e-6, 1e-2, 0.7]:
+    # scales chosen to land on every branch: series / closed form of V (|w|^2 = 0.5), polynomial / closed form of the
+    # quaternion exponential (|w|^2 = 2.4), and the neighbourhoods of both switch points
+    for sc in [1e-12, 1e-6, 1e-2, 0.7] + [0.35, 0.41, 0.45, 0.85, 0.9, 1.0, 1.6] * 8:
         T = synth.se3_from_Rt(synth.so3_exp_matrix(rng.normal(size=3)), rng.normal(size=3))
         dl = rng.normal(size=6) * sc
         a = np.zeros(7); b = np.zeros(7)

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void k_part_sum(DevView v) {
 // Sbuf = [ S = H_ss - sum Y^T Y (full symmetric, undamped) | g_red | diag(H_ss) | g_s | cost, 0 ]
 struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[kMaxCams * 256]; double T1[kMaxCams * 256]; double red[256]; double camq[kMaxCams * 4]; };
 #define VC_STAMP(i) do { if (threadIdx.x == 0) v.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
-__device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double* x2_noobs) {
+__device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */) {
   VC_STAMP(0);
   const int tid = threadIdx.x, D = v.D, C = v.n_cams;
   double* S = v.Sbuf;
@@ -584,7 +584,7 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double
   // run over all 16 columns (the padding of G and P is zero): fully unrolled, all LDS loads of a thread issue together.
   // Every phase runs over all cameras before the barrier (own P / T1 per camera): two barriers, not three per camera.
   for (int c = 0; c < C; ++c) {
-    const int flags = v.cd[c].flags, nk = model_nk(v.cd[c].model);
+    const int flags = cd[c].flags, nk = model_nk(cd[c].model);
     const int nu = 6 + nk, nc = cam_ncols(flags, nk);
     const int nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
     const int i = tid >> 4, a = tid & 15;     // P[i][a]
@@ -600,7 +600,7 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double
   }
   __syncthreads();
   for (int c = 0; c < C; ++c) {
-    const int nu = 6 + model_nk(v.cd[c].model);
+    const int nu = 6 + model_nk(cd[c].model);
     const double* G = L.gsum + c * kGStride;
     const double* P = L.P + c * 256;
     const int i = tid >> 4, a = tid & 15;     // T1[i][a] = sum_k G[i][k] P[k][a]; row 15 := g_c = sum_k P[k][a] G[k][nu]
@@ -617,8 +617,8 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double
   }
   __syncthreads();
   for (int c = 0; c < C; ++c) {
-    const int flags = v.cd[c].flags, nk = model_nk(v.cd[c].model);
-    const int nc = cam_ncols(flags, nk), c0 = v.cd[c].col0;
+    const int flags = cd[c].flags, nk = model_nk(cd[c].model);
+    const int nc = cam_ncols(flags, nk), c0 = cd[c].col0;
     const double* P = L.P + c * 256;
     const double* T1 = L.T1 + c * 256;
     const int b = tid >> 4, a = tid & 15;     // Hcc[b][a] = sum_i P[i][b] T1[i][a]  (rows i >= nu of P are zero; row 15 of T1 is g_c)
@@ -887,7 +887,7 @@ __device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M,
 }
 
 __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dyn, double* red /* 6 x 256 */, const double* s_cam,
-                                    double pre_sc2, double pre_dg, const double* x2_noobs) {
+                                    double pre_sc2, double pre_dg, const double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */) {
   const int tid = threadIdx.x, D = v.D, cur = ct->cur;
   double* x;
   VC_STAMP(4);
@@ -923,8 +923,8 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
     const int c = tid;
     const double* cin = s_cam + (size_t)c * kCamStride;
     double* cout = v.cams[1 - cur] + (size_t)c * kCamStride;
-    const int flags = v.cd[c].flags, nk = model_nk(v.cd[c].model);
-    int cc = v.cd[c].col0;
+    const int flags = cd[c].flags, nk = model_nk(cd[c].model);
+    int cc = cd[c].col0;
     if (flags & kCamRotFree) {
       double q[4], w[3] = {x[cc], x[cc + 1], x[cc + 2]}, qi[4] = {cin[0], cin[1], cin[2], cin[3]};
       so3_plus(qi, w, q);
@@ -1004,15 +1004,17 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   __shared__ double red[6 * 256];
   __shared__ double s_cam[kMaxCams * kCamStride];     // accepted camera records: requested at kernel entry, used by the tail
   __shared__ double s_x2;
+  __shared__ CamDesc s_cd[kMaxCams];     // the kernel-argument table costs a scalar memory round trip per (dynamically indexed) access
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
+  if (threadIdx.x < kMaxCams) s_cd[threadIdx.x] = v.cd[threadIdx.x];
   double pre_sc2 = 1.0, pre_dg = 1.0;      // damping inputs of the small solve: requested now, consumed after phase A
   if (mode != 1) {
     for (int i = threadIdx.x; i < v.n_cams * kCamStride; i += 256) s_cam[i] = v.cams[ct->cur][i];
     if (v.D <= kSmallD && (int)threadIdx.x < v.D) { pre_sc2 = v.sscale2[threadIdx.x]; pre_dg = v.sdiag[threadIdx.x]; }
   }
-  if (mode != 2) { schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2); __syncthreads(); }
-  if (mode != 1) reduced_solve_phase(v, ct, dyn, red, s_cam, pre_sc2, pre_dg, mode == 0 ? &s_x2 : nullptr);
+  if (mode != 2) { schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2, s_cd); __syncthreads(); }
+  if (mode != 1) reduced_solve_phase(v, ct, dyn, red, s_cam, pre_sc2, pre_dg, mode == 0 ? &s_x2 : nullptr, s_cd);
 }
 
 // ------------------------------------------------------------------------------------------ trial point

@@ -58,16 +58,36 @@ VC_HD void quat_rotate(const double* q, const double* v, double* o) {
   const double rz = v[2] + q[3] * uz + (q[0] * uy - q[1] * ux);
   o[0] = rx; o[1] = ry; o[2] = rz;
 }
+// 1/sqrt(d) to full double precision: hardware estimate (v_rsq_f64) + two Newton steps on the device
+// (replaces an IEEE sqrt + an IEEE divide, ~70 dependent instructions, on the factorisation's critical path)
+VC_HD double fast_rsqrt(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * (1.5 - 0.5 * d * y * y);
+  y = y * (1.5 - 0.5 * d * y * y);
+  return y;
+#else
+  return 1.0 / sqrt(d);
+#endif
+}
+// exp of a rotation vector as a unit quaternion [sin(th/2) w/th, cos(th/2)].  For th/2 <= pi/4 both factors are
+// polynomials in z = th^2/4 (the fdlibm kernel forms sin h = h + h^3 S(z), cos h = 1 - z/2 + z^2 C(z), < 1 ulp): no square
+// root, no division, no library call and no special case at th -> 0 -- LM steps practically never leave this range, and
+// the math library's sin / cos / IEEE divide are ~1k cycles of a single lane's time on the GPU.  Larger angles take the
+// closed form.
 VC_HD void so3_exp(const double* w, double* q) {
   const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-  const double th = sqrt(th2);
   double imag, real;
-  if (th < kSophusEps) {
-    const double th4 = th2 * th2;
-    imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
-    real = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
+  if (th2 <= 2.4) {
+    const double z = 0.25 * th2;
+    const double S = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                     z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double Cc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    imag = 0.5 + 0.5 * z * S;                     // sin(th/2) / th
+    real = (1.0 - 0.5 * z) + z * z * Cc;
   } else {
-    const double half = 0.5 * th;
+    const double th = sqrt(th2), half = 0.5 * th;
     imag = sin(half) / th;
     real = cos(half);
   }
@@ -78,28 +98,31 @@ VC_HD void so3_plus(const double* q, const double* w, double* o) {
   double e[4], r[4];
   so3_exp(w, e);
   quat_mul(q, e, r);
-  const double n = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
-  o[0] = r[0] / n; o[1] = r[1] / n; o[2] = r[2] / n; o[3] = r[3] / n;
+  const double in = fast_rsqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+  o[0] = r[0] * in; o[1] = r[1] * in; o[2] = r[2] * in; o[3] = r[3] * in;
 }
-// T <- T * exp([v, w]) (LocalParamSe3::Plus, local-param-se3.h:14-26)
+// T <- T * exp([v, w]) (LocalParamSe3::Plus, local-param-se3.h:14-26).  V = I + a [w]x + b [w]x^2 with
+// a = (1 - cos th) / th^2, b = (th - sin th) / th^3: their Taylor series in t = th^2 below t = 0.5 (truncation < 1e-16; the
+// closed forms cancel there anyway), the closed forms above.
 VC_HD void se3_plus(const double* T, const double* d, double* o) {
   const double* w = d + 3;
-  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-  const double th = sqrt(th2);
-  double e[4];
-  so3_exp(w, e);
-  double V[9];
-  if (th < kSophusEps) {
-    quat_to_R(e, V);
+  const double t = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double a, b;
+  if (t < 0.5) {
+    a = 1.0 / 2 + t * (-1.0 / 24 + t * (1.0 / 720 + t * (-1.0 / 40320 + t * (1.0 / 3628800 + t * (-1.0 / 479001600 +
+        t * (1.0 / 87178291200.0 + t * (-1.0 / 20922789888000.0)))))));
+    b = 1.0 / 6 + t * (-1.0 / 120 + t * (1.0 / 5040 + t * (-1.0 / 362880 + t * (1.0 / 39916800 + t * (-1.0 / 6227020800.0 +
+        t * (1.0 / 1307674368000.0 + t * (-1.0 / 355687428096000.0)))))));
   } else {
-    const double a = (1.0 - cos(th)) / th2;
-    const double b = (th - sin(th)) / (th2 * th);
-    // V = I + a [w]x + b [w]x^2
-    const double wx = w[0], wy = w[1], wz = w[2];
-    V[0] = 1.0 + b * (-(wy * wy + wz * wz)); V[1] = -a * wz + b * (wx * wy); V[2] = a * wy + b * (wx * wz);
-    V[3] = a * wz + b * (wx * wy); V[4] = 1.0 + b * (-(wx * wx + wz * wz)); V[5] = -a * wx + b * (wy * wz);
-    V[6] = -a * wy + b * (wx * wz); V[7] = a * wx + b * (wy * wz); V[8] = 1.0 + b * (-(wx * wx + wy * wy));
+    const double th = sqrt(t);
+    a = (1.0 - cos(th)) / t;
+    b = (th - sin(th)) / (t * th);
   }
+  const double wx = w[0], wy = w[1], wz = w[2];
+  double V[9];
+  V[0] = 1.0 + b * (-(wy * wy + wz * wz)); V[1] = -a * wz + b * (wx * wy); V[2] = a * wy + b * (wx * wz);
+  V[3] = a * wz + b * (wx * wy); V[4] = 1.0 + b * (-(wx * wx + wz * wz)); V[5] = -a * wx + b * (wy * wz);
+  V[6] = -a * wy + b * (wx * wz); V[7] = a * wx + b * (wy * wz); V[8] = 1.0 + b * (-(wx * wx + wy * wy));
   const double tv[3] = {V[0] * d[0] + V[1] * d[1] + V[2] * d[2], V[3] * d[0] + V[4] * d[1] + V[5] * d[2],
                         V[6] * d[0] + V[7] * d[1] + V[8] * d[2]};
   double rt[3];
@@ -382,18 +405,6 @@ VC_HD void cam_block_from_gsum(const double* G, const double* Rck, int nk, int f
   }
 }
 
-// 1/sqrt(d) to full double precision: hardware estimate (v_rsq_f64) + two Newton steps on the device
-// (replaces an IEEE sqrt + an IEEE divide, ~70 dependent instructions, on the factorisation's critical path)
-VC_HD double fast_rsqrt(double d) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  double y = __builtin_amdgcn_rsq(d);
-  y = y * (1.5 - 0.5 * d * y * y);
-  y = y * (1.5 - 0.5 * d * y * y);
-  return y;
-#else
-  return 1.0 / sqrt(d);
-#endif
-}
 // N x N in-place lower Cholesky (row-major); returns false if not positive definite.
 template <int N>
 VC_HD bool chol_small(double* M, double* dinv = nullptr) {   // dinv[j] = 1 / L[j][j] (optional)
