@@ -1,3 +1,4 @@
+# needs a profiling build: bash vicalib_amd/csrc/build.sh -DVC_REDUCED_STAMPS (and -DVC_JAC_STAMPS for the sweep stamps)
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vicalib_amd import synth
 from vicalib_amd.lib import ViCalibrator

@@ -296,8 +296,11 @@ template <int MAXC, int MAXP, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   __shared__ Ctrl s_ctrl;
+  __shared__ CamDesc s_cd[kMaxCams];     // LDS copy of the kernel-argument table (dynamically indexed below)
+  if (threadIdx.x < kMaxCams) s_cd[threadIdx.x] = v.cd[threadIdx.x];
   const Ctrl* ct = v.ctrl;
   if (v.merged) { merged_control(v, &s_ctrl, sh, blockIdx.x == 0); ct = &s_ctrl; }
+  else __syncthreads();
   if (ct->done) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int C = v.n_cams, D = v.D;
@@ -328,6 +331,14 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
     const int t0 = (f < f1) ? v.frame_tile_off[f] : 0;
     const int nt = (f < f1) ? v.frame_tile_off[f + 1] - t0 : 0;
     if (lane < nt) csum += v.tile_costb[cur][t0 + lane];
+    // requested once per frame, ahead of their use: the camera of every tile (lane t) and the frame's damping inputs
+    const int my_cam = (lane < nt) ? v.tile_cam[t0 + lane] : 0;
+    double pre_sc2[6], pre_dg[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      pre_sc2[i] = (nt > 0 && !init_scale) ? v.fscale2[(size_t)f * 6 + i] : 1.0;
+      pre_dg[i] = (nt > 0 && reuse) ? v.fdiag[(size_t)f * 6 + i] : 1.0;
+    }
     if (f < f1 && nt == 0 && lane == 0) {     // frame without observations: nothing to eliminate, keeps its pose
       const double* p = v.poses[cur] + (size_t)f * kPoseStride;
       double x2 = 0;
@@ -344,7 +355,7 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
         for (int q = 0; q < 4; ++q) val[q] = v.Gb[cur][(size_t)(t0 + t) * kGStride + q * 64 + lane];
 #pragma unroll
         for (int q = 0; q < 4; ++q) Gw[t * kGStride + q * 64 + lane] = val[q];
-        const int c = v.tile_cam[t0 + t];      // wave-uniform: scalar branch, one camera's accumulators touched
+        const int c = __builtin_amdgcn_readlane(my_cam, t);      // wave-uniform: scalar branch, one camera's accumulators touched
 #pragma unroll
         for (int k = 0; k < MAXC; ++k)
           if (k == c) {
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
       double hval = 0.0;
       if (lane < 42) {
         for (int t = 0; t < nt; ++t) {
-          const int c = v.tile_cam[t0 + t];
+          const int c = __builtin_amdgcn_readlane(my_cam, t);
           double Rm[9];
           quat_to_R(cams + (size_t)c * kCamStride, Rm);
           const double* g = Gw + t * kGStride;
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
             hval += (a == b) ? s : -s;
           } else {
             const int i = lane - 36, a = i / 3, ii = i % 3;
-            const int rc = 6 + model_nk(v.cd[c].model);
+            const int rc = 6 + model_nk(s_cd[c].model);
             double s = 0.0;
 #pragma unroll
             for (int p = 0; p < 3; ++p) s += Rm[3 * p + ii] * g[(3 * a + p) * 16 + rc];
@@ -390,9 +401,9 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
         const double hd = H[i * 6 + i];
         double sc2, dg;
         if (init_scale) { sc2 = jacobi_scale2(hd); if (lane == 0) v.fscale2[(size_t)f * 6 + i] = sc2; }
-        else sc2 = v.fscale2[(size_t)f * 6 + i];
+        else sc2 = pre_sc2[i];
         if (!reuse) { dg = lm_clamped_diag(hd, sc2); if (lane == 0) v.fdiag[(size_t)f * 6 + i] = dg; }
-        else dg = v.fdiag[(size_t)f * 6 + i];
+        else dg = pre_dg[i];
         lam[i] = dg / (radius * sc2);
         H[i * 6 + i] = hd + lam[i];
       }
@@ -420,8 +431,8 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
       }
       for (int idx = lane; idx < nt * 16; idx += 64) {      // Y columns: lane -> (tile, column)
         const int t = idx >> 4, j = idx & 15;
-        const int c = v.tile_cam[t0 + t];
-        const int flags = v.cd[c].flags, nk = model_nk(v.cd[c].model);
+        const int c = __shfl(my_cam, t, 64);
+        const int flags = s_cd[c].flags, nk = model_nk(s_cd[c].model);
         const int nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
         const int nc = nrot + ntr + ((flags & kCamKFree) ? nk : 0);
         double w[6] = {0, 0, 0, 0, 0, 0};
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
             w[3 + i] = Rm[i] * u[3] + Rm[3 + i] * u[4] + Rm[6 + i] * u[5];
           }
           fwd_solve_inv<6>(H, dinv, w);
-          const int col = v.cd[c].col0 + j;
+          const int col = s_cd[c].col0 + j;
 #pragma unroll
           for (int r = 0; r < 6; ++r) R[(wave * 6 + r) * ld + col] = w[r];
         }
@@ -540,7 +551,13 @@ __global__ __launch_bounds__(256) void k_part_sum(DevView v) {
 // Phase A of the reduced system (one workgroup):
 // Sbuf = [ S = H_ss - sum Y^T Y (full symmetric, undamped) | g_red | diag(H_ss) | g_s | cost, 0 ]
 struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[kMaxCams * 256]; double T1[kMaxCams * 256]; double red[256]; double camq[kMaxCams * 4]; };
+// shader-clock stamps of k_reduced's phases (tools/dbg_stamps.py): profiling builds only (-DVC_REDUCED_STAMPS) -- each stamp is
+// a global store whose acknowledgement the next barrier waits for (~1.5k cycles apiece)
+#ifdef VC_REDUCED_STAMPS
 #define VC_STAMP(i) do { if (threadIdx.x == 0) v.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define VC_STAMP(i) do { } while (0)
+#endif
 __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */) {
   VC_STAMP(0);
   const int tid = threadIdx.x, D = v.D, C = v.n_cams;
