@@ -160,6 +160,7 @@ struct vc_calibrator {
   DevView dv{};
   int cur = 0;
   DBuf<double2> d_uv; DBuf<unsigned short> d_pt; DBuf<double> d_points;
+  DBuf<TileHdr> d_tile_hdr;
   DBuf<int> d_tile_frame, d_tile_cam, d_tile_off, d_frame_tile_off, d_frame_cam_tile, d_cam_model, d_cam_flags, d_cam_col0,
       d_col_cam, d_col_local, d_flags;
   DBuf<double> d_wgpart;
@@ -329,6 +330,22 @@ struct vc_calibrator {
     if (((size_t)(D + 1) * (D + 2) / 2 + 3 * (D + 1) + 528) * sizeof(double) + 13 * 1024 > 160 * 1024 || D + 1 > 12 * 16) return VC_ERR_UNSUPPORTED;
     for (int c = 0; c < C; ++c) cam_model[c] = cams[c].model;
     // ---- upload ---------------------------------------------------------------------------------
+    {   // tile headers: depend on the tile layout and on this stage's column layout
+      std::vector<TileHdr> hdr((size_t)T);
+      for (int t = 0; t < T; ++t) {
+        TileHdr& h = hdr[(size_t)t];
+        const int f = h_tile_frame[t];
+        h.frame = f; h.cam = h_tile_cam[t]; h.t0 = frame_tile_off[f]; h.nt = frame_tile_off[f + 1] - frame_tile_off[f];
+        h.off = h_tile_off[t]; h.cnt = h_tile_off[t + 1] - h_tile_off[t]; h.model = cams[h.cam].model; h.pad = 0;
+        h.col0 = 0; h.ncols = 0;
+        for (int k = 0; k < h.nt && k < kMaxCams; ++k) {
+          const int c = h_tile_cam[h.t0 + k];
+          h.col0 |= (unsigned long long)(cam_col0[c] & 0xff) << (8 * k);
+          h.ncols |= (unsigned long long)(cam_ncols(cam_flags[c], cams[c].nk) & 0xff) << (8 * k);
+        }
+      }
+      HIP_OK(d_tile_hdr.upload(hdr, stream));
+    }
     HIP_OK(d_frame_tile_off.upload(frame_tile_off, stream));
     HIP_OK(d_frame_cam_tile.upload(frame_cam_tile, stream)); HIP_OK(d_cam_model.upload(cam_model, stream));
     HIP_OK(d_cam_flags.upload(cam_flags, stream)); HIP_OK(d_cam_col0.upload(cam_col0, stream));
@@ -370,6 +387,7 @@ struct vc_calibrator {
     dv.n_frames = N; dv.n_cams = C; dv.n_tiles = T; dv.n_points = n_points_dev; dv.D = D;
     dv.n_chunks = n_chunks; dv.chunk_frames = chunk_frames; dv.n_obs = (long long)n_active;
     dv.obs_uv = d_uv.p; dv.obs_pt = d_pt.p; dv.points = d_points.p;
+    dv.tile_hdr = d_tile_hdr.p;
     dv.tile_frame = d_tile_frame.p; dv.tile_cam = d_tile_cam.p; dv.tile_off = d_tile_off.p;
     dv.frame_tile_off = d_frame_tile_off.p; dv.frame_cam_tile = d_frame_cam_tile.p;
     dv.cam_model = d_cam_model.p; dv.cam_flags = d_cam_flags.p; dv.cam_col0 = d_cam_col0.p;

@@ -45,6 +45,10 @@ struct Ctrl {
 
 // per-camera descriptor, carried in the kernel arguments (scalar loads, no dependent global look-ups)
 struct CamDesc { int model, flags, col0, ncols; };
+// Everything a wavefront of k_trial needs to start on its tile, in one 48-byte record: one load instead of a chain of
+// dependent ones (tile -> frame -> the frame's tiles -> their cameras -> their reduced-system columns).  col0 / ncols: one
+// byte per tile of the frame (at most kMaxCams tiles per frame, at most 191 reduced columns).
+struct TileHdr { int frame, cam, t0, nt, off, cnt, model, pad; unsigned long long col0, ncols; };
 
 struct DevView {
   CamDesc cd[kMaxCams];
@@ -53,6 +57,7 @@ struct DevView {
   const double2* obs_uv;
   const unsigned short* obs_pt;
   const double* points;            // n_points x 3
+  const TileHdr* tile_hdr;         // n_tiles
   const int* tile_frame;
   const int* tile_cam;
   const int* tile_off;             // n_tiles + 1

@@ -44,11 +44,11 @@ __device__ void merged_control(const DevView& v, Ctrl* out, double* red, bool wr
 //   otherwise  : 3 instructions -- B = A rotated by 0, 1, 2 blocks: diagonal, (0,1)(1,2)(2,3)(3,0), (0,2)(1,3)(2,0)(3,1)
 template <int MODEL>
 __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* pose, const double* cam, double mult, int tile, int lane,
-                                                double* wl, double* G) {
+                                                double* wl, double* G, int off_in, int cnt_in /* corner range if known (cnt_in >= 0) */) {
   constexpr int nk = MODEL == kFov ? 5 : MODEL == kPoly2 ? 6 : MODEL == kPoly3 ? 7 : MODEL == kKb4 ? 8 : 4;
   constexpr bool kThreeCols = (7 + nk) <= 12;
-  const int off = __builtin_amdgcn_readfirstlane(v.tile_off[tile]);
-  const int cnt = __builtin_amdgcn_readfirstlane(v.tile_off[tile + 1]) - off;
+  const int off = cnt_in >= 0 ? off_in : __builtin_amdgcn_readfirstlane(v.tile_off[tile]);
+  const int cnt = cnt_in >= 0 ? cnt_in : __builtin_amdgcn_readfirstlane(v.tile_off[tile + 1]) - off;
   const int b = (lane >> 2) & 3, i4 = lane & 3;
   // column-block patterns of the three operand reads
   const int xa = b;
@@ -166,13 +166,13 @@ __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* 
   return wave_sum(cost);          // valid in lane 0
 }
 __device__ __forceinline__ double jac_tile_dispatch(const DevView& v, int model, const double* pose, const double* cam, double mult, int tile,
-                                                    int lane, double* wl, double* G) {
+                                                    int lane, double* wl, double* G, int off = 0, int cnt = -1) {
   switch (model) {   // wave-uniform
-    case kFov: return jac_tile_body<kFov>(v, pose, cam, mult, tile, lane, wl, G);
-    case kPoly2: return jac_tile_body<kPoly2>(v, pose, cam, mult, tile, lane, wl, G);
-    case kPoly3: return jac_tile_body<kPoly3>(v, pose, cam, mult, tile, lane, wl, G);
-    case kKb4: return jac_tile_body<kKb4>(v, pose, cam, mult, tile, lane, wl, G);
-    default: return jac_tile_body<kLinear>(v, pose, cam, mult, tile, lane, wl, G);
+    case kFov: return jac_tile_body<kFov>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
+    case kPoly2: return jac_tile_body<kPoly2>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
+    case kPoly3: return jac_tile_body<kPoly3>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
+    case kKb4: return jac_tile_body<kKb4>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
+    default: return jac_tile_body<kLinear>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
   }
 }
 
@@ -1042,8 +1042,8 @@ __device__ void final_phase(const DevView& v, int mode, double* red /* 7 x 256 *
 // Back-substitution of one frame: delta_p = -L^-T (z + sum_tiles Y delta_s) (lanes = (tile, column), six-value butterfly),
 // T_trial = T exp(delta_p).  With `publish` lane 0 stores the trial pose and the frame's step terms (fpart).
 __device__ __forceinline__ void backsub_frame(const DevView& v, int cur, int f, int lane, const double* ds_s, double* Tout, bool publish,
-                                              double* wsum) {
-  const int t0 = v.frame_tile_off[f], nt = v.frame_tile_off[f + 1] - t0;
+                                              double* wsum, const TileHdr* hdr = nullptr /* k_trial: the tile's header (registers) */) {
+  const int t0 = hdr ? hdr->t0 : v.frame_tile_off[f], nt = hdr ? hdr->nt : v.frame_tile_off[f + 1] - t0;
   const double* fr = v.fr + (size_t)f * kFrStride;
   const double* pin = v.poses[cur] + (size_t)f * kPoseStride;
   double Lr[21], zr[6], di[6], Tin[7];
@@ -1057,12 +1057,27 @@ __device__ __forceinline__ void backsub_frame(const DevView& v, int cur, int f, 
   const bool small_d = v.D <= kMaxCams * 16 + 16;
   for (int idx = lane; idx < nt * 16; idx += 64) {
     const int t = idx >> 4, j = idx & 15;
-    const CamDesc cd = v.cd[v.tile_cam[t0 + t]];
-    if (j < cd.ncols) {
-      const double dj = small_d ? ds_s[cd.col0 + j] : v.delta_s[cd.col0 + j];
+    if (hdr) {
+      // columns and widths of the frame's tiles come with the header: the Y loads depend on nothing but t0 and go out
+      // together with the frame record (Y's padding columns are zero and take a zero step)
+      const int col0 = (int)((hdr->col0 >> (8 * t)) & 0xff), nc = (int)((hdr->ncols >> (8 * t)) & 0xff);
       const double* Yt = v.Y + (size_t)(t0 + t) * kYStride + j;
+      double yv[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) y[k] += Yt[k * kUCols] * dj;
+      for (int k = 0; k < 6; ++k) yv[k] = Yt[k * kUCols];
+      const int col = (j < nc) ? col0 + j : 0;
+      double dj = small_d ? ds_s[col] : v.delta_s[col];
+      dj = (j < nc) ? dj : 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) y[k] += yv[k] * dj;
+    } else {
+      const CamDesc cd = v.cd[v.tile_cam[t0 + t]];
+      if (j < cd.ncols) {
+        const double dj = small_d ? ds_s[cd.col0 + j] : v.delta_s[cd.col0 + j];
+        const double* Yt = v.Y + (size_t)(t0 + t) * kYStride + j;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) y[k] += Yt[k * kUCols] * dj;
+      }
     }
   }
   double L[36];
@@ -1117,10 +1132,16 @@ __global__ __launch_bounds__(256) void k_backsub(DevView v) {
 template <bool FUSED>
 __device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int tile, int wave, int lane, const double* ds_s, double* lds_rows,
                                            double* wsum /* kNumScal, lane 0: this wave's step scalars */) {
+  // the tile's header: one (wave-uniform) record instead of the chain tile -> frame -> frame's tiles -> cameras -> columns
+  TileHdr h = v.tile_hdr[tile];
+  h.frame = __builtin_amdgcn_readfirstlane(h.frame); h.cam = __builtin_amdgcn_readfirstlane(h.cam);
+  h.t0 = __builtin_amdgcn_readfirstlane(h.t0); h.nt = __builtin_amdgcn_readfirstlane(h.nt);
+  h.off = __builtin_amdgcn_readfirstlane(h.off); h.cnt = __builtin_amdgcn_readfirstlane(h.cnt);
+  h.model = __builtin_amdgcn_readfirstlane(h.model);
   const int cur = ct->cur;
   const double mult = ct->mult;
-  const int f = v.tile_frame[tile], c = v.tile_cam[tile];
-  const int t0 = v.frame_tile_off[f];
+  const int f = h.frame, c = h.cam;
+  const int t0 = h.t0;
   const double* cam = v.cams[1 - cur] + (size_t)c * kCamStride;
   double camr[16];
 #pragma unroll
@@ -1136,14 +1157,14 @@ __device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int
       wsum[kScGmax] = o[kScGmax];
     }
   } else {
-    backsub_frame(v, cur, f, lane, ds_s, Tout, tile == t0, wsum);
+    backsub_frame(v, cur, f, lane, ds_s, Tout, tile == t0, wsum, &h);
   }
   double cost, sq = 0.0;
   if (FUSED) {
     // Jacobian sweep at the trial point: its cost is the trial cost, its Gram block is the next linearisation if the
     // step is accepted (k_final flips `cur`); a rejected step leaves Gb[cur] untouched
-    cost = jac_tile_dispatch(v, v.cd[c].model, Tout, camr, mult, tile, lane, lds_rows + wave * 64 * kDotStride,
-                             v.Gb[1 - cur] + (size_t)tile * kGStride);
+    cost = jac_tile_dispatch(v, h.model, Tout, camr, mult, tile, lane, lds_rows + wave * 64 * kDotStride,
+                             v.Gb[1 - cur] + (size_t)tile * kGStride, h.off, h.cnt);
     if (lane == 0) v.tile_costb[1 - cur][tile] = cost;
   } else {
     TileXf x;
@@ -1151,7 +1172,7 @@ __device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int
     double K[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) K[i] = camr[kCamK + i];
-    res_tile_dispatch(v, v.cd[c].model, x, K, v.tile_off[tile], v.tile_off[tile + 1] - v.tile_off[tile], lane, mult, &cost, &sq);
+    res_tile_dispatch(v, h.model, x, K, h.off, h.cnt, lane, mult, &cost, &sq);
   }
   if (lane == 0) {
     v.tile_trial[2 * tile] = cost;
