@@ -21,8 +21,8 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-# HBM bytes per launch at the default workload, measured with rocprofv3 --pmc (profiles/r01_v9_pmc_traffic_cfg2.txt)
-PMC_TRAFFIC = {"k_trial": 5893291.0, "k_reproj_res": 3336960.0}
+# HBM bytes per launch at the default workload, measured with rocprofv3 --pmc (profiles/r01_v10_pmc_traffic_cfg2.txt)
+PMC_TRAFFIC = {"k_trial": 6035060.0, "k_reproj_res": 3344207.0}
 
 
 def main():
@@ -122,7 +122,7 @@ def main():
     flops_jac = 1050.0 * n_obs_local          # ~1.0-1.1 kflop per corner (fp64)
     ach = flops_jac / (trial_ms * 1e-3) / 1e12
     # traffic: HBM bytes per launch from rocprofv3 PMC passes on this exact workload (FETCH_SIZE and WRITE_SIZE in
-    # separate runs, KB -> bytes, FETCH x2 per the gfx950 note in MI355X_MICROARCH.md): profiles/r01_v9_pmc_traffic_cfg2.txt
+    # separate runs, KB -> bytes, FETCH x2 per the gfx950 note in MI355X_MICROARCH.md): profiles/r01_v10_pmc_traffic_cfg2.txt
     base_cfg = (args.frames == 500 and world == 1)
     traffic_trial = PMC_TRAFFIC.get("k_trial") if base_cfg else None
     traffic_res = PMC_TRAFFIC.get("k_reproj_res") if base_cfg else None
