@@ -1130,19 +1130,17 @@ __global__ __launch_bounds__(256) void k_backsub(DevView v) {
   backsub_frame(v, ct->cur, f, lane, ds_s, Tout, true, nullptr);
 }
 template <bool FUSED>
-__device__ __forceinline__ void trial_tile(const DevView& v, const Ctrl* ct, int tile, int wave, int lane, const double* ds_s, double* lds_rows,
+__device__ __forceinline__ void trial_tile(const DevView& v, int cur, double mult, TileHdr h, const double* cams_trial /* LDS */, int tile, int wave,
+                                           int lane, const double* ds_s, double* lds_rows,
                                            double* wsum /* kNumScal, lane 0: this wave's step scalars */) {
   // the tile's header: one (wave-uniform) record instead of the chain tile -> frame -> frame's tiles -> cameras -> columns
-  TileHdr h = v.tile_hdr[tile];
   h.frame = __builtin_amdgcn_readfirstlane(h.frame); h.cam = __builtin_amdgcn_readfirstlane(h.cam);
   h.t0 = __builtin_amdgcn_readfirstlane(h.t0); h.nt = __builtin_amdgcn_readfirstlane(h.nt);
   h.off = __builtin_amdgcn_readfirstlane(h.off); h.cnt = __builtin_amdgcn_readfirstlane(h.cnt);
   h.model = __builtin_amdgcn_readfirstlane(h.model);
-  const int cur = ct->cur;
-  const double mult = ct->mult;
   const int f = h.frame, c = h.cam;
   const int t0 = h.t0;
-  const double* cam = v.cams[1 - cur] + (size_t)c * kCamStride;
+  const double* cam = cams_trial + (size_t)c * kCamStride;
   double camr[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) camr[i] = cam[i];
@@ -1187,16 +1185,27 @@ template <bool FUSED>
 __global__ __launch_bounds__(256, 2) void k_trial(DevView v) {
   extern __shared__ __attribute__((aligned(16))) double lds_rows[];   // fused Jacobian sweep: 4 x 64 x kDotStride row images
   __shared__ double ds_s[kMaxCams * 16 + 16];     // delta_s of the workgroup's cameras is read many times: keep it in LDS
-  const Ctrl* ct = v.ctrl;
-  if (ct->done) return;
+  __shared__ double s_cams[2 * kMaxCams * kCamStride];   // both camera buffers: requested before the control record says which is the trial one
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
+  // everything that depends on nothing is requested first -- the tile's header, the shared step, the camera records --
+  // then the control record; one memory latency instead of four in a row
+  TileHdr h = v.tile_hdr[tile < v.n_tiles ? tile : 0];
   for (int i = threadIdx.x; i < v.D; i += 256) if (i < kMaxCams * 16 + 16) ds_s[i] = v.delta_s[i];
+  for (int i = threadIdx.x; i < 2 * v.n_cams * kCamStride; i += 256) {
+    const int b = i >= v.n_cams * kCamStride, o = i - b * v.n_cams * kCamStride;
+    const double* src = b ? v.cams[1] : v.cams[0];
+    s_cams[b * kMaxCams * kCamStride + o] = src[o];
+  }
+  const Ctrl* ct = v.ctrl;
+  const int cur = ct->cur;
+  const double mult = ct->mult;
+  if (ct->done) return;
   __syncthreads();
   double wsum[kNumScal];
 #pragma unroll
   for (int k = 0; k < kNumScal; ++k) wsum[k] = 0.0;
-  if (tile < v.n_tiles) trial_tile<FUSED>(v, ct, tile, wave, lane, ds_s, lds_rows, wsum);
+  if (tile < v.n_tiles) trial_tile<FUSED>(v, cur, mult, h, s_cams + (1 - cur) * kMaxCams * kCamStride, tile, wave, lane, ds_s, lds_rows, wsum);
   if (v.merged) {      // the workgroup's step scalars in one record: the next pass's decision reads n_tiles / 4 of these
     __shared__ double s_w[4 * kNumScal];
     if (lane == 0) {
