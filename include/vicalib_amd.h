@@ -32,7 +32,9 @@ enum {
   VC_ERR_TIME_ORDER = -4,     /* IMU timestamps not strictly increasing (vicalibrator.h:373-378) */
   VC_ERR_TOO_MANY_POINTS = -5,/* more than 32768 distinct target points */
   VC_ERR_NUMERIC = -6,        /* factorisation failed repeatedly */
-  VC_ERR_UNSUPPORTED = -7     /* feature of the reference not available in this build */
+  VC_ERR_UNSUPPORTED = -7,    /* feature of the reference not available in this build */
+  VC_ERR_NO_CONVERGENCE = -8  /* one stage's problem ended NO_CONVERGENCE 64 times in a row (the reference would keep
+                                 cranking, vicalibrator.h:952); state and multiplicities are left as they were */
 };
 
 /* -models strings of vicalib-engine.cc:203-253, in this order */
@@ -61,6 +63,11 @@ int vc_pnp_planar(int model, const double* params, int nparams, int n, const dou
 /* AddObservation(frame, cam, p_w, p_c, time) :385-468, in bulk: n corners of one (frame, camera) */
 int vc_add_observations(vc_calibrator* h, int frame, int camera, int n, const double* p_w /* n x 3 */,
                         const double* p_c /* n x 2 */);
+/* The same over many (frame, camera) groups in one call, target points by index: group t holds corners
+ * [tile_off[t], tile_off[t+1]) of point_id / p_c; points is the caller's table of target points (n_points x 3). */
+int vc_add_observation_tiles(vc_calibrator* h, int n_tiles, const int* tile_frame, const int* tile_cam,
+                             const long long* tile_off /* n_tiles + 1 */, const double* points, int n_points,
+                             const int* point_id, const double* p_c /* x 2 */);
 /* AddImuMeasurements(gyro, accel, time) :370-380, in bulk */
 int vc_add_imu(vc_calibrator* h, int n, const double* gyro /* n x 3 */, const double* accel /* n x 3 */,
                const double* time /* n */);
@@ -82,6 +89,14 @@ int vc_set_remove_outliers(vc_calibrator* h, int remove_outliers, double outlier
 /* Start() :263 / IsRunning() :314 / Stop() :317; vc_solve = Start() + join (blocking SolveThread :919) */
 int vc_solve(vc_calibrator* h);
 int vc_start(vc_calibrator* h);
+/* is_finished_ is sticky until Clear() as in the reference (:246, :922): Start()/Solve() on a finished calibrator return at
+ * once.  vc_resume clears the flag (engine-level, no reference counterpart) so that the next Solve() runs SetupProblem +
+ * the solve loop again from the current state (re-adding every block once more, as any pass of the outer loop does). */
+int vc_resume(vc_calibrator* h);
+/* Bench / test hook: Solve() runs the first n stages of the schedule (:977-1000), sets up stage n + 1 (constancy flags,
+ * block multiplicities, gravity) and returns without running it; n < 0 (default) = the whole schedule.  With the state
+ * left there, vc_prepare + vc_run_iterations time LM iterations of exactly that stage. */
+int vc_set_stage_limit(vc_calibrator* h, int n);
 int vc_is_running(vc_calibrator* h);
 int vc_stop(vc_calibrator* h);
 

@@ -33,6 +33,13 @@ struct VicalibFrame {          // vicalibrator.h:76-97
   double time = 0;
 };
 
+// The reference CHECK-aborts on misuse (bad index, setter while running, :333-:391); the wrapper throws instead of
+// dropping the status code.
+inline int vc_checked(int rc, const char* what) {
+  if (rc < 0) throw std::runtime_error(std::string("vicalib_amd: ") + what + " failed (status " + std::to_string(rc) + ")");
+  return rc;
+}
+
 class ViCalibrator {
  public:
   explicit ViCalibrator(int device = 0) {
@@ -43,42 +50,42 @@ class ViCalibrator {
   ViCalibrator(const ViCalibrator&) = delete;
   ViCalibrator& operator=(const ViCalibrator&) = delete;
 
-  void Clear() { vc_clear(h_); }                                                         // :232
+  void Clear() { vc_checked(vc_clear(h_), "Clear"); }                                                         // :232
   int AddCamera(const CameraAndPose& c) {                                               // :332
-    return vc_add_camera(h_, c.model, c.params.data(), (int)c.params.size(), c.width, c.height, c.T_ck.data());
+    return vc_checked(vc_add_camera(h_, c.model, c.params.data(), (int)c.params.size(), c.width, c.height, c.T_ck.data()), "AddCamera");
   }
-  void FixCameraIntrinsics(bool should_fix = true) { vc_fix_camera_intrinsics(h_, should_fix); }   // :346
-  int AddFrame(const Se3& t_wk, double time) { return vc_add_frame(h_, t_wk.data(), time); }        // :355
-  void SetFramePose(int frame, const Se3& t_wk) { vc_set_frame_pose(h_, frame, t_wk.data()); }      // GetFrame(id)->t_wp_ = ...
+  void FixCameraIntrinsics(bool should_fix = true) { vc_checked(vc_fix_camera_intrinsics(h_, should_fix), "FixCameraIntrinsics"); }   // :346
+  int AddFrame(const Se3& t_wk, double time) { return vc_checked(vc_add_frame(h_, t_wk.data(), time), "AddFrame"); }        // :355
+  void SetFramePose(int frame, const Se3& t_wk) { vc_checked(vc_set_frame_pose(h_, frame, t_wk.data()), "SetFramePose"); }      // GetFrame(id)->t_wp_ = ...
   // AddObservation(frame, cam, p_w, p_c, time) :385 -- and its bulk form
   void AddObservation(size_t frame, size_t cam, const double p_w[3], const double p_c[2], double /*time*/) {
-    vc_add_observations(h_, (int)frame, (int)cam, 1, p_w, p_c);
+    vc_checked(vc_add_observations(h_, (int)frame, (int)cam, 1, p_w, p_c), "AddObservation");
   }
   void AddObservations(size_t frame, size_t cam, int n, const double* p_w, const double* p_c) {
-    vc_add_observations(h_, (int)frame, (int)cam, n, p_w, p_c);
+    vc_checked(vc_add_observations(h_, (int)frame, (int)cam, n, p_w, p_c), "AddObservations");
   }
   bool AddImuMeasurements(const double gyro[3], const double accel[3], double time) {    // :370
     return vc_add_imu(h_, 1, gyro, accel, &time) == VC_OK;
   }
   int AddImuMeasurements(int n, const double* gyro, const double* accel, const double* time) { return vc_add_imu(h_, n, gyro, accel, time); }
-  int InitFramePosesPnP() { int n = 0; vc_init_frame_poses_pnp(h_, &n); return n; }      // vicalib-task.cc:335-348
+  int InitFramePosesPnP() { int n = 0; vc_checked(vc_init_frame_poses_pnp(h_, &n), "InitFramePosesPnP"); return n; }      // vicalib-task.cc:335-348
 
   void SetOptimizationFlags(bool bias_active, bool inertial_active, bool rotation_only, bool optimize_imu_time_offset) {   // :252
-    vc_set_optimization_flags(h_, bias_active, inertial_active, rotation_only, optimize_imu_time_offset);
+    vc_checked(vc_set_optimization_flags(h_, bias_active, inertial_active, rotation_only, optimize_imu_time_offset), "SetOptimizationFlags");
   }
-  void SetFunctionTolerance(double t) { vc_set_function_tolerance(h_, t); }              // :277
-  void SetSigmas(double gyro_sigma, double accel_sigma) { vc_set_sigmas(h_, gyro_sigma, accel_sigma); }   // :290
-  void SetTimeOffset(double t) { vc_set_time_offset(h_, t); }                            // :296
-  void SetBiases(const double b[6]) { vc_set_biases(h_, b); }                            // :301
-  void SetScaleFactor(const double s[6]) { vc_set_scale_factor(h_, s); }                 // :308
+  void SetFunctionTolerance(double t) { vc_checked(vc_set_function_tolerance(h_, t), "SetFunctionTolerance"); }              // :277
+  void SetSigmas(double gyro_sigma, double accel_sigma) { vc_checked(vc_set_sigmas(h_, gyro_sigma, accel_sigma), "SetSigmas"); }   // :290
+  void SetTimeOffset(double t) { vc_checked(vc_set_time_offset(h_, t), "SetTimeOffset"); }                            // :296
+  void SetBiases(const double b[6]) { vc_checked(vc_set_biases(h_, b), "SetBiases"); }                            // :301
+  void SetScaleFactor(const double s[6]) { vc_checked(vc_set_scale_factor(h_, s), "SetScaleFactor"); }                 // :308
   // gflags the reference reads inside the class
-  void SetMaxIters(int n) { vc_set_max_iters(h_, n); }
-  void SetCalibrateImu(bool b) { vc_set_calibrate_imu(h_, b); }
-  void SetRemoveOutliers(bool b, double threshold) { vc_set_remove_outliers(h_, b, threshold); }
+  void SetMaxIters(int n) { vc_checked(vc_set_max_iters(h_, n), "SetMaxIters"); }
+  void SetCalibrateImu(bool b) { vc_checked(vc_set_calibrate_imu(h_, b), "SetCalibrateImu"); }
+  void SetRemoveOutliers(bool b, double threshold) { vc_checked(vc_set_remove_outliers(h_, b, threshold), "SetRemoveOutliers"); }
 
-  void Start() { vc_start(h_); }                                                         // :263
+  void Start() { vc_checked(vc_start(h_), "Start"); }                                                         // :263
   bool IsRunning() { return vc_is_running(h_) > 0; }                                     // :314
-  void Stop() { vc_stop(h_); }                                                           // :317
+  void Stop() { vc_checked(vc_stop(h_), "Stop"); }                                                           // :317
   int Solve() { return vc_solve(h_); }                                                   // Start() + join
 
   size_t NumFrames() { return (size_t)vc_num_frames(h_); }                               // :471
@@ -103,7 +110,7 @@ class ViCalibrator {
     if (vc_get_frame(h_, (int)id, f.t_wp_.data(), f.v_w_.data(), &f.time) != VC_OK) throw std::out_of_range("GetFrame");
     return f;
   }
-  void WriteCameraModels(const std::string& filename) { vc_write_camera_models(h_, filename.c_str()); }   // :208
+  void WriteCameraModels(const std::string& filename) { vc_checked(vc_write_camera_models(h_, filename.c_str()), "WriteCameraModels"); }   // :208
   // GetSolutionCovariance(problem) :802-857: row-major n x n over the blocks named by covariance_names
   std::vector<double> GetSolutionCovariance(int* n_out = nullptr) {
     const int n = vc_solution_covariance_dim(h_);

@@ -166,7 +166,10 @@ def test_full_size_properties_cfg2_scale():
     _, T1 = cal.GetCamera(1)
     np.testing.assert_allclose(np.linalg.norm(T1[4:]), 0.06, rtol=2e-2)
     K0 = cal.GetCamera(0)[0].copy()
-    cal.Solve()      # second solve from the optimum moves nothing (idempotence)
+    cal.Solve()      # is_finished_ is sticky (vicalibrator.h:922): returns at once
+    assert len(cal.trace()) == len(tr)
+    cal.Resume(); cal.Solve()      # second solve from the optimum moves nothing (idempotence)
+    assert len(cal.trace()) > len(tr)
     np.testing.assert_allclose(cal.GetCamera(0)[0], K0, rtol=1e-7)
 
 

@@ -120,5 +120,5 @@ def test_handle_reuse_clear_and_reconfigure():
     cal.Solve()
     np.testing.assert_array_equal(cal.GetCamera(0)[0], k1)                 # untouched
     assert cal.GetCameraProjRMSE()[0] < 0.15
-    cal.SetFunctionTolerance(1e-12); cal.Solve()                           # tighter tolerance: a few more iterations, same optimum
+    cal.SetFunctionTolerance(1e-12); cal.Resume(); cal.Solve()                           # tighter tolerance: a few more iterations, same optimum
     assert cal.GetCameraProjRMSE()[0] < 0.15

@@ -53,6 +53,13 @@ template <class T> struct DBuf {
   }
 };
 
+// a fixed set of timing events, destroyed on every exit path
+template <int N> struct EventSet {
+  hipEvent_t e[N] = {};
+  bool create() { for (int i = 0; i < N; ++i) if (hipEventCreate(&e[i]) != hipSuccess) return false; return true; }
+  ~EventSet() { for (int i = 0; i < N; ++i) if (e[i]) (void)hipEventDestroy(e[i]); }
+};
+
 struct HostCam { int model, nk, width, height; double K[10]; double T_ck[7]; };
 struct HostFrame { double T[7]; double v[3]; double time; };
 struct IterRecord { int iteration; double cost, cost_change, gmax, gnorm, step_norm, rho, radius; int accepted, stage; };
@@ -68,6 +75,38 @@ struct PointHash {
     uint64_t h = 0x9E3779B97F4A7C15ull;
     for (int i = 0; i < 3; ++i) { h ^= b[i] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); h *= 0xBF58476D1CE4E5B9ull; }
     return (size_t)h;
+  }
+};
+
+// Distinct target points in the order they were first seen: open-addressing table over the bit pattern of (x, y, z).
+struct PointTable {
+  std::vector<double> xyz;          // 3 per point
+  std::vector<int> slot;            // power-of-two sized, -1 = empty
+  int size() const { return (int)(xyz.size() / 3); }
+  void clear() { xyz.clear(); slot.clear(); }
+  void grow() {
+    const size_t cap = slot.empty() ? 1024 : slot.size() * 2;
+    slot.assign(cap, -1);
+    for (int i = 0; i < size(); ++i) {
+      const PointKey k{xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+      size_t h = PointHash()(k) & (cap - 1);
+      while (slot[h] >= 0) h = (h + 1) & (cap - 1);
+      slot[h] = i;
+    }
+  }
+  int intern(const double* p) {
+    if ((size_t)size() * 2 >= slot.size()) grow();
+    const PointKey k{p[0], p[1], p[2]};
+    const size_t mask = slot.size() - 1;
+    size_t h = PointHash()(k) & mask;
+    while (slot[h] >= 0) {
+      const double* q = &xyz[3 * (size_t)slot[h]];
+      if (std::memcmp(q, p, 24) == 0) return slot[h];
+      h = (h + 1) & mask;
+    }
+    slot[h] = size();
+    xyz.insert(xyz.end(), p, p + 3);
+    return slot[h];
   }
 };
 
@@ -114,8 +153,9 @@ struct vc_calibrator {
   // ---- problem (host copy) ---------------------------------------------------------------
   std::vector<HostCam> cams;
   std::vector<HostFrame> frames;
-  std::vector<int> o_frame, o_cam;
-  std::vector<double> o_pw, o_pc;
+  std::vector<int> o_frame, o_cam, o_pid;     // o_pid: index into the table of distinct target points
+  std::vector<double> o_pc;
+  PointTable pts;                             // exact-bit de-duplication of the p_w the caller passes, done once at AddObservation
   std::vector<signed char> o_removed;       // RemoveOutliers: 1 = no copy left (dropped), 2 = one copy fewer than vis_mult (kObsOneLess)
   long n_one_less = 0;
   bool obs_dirty = true;          // the observation set (or its multiplicity bits) changed since the tile layout was built
@@ -278,12 +318,16 @@ struct vc_calibrator {
       const size_t n_all = o_frame.size();
       std::vector<int> idx; idx.reserve(n_all);
       for (size_t i = 0; i < n_all; ++i) if (o_removed[i] != 1) idx.push_back((int)i);
-      std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+      bool in_order = true;             // the usual caller adds frame by frame, camera by camera: nothing to sort then
+      for (size_t k = 1; k < idx.size() && in_order; ++k) {
+        const int a = idx[k - 1], b = idx[k];
+        in_order = o_frame[a] != o_frame[b] ? o_frame[a] < o_frame[b] : o_cam[a] <= o_cam[b];
+      }
+      if (!in_order) std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
         return o_frame[a] != o_frame[b] ? o_frame[a] < o_frame[b] : o_cam[a] < o_cam[b]; });
       h_obs_index = idx;
       h_tile_frame.clear(); h_tile_cam.clear(); h_tile_off.clear();
-      std::unordered_map<PointKey, int, PointHash> pmap;
-      std::vector<double> points;
+      if (pts.size() > kObsPointMask + 1) return VC_ERR_TOO_MANY_POINTS;
       std::vector<double2> uv(idx.size());
       std::vector<unsigned short> pt(idx.size());
       n_one_less = 0;
@@ -292,22 +336,13 @@ struct vc_calibrator {
         if (k == 0 || o_frame[i] != o_frame[idx[k - 1]] || o_cam[i] != o_cam[idx[k - 1]]) {
           h_tile_frame.push_back(o_frame[i]); h_tile_cam.push_back(o_cam[i]); h_tile_off.push_back((int)k);
         }
-        PointKey key{o_pw[3 * (size_t)i], o_pw[3 * (size_t)i + 1], o_pw[3 * (size_t)i + 2]};
-        auto it = pmap.find(key);
-        int id;
-        if (it == pmap.end()) {
-          id = (int)pmap.size();
-          if (id >= kObsPointMask + 1) return VC_ERR_TOO_MANY_POINTS;
-          pmap.emplace(key, id);
-          points.push_back(key.x); points.push_back(key.y); points.push_back(key.z);
-        } else id = it->second;
-        pt[k] = (unsigned short)(id | (o_removed[i] == 2 ? kObsOneLess : 0));
+        pt[k] = (unsigned short)(o_pid[i] | (o_removed[i] == 2 ? kObsOneLess : 0));
         if (o_removed[i] == 2) ++n_one_less;
         uv[k] = make_double2(o_pc[2 * (size_t)i], o_pc[2 * (size_t)i + 1]);
       }
       h_tile_off.push_back((int)idx.size());
-      n_points_dev = (int)pmap.size();
-      HIP_OK(d_uv.upload(uv, stream)); HIP_OK(d_pt.upload(pt, stream)); HIP_OK(d_points.upload(points, stream));
+      n_points_dev = pts.size();
+      HIP_OK(d_uv.upload(uv, stream)); HIP_OK(d_pt.upload(pt, stream)); HIP_OK(d_points.upload(pts.xyz, stream));
       HIP_OK(d_tile_frame.upload(h_tile_frame, stream)); HIP_OK(d_tile_cam.upload(h_tile_cam, stream));
       HIP_OK(d_tile_off.upload(h_tile_off, stream));
       HIP_OK(d_mask.alloc(std::max<size_t>(idx.size(), 1)));
@@ -630,6 +665,13 @@ struct vc_calibrator {
       HIP_OK(hipMemcpyAsync(&pin->down, ctrl_result(), sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
       HIP_OK(hipMemcpyAsync(pin->trace, d_trace.p, trace_bytes, hipMemcpyDeviceToHost, stream));
       HIP_OK(hipStreamSynchronize(stream));
+      // Stop() is a collective decision when the frames are sharded: a rank that left its enqueue loop alone would leave
+      // its peers waiting in the next all-reduce (every rank runs the same batch schedule, so the counts line up)
+      if (sharded()) {
+        std::vector<double> v = {should_run ? 0.0 : 1.0};
+        int rc = host_allreduce_sum(v); if (rc) return rc;
+        if (v[0] > 0.0) should_run = false;
+      }
       if (pin->down.done || !should_run || ++guard > max_iters + 8) break;
       batch = 2;
     }
@@ -639,10 +681,13 @@ struct vc_calibrator {
     std::vector<double> rows((size_t)std::max(n, 1) * kTraceCols);
     if (n <= 64) std::memcpy(rows.data(), pin->trace, (size_t)n * kTraceCols * 8);
     else HIP_OK(hipMemcpy(rows.data(), d_trace.p, (size_t)n * kTraceCols * 8, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; ++i) {
-      const double* r = &rows[(size_t)i * kTraceCols];
-      IterRecord rec = {(int)r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], (int)r[8], (int)r[9]};
-      trace.push_back(rec);
+    {
+      std::lock_guard<std::mutex> lk(result_mutex);
+      for (int i = 0; i < n; ++i) {
+        const double* r = &rows[(size_t)i * kTraceCols];
+        IterRecord rec = {(int)r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], (int)r[8], (int)r[9]};
+        trace.push_back(rec);
+      }
     }
     cur = c.cur;
     num_iterations += (unsigned)c.num_callbacks;
@@ -743,22 +788,32 @@ struct vc_calibrator {
       int rc = host_allreduce_sum(v); if (rc) return rc;
       g[0] = v[0]; g[1] = v[1];
     } else if (!(N > 0 && n > 0)) return VC_OK;
-    g_dir[0] = g[0]; g_dir[1] = g[1];
+    { std::lock_guard<std::mutex> lk(result_mutex); g_dir[0] = g[0]; g_dir[1] = g[1]; }
     return VC_OK;
   }
 
   // SolveThread, vicalibrator.h:919-1040
+  static constexpr int kMaxRepeats = 64;
+  int stage_limit = -1;
   int solve() {
-    is_finished = false;
-    int status = VC_OK, guard = 0;
-    while (should_run && !is_finished && guard++ < 64) {
+    // the worker thread of Start() (and any caller's thread) starts on device 0: bind this calibrator's device first
+    HIP_OK(hipSetDevice(device));
+    // is_finished_ is sticky until Clear() (vicalibrator.h:246, :922): a finished calibrator's Start()/Solve() returns at once
+    int status = VC_OK;
+    int stages_done = 0;
+    while (should_run && !is_finished) {
       if (is_visual_active) vis_mult += 1;                      // SetupProblem re-adds every block (:641-649)
       if (calibrate_imu && is_inertial_active) imu_mult += 1;   // :651-655
       if (is_inertial_active && !rotation_only && !gravity_initialized) { status = init_gravity(); if (status) break; }   // :927-949
       device_dirty = true;                                      // constancy flags may have changed
+      if (stage_limit >= 0 && stages_done++ >= stage_limit) break;   // bench / test hook: the next stage is set up, not run
       bool stage_done = false;
       int inner = 0;
-      while (!stage_done && should_run && !is_finished && inner++ < 64) {
+      // "Crank optimization" (:952): the same problem is solved again while Ceres reports NO_CONVERGENCE.  The reference
+      // loops without bound; here a run of kMaxRepeats unconverged solves returns VC_ERR_NO_CONVERGENCE with the
+      // multiplicities untouched (the outer loop is NOT re-entered, which would re-add every block).
+      while (!stage_done && should_run && !is_finished) {
+        if (inner++ >= kMaxRepeats) { status = VC_ERR_NO_CONVERGENCE; break; }
         if (o_frame.empty()) { is_finished = true; break; }
         Termination t; double fc = 0; long nr = 1;
         status = solve_once(&t, &fc, &nr); if (status) break;
@@ -811,7 +866,7 @@ void vc_destroy(vc_calibrator* h) { delete h; }
 int vc_clear(vc_calibrator* h) {
   if (!h) return VC_ERR_BAD_ARG;
   h->stop();
-  h->cams.clear(); h->frames.clear(); h->o_frame.clear(); h->o_cam.clear(); h->o_pw.clear(); h->o_pc.clear(); h->o_removed.clear();
+  h->cams.clear(); h->frames.clear(); h->o_frame.clear(); h->o_cam.clear(); h->o_pid.clear(); h->pts.clear(); h->o_pc.clear(); h->o_removed.clear();
   h->mse = 0; h->num_iterations = 0; h->is_bias_active = false; h->is_scale_active = false; h->is_inertial_active = false;
   h->is_visual_active = true; h->rotation_only = true; h->is_finished = false; h->gravity_initialized = false;
   h->outliers_removed = false; h->vis_mult = 0; h->imu_mult = 0; h->wsqrt_frames = 0; h->imu_w.clear(); h->imu_a.clear(); h->imu_t.clear(); h->imu_end_time = -1.0; h->trace.clear(); h->stage = 0; h->device_dirty = true; h->obs_dirty = true;
@@ -865,7 +920,7 @@ int vc_init_frame_poses_pnp(vc_calibrator* h, int* n_initialised) {
       if (c != 0 && cam0_good) break;           // `ii == 0 || !tracking_good_[0]` (vicalib-task.cc:341)
       pw.resize(3 * ids.size()); pc.resize(2 * ids.size());
       for (size_t k = 0; k < ids.size(); ++k) {
-        std::memcpy(&pw[3 * k], &h->o_pw[3 * (size_t)ids[k]], 24); std::memcpy(&pc[2 * k], &h->o_pc[2 * (size_t)ids[k]], 16);
+        std::memcpy(&pw[3 * k], &h->pts.xyz[3 * (size_t)h->o_pid[ids[k]]], 24); std::memcpy(&pc[2 * k], &h->o_pc[2 * (size_t)ids[k]], 16);
       }
       const HostCam& cm = h->cams[c];
       double T_cw[7], rms;
@@ -893,8 +948,33 @@ int vc_add_observations(vc_calibrator* h, int frame, int camera, int n, const do
   if (n < 0 || (n > 0 && (!p_w || !p_c))) return VC_ERR_BAD_ARG;
   if (frame < 0 || frame >= (int)h->frames.size() || camera < 0 || camera >= (int)h->cams.size()) return VC_ERR_BAD_ARG;
   h->o_frame.insert(h->o_frame.end(), n, frame); h->o_cam.insert(h->o_cam.end(), n, camera);
-  h->o_pw.insert(h->o_pw.end(), p_w, p_w + 3 * (size_t)n); h->o_pc.insert(h->o_pc.end(), p_c, p_c + 2 * (size_t)n);
+  for (int i = 0; i < n; ++i) h->o_pid.push_back(h->pts.intern(p_w + 3 * (size_t)i));
+  h->o_pc.insert(h->o_pc.end(), p_c, p_c + 2 * (size_t)n);
   h->o_removed.insert(h->o_removed.end(), n, 0); h->device_dirty = true; h->obs_dirty = true;
+  return VC_OK;
+}
+int vc_add_observation_tiles(vc_calibrator* h, int n_tiles, const int* tile_frame, const int* tile_cam, const long long* tile_off,
+                             const double* points, int n_points, const int* point_id, const double* p_c) {
+  NOT_RUNNING(h);
+  if (n_tiles < 0 || (n_tiles > 0 && (!tile_frame || !tile_cam || !tile_off || !points || !point_id || !p_c)) || n_points < 0) return VC_ERR_BAD_ARG;
+  const int N = (int)h->frames.size(), C = (int)h->cams.size();
+  for (int t = 0; t < n_tiles; ++t)
+    if (tile_frame[t] < 0 || tile_frame[t] >= N || tile_cam[t] < 0 || tile_cam[t] >= C || tile_off[t + 1] < tile_off[t]) return VC_ERR_BAD_ARG;
+  if (n_tiles == 0) return VC_OK;
+  const long long n0 = tile_off[0], n1 = tile_off[n_tiles];
+  if ((long long)h->o_frame.size() + (n1 - n0) > 0x7fffffffLL) return VC_ERR_UNSUPPORTED;
+  for (long long i = n0; i < n1; ++i) if (point_id[i] < 0 || point_id[i] >= n_points) return VC_ERR_BAD_ARG;
+  std::vector<int> remap((size_t)n_points);
+  for (int i = 0; i < n_points; ++i) remap[i] = h->pts.intern(points + 3 * (size_t)i);
+  const size_t add = (size_t)(n1 - n0), base = h->o_frame.size();
+  h->o_frame.resize(base + add); h->o_cam.resize(base + add); h->o_pid.resize(base + add);
+  for (int t = 0; t < n_tiles; ++t)
+    for (long long i = tile_off[t]; i < tile_off[t + 1]; ++i) {
+      const size_t k = base + (size_t)(i - n0);
+      h->o_frame[k] = tile_frame[t]; h->o_cam[k] = tile_cam[t]; h->o_pid[k] = remap[point_id[i]];
+    }
+  h->o_pc.insert(h->o_pc.end(), p_c + 2 * n0, p_c + 2 * n1);
+  h->o_removed.insert(h->o_removed.end(), add, 0); h->device_dirty = true; h->obs_dirty = true;
   return VC_OK;
 }
 int vc_add_imu(vc_calibrator* h, int n, const double* gyro, const double* accel, const double* time) {
@@ -905,12 +985,13 @@ int vc_add_imu(vc_calibrator* h, int n, const double* gyro, const double* accel,
     h->imu_w.insert(h->imu_w.end(), gyro + 3 * i, gyro + 3 * i + 3); h->imu_a.insert(h->imu_a.end(), accel + 3 * i, accel + 3 * i + 3);
     h->imu_t.push_back(time[i]); h->imu_end_time = time[i];
   }
+  h->device_dirty = true;
   return VC_OK;
 }
-int vc_set_sigmas(vc_calibrator* h, double g, double a) { NOT_RUNNING(h); h->gyro_sigma = g; h->accel_sigma = a; return VC_OK; }
-int vc_set_biases(vc_calibrator* h, const double b[6]) { NOT_RUNNING(h); if (!b) return VC_ERR_BAD_ARG; std::memcpy(h->biases, b, 48); return VC_OK; }
-int vc_set_scale_factor(vc_calibrator* h, const double s[6]) { NOT_RUNNING(h); if (!s) return VC_ERR_BAD_ARG; std::memcpy(h->scale, s, 48); return VC_OK; }
-int vc_set_time_offset(vc_calibrator* h, double o) { if (!h) return VC_ERR_BAD_ARG; h->time_offset = o; return VC_OK; }
+int vc_set_sigmas(vc_calibrator* h, double g, double a) { NOT_RUNNING(h); h->gyro_sigma = g; h->accel_sigma = a; h->device_dirty = true; return VC_OK; }
+int vc_set_biases(vc_calibrator* h, const double b[6]) { NOT_RUNNING(h); if (!b) return VC_ERR_BAD_ARG; std::memcpy(h->biases, b, 48); h->device_dirty = true; return VC_OK; }
+int vc_set_scale_factor(vc_calibrator* h, const double s[6]) { NOT_RUNNING(h); if (!s) return VC_ERR_BAD_ARG; std::memcpy(h->scale, s, 48); h->device_dirty = true; return VC_OK; }
+int vc_set_time_offset(vc_calibrator* h, double o) { NOT_RUNNING(h); h->time_offset = o; h->device_dirty = true; return VC_OK; }
 int vc_set_function_tolerance(vc_calibrator* h, double t) { NOT_RUNNING(h); h->function_tolerance = t; return VC_OK; }
 int vc_set_optimization_flags(vc_calibrator* h, int bias, int inertial, int rot_only, int toff) {
   NOT_RUNNING(h);
@@ -936,6 +1017,8 @@ int vc_start(vc_calibrator* h) {
   h->worker = std::thread([h]() { (void)h->solve(); h->is_running = false; });
   return VC_OK;
 }
+int vc_set_stage_limit(vc_calibrator* h, int n) { NOT_RUNNING(h); h->stage_limit = n; return VC_OK; }
+int vc_resume(vc_calibrator* h) { NOT_RUNNING(h); h->is_finished = false; return VC_OK; }
 int vc_is_running(vc_calibrator* h) { return h && h->is_running && !h->is_finished; }
 int vc_stop(vc_calibrator* h) { if (!h) return VC_ERR_BAD_ARG; h->stop(); return VC_OK; }
 
@@ -957,10 +1040,10 @@ int vc_get_frame(vc_calibrator* h, int f, double T_wk[7], double v_w[3], double*
   if (time) *time = h->frames[f].time;
   return VC_OK;
 }
-int vc_get_biases(vc_calibrator* h, double b[6]) { if (!h || !b) return VC_ERR_BAD_ARG; std::memcpy(b, h->biases, 48); return VC_OK; }
-int vc_get_scale_factor(vc_calibrator* h, double s[6]) { if (!h || !s) return VC_ERR_BAD_ARG; std::memcpy(s, h->scale, 48); return VC_OK; }
-int vc_get_gravity(vc_calibrator* h, double g[2]) { if (!h || !g) return VC_ERR_BAD_ARG; std::memcpy(g, h->g_dir, 16); return VC_OK; }
-double vc_time_offset(vc_calibrator* h) { return h ? h->time_offset : 0.0; }
+int vc_get_biases(vc_calibrator* h, double b[6]) { if (!h || !b) return VC_ERR_BAD_ARG; std::lock_guard<std::mutex> lk(h->result_mutex); std::memcpy(b, h->biases, 48); return VC_OK; }
+int vc_get_scale_factor(vc_calibrator* h, double s[6]) { if (!h || !s) return VC_ERR_BAD_ARG; std::lock_guard<std::mutex> lk(h->result_mutex); std::memcpy(s, h->scale, 48); return VC_OK; }
+int vc_get_gravity(vc_calibrator* h, double g[2]) { if (!h || !g) return VC_ERR_BAD_ARG; std::lock_guard<std::mutex> lk(h->result_mutex); std::memcpy(g, h->g_dir, 16); return VC_OK; }
+double vc_time_offset(vc_calibrator* h) { if (!h) return 0.0; std::lock_guard<std::mutex> lk(h->result_mutex); return h->time_offset; }
 double vc_mean_squared_error(vc_calibrator* h) { if (!h) return 0.0; std::lock_guard<std::mutex> lk(h->result_mutex); return h->mse; }
 int vc_get_camera_proj_rmse(vc_calibrator* h, double* rmse) {
   if (!h || !rmse) return VC_ERR_BAD_ARG;
@@ -1007,9 +1090,10 @@ int vc_write_camera_models(vc_calibrator* h, const char* filename) {
 }
 
 // ---- engine-level ------------------------------------------------------------------------------------
-int vc_trace_len(vc_calibrator* h) { return h ? (int)h->trace.size() : VC_ERR_BAD_ARG; }
+int vc_trace_len(vc_calibrator* h) { if (!h) return VC_ERR_BAD_ARG; std::lock_guard<std::mutex> lk(h->result_mutex); return (int)h->trace.size(); }
 int vc_get_trace(vc_calibrator* h, double* rows, int max_rows) {
   if (!h || !rows) return VC_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(h->result_mutex);
   const int n = std::min<int>(max_rows, (int)h->trace.size());
   for (int i = 0; i < n; ++i) {
     const IterRecord& r = h->trace[i];
@@ -1022,7 +1106,7 @@ int vc_get_trace(vc_calibrator* h, double* rows, int max_rows) {
 int vc_set_shard(vc_calibrator* h, int rank, int world_size, vc_allreduce_fn fn, void* ctx) {
   NOT_RUNNING(h);
   if (world_size < 1 || rank < 0 || rank >= world_size || (world_size > 1 && !fn)) return VC_ERR_BAD_ARG;
-  h->rank = rank; h->world = world_size; h->allreduce = fn; h->allreduce_ctx = ctx;
+  h->rank = rank; h->world = world_size; h->allreduce = fn; h->allreduce_ctx = ctx; h->device_dirty = true;
   { const char* e = std::getenv("VICALIB_AMD_FORCE_SHARD_PATH"); h->force_shard_path = e && e[0] == '1'; }
   return VC_OK;
 }
@@ -1043,7 +1127,7 @@ int vc_set_shard_rccl(vc_calibrator* h, int rank, int world_size, const void* un
   std::memcpy(&id, unique_id128, sizeof(id));
   if (h->rccl_comm) { (void)g_rccl.CommDestroy(h->rccl_comm); h->rccl_comm = nullptr; }
   if (g_rccl.CommInitRank(&h->rccl_comm, world_size, id, rank) != 0) { h->rccl_comm = nullptr; return VC_ERR_NO_DEVICE; }
-  h->rank = rank; h->world = world_size; h->allreduce = nullptr; h->allreduce_ctx = nullptr;
+  h->rank = rank; h->world = world_size; h->allreduce = nullptr; h->allreduce_ctx = nullptr; h->device_dirty = true;
   { const char* e = std::getenv("VICALIB_AMD_FORCE_SHARD_PATH"); h->force_shard_path = e && e[0] == '1'; }
   return VC_OK;
 }
@@ -1126,8 +1210,9 @@ int vc_run_iterations(vc_calibrator* h, int iters, int* jac_sweeps, int* res_swe
 int vc_time_kernels(vc_calibrator* h, int reps, double* jac_ms, double* res_ms) {
   NOT_RUNNING(h);
   if (h->device_dirty) { int rc = vc_prepare(h); if (rc) return rc; }
-  hipEvent_t e0, e1, e2;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) return VC_ERR_NO_DEVICE;
+  EventSet<3> evs;
+  if (!evs.create()) return VC_ERR_NO_DEVICE;
+  hipEvent_t e0 = evs.e[0], e1 = evs.e[1], e2 = evs.e[2];
   Ctrl c; h->init_ctrl(&c); c.hold = 1; if (c.mult < 1) c.mult = 1;
   if (hipMemcpy(h->d_ctrl.p, &c, sizeof(Ctrl), hipMemcpyHostToDevice) != hipSuccess) return VC_ERR_NO_DEVICE;
   h->dv.merged = 0; h->dv.par = 0; h->dv.ctrl = h->d_ctrl.p; h->dv.ctrl_prev = h->d_ctrl.p + 1;
@@ -1143,7 +1228,6 @@ int vc_time_kernels(vc_calibrator* h, int reps, double* jac_ms, double* res_ms) 
   (void)hipEventElapsedTime(&m1, e0, e1); (void)hipEventElapsedTime(&m2, e1, e2);
   if (jac_ms) *jac_ms = m1 / reps;
   if (res_ms) *res_ms = m2 / reps;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
   return VC_OK;
 }
 // Average ms per launch of every stage of one pass, each launched `reps` times back to back with the
@@ -1160,8 +1244,9 @@ int vc_time_stages(vc_calibrator* h, int reps, double* out) {
   const int rc_pass = h->enqueue_pass();
   h->merged_enabled = was_merged;
   if (rc_pass) return VC_ERR_NO_DEVICE;
-  hipEvent_t ev[7];
-  for (int i = 0; i < 7; ++i) if (hipEventCreate(&ev[i]) != hipSuccess) return VC_ERR_NO_DEVICE;
+  EventSet<7> evs;
+  if (!evs.create()) return VC_ERR_NO_DEVICE;
+  hipEvent_t* ev = evs.e;
   hipStream_t s = h->stream;
   for (int w = 0; w < 2; ++w) {   // first round warms clocks and caches
     (void)hipEventRecord(ev[0], s); for (int i = 0; i < reps; ++i) launch_reproj_jac(h->dv, s);
@@ -1174,7 +1259,6 @@ int vc_time_stages(vc_calibrator* h, int reps, double* out) {
     if (hipEventSynchronize(ev[6]) != hipSuccess) return VC_ERR_NO_DEVICE;
   }
   for (int i = 0; i < 6; ++i) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); out[i] = ms / reps; }
-  for (int i = 0; i < 7; ++i) (void)hipEventDestroy(ev[i]);
   return VC_OK;
 }
 // Weighted J^T J (33 x 33), J^T r (33) and cost of every IMU block after vc_linearize, columns

@@ -17,15 +17,15 @@ _lib = None
 
 VC_OK = 0
 ERRORS = {-1: "VC_ERR_NO_DEVICE", -2: "VC_ERR_BAD_ARG", -3: "VC_ERR_RUNNING", -4: "VC_ERR_TIME_ORDER",
-          -5: "VC_ERR_TOO_MANY_POINTS", -6: "VC_ERR_NUMERIC", -7: "VC_ERR_UNSUPPORTED"}
+          -5: "VC_ERR_TOO_MANY_POINTS", -6: "VC_ERR_NUMERIC", -7: "VC_ERR_UNSUPPORTED", -8: "VC_ERR_NO_CONVERGENCE"}
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
 
 # every symbol include/vicalib_amd.h declares
 SYMBOLS = [
     "vc_create", "vc_destroy", "vc_clear", "vc_add_camera", "vc_fix_camera_intrinsics", "vc_add_frame", "vc_set_frame_pose",
-    "vc_add_observations", "vc_add_imu", "vc_set_sigmas", "vc_set_biases", "vc_set_scale_factor", "vc_set_time_offset",
+    "vc_add_observations", "vc_add_observation_tiles", "vc_add_imu", "vc_set_sigmas", "vc_set_biases", "vc_set_scale_factor", "vc_set_time_offset",
     "vc_set_function_tolerance", "vc_set_optimization_flags", "vc_set_max_iters", "vc_set_calibrate_imu", "vc_set_remove_outliers",
-    "vc_solve", "vc_start", "vc_is_running", "vc_stop", "vc_num_frames", "vc_num_cameras", "vc_get_camera", "vc_get_frame",
+    "vc_solve", "vc_start", "vc_resume", "vc_set_stage_limit", "vc_is_running", "vc_stop", "vc_num_frames", "vc_num_cameras", "vc_get_camera", "vc_get_frame",
     "vc_get_biases", "vc_get_scale_factor", "vc_get_gravity", "vc_time_offset", "vc_mean_squared_error", "vc_get_camera_proj_rmse",
     "vc_get_num_iterations", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
     "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
@@ -126,6 +126,14 @@ class ViCalibrator:
         p_w = np.ascontiguousarray(p_w, dtype=np.float64); p_c = np.ascontiguousarray(p_c, dtype=np.float64)
         _check(self.L.vc_add_observations(self.h, int(frame), int(camera), int(len(p_w)), _d(p_w), _d(p_c)), "AddObservation")
 
+    def AddObservationTiles(self, tile_frame, tile_cam, tile_off, points, point_id, p_c):
+        """AddObservation over many (frame, camera) groups in one call (vc_add_observation_tiles)."""
+        tf = np.ascontiguousarray(tile_frame, dtype=np.int32); tc = np.ascontiguousarray(tile_cam, dtype=np.int32)
+        off = np.ascontiguousarray(tile_off, dtype=np.int64); pid = np.ascontiguousarray(point_id, dtype=np.int32)
+        pts = np.ascontiguousarray(points, dtype=np.float64); pc = np.ascontiguousarray(p_c, dtype=np.float64)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
+        _check(self.L.vc_add_observation_tiles(self.h, len(tf), vp(tf), vp(tc), vp(off), vp(pts), len(pts), vp(pid), vp(pc)), "AddObservationTiles")
+
     def AddImuMeasurements(self, gyro, accel, time):
         time = np.ascontiguousarray(time, dtype=np.float64)
         _check(self.L.vc_add_imu(self.h, int(len(time)), _d(gyro), _d(accel), _d(time)), "AddImuMeasurements")
@@ -145,6 +153,8 @@ class ViCalibrator:
 
     def Solve(self): return _check(self.L.vc_solve(self.h), "Solve")
     def Start(self): _check(self.L.vc_start(self.h), "Start")
+    def SetStageLimit(self, n): _check(self.L.vc_set_stage_limit(self.h, int(n)), "SetStageLimit")
+    def Resume(self): _check(self.L.vc_resume(self.h), "Resume")
     def IsRunning(self): return bool(self.L.vc_is_running(self.h))
     def Stop(self): _check(self.L.vc_stop(self.h), "Stop")
     def NumFrames(self): return self.L.vc_num_frames(self.h)
@@ -201,8 +211,12 @@ class ViCalibrator:
         T = prob.frame_T_wk_init if init else prob.frame_T_wk_gt
         for n in range(len(prob.frame_time)):
             self.AddFrame(T[n], prob.frame_time[n])
-        for (f, c, ids, pix) in prob.tiles:
-            self.AddObservations(f, c, prob.grid_points[ids], pix)
+        if getattr(prob, "flat", None) is not None:
+            tf, tc, off, ids, pix = prob.flat
+            self.AddObservationTiles(tf, tc, off, prob.grid_points, ids, pix)
+        else:
+            for (f, c, ids, pix) in prob.tiles:
+                self.AddObservations(f, c, prob.grid_points[ids], pix)
         if prob.imu_t is not None:
             self.AddImuMeasurements(prob.imu_gyro, prob.imu_accel, prob.imu_t)
         return self

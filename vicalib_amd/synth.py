@@ -17,8 +17,8 @@ from __future__ import annotations
 import dataclasses
 import numpy as np
 
-MODEL_IDS = {"fov": 0, "poly2": 1, "poly3": 2, "poly": 2, "kb4": 3, "linear": 4}
-MODEL_NK = {0: 5, 1: 6, 2: 7, 3: 8, 4: 4}
+MODEL_IDS = {"fov": 0, "poly2": 1, "poly3": 2, "poly": 2, "kb4": 3, "linear": 4, "rational6": 5, "rational": 5}
+MODEL_NK = {0: 5, 1: 6, 2: 7, 3: 8, 4: 4, 5: 10}
 GRAVITY = 9.8007  # types.h:40-42
 
 GT_INTRINSICS = {
@@ -27,6 +27,7 @@ GT_INTRINSICS = {
     2: [400.0, 400.0, 320.0, 240.0, -0.28, 0.09, -0.012],
     3: [260.0, 260.0, 320.0, 240.0, -0.012, 0.004, -0.0015, 0.0002],
     4: [400.0, 400.0, 320.0, 240.0],
+    5: [400.0, 400.0, 320.0, 240.0, 0.12, 0.05, 0.004, 0.40, -0.04, 0.002],
 }
 GRIDS = {"small": (19, 10, 0.254 / 18.0), "large": (25, 36, 0.03156)}
 RDF_ROBOTICS = np.array([[0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
@@ -137,6 +138,8 @@ def project(model: int, K: np.ndarray, P: np.ndarray) -> np.ndarray:
         fac = 1 + K[4] * r2 + K[5] * r2 * r2
     elif model == 2:
         fac = 1 + K[4] * r2 + K[5] * r2 * r2 + K[6] * r2 * r2 * r2
+    elif model == 5:
+        fac = (1 + K[4] * r2 + K[5] * r2 * r2 + K[6] * r2 * r2 * r2) / (1 + K[7] * r2 + K[8] * r2 * r2 + K[9] * r2 * r2 * r2)
     else:
         fac = np.ones_like(r2)
     return np.stack([K[0] * x * fac + K[2], K[1] * y * fac + K[3]], axis=-1)
@@ -189,9 +192,24 @@ class Problem:
     imu_accel: np.ndarray = None # (S,3)
     imu_gt: dict = None
 
+    flat: tuple = None           # native generator: (tile_frame, tile_cam, tile_off int64 (T+1), ids int32 (n), pix (n,2))
+
     @property
     def n_obs(self) -> int:
+        if self.flat is not None:
+            return int(self.flat[2][-1])
         return int(sum(len(t[2]) for t in self.tiles))
+
+    def __getattribute__(self, name):
+        # `tiles` of a natively generated problem is built on first use (4e5 tuples at cfg5: most callers use `flat`)
+        if name == "tiles":
+            t = object.__getattribute__(self, "tiles")
+            if t is None and object.__getattribute__(self, "flat") is not None:
+                tf, tc, off, ids, pix = object.__getattribute__(self, "flat")
+                t = [(int(tf[k]), int(tc[k]), ids[off[k]:off[k + 1]], pix[off[k]:off[k + 1]]) for k in range(len(tf))]
+                object.__setattr__(self, "tiles", t)
+            return t
+        return object.__getattribute__(self, name)
 
 
 def _trajectory(cfg: Config, t: np.ndarray, grid_w: float, grid_h: float):
@@ -320,9 +338,84 @@ def _add_imu(prob: Problem, grid_w: float, grid_h: float, R_ck0: np.ndarray) -> 
     prob.imu_t, prob.imu_gyro, prob.imu_accel, prob.imu_gt = t_imu, zg, za, gt
 
 
+# ----------------------------------------------------------------------------- native generator (csrc/vc_synth.cpp)
+_synth_lib = None
+
+
+def _native_lib():
+    global _synth_lib
+    if _synth_lib is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvicalib_synth.so")
+        if not os.path.exists(path):
+            raise RuntimeError(path + " is missing: build it with vicalib_amd/csrc/build.sh")
+        L = C.CDLL(path)
+        L.vcs_generate.restype = C.c_void_p; L.vcs_generate.argtypes = [C.c_void_p, C.c_int]
+        L.vcs_free.restype = None; L.vcs_free.argtypes = [C.c_void_p]
+        L.vcs_count.restype = C.c_longlong; L.vcs_count.argtypes = [C.c_void_p, C.c_int]
+        L.vcs_array.restype = C.c_void_p; L.vcs_array.argtypes = [C.c_void_p, C.c_int]
+        _synth_lib = L
+    return _synth_lib
+
+
+def generate_native(cfg: Config, threads: int = 0) -> Problem:
+    """The same problem as generate(cfg), produced by the C++ generator (all host cores): identical visible-dot sets,
+    floating-point fields equal up to the last bits of the two math libraries.  BASELINE cfg4 / cfg5 take seconds."""
+    import ctypes as C
+
+    class _Cfg(C.Structure):
+        _fields_ = [("n_cams", C.c_int), ("models", C.c_int * 8), ("grid", C.c_int), ("n_frames", C.c_int), ("imu", C.c_int),
+                    ("seed", C.c_longlong), ("width", C.c_int), ("height", C.c_int), ("frame_rate", C.c_double),
+                    ("imu_rate", C.c_double), ("pixel_sigma", C.c_double), ("pose_sigma_t", C.c_double),
+                    ("pose_sigma_r", C.c_double), ("first_frame", C.c_longlong), ("threads", C.c_int)]
+    L = _native_lib()
+    models = [MODEL_IDS[m] for m in cfg.models]
+    c = _Cfg()
+    c.n_cams = len(models)
+    for i, m in enumerate(models):
+        c.models[i] = m
+    c.grid = 1 if cfg.grid == "large" else 0
+    c.n_frames = cfg.n_frames; c.imu = int(cfg.imu); c.seed = cfg.seed; c.width = cfg.width; c.height = cfg.height
+    c.frame_rate = cfg.frame_rate; c.imu_rate = cfg.imu_rate; c.pixel_sigma = cfg.pixel_sigma
+    c.pose_sigma_t = cfg.pose_sigma_t; c.pose_sigma_r = float(cfg.pose_sigma_r); c.first_frame = cfg.first_frame; c.threads = threads
+    assert L.vcs_config_size() == C.sizeof(_Cfg)
+    h = L.vcs_generate(C.byref(c), C.sizeof(_Cfg))
+    if not h:
+        raise RuntimeError("vcs_generate failed")
+    try:
+        def arr(what, n, dtype, shape=None):
+            if n == 0:
+                a = np.zeros(0, dtype=dtype)
+            else:
+                ptr = L.vcs_array(h, what)
+                ct = {np.float64: C.c_double, np.int32: C.c_int, np.int64: C.c_longlong}[dtype]
+                a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,)).copy()
+            return a.reshape(shape) if shape else a
+        M, T, n, S, N, Cn = (int(L.vcs_count(h, k)) for k in range(6))
+        grid = arr(0, M * 3, np.float64, (M, 3))
+        Kg = arr(1, Cn * 10, np.float64, (Cn, 10)); Ki = arr(2, Cn * 10, np.float64, (Cn, 10))
+        K_gt = [Kg[i, :MODEL_NK[m]].copy() for i, m in enumerate(models)]
+        K_init = [Ki[i, :MODEL_NK[m]].copy() for i, m in enumerate(models)]
+        flat = (arr(9, T, np.int32), arr(10, T, np.int32), arr(11, T + 1, np.int64), arr(12, n, np.int32), arr(13, n * 2, np.float64, (n, 2)))
+        prob = Problem(cfg, grid, models, K_gt, K_init, arr(3, Cn * 7, np.float64, (Cn, 7)), arr(4, Cn * 7, np.float64, (Cn, 7)),
+                       arr(5, N, np.float64), arr(6, N * 7, np.float64, (N, 7)), arr(7, N * 7, np.float64, (N, 7)),
+                       arr(8, N * 3, np.float64, (N, 3)), None, flat=flat)
+        if cfg.imu and S:
+            gt = arr(17, 15, np.float64)
+            prob.imu_t = arr(14, S, np.float64); prob.imu_gyro = arr(15, S * 3, np.float64, (S, 3)); prob.imu_accel = arr(16, S * 3, np.float64, (S, 3))
+            prob.imu_gt = dict(bg=gt[0:3], ba=gt[3:6], sg=gt[6:9], sa=gt[9:12], g_dir=gt[12:14], time_offset=float(gt[14]))
+        return prob
+    finally:
+        L.vcs_free(h)
+
+
 # ----------------------------------------------------------------------------- flat arrays for bulk ingest
 def flatten(prob: Problem):
     """tile_frame, tile_cam, tile_off (T+1), p_w (n,3), p_c (n,2) in tile order."""
+    if prob.flat is not None:
+        tf, tc, off, ids, pix = prob.flat
+        return tf, tc, off, np.ascontiguousarray(prob.grid_points[ids]), pix
     tf = np.array([t[0] for t in prob.tiles], dtype=np.int32)
     tc = np.array([t[1] for t in prob.tiles], dtype=np.int32)
     cnt = np.array([len(t[2]) for t in prob.tiles], dtype=np.int64)
