@@ -1,18 +1,28 @@
 #!/usr/bin/env python
 """bench.py -- LM-iteration throughput of the calibration hot path on MI355X.
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on): stereo fov,fov rig, small
-grid (19x10 dots), 500 synthetic frames per GPU, intrinsics + extrinsics, no IMU.  A "step" is one
-Levenberg-Marquardt iteration of the real solver (Jacobian sweep over all corners + frame-block Schur
-elimination + reduced solve + manifold update + residual sweep of the trial point + accept/reject);
-complete solves are run back to back from the same initial state until exactly K iterations are done.
-N > 1: one process per GPU, frames sharded (weak scaling: 500 frames per rank), one all-reduce of the
-reduced system + one of the step scalars per iteration over RCCL (torch.distributed "nccl").
-Prints ONE JSON line on rank 0.
+Workload per GPU count (BASELINE.json `configs`; the metric is not quoted on one of them, so N = 1 runs the largest
+single-GPU configuration):
+  N = 1   cfg3: mono kb4 + IMU (biases, scale factors, time offset), small grid, 2000 frames
+  N = 2   cfg3, its frames sharded over the two ranks
+  N = 4   cfg4: 4 x poly3 + IMU, large grid (900 dots), 10 000 frames sharded over 4 ranks
+  N = 8   cfg5: 8 cameras fov/kb4 + IMU, small grid, 50 000 frames sharded over 8 ranks
+(--workload cfg2|cfg3|cfg4|cfg5 overrides; cfg2 = stereo fov, 500 frames, no IMU -- last round's headline.)
+
+A "step" is one Levenberg-Marquardt iteration of the real solver in the FINAL stage of the reference's schedule
+(vicalibrator.h:977-1000: camera-to-IMU transform, intrinsics, gravity, biases, scale factors and time offset all free):
+IMU weight update (UpdateImuWeights) + Jacobian sweep over all corners + IMU Jacobians + elimination of the frame chain +
+reduced solve + back-substitution + manifold update + residual sweeps of the trial point + accept/reject.  The stages before
+it run first (untimed); complete final-stage solves are then run back to back from that state until exactly K iterations are
+done.  N > 1: one process per GPU, frames sharded, one all-reduce of the reduced system and one of the step scalars per
+iteration over RCCL.  `python bench.py --gpus N` launches its own N ranks when it is not already running under
+torch.distributed.run.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,45 +31,76 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-# HBM bytes per launch at the default workload, measured with rocprofv3 --pmc (profiles/r01_v10_pmc_traffic_cfg2.txt)
-PMC_TRAFFIC = {"k_trial": 6035060.0, "k_reproj_res": 3344207.0}
+WORKLOADS = {
+    "cfg2": dict(name="BASELINE cfg2: stereo fov,fov, small grid 19x10, 500 frames, intrinsics+extrinsics, no IMU"),
+    "cfg3": dict(name="BASELINE cfg3: mono kb4 + IMU (biases, scale, time offset), small grid 19x10, 2000 frames"),
+    "cfg4": dict(name="BASELINE cfg4: 4-camera poly3 rig + IMU, large grid 25x36, 10000 frames"),
+    "cfg5": dict(name="BASELINE cfg5: 8-camera fov/kb4 rig + IMU, small grid 19x10, 50000 frames"),
+}
+# HBM bytes per launch from rocprofv3 --pmc passes on the N = 1 default workload (profiles/, see README there)
+PMC_TRAFFIC = {}
+try:
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as _f:
+        PMC_TRAFFIC = json.load(_f)
+except (OSError, ValueError):
+    pass
+
+
+def default_workload(n):
+    return "cfg3" if n <= 2 else ("cfg4" if n <= 4 else "cfg5")
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=500, help="frames per GPU")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=0, help="override the workload's total frame count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-at-scale", action="store_true", help="skip the extra kernel timing on the 10x larger problem")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (cfg2 / at-scale) measurements")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: one rank per GPU over RCCL
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
     from vicalib_amd import synth
     from vicalib_amd.lib import ViCalibrator
+    from vicalib_amd.parallel import frame_shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    # VICALIB_AMD_FORCE_SHARD_PATH=1 (test hook): one rank, but through the sharded code path (split kernels + RCCL callbacks)
+    # VICALIB_AMD_FORCE_SHARD_PATH=1 (test hook): one rank, but through the sharded code path (split kernels + RCCL)
     force_shard = world == 1 and os.environ.get("VICALIB_AMD_FORCE_SHARD_PATH") == "1"
     if world > 1 or force_shard:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    # ---- this rank's frame shard of the N*frames problem ------------------------------------------
-    cfg = synth.Config(models=("fov", "fov"), grid="small", n_frames=args.frames, imu=False, first_frame=rank * args.frames)
-    prob = synth.generate(cfg)
-    cal = ViCalibrator(local_rank).load_problem(prob)
-    cal.SetCalibrateImu(False)
+    wl = default_workload(world) if args.workload == "auto" else args.workload
+    base = synth.BASELINE_CONFIGS[wl]
+    n_total = args.frames or base.n_frames
+    lo, hi = frame_shard(n_total, rank, world)
+    cfg = synth.Config(models=base.models, grid=base.grid, n_frames=hi - lo, imu=base.imu, first_frame=lo, extrinsics_prior=base.extrinsics_prior)
+    prob = synth.generate_native(cfg)
+    vi = bool(base.imu)
 
-    # Per-iteration all-reduces: the library's own RCCL communicator, enqueued straight onto the calibrator's stream
-    # (VICALIB_AMD_SHARD_COMM=torch selects the torch.distributed callback instead; it is also the fallback).
     def attach(c):
         if world == 1 and not force_shard:
             return "none"
@@ -72,10 +113,6 @@ def main():
         from vicalib_amd.parallel import FrameShardComm
         c.set_shard(rank, world, FrameShardComm(device="cuda:%d" % local_rank, stream_ptr=c.stream()))
         return "torch"
-    comm_kind = attach(cal)
-
-    cal.prepare()
-    n_obs_local = cal.num_observations()
 
     def barrier():
         torch.cuda.synchronize()
@@ -83,6 +120,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- one complete calibration: the metric's "final RMS reproj err" and the wall time of the whole schedule ---------
+    cal2 = ViCalibrator(local_rank).load_problem(prob)
+    cal2.SetCalibrateImu(vi)
+    attach(cal2)
+    barrier(); t0 = time.perf_counter()
+    cal2.Solve()
+    barrier(); t_full = time.perf_counter() - t0
+    rmse = [float(x) for x in cal2.GetCameraProjRMSE()]
+    full_trace = cal2.trace()
+    full = {"seconds": t_full, "lm_iterations": int(np.sum(full_trace[:, 0] > 0)), "stages": int(full_trace[-1, 9]) + 1 if len(full_trace) else 0}
+    if vi:
+        gt = prob.imu_gt
+        full["time_offset_error_s"] = abs(cal2.time_offset() - gt["time_offset"])
+        full["gyro_bias_error"] = float(np.abs(cal2.GetBiases()[:3] - gt["bg"]).max())
+    del cal2
+
+    # ---- the timed loop: LM iterations of the final stage --------------------------------------------------------
+    cal = ViCalibrator(local_rank).load_problem(prob)
+    cal.SetCalibrateImu(vi)
+    comm_kind = attach(cal)
+    if vi:
+        cal.SetStageLimit(3)        # stages A (vision), B (rotation), C (+ translation, gravity, biases) run; D is set up
+        cal.Solve()
+    cal.prepare()
+    n_obs_local = cal.num_observations()
     cal.run_iterations(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -98,41 +160,59 @@ def main():
         n_obs_total = int(no.item())
     else:
         n_obs_total = n_obs_local
+    allreduce_calls = cal.allreduce_calls() if comm_kind == "rccl" else None
 
-    # ---- final accuracy of one complete solve (the metric's "final RMS reproj err") --------------------
-    cal2 = ViCalibrator(local_rank).load_problem(prob)
-    cal2.SetCalibrateImu(False)
-    attach(cal2)
-    cal2.Solve()
-    rmse = [float(x) for x in cal2.GetCameraProjRMSE()]
-
-    # ---- kernel-level roofline of the dominant kernel (HIP events on the calibrator's stream) --------
-    # Vision-only passes evaluate the Jacobian sweep at the trial point inside k_trial (one projection sweep per LM
-    # iteration): k_trial<true> = back-substitution of the tile's frame + manifold update + Jacobian/Gram sweep of the tile.
-    stages = cal.time_stages(50)                 # us per launch, each stage launched 50x back to back
-    trial_ms = stages["trial"] * 1e-3
-    jac_ms, res_ms = cal.time_kernels(50)        # stand-alone sweeps: k_reproj_jac (first pass of a solve), k_reproj_res (RMSE)
+    # ---- in-loop kernel durations (HIP events on the calibrator's stream around every launch group of the same loop) ----
+    cal.set_kernel_timing(True)
+    cal.run_iterations(args.steps)
+    kt = cal.kernel_timing()
+    cal.set_kernel_timing(False)
     n_tiles = cal.num_tiles()
-    kc = 5   # fov
-    # 18 B/corner + per tile [64 B in + 8*(21 + 6 + 6*S_c + 1) B out], S_c = 6 + K_c; the fused kernel also
-    # reads the frame factor (48 doubles / frame) and Y (6 x 16 doubles / tile) for the back-substitution
-    bytes_jac = 18.0 * n_obs_local + n_tiles * (64 + 8 * (28 + 6 * (6 + kc)))
-    bytes_trial = bytes_jac + n_tiles * 8 * 96 + len(prob.frame_time) * 8 * 48
+    n_frames_local = len(prob.frame_time)
+    n_imu_blocks = max(n_frames_local - 1, 0)
+    nk = {0: 5, 1: 6, 2: 7, 3: 8, 4: 4, 5: 10}
+    kc_mean = float(np.mean([nk[m] for m in prob.cam_model]))
+    # Jacobian sweep 18 B/corner + per tile [64 B in + 8*(21 + 6 + 6*S_c + 1) B out], S_c = 6 + K_c; ~1.05 kflop/corner
+    bytes_jac = 18.0 * n_obs_local + n_tiles * (64 + 8 * (28 + 6 * (6 + kc_mean)))
+    flops_jac = 1050.0 * n_obs_local
     bytes_res = 18.0 * n_obs_local + n_tiles * (64 + 8)
-    flops_jac = 1050.0 * n_obs_local          # ~1.0-1.1 kflop per corner (fp64)
-    ach = flops_jac / (trial_ms * 1e-3) / 1e12
-    # traffic: HBM bytes per launch from rocprofv3 PMC passes on this exact workload (FETCH_SIZE and WRITE_SIZE in
-    # separate runs, KB -> bytes, FETCH x2 per the gfx950 note in MI355X_MICROARCH.md): profiles/r01_v10_pmc_traffic_cfg2.txt
-    base_cfg = (args.frames == 500 and world == 1)
-    traffic_trial = PMC_TRAFFIC.get("k_trial") if base_cfg else None
-    traffic_res = PMC_TRAFFIC.get("k_reproj_res") if base_cfg else None
-    roofline = {"kernel": "k_trial<fused Jacobian sweep>", "bound": "mfma", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6,
-                "traffic": traffic_trial, "hbm_gbs": bytes_trial / (trial_ms * 1e-3) / 1e9, "hbm_frac": bytes_trial / (trial_ms * 1e-3) / 8e12,
-                "avg_ms": trial_ms, "algorithmic_bytes": bytes_trial, "algorithmic_flops": flops_jac,
-                "standalone_jacobian_sweep_ms": jac_ms, "stage_us": stages}
-    roofline_res = {"kernel": "k_reproj_res", "bound": "hbm", "achieved": bytes_res / (res_ms * 1e-3) / 1e9, "peak": 8000.0,
-                    "unit": "GB/s", "frac": bytes_res / (res_ms * 1e-3) / 8e12, "traffic": traffic_res, "avg_ms": res_ms,
-                    "algorithmic_bytes": bytes_res}
+    imu_samples = len(prob.imu_t) if vi else 0
+    # IMU block (SURVEY 8(d) "IMU segment"): n_meas * 56 B in + 2 * 80 B states, out 9 + 9 x 35; ~n_meas * 4 stages * 36 lanes * 400 flop
+    n_meas = imu_samples / max(n_imu_blocks, 1) + 2
+    bytes_imu = n_imu_blocks * (n_meas * 56 + 160 + 8 * (9 + 9 * 35))
+    flops_imu = n_imu_blocks * n_meas * 4 * 36 * 400.0
+    # weight update: per RK4 step 16 sensitivity columns through 4 stages (~9 kflop) + Sigma <- F Sigma F^T + G R G^T (~5.2 kflop)
+    flops_w = n_imu_blocks * n_meas * 14200.0
+    bytes_w = n_imu_blocks * (n_meas * 56 + 160 + 2 * 81 * 8)
+    algo = {"k_reproj_jac": ("mfma", flops_jac, bytes_jac), "k_trial": ("mfma", flops_jac, bytes_jac + n_tiles * 8 * 96 + n_frames_local * 8 * 48),
+            "k_imu_jac": ("mfma", flops_imu, bytes_imu), "k_imu_weights": ("mfma", flops_w, bytes_w)}
+    kernels = {}
+    for name, (cnt, avg_ms) in kt.items():
+        e = {"launch_groups": cnt, "avg_ms": avg_ms, "ms_per_step": avg_ms * cnt / max(done, 1)}
+        if name in algo:
+            bound, fl, by = algo[name]
+            e.update({"algorithmic_flops": fl, "algorithmic_bytes": by, "tflops": fl / (avg_ms * 1e-3) / 1e12, "fp64_frac": fl / (avg_ms * 1e-3) / 78.6e12,
+                      "hbm_gbs": by / (avg_ms * 1e-3) / 1e9, "hbm_frac": by / (avg_ms * 1e-3) / 8e12})
+        kernels[name] = e
+    # the dominant kernel = the single kernel with the largest share of the step (launch groups of several kernels excluded)
+    single = [k for k in kernels if k in algo]
+    dom = max(single, key=lambda k: kernels[k]["ms_per_step"]) if single else None
+    roofline = None
+    if dom:
+        bound, fl, by = algo[dom]
+        e = kernels[dom]
+        roofline = {"kernel": dom, "bound": bound, "achieved": e["tflops"], "peak": 78.6, "unit": "TFLOP/s", "frac": e["fp64_frac"],
+                    "traffic": PMC_TRAFFIC.get(wl, {}).get(dom) if world == 1 and not args.frames else None, "avg_ms": e["avg_ms"],
+                    "algorithmic_flops": fl, "algorithmic_bytes": by, "hbm_gbs": e["hbm_gbs"], "hbm_frac": e["hbm_frac"],
+                    "timing": "HIP events around every launch of this kernel inside the timed LM loop (decisions live)"}
+    jac = kernels.get("k_reproj_jac") or kernels.get("k_trial")
+    roofline_sweep = None
+    if jac:
+        nm = "k_reproj_jac" if "k_reproj_jac" in kernels and vi else "k_trial"
+        e = kernels[nm]
+        roofline_sweep = {"kernel": nm + " (residual + Jacobian + tile normal equations sweep)", "avg_ms": e["avg_ms"], "tflops": e["tflops"],
+                          "fp64_frac": e["fp64_frac"], "hbm_gbs": e["hbm_gbs"], "hbm_frac": e["hbm_frac"],
+                          "traffic": PMC_TRAFFIC.get(wl, {}).get(nm) if world == 1 and not args.frames else None}
 
     out = None
     if rank == 0:
@@ -141,17 +221,20 @@ def main():
         out = {
             "metric": "corner_residuals_per_sec", "value": value, "unit": "corner-residuals/s (LM iterations x corners)",
             "n_gpus": world, "steps": done, "warmup": args.warmup, "ms_per_step": 1e3 * dt / done, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg2: stereo fov,fov, small grid 19x10, %d frames/GPU, intrinsics+extrinsics, no IMU" % args.frames,
-                       "frames_total": args.frames * world, "corners_total": n_obs_total, "tiles_per_gpu": n_tiles,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": WORKLOADS[wl]["name"] + (" [frames overridden: %d]" % n_total if args.frames else ""),
+                       "stage": "final stage of the schedule (all camera / IMU parameters free)" if vi else "vision-only solve",
+                       "frames_total": n_total, "corners_total": n_obs_total, "tiles_rank0": n_tiles, "imu_samples_rank0": imu_samples,
+                       "reduced_dim": cal.shared_dim(),
                        "parallelism": "frames sharded x%d, all-reduce of reduced system per LM iteration (%s)" % (world, comm_kind)},
-            "lm_iters_per_sec": iters_per_s, "jacobian_sweeps": jac_sweeps, "residual_sweeps": res_sweeps,
-            "final_rmse_px": rmse, "roofline": roofline, "roofline_residual_sweep": roofline_res,
+            "lm_iters_per_sec": iters_per_s, "jacobian_sweeps": jac_sweeps, "residual_sweeps": res_sweeps, "allreduce_calls": allreduce_calls,
+            "final_rmse_px": rmse, "complete_calibration": full, "roofline": roofline, "roofline_jacobian_sweep": roofline_sweep,
+            "kernels_in_loop": kernels,
         }
-        if not args.no_at_scale and world == 1 and not force_shard:
-            out["roofline_at_scale"] = roofline_at_scale(local_rank, args.frames * 10)
+        if not args.no_secondary and world == 1 and not force_shard:
+            out["secondary"] = secondary(local_rank)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(prob)
+            out["cpu_baseline"] = cpu_baseline(wl, prob)
     if rank == 0:
         # the one JSON line comes last: RCCL writes a version banner to the C-level stdout, flush that first
         sys.stdout.flush()
@@ -172,55 +255,75 @@ def main():
         os._exit(0)
 
 
-def roofline_at_scale(device, n_frames):
-    """The same kernels on the same rig with 10x the frames (cfg2 is one wave per SIMD: latency-bound by construction);
-    informational, the bench value above is the cfg2 number."""
+def secondary(device):
+    """Last round's vision-only headline (cfg2) and the same rig with 10x the frames, measured the same way (complete solves back
+    to back, in-loop kernel timing): informational, `value` above is the N = 1 workload's number."""
     from vicalib_amd import synth
     from vicalib_amd.lib import ViCalibrator
-    p = synth.generate(synth.Config(models=("fov", "fov"), grid="small", n_frames=n_frames, imu=False))
-    cal = ViCalibrator(device).load_problem(p); cal.SetCalibrateImu(False); cal.prepare()
-    st = cal.time_stages(20)
-    n = cal.num_observations()
-    tf = 1050.0 * n / (st["trial"] * 1e-6) / 1e12
-    return {"workload": "stereo fov,fov, small grid, %d frames" % n_frames, "corners": n, "kernel": "k_trial<fused Jacobian sweep>",
-            "avg_ms": st["trial"] * 1e-3, "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
-            "corners_per_sec": n / (st["trial"] * 1e-6), "stage_us": st,
-            "lm_iteration_us_sum_of_stages": st["frame_schur"] + st["reduced"] + st["trial"] + st["final"]}
+    out = {}
+    for tag, frames in (("cfg2", 500), ("cfg2_x10", 5000)):
+        p = synth.generate_native(synth.Config(models=("fov", "fov"), grid="small", n_frames=frames, imu=False))
+        cal = ViCalibrator(device).load_problem(p); cal.SetCalibrateImu(False); cal.prepare()
+        n = cal.num_observations()
+        cal.run_iterations(20)
+        t0 = time.perf_counter(); done, _, _ = cal.run_iterations(200); dt = time.perf_counter() - t0
+        cal.set_kernel_timing(True); cal.run_iterations(100); kt = cal.kernel_timing(); cal.set_kernel_timing(False)
+        tr = kt.get("k_trial", (0, float("nan")))[1]
+        out[tag] = {"frames": frames, "corners": n, "us_per_lm_iteration": 1e6 * dt / done, "corner_residuals_per_sec": n * done / dt,
+                    "kernels_in_loop_us": {k: 1e3 * v[1] for k, v in kt.items()},
+                    "k_trial_tflops": 1050.0 * n / (tr * 1e-3) / 1e12, "k_trial_fp64_frac": 1050.0 * n / (tr * 1e-3) / 78.6e12}
+    return out
 
 
-def cpu_baseline(prob):
-    """The CPU oracle (a port of the reference's autodiff + solver path, since Ceres cannot be built here)
-    timed on this host on a bounded sample of the same workload: full LM-iteration work units on the
-    first frames of the same problem, 4 threads (the reference's num_threads, vicalibrator.h:141)."""
+def cpu_baseline(wl, prob):
+    """The CPU oracle (a port of the reference's autodiff + solver path: Ceres cannot be built here) timed on this host on a
+    bounded sample of the same workload: complete LM-iteration work units (weight update, dual-number Jacobian sweep, IMU
+    blocks, block solve, cost sweep) of the same stage on the first frames of the same problem, 4 threads (the reference's
+    num_threads, vicalibrator.h:141)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
+    vi = prob.imu_t is not None
     threads = 4
-    n_sub = min(100, len(prob.frame_time))
-    orc = ol.Oracle()
-    for c, m in enumerate(prob.cam_model):
-        orc.add_camera(m, prob.cam_K_init[c], prob.cam_T_ck_init[c])
-    for n in range(n_sub):
-        orc.add_frame(prob.frame_T_wk_init[n], prob.frame_time[n])
-    nobs = 0
-    for (f, c, ids, pix) in prob.tiles:
-        if f < n_sub:
-            orc.add_observations(f, c, prob.grid_points[ids], pix); nobs += len(ids)
-    orc.set_options(calibrate_imu=False, num_threads=threads)
-    orc.prepare(vis_mult=1)
-    orc.time_iterations(1)
-    iters = 0; t = 0.0
-    while t < 10.0 and iters < 400:
-        t += orc.time_iterations(4); iters += 4
-    # the same work on every host core (SURVEY 8d asks for both; `value` stays the reference's 4-thread configuration)
+    n_sub = min(200 if vi else 100, len(prob.frame_time))
+    tf, tc, off, ids, pix = prob.flat
+
+    def build(nthreads):
+        orc = ol.Oracle()
+        for c, m in enumerate(prob.cam_model):
+            orc.add_camera(m, prob.cam_K_gt[c], prob.cam_T_ck_gt[c])
+        for n in range(n_sub):
+            orc.add_frame(prob.frame_T_wk_gt[n], prob.frame_time[n])
+        nobs = 0
+        for k in range(len(tf)):
+            if tf[k] < n_sub:
+                sl = slice(off[k], off[k + 1])
+                orc.add_observations(int(tf[k]), int(tc[k]), prob.grid_points[ids[sl]], pix[sl]); nobs += int(off[k + 1] - off[k])
+        if vi:
+            sel = prob.imu_t <= prob.frame_time[n_sub - 1] + 0.1
+            orc.add_imu(prob.imu_gyro[sel], prob.imu_accel[sel], prob.imu_t[sel])
+            orc.set_options(calibrate_imu=True, num_threads=nthreads)
+            orc.set_flags(True, True, False, True)          # final stage: everything free
+            orc.prepare(vis_mult=4, imu_mult=3)
+        else:
+            orc.set_options(calibrate_imu=False, num_threads=nthreads)
+            orc.prepare(vis_mult=1)
+        return orc, nobs
+
+    def run(orc, budget):
+        orc.time_iterations(1)
+        iters = 0; t = 0.0
+        while t < budget and iters < 400:
+            t += orc.time_iterations(2); iters += 2
+        return iters, t
+
+    orc, nobs = build(threads)
+    iters, t = run(orc, 12.0)
     ncpu = os.cpu_count() or threads
     all_cores = None
     if ncpu > threads:
-        orc.set_options(calibrate_imu=False, num_threads=ncpu)
-        orc.time_iterations(1)
-        it2 = 0; t2 = 0.0
-        while t2 < 5.0 and it2 < 400:
-            t2 += orc.time_iterations(4); it2 += 4
-        all_cores = {"value": nobs * it2 / t2, "cores": ncpu}
+        orc2, _ = build(min(ncpu, 64))
+        it2, t2 = run(orc2, 5.0)
+        all_cores = {"value": nobs * it2 / t2, "cores": min(ncpu, 64)}
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -230,8 +333,8 @@ def cpu_baseline(prob):
     except OSError:
         pass
     return {"value": nobs * iters / t, "unit": "corner-residuals/s (LM iterations x corners)", "cores": threads, "kind": "port",
-            "sample": "%d LM-iteration work units (dual-number Jacobian sweep + block solve + cost sweep) on the first %d of %d frames (%d corners), %.1f s"
-                      % (iters, n_sub, len(prob.frame_time), nobs, t),
+            "sample": "%d LM-iteration work units of the %s (IMU weight update, dual-number Jacobian sweep, IMU blocks, block solve, cost sweep) on the "
+                      "first %d of %d frames (%d corners) of %s, %.1f s" % (iters, "final stage" if vi else "vision-only solve", n_sub, len(prob.frame_time), nobs, wl, t),
             "lm_iters_per_sec_extrapolated_to_full": (nobs * iters / t) / prob.n_obs,
             "all_cores": all_cores, "host": {"nproc": ncpu, "cpu": cpu_model}}
 

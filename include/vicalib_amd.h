@@ -159,6 +159,11 @@ int vc_run_iterations(vc_calibrator* h, int iters, int* jac_sweeps, int* res_swe
 int vc_evaluate(vc_calibrator* h, double* cost, double* sum_sq);
 /* Times the dominant kernels with HIP events on the calibrator's stream: average ms per launch over reps */
 int vc_time_kernels(vc_calibrator* h, int reps, double* jac_ms, double* res_ms);
+/* In-loop kernel timing: with `on`, every launch group of every LM pass of the following solves is bracketed by HIP events
+ * on the calibrator's stream (the real loop, decisions live -- not held back-to-back launches); vc_get_kernel_timing
+ * returns, per group that ran, its name (';'-joined into names), the summed duration and the launch count. */
+int vc_set_kernel_timing(vc_calibrator* h, int on);
+int vc_get_kernel_timing(vc_calibrator* h, char* names, int names_len, double* total_ms, long long* count, int max_entries);
 /* Average ms per launch of each stage of one LM pass (Jacobian sweep, frame elimination, Schur partials,
  * reduced solve, trial sweep, decision), `reps` back-to-back launches each */
 int vc_time_stages(vc_calibrator* h, int reps, double out[6]);

@@ -202,6 +202,7 @@ double vco_time_iterations(void* h, int iters) {
   Calibrator* c = CAL;
   const auto t0 = std::chrono::steady_clock::now();
   for (int k = 0; k < iters; ++k) {
+    c->update_imu_weights();        // the iteration callback's UpdateImuWeights (a no-op unless the inertial terms are fully active)
     c->linearize();
     std::vector<double> hd, lam, a, b;
     c->hdiag(hd);

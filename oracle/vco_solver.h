@@ -220,13 +220,16 @@ class Calibrator {
       }
     }
     if (L.imu) {
+      double ci = 0;
+#pragma omp parallel for reduction(+ : ci) schedule(static) num_threads(opt.num_threads)
       for (int j = 1; j < N(); ++j) {
         double r[9], rho[3], s = 0;
         imu_value(j, r);
         for (int i = 0; i < 9; ++i) s += r[i] * r[i];
         loss_cauchy(100.0, s, rho);
-        cost += 0.5 * imu_mult * rho[0];
+        ci += 0.5 * imu_mult * rho[0];
       }
+      cost += ci;
     }
     return cost;
   }
@@ -307,9 +310,13 @@ class Calibrator {
       }
     }
     if (L.imu) {
+      // the dual-number evaluation of the blocks is independent per block (threads); the accumulation into the shared
+      // normal equations stays sequential, in block order
+      std::vector<ImuJac> blocks((size_t)std::max(N(), 1));
+#pragma omp parallel for schedule(dynamic, 4) num_threads(opt.num_threads)
+      for (int j = 1; j < N(); ++j) imu_block(j, &blocks[j]);
       for (int j = 1; j < N(); ++j) {
-        ImuJac B;
-        imu_block(j, &B);
+        const ImuJac& B = blocks[j];
         double s = 0, rho[3];
         for (int i = 0; i < 9; ++i) s += B.r[i] * B.r[i];
         loss_cauchy(100.0, s, rho);
@@ -467,6 +474,7 @@ class Calibrator {
   // UpdateImuWeights, vicalibrator.h:723-799.
   void update_imu_weights() {
     if (!(is_inertial_active && !rotation_only)) return;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(opt.num_threads)
     for (int j = 1; j < N(); ++j) {
       std::vector<ImuMeas<double>> meas;
       imu.range(frames[j - 1].time, frames[j].time, time_offset, &meas);

@@ -86,12 +86,12 @@ def load_slice(cal, prob, lo, hi):
     return cal
 
 
-def main_imu(models=("kb4",), n_total=80, max_iters=100, strict=True):
+def main_imu(models=("kb4",), n_total=80, max_iters=100, strict=True, oracle=False, prior=False):
     """Frame-sharded visual-inertial calibration: separators in the reduced system, interior chains per rank."""
     from vicalib_amd.lib import ViCalibrator
     rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    full = synth.generate(synth.Config(models=models, n_frames=n_total, imu=True, seed=5))
+    full = synth.generate(synth.Config(models=models, n_frames=n_total, imu=True, seed=5, extrinsics_prior=prior))
     lo, hi = frame_shard(n_total, rank, world)
     cal = load_slice(ViCalibrator(0), full, lo, hi); cal.SetMaxIters(max_iters)
     comm = FrameShardComm(device="cuda:0", stream_ptr=cal.stream())
@@ -127,6 +127,24 @@ def main_imu(models=("kb4",), n_total=80, max_iters=100, strict=True):
     assert abs(cal.time_offset() - ref.time_offset()) < 1e-9
     np.testing.assert_allclose(cal.GetCameraProjRMSE(), ref.GetCameraProjRMSE(), rtol=1e-7)
     assert abs(cal.MeanSquaredError() - ref.MeanSquaredError()) <= 1e-7 * abs(ref.MeanSquaredError())
+    if oracle and rank == 0:
+        # ... and the sharded solve against the CPU oracle on the whole problem: final parameters at 1e-6 (north_star)
+        import oracle_lib as ol
+        orc = ol.Oracle().load(full); orc.set_options(calibrate_imu=True, max_iters=max_iters, num_threads=16); orc.solve()
+        to = orc.trace()
+        assert len(to) == len(tg), (len(to), len(tg))
+        np.testing.assert_allclose(tg[:, 1], to[:, 1], rtol=1e-6)
+        np.testing.assert_array_equal(tg[:, 8], to[:, 8])
+        for c in range(len(models)):
+            np.testing.assert_allclose(cal.GetCamera(c)[0], orc.camera(c)[0], rtol=1e-6)
+            np.testing.assert_allclose(cal.GetCamera(c)[1], orc.camera(c)[1], rtol=1e-6, atol=1e-8)
+        ob, osf, og, ot = orc.imu_state()
+        np.testing.assert_allclose(cal.GetBiases(), ob, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(cal.GetScaleFactor(), osf, rtol=1e-6)
+        np.testing.assert_allclose(cal.GetGravity(), og, rtol=1e-6, atol=1e-9)
+        assert abs(cal.time_offset() - ot) < 1e-9
+        np.testing.assert_allclose(cal.GetCameraProjRMSE(), orc.rmse(), rtol=1e-6)
+        print("oracle agrees: %d iterations, D = %d" % (len(to), cal.shared_dim()))
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
@@ -135,7 +153,7 @@ def main_imu(models=("kb4",), n_total=80, max_iters=100, strict=True):
 if __name__ == "__main__":
     if sys.argv[1] == "gpu_imu":
         main_imu()
-    elif sys.argv[1] == "gpu_imu8":      # cfg5-like rig: 8 cameras + IMU, reduced dimension 115 + 9 per shard boundary
-        main_imu(models=("fov", "kb4") * 4, n_total=32, max_iters=25, strict=False)
+    elif sys.argv[1] == "gpu_imu8":      # cfg5's rig: 8 cameras + IMU, reduced dimension 115 + 9 per shard boundary; well conditioned
+        main_imu(models=("fov", "kb4") * 4, n_total=240, max_iters=200, strict=True, oracle=True, prior=True)
     else:
         main(sys.argv[1])

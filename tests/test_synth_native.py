@@ -11,10 +11,11 @@ CASES = [
     synth.BASELINE_CONFIGS["cfg1"],
     synth.Config(models=("kb4", "fov", "poly2"), n_frames=40, imu=True, seed=7, first_frame=13),
     synth.Config(models=("poly3", "linear"), grid="large", n_frames=30, imu=True, seed=9),
+    synth.Config(models=("fov", "kb4", "fov"), n_frames=12, imu=True, seed=5, extrinsics_prior=True),
 ]
 
 
-@pytest.mark.parametrize("cfg", CASES, ids=["cfg1", "mixed_rig_imu_shard", "large_grid_imu"])
+@pytest.mark.parametrize("cfg", CASES, ids=["cfg1", "mixed_rig_imu_shard", "large_grid_imu", "extrinsics_prior"])
 def test_native_generator_matches_numpy(cfg):
     a, b = synth.generate(cfg), synth.generate_native(cfg)
     fa, fb = synth.flatten(a), synth.flatten(b)

@@ -223,6 +223,7 @@ struct vc_calibrator {
     stop();
     if (rccl_comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(stream); (void)g_rccl.CommDestroy(rccl_comm); }
     drop_graphs();
+    kt_free();
     if (stream2) (void)hipStreamDestroy(stream2);
     if (ev_state) (void)hipEventDestroy(ev_state);
     if (ev_weights) (void)hipEventDestroy(ev_weights);
@@ -538,6 +539,39 @@ struct vc_calibrator {
     return VC_OK;
   }
 
+  // ---- in-loop kernel timing (vc_set_kernel_timing): every launch group of a pass bracketed by a pair of events on the
+  // calibrator's stream; durations are read back after the solve.  Off by default (an event record costs ~1 us of stream time).
+  bool ktime_on = false;
+  std::vector<hipEvent_t> kt_ev;            // pool: 2 per bracket
+  std::vector<int> kt_label;                // label of bracket i
+  size_t kt_used = 0;
+  std::vector<std::string> kt_names;
+  std::vector<double> kt_total_ms; std::vector<long> kt_count;
+  int kt_label_id(const char* name) {
+    for (size_t i = 0; i < kt_names.size(); ++i) if (kt_names[i] == name) return (int)i;
+    kt_names.push_back(name); kt_total_ms.push_back(0.0); kt_count.push_back(0);
+    return (int)kt_names.size() - 1;
+  }
+  void kt_begin(const char* name) {
+    if (kt_ev.size() < 2 * (kt_used + 1)) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { ktime_on = false; return; }
+      kt_ev.push_back(a); kt_ev.push_back(b);
+    }
+    kt_label.resize(kt_used + 1); kt_label[kt_used] = kt_label_id(name);
+    (void)hipEventRecord(kt_ev[2 * kt_used], stream);
+  }
+  void kt_end() { (void)hipEventRecord(kt_ev[2 * kt_used + 1], stream); ++kt_used; }
+  void kt_collect() {          // after a stream synchronisation
+    for (size_t i = 0; i < kt_used; ++i) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, kt_ev[2 * i], kt_ev[2 * i + 1]) == hipSuccess) { kt_total_ms[kt_label[i]] += ms; kt_count[kt_label[i]] += 1; }
+    }
+    kt_used = 0;
+  }
+  void kt_free() { for (hipEvent_t e : kt_ev) (void)hipEventDestroy(e); kt_ev.clear(); kt_used = 0; }
+#define KT(name, call) do { if (ktime_on) kt_begin(name); call; if (ktime_on) kt_end(); } while (0)
+
   // ---- one pass of the device pipeline (all asynchronous; the decision is taken on the device) ------
   int do_allreduce(double* p, int n, int op) {
     if (sharded() && rccl_comm) {
@@ -556,35 +590,34 @@ struct vc_calibrator {
       // the Jacobian sweeps and the chain solve and writes the other weight buffer.
       const bool upd = dv.weights_on != 0;
       if (upd && serial_weights) {
-        launch_imu_weights(dv, wcur, stream);
+        KT("k_imu_weights", launch_imu_weights(dv, wcur, stream));
       } else if (upd) {
         HIP_OK(hipEventRecord(ev_state, stream));
         HIP_OK(hipStreamWaitEvent(stream2, ev_state, 0));
         launch_imu_weights(dv, wcur, stream2);
         HIP_OK(hipEventRecord(ev_weights, stream2));
       }
-      launch_reproj_jac(dv, stream);
-      launch_imu_jac(dv, wcur, stream);
-      launch_chain_solve_a(dv, stream);
-      launch_part_sum(dv, stream);
+      KT("k_reproj_jac", launch_reproj_jac(dv, stream));
+      KT("k_imu_jac", launch_imu_jac(dv, wcur, stream));
+      KT("chain_forward", launch_chain_solve_a(dv, stream));
+      KT("k_part_sum", launch_part_sum(dv, stream));
       int rc = VC_OK;
       if (sharded()) {
         launch_reduced(dv, 1, stream);
         rc = do_allreduce(dv.Sbuf, D * D + 3 * D + 2, 0); if (rc) return rc;
         launch_reduced(dv, 2, stream);
       } else {
-        launch_reduced(dv, 0, stream);
+        KT("k_reduced", launch_reduced(dv, 0, stream));
       }
-      launch_chain_solve_b(dv, stream);
-      launch_reproj_res(dv, 3, 0.0, stream);
+      KT("chain_backward", launch_chain_solve_b(dv, stream));
       if (upd) { if (!serial_weights) HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0)); wcur = 1 - wcur; }
-      launch_imu_res(dv, 3, wcur, stream);
+      KT("trial_residuals", { launch_reproj_res(dv, 3, 0.0, stream); launch_imu_res(dv, 3, wcur, stream); });
       if (sharded()) {
         launch_final(dv, 1, stream);
         rc = do_allreduce(dv.gath, world * kNumScal, 0); if (rc) return rc;
         launch_final(dv, 2, stream);
       } else {
-        launch_final(dv, 0, stream);
+        KT("k_final", launch_final(dv, 0, stream));
       }
       return VC_OK;
     }
@@ -596,23 +629,23 @@ struct vc_calibrator {
       dv.merged = 1; dv.par = kpass & 1; dv.ctrl = d_ctrl.p + (kpass & 1); dv.ctrl_prev = d_ctrl.p + ((kpass + 1) & 1);
       ++kpass;
     }
-    if (first_pass || !dv.fused) launch_reproj_jac(dv, stream);
-    launch_frame_schur(dv, stream);
+    if (first_pass || !dv.fused) KT("k_reproj_jac", launch_reproj_jac(dv, stream));
+    KT("k_frame_schur+k_part_sum", launch_frame_schur(dv, stream));
     int rc = VC_OK;
     if (sharded()) {
       launch_reduced(dv, 1, stream);
       rc = do_allreduce(dv.Sbuf, D * D + 3 * D + 2, 0); if (rc) return rc;
       launch_reduced(dv, 2, stream);
     } else {
-      launch_reduced(dv, 0, stream);
+      KT("k_reduced", launch_reduced(dv, 0, stream));
     }
-    launch_trial(dv, stream);
+    KT("k_trial", launch_trial(dv, stream));
     if (sharded()) {
       launch_final(dv, 1, stream);
       rc = do_allreduce(dv.gath, world * kNumScal, 0); if (rc) return rc;
       if (!merged) launch_final(dv, 2, stream);      // merged: the next pass's frame elimination combines the ranks and decides
     } else if (!merged) {
-      launch_final(dv, 0, stream);
+      KT("k_final", launch_final(dv, 0, stream));
     }
     return VC_OK;
   }
@@ -665,6 +698,7 @@ struct vc_calibrator {
       HIP_OK(hipMemcpyAsync(&pin->down, ctrl_result(), sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
       HIP_OK(hipMemcpyAsync(pin->trace, d_trace.p, trace_bytes, hipMemcpyDeviceToHost, stream));
       HIP_OK(hipStreamSynchronize(stream));
+      if (ktime_on) kt_collect();
       // Stop() is a collective decision when the frames are sharded: a rank that left its enqueue loop alone would leave
       // its peers waiting in the next all-reduce (every rank runs the same batch schedule, so the counts line up)
       if (sharded()) {
@@ -1018,6 +1052,28 @@ int vc_start(vc_calibrator* h) {
   return VC_OK;
 }
 int vc_set_stage_limit(vc_calibrator* h, int n) { NOT_RUNNING(h); h->stage_limit = n; return VC_OK; }
+int vc_set_kernel_timing(vc_calibrator* h, int on) {
+  NOT_RUNNING(h);
+  h->ktime_on = on != 0;
+  for (double& t : h->kt_total_ms) t = 0.0;
+  for (long& c : h->kt_count) c = 0;
+  return VC_OK;
+}
+int vc_get_kernel_timing(vc_calibrator* h, char* names, int names_len, double* total_ms, long long* count, int max_entries) {
+  NOT_RUNNING(h);
+  if (!names || !total_ms || !count || names_len <= 0) return VC_ERR_BAD_ARG;
+  std::string joined;
+  int n = 0;
+  for (size_t i = 0; i < h->kt_names.size() && n < max_entries; ++i) {
+    if (h->kt_count[i] == 0) continue;
+    if (!joined.empty()) joined += ";";
+    joined += h->kt_names[i];
+    total_ms[n] = h->kt_total_ms[i]; count[n] = h->kt_count[i]; ++n;
+  }
+  if ((int)joined.size() + 1 > names_len) return VC_ERR_BAD_ARG;
+  std::memcpy(names, joined.c_str(), joined.size() + 1);
+  return n;
+}
 int vc_resume(vc_calibrator* h) { NOT_RUNNING(h); h->is_finished = false; return VC_OK; }
 int vc_is_running(vc_calibrator* h) { return h && h->is_running && !h->is_finished; }
 int vc_stop(vc_calibrator* h) { if (!h) return VC_ERR_BAD_ARG; h->stop(); return VC_OK; }

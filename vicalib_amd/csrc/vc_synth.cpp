@@ -120,7 +120,7 @@ void project(int model, const double* K, const double P[3], double pix[2]) {
 
 struct Config {
   int n_cams; int models[8]; int grid, n_frames, imu; long long seed; int width, height;
-  double frame_rate, imu_rate, pixel_sigma, pose_sigma_t, pose_sigma_r; long long first_frame; int threads;
+  double frame_rate, imu_rate, pixel_sigma, pose_sigma_t, pose_sigma_r; long long first_frame; int threads, extrinsics_prior;
 };
 struct Grid { int gw, gh; double sp, w, h; };
 Grid grid_of(int g) {
@@ -208,6 +208,16 @@ vcs_problem* vcs_generate(const void* cfg_bytes, int cfg_size) {
     quat_from_matrix(Rck, T);
     for (int i = 0; i < 3; ++i) T[4 + i] = -t[i];
     P->T_ck_init[(size_t)c * 7 + 3] = 1.0;
+    if (cfg.extrinsics_prior && c > 0) {      // a rough prior on the rig instead of the engine's identity (synth.py: extrinsics_prior)
+      double dw[3], dtr[3];
+      for (int i = 0; i < 3; ++i) {
+        dw[i] = (0.5 * kPi / 180.0) * (2.0 * Hash(seed + 31).key(c).key(i).uniform() - 1.0);
+        dtr[i] = 0.01 * (2.0 * Hash(seed + 37).key(c).key(i).uniform() - 1.0);
+      }
+      double* Ti = &P->T_ck_init[(size_t)c * 7];
+      quat_from_matrix(mul(so3_exp(dw), R_c_c0), Ti);
+      for (int i = 0; i < 3; ++i) Ti[4 + i] = -t[i] + dtr[i];
+    }
     R_ck[c] = quat_to_matrix(T);                 // the detections are generated from the stored quaternion, as in synth.py
     for (int i = 0; i < 3; ++i) t_ck[(size_t)c * 3 + i] = T[4 + i];
   }
