@@ -189,30 +189,30 @@ def main():
     kernels = {}
     for name, (cnt, avg_ms) in kt.items():
         e = {"launch_groups": cnt, "avg_ms": avg_ms, "ms_per_step": avg_ms * cnt / max(done, 1)}
-        if name in algo:
-            bound, fl, by = algo[name]
+        base_name = name.replace("(trial)", "")
+        if base_name in algo:
+            bound, fl, by = algo[base_name]
             e.update({"algorithmic_flops": fl, "algorithmic_bytes": by, "tflops": fl / (avg_ms * 1e-3) / 1e12, "fp64_frac": fl / (avg_ms * 1e-3) / 78.6e12,
                       "hbm_gbs": by / (avg_ms * 1e-3) / 1e9, "hbm_frac": by / (avg_ms * 1e-3) / 8e12})
         kernels[name] = e
     # the dominant kernel = the single kernel with the largest share of the step (launch groups of several kernels excluded)
-    single = [k for k in kernels if k in algo]
+    single = [k for k in kernels if k.replace("(trial)", "") in algo]
     dom = max(single, key=lambda k: kernels[k]["ms_per_step"]) if single else None
     roofline = None
     if dom:
-        bound, fl, by = algo[dom]
+        bound, fl, by = algo[dom.replace("(trial)", "")]
         e = kernels[dom]
         roofline = {"kernel": dom, "bound": bound, "achieved": e["tflops"], "peak": 78.6, "unit": "TFLOP/s", "frac": e["fp64_frac"],
-                    "traffic": PMC_TRAFFIC.get(wl, {}).get(dom) if world == 1 and not args.frames else None, "avg_ms": e["avg_ms"],
+                    "traffic": PMC_TRAFFIC.get(wl, {}).get(dom.replace("(trial)", "")) if world == 1 and not args.frames else None, "avg_ms": e["avg_ms"],
                     "algorithmic_flops": fl, "algorithmic_bytes": by, "hbm_gbs": e["hbm_gbs"], "hbm_frac": e["hbm_frac"],
                     "timing": "HIP events around every launch of this kernel inside the timed LM loop (decisions live)"}
-    jac = kernels.get("k_reproj_jac") or kernels.get("k_trial")
+    nm = "k_reproj_jac(trial)" if "k_reproj_jac(trial)" in kernels else ("k_trial" if "k_trial" in kernels else None)
     roofline_sweep = None
-    if jac:
-        nm = "k_reproj_jac" if "k_reproj_jac" in kernels and vi else "k_trial"
+    if nm:
         e = kernels[nm]
         roofline_sweep = {"kernel": nm + " (residual + Jacobian + tile normal equations sweep)", "avg_ms": e["avg_ms"], "tflops": e["tflops"],
                           "fp64_frac": e["fp64_frac"], "hbm_gbs": e["hbm_gbs"], "hbm_frac": e["hbm_frac"],
-                          "traffic": PMC_TRAFFIC.get(wl, {}).get(nm) if world == 1 and not args.frames else None}
+                          "traffic": PMC_TRAFFIC.get(wl, {}).get(nm.replace("(trial)", "")) if world == 1 and not args.frames else None}
 
     out = None
     if rank == 0:

@@ -83,6 +83,9 @@ int vc_set_optimization_flags(vc_calibrator* h, int bias_active, int inertial_ac
 /* gflags read inside the calibrator: FLAGS_max_iters (:142), FLAGS_calibrate_imu (:214, :651, :977),
  * FLAGS_remove_outliers / FLAGS_outlier_threshold (:870, :995, :1024) */
 int vc_set_max_iters(vc_calibrator* h, int max_iters);
+/* ceres::Solver::Options::gradient_tolerance / parameter_tolerance, which the reference leaves at the Ceres defaults
+ * (1e-10 / 1e-8, vicalibrator.h:141-151); settable here so that tests can converge a solve to rounding level */
+int vc_set_tolerances(vc_calibrator* h, double gradient_tolerance, double parameter_tolerance);
 int vc_set_calibrate_imu(vc_calibrator* h, int calibrate_imu);
 int vc_set_remove_outliers(vc_calibrator* h, int remove_outliers, double outlier_threshold);
 

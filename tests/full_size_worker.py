@@ -60,4 +60,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:      # noqa: BLE001
+        import traceback
+        print("WORKER-FAILURE rank %s: %s\n%s" % (os.environ.get("RANK"), type(e).__name__, (str(e) + "\n" + traceback.format_exc())[:6000]), flush=True)
+        os._exit(1)

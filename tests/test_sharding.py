@@ -19,7 +19,8 @@ def _run(mode, timeout, nproc=2):
            "--master-port", str(_free_port()), os.path.join(HERE, "dist_worker.py"), mode]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    fail = out.stdout.find("WORKER-FAILURE")
+    assert out.returncode == 0, (out.stdout[fail:fail + 7000] if fail >= 0 else out.stdout[-3000:] + out.stderr[-3000:])
     assert out.stdout.count("ok") >= nproc
 
 

@@ -142,9 +142,9 @@ struct vc_calibrator {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;        // the IMU weight update of a pass runs here, under the pass's Jacobian sweeps and chain solve
-  hipEvent_t ev_state = nullptr, ev_weights = nullptr;
+  hipEvent_t ev_state = nullptr, ev_weights = nullptr, ev_imujac = nullptr, ev_back = nullptr;
   int wcur = 0;                         // weight buffer holding the current weight_sqrt_
-  bool serial_weights = true;           // weight update in line on the main stream; VICALIB_AMD_OVERLAP_WEIGHTS=1 moves it to a second
+  bool serial_weights = false;          // false: IMU Jacobians + weight update on the second stream (VICALIB_AMD_OVERLAP_WEIGHTS=0: in line); was: VICALIB_AMD_OVERLAP_WEIGHTS=1 moves it to a second
                                         // stream under the Jacobian sweeps / chain solve (measured: the two latency-bound kernels then
                                         // share the CUs and the pass gets 4 % slower on cfg3)
   hipGraphExec_t pass_graph[2] = {nullptr, nullptr};   // one captured LM pass per weight-buffer parity (single process)
@@ -208,8 +208,8 @@ struct vc_calibrator {
   DBuf<double> d_pose[2], d_cam[2], d_G[2], d_tile_cost[2], d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_sdiag,
       d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total;
   DBuf<Ctrl> d_ctrl;
-  DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_segH, d_segg, d_seg_cost, d_seg_trial,
-      d_cA, d_cB, d_cP, d_cQ, d_cW, d_cdelta, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init;
+  DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_segH[2], d_segg[2], d_seg_cost[2], d_seg_trial,
+      d_cW, d_cdelta, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init, d_rX[2];
   size_t wsqrt_frames = 0;       // number of frames the device weight_sqrt_ array was initialised for
   int trace_cap = 0;
   struct Pinned { Ctrl up; Ctrl down; double trace[64 * kTraceCols]; };
@@ -227,6 +227,8 @@ struct vc_calibrator {
     if (stream2) (void)hipStreamDestroy(stream2);
     if (ev_state) (void)hipEventDestroy(ev_state);
     if (ev_weights) (void)hipEventDestroy(ev_weights);
+    if (ev_imujac) (void)hipEventDestroy(ev_imujac);
+    if (ev_back) (void)hipEventDestroy(ev_back);
     if (stream) (void)hipStreamDestroy(stream);
     if (pin) (void)hipHostFree(pin);
   }
@@ -430,7 +432,7 @@ struct vc_calibrator {
     dv.col_cam = d_col_cam.p; dv.col_local = d_col_local.p;
     dv.poses[0] = d_pose[0].p; dv.poses[1] = d_pose[1].p; dv.cams[0] = d_cam[0].p; dv.cams[1] = d_cam[1].p;
     for (int b = 0; b < 2; ++b) { dv.Gb[b] = d_G[b].p; dv.tile_costb[b] = d_tile_cost[b].p; }
-    dv.fused = imu_on() ? 0 : 1;
+    dv.fused = 1;
  dv.tile_trial = d_tile_trial.p; dv.Y = d_Y.p; dv.fr = d_fr.p;
     dv.fdiag = d_fdiag.p; dv.fscale2 = d_fscale2.p; dv.part = d_part.p; dv.part_total = d_part_total.p; dv.Sbuf = d_Sbuf.p;
     dv.sdiag = d_sdiag.p; dv.sscale2 = d_sscale2.p; dv.slam = d_slam.p; dv.delta_s = d_delta_s.p;
@@ -455,6 +457,7 @@ struct vc_calibrator {
     dv.gyro_sigma = gyro_sigma; dv.accel_sigma = accel_sigma;
     for (int a = 0; a < 15; ++a) dv.imu_param_col[a] = imu_param_col[a];
     dv.ldw = (((D + 1 + 15) / 16) * 16 % 32 == 0) ? ((D + 1 + 15) / 16) * 16 + 16 : ((D + 1 + 15) / 16) * 16;
+    dv.ldx = dv.ldw + 32;
     dv.pin_first = (shard_imu && rank > 0) ? 1 : 0; dv.pin_last = ghost ? 1 : 0;
     dv.sep_col0 = D0 + 9 * (rank - 1); dv.sep_col1 = D0 + 9 * rank;
     HIP_OK(d_sep_strip.alloc((size_t)2 * 9 * dv.ldw)); dv.sep_strip = d_sep_strip.p;
@@ -468,17 +471,20 @@ struct vc_calibrator {
         HIP_OK(d_wsqrt[0].upload(w, stream)); HIP_OK(d_wsqrt[1].upload(w, stream)); wsqrt_frames = (size_t)N; wcur = 0;
         HIP_OK(hipStreamSynchronize(stream));
       }
-      HIP_OK(d_segH.alloc(ns * 33 * 33)); HIP_OK(d_segg.alloc(ns * 33)); HIP_OK(d_seg_cost.alloc(ns)); HIP_OK(d_seg_trial.alloc(ns));
+      for (int b = 0; b < 2; ++b) { HIP_OK(d_segH[b].alloc(ns * 33 * 33)); HIP_OK(d_segg[b].alloc(ns * 33)); HIP_OK(d_seg_cost[b].alloc(ns)); }
+      HIP_OK(d_seg_trial.alloc(ns));
       const size_t nf = (size_t)std::max(N, 1);
-      HIP_OK(d_cA.alloc(nf * 81)); HIP_OK(d_cB.alloc(nf * 81)); HIP_OK(d_cP.alloc(nf * 81)); HIP_OK(d_cQ.alloc(nf * 81));
-      HIP_OK(d_cW.alloc(nf * 9 * dv.ldw)); HIP_OK(d_cdelta.alloc(nf * 9)); HIP_OK(d_cg.alloc(nf * 9)); HIP_OK(d_clam.alloc(nf * 9));
+      HIP_OK(d_cW.alloc(nf * 9 * dv.ldx)); HIP_OK(d_cdelta.alloc(nf * 9)); HIP_OK(d_cg.alloc(nf * 9)); HIP_OK(d_clam.alloc(nf * 9));
       HIP_OK(d_cdiag.alloc(nf * 9)); HIP_OK(d_cscale2.alloc(nf * 9));
+      for (int b = 0; b < 2; ++b) HIP_OK(d_rX[b].alloc((nf / 8 + 2) * 9 * dv.ldx));
     }
     dv.imu_t = d_imu_t.p; dv.imu_w = d_imu_w.p; dv.imu_a = d_imu_a.p; dv.frame_time = d_frame_time.p;
     dv.vel[0] = d_vel[0].p; dv.vel[1] = d_vel[1].p; dv.imus[0] = d_imus[0].p; dv.imus[1] = d_imus[1].p;
-    dv.wsqrtb[0] = d_wsqrt[0].p; dv.wsqrtb[1] = d_wsqrt[1].p; dv.segH = d_segH.p; dv.segg = d_segg.p; dv.seg_cost = d_seg_cost.p; dv.seg_trial = d_seg_trial.p;
-    dv.cA = d_cA.p; dv.cB = d_cB.p; dv.cP = d_cP.p; dv.cQ = d_cQ.p; dv.cW = d_cW.p; dv.cdelta = d_cdelta.p; dv.cg = d_cg.p;
+    dv.wsqrtb[0] = d_wsqrt[0].p; dv.wsqrtb[1] = d_wsqrt[1].p; dv.seg_trial = d_seg_trial.p;
+    for (int b = 0; b < 2; ++b) { dv.segHb[b] = d_segH[b].p; dv.seggb[b] = d_segg[b].p; dv.seg_costb[b] = d_seg_cost[b].p; }
+    dv.cW = d_cW.p; dv.cdelta = d_cdelta.p; dv.cg = d_cg.p;
     dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p;
+    for (int b = 0; b < 2; ++b) dv.rX[b] = d_rX[b].p;
     HIP_OK(hipStreamSynchronize(stream));   // the staging vectors above go out of scope
     device_dirty = false;
     return VC_OK;
@@ -552,16 +558,18 @@ struct vc_calibrator {
     kt_names.push_back(name); kt_total_ms.push_back(0.0); kt_count.push_back(0);
     return (int)kt_names.size() - 1;
   }
-  void kt_begin(const char* name) {
+  hipStream_t kt_stream = nullptr;
+  void kt_begin(const char* name, hipStream_t strm = nullptr) {
+    kt_stream = strm ? strm : stream;
     if (kt_ev.size() < 2 * (kt_used + 1)) {
       hipEvent_t a = nullptr, b = nullptr;
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { ktime_on = false; return; }
       kt_ev.push_back(a); kt_ev.push_back(b);
     }
     kt_label.resize(kt_used + 1); kt_label[kt_used] = kt_label_id(name);
-    (void)hipEventRecord(kt_ev[2 * kt_used], stream);
+    (void)hipEventRecord(kt_ev[2 * kt_used], kt_stream);
   }
-  void kt_end() { (void)hipEventRecord(kt_ev[2 * kt_used + 1], stream); ++kt_used; }
+  void kt_end() { (void)hipEventRecord(kt_ev[2 * kt_used + 1], kt_stream); ++kt_used; }
   void kt_collect() {          // after a stream synchronisation
     for (size_t i = 0; i < kt_used; ++i) {
       float ms = 0;
@@ -571,6 +579,7 @@ struct vc_calibrator {
   }
   void kt_free() { for (hipEvent_t e : kt_ev) (void)hipEventDestroy(e); kt_ev.clear(); kt_used = 0; }
 #define KT(name, call) do { if (ktime_on) kt_begin(name); call; if (ktime_on) kt_end(); } while (0)
+#define KT2(name, call) do { if (ktime_on) kt_begin(name, stream2); call; if (ktime_on) kt_end(); } while (0)
 
   // ---- one pass of the device pipeline (all asynchronous; the decision is taken on the device) ------
   int do_allreduce(double* p, int n, int op) {
@@ -586,19 +595,28 @@ struct vc_calibrator {
     dv.merged = 0; dv.par = 0; dv.ctrl = d_ctrl.p; dv.ctrl_prev = d_ctrl.p + 1;
     if (dv.imu_on) {
       // UpdateImuWeights of the iteration callback (vicalibrator.h:691): linearise with the current weights, evaluate the
-      // trial point with the updated ones.  The update only needs the accepted state, so it runs on a second stream under
-      // the Jacobian sweeps and the chain solve and writes the other weight buffer.
+      // trial point with the updated ones.  The pass is a small graph over two streams: the IMU Jacobians and, behind them,
+      // the weight update (which only needs the accepted state and writes the other weight buffer) run on the second
+      // stream next to the vision sweep and the chain solve -- every one of these kernels is a few hundred latency-bound
+      // wavefronts, far from filling the chip on its own.
       const bool upd = dv.weights_on != 0;
-      if (upd && serial_weights) {
-        KT("k_imu_weights", launch_imu_weights(dv, wcur, stream));
-      } else if (upd) {
+      // The Jacobian sweeps at the head of the pass only run when the control record asks for a linearisation: the first pass
+      // of a solve.  Afterwards the trial point is evaluated by the same sweeps in trial mode (below), which leave the next
+      // linearisation behind if the step is accepted; after a rejected step the old one is still in place.
+      if (!serial_weights) {
         HIP_OK(hipEventRecord(ev_state, stream));
         HIP_OK(hipStreamWaitEvent(stream2, ev_state, 0));
-        launch_imu_weights(dv, wcur, stream2);
-        HIP_OK(hipEventRecord(ev_weights, stream2));
+        if (first_pass) KT2("k_imu_jac", launch_imu_jac(dv, wcur, stream2, 0));
+        if (upd) KT2("k_imu_weights", launch_imu_weights(dv, wcur, stream2));
+        if (first_pass) {
+          KT("k_reproj_jac", launch_reproj_jac(dv, stream, 0));
+          HIP_OK(hipEventRecord(ev_imujac, stream2));       // (recorded behind the weight update: first pass only)
+          HIP_OK(hipStreamWaitEvent(stream, ev_imujac, 0));
+        }
+      } else {
+        if (upd) KT("k_imu_weights", launch_imu_weights(dv, wcur, stream));
+        if (first_pass) { KT("k_reproj_jac", launch_reproj_jac(dv, stream, 0)); KT("k_imu_jac", launch_imu_jac(dv, wcur, stream, 0)); }
       }
-      KT("k_reproj_jac", launch_reproj_jac(dv, stream));
-      KT("k_imu_jac", launch_imu_jac(dv, wcur, stream));
       KT("chain_forward", launch_chain_solve_a(dv, stream));
       KT("k_part_sum", launch_part_sum(dv, stream));
       int rc = VC_OK;
@@ -610,8 +628,20 @@ struct vc_calibrator {
         KT("k_reduced", launch_reduced(dv, 0, stream));
       }
       KT("chain_backward", launch_chain_solve_b(dv, stream));
-      if (upd) { if (!serial_weights) HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0)); wcur = 1 - wcur; }
-      KT("trial_residuals", { launch_reproj_res(dv, 3, 0.0, stream); launch_imu_res(dv, 3, wcur, stream); });
+      // trial point: both sweeps in trial mode, the IMU blocks with the weights this pass has just updated -- on the second
+      // stream behind the weight update, next to the vision sweep on the main one
+      if (upd) wcur = 1 - wcur;
+      if (!serial_weights) {
+        HIP_OK(hipEventRecord(ev_back, stream));
+        HIP_OK(hipStreamWaitEvent(stream2, ev_back, 0));
+        KT2("k_imu_jac(trial)", launch_imu_jac(dv, wcur, stream2, 1));
+        HIP_OK(hipEventRecord(ev_weights, stream2));
+        KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
+        HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0));
+      } else {
+        KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
+        KT("k_imu_jac(trial)", launch_imu_jac(dv, wcur, stream, 1));
+      }
       if (sharded()) {
         launch_final(dv, 1, stream);
         rc = do_allreduce(dv.gath, world * kNumScal, 0); if (rc) return rc;
@@ -888,10 +918,12 @@ int vc_create(vc_calibrator** out, int device) {
   h->device = device;
   { const char* e = std::getenv("VICALIB_AMD_GRAPHS"); if (e && e[0] == '1') h->use_graphs = true; }
   { const char* e = std::getenv("VICALIB_AMD_NO_MERGED_DECISION"); if (e && e[0] == '1') h->merged_enabled = false; }
-  { const char* e = std::getenv("VICALIB_AMD_OVERLAP_WEIGHTS"); if (e && e[0] == '1') h->serial_weights = false; }
+  { const char* e = std::getenv("VICALIB_AMD_OVERLAP_WEIGHTS"); if (e && e[0] == '0') h->serial_weights = true; }
   if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_weights, hipEventDisableTiming) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }
+      hipEventCreateWithFlags(&h->ev_weights, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_imujac, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_back, hipEventDisableTiming) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }
   *out = h;
   return VC_OK;
 }
@@ -1031,6 +1063,11 @@ int vc_set_optimization_flags(vc_calibrator* h, int bias, int inertial, int rot_
   NOT_RUNNING(h);
   h->is_scale_active = bias != 0; h->is_bias_active = bias != 0; h->is_inertial_active = inertial != 0;
   h->rotation_only = rot_only != 0; h->optimize_time_offset = toff != 0; h->device_dirty = true;
+  return VC_OK;
+}
+int vc_set_tolerances(vc_calibrator* h, double gradient_tolerance, double parameter_tolerance) {
+  NOT_RUNNING(h);
+  h->gradient_tolerance = gradient_tolerance; h->parameter_tolerance = parameter_tolerance;
   return VC_OK;
 }
 int vc_set_max_iters(vc_calibrator* h, int m) { NOT_RUNNING(h); h->max_iters = m; return VC_OK; }
@@ -1323,9 +1360,10 @@ int vc_get_imu_blocks(vc_calibrator* h, double* H, double* g, double* cost) {
   NOT_RUNNING(h);
   if (!h->dv.imu_on) return VC_ERR_BAD_ARG;
   const size_t ns = (size_t)std::max(h->dv.n_frames - 1, 0);
-  if (H && hipMemcpy(H, h->dv.segH, ns * 33 * 33 * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
-  if (g && hipMemcpy(g, h->dv.segg, ns * 33 * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
-  if (cost && hipMemcpy(cost, h->dv.seg_cost, ns * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
+  const int b = h->cur;
+  if (H && hipMemcpy(H, h->dv.segHb[b], ns * 33 * 33 * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
+  if (g && hipMemcpy(g, h->dv.seggb[b], ns * 33 * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
+  if (cost && hipMemcpy(cost, h->dv.seg_costb[b], ns * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
   return VC_OK;
 }
 int vc_get_imu_weights(vc_calibrator* h, double* out) {

@@ -75,7 +75,8 @@ struct DevView {
   // iteration instead of two); accepting the step flips `cur` and the linearisation is already there.
   double* Gb[2];                   // n_tiles x 256
   double* tile_costb[2];           // n_tiles   (Jacobian sweep: cost at the linearisation point)
-  int fused;                       // 1: k_trial produces Gb[1-cur] (vision-only passes); 0: k_reproj_jac at the start of a pass
+  int fused;                       // 1: the trial point is evaluated by the Jacobian sweeps themselves (k_trial on vision-only passes,
+                                   // k_reproj_jac / k_imu_jac in trial mode with the IMU), which leave the next linearisation in buffer 1-cur
   double* tile_trial;              // n_tiles x 2: trial cost, sum of squared residuals
   double* Y;                       // n_tiles x 96
   double* fr;                      // n_frames x 40
@@ -110,22 +111,24 @@ struct DevView {
   double gyro_sigma, accel_sigma;
   double* wsqrtb[2];               // (n_frames-1) x 81  weight_sqrt_ of every IMU cost, double-buffered: the update of pass p
                                    // (k_imu_weights on a second stream) writes the buffer the Jacobian sweep of pass p is not reading
-  double* segH;                    // (n_frames-1) x 33 x 33  weighted J^T J, columns [frame j (9) | frame j-1 (9) | imu (15)]
-  double* segg;                    // (n_frames-1) x 33       weighted J^T r
-  double* seg_cost;                // (n_frames-1)  imu_mult * rho at the linearisation point
+  // linearisation of the IMU blocks, double-buffered like the state (buffer b belongs to state buffer b)
+  double* segHb[2];                // (n_frames-1) x 33 x 33  weighted J^T J, columns [frame j (9) | frame j-1 (9) | imu (15)]
+  double* seggb[2];                // (n_frames-1) x 33       weighted J^T r
+  double* seg_costb[2];            // (n_frames-1)  imu_mult * rho at the linearisation point
   double* seg_trial;               // (n_frames-1)  same at the trial point
   // ---- block-tridiagonal frame chain (9 x 9 blocks: pose 6 + velocity 3), cyclic reduction ----------------
-  double* cA;                      // n_frames x 81  diagonal blocks, then their Cholesky factors
-  double* cB;                      // n_frames x 81  coupling to the next active frame (rows f, cols next)
-  double* cP;                      // n_frames x 81  L^-1 B_prev^T of an eliminated frame
-  double* cQ;                      // n_frames x 81  L^-1 B_self
-  double* cW;                      // n_frames x 9 x ldw: columns 0..D-1 W -> Y = L^-1 W, column D: g -> z
+  double* cW;                      // n_frames x 9 x ldx, one image per frame: columns 0..D-1 W -> Y = L^-1 W, column D: g -> z, then
+                                   // from column ldw three 9 x 9 blocks: C (coupling to the group's left separator) -> X_s = L^-1 C,
+                                   // A (diagonal block) -> L, B (coupling to the next active frame, rows = this frame) -> X_n = L^-1 B
   double* cdelta;                  // n_frames x 9
   double* cg;                      // n_frames x 9  gradient
   double* clam;                    // n_frames x 9
   double* cdiag;                   // n_frames x 9
   double* cscale2;                 // n_frames x 9
-  int ldw;
+  int ldw, ldx;                    // ldw: padded width of the border (D + 1 columns); ldx = ldw + 32: row stride of a frame's image
+  // side images of the partitioned chain elimination: the update a group sends to its RIGHT separator (a frame of the
+  // neighbouring group), by level parity; entry = frame / stride of the level that reads it
+  double* rX[2];                   // (n_frames / 8 + 2) x 9 x ldx
   // frame sharding of the IMU chain: the first frame of every rank but rank 0 is a *separator* -- its 9 unknowns live in
   // the reduced system (columns sep_col0..+8) instead of the chain, so the interior chains of the ranks are independent.
   // pin_first: local frame 0 is this rank's separator; pin_last: local frame n_frames-1 is a copy ("ghost") of the next
@@ -145,7 +148,7 @@ struct DevView {
 };
 
 // launchers (vc_kernels.hip); all asynchronous on `s`
-void launch_reproj_jac(const DevView& v, hipStream_t s);
+void launch_reproj_jac(const DevView& v, hipStream_t s, int trial = 0);   // trial: sweep the trial state into buffer 1-cur (its cost = the trial cost)
 void launch_part_sum(const DevView& v, hipStream_t s);         // fixed-order sum of the chunk partials
 void launch_frame_schur(const DevView& v, hipStream_t s);      // frame elimination + per-chunk partial Schur sums
 // mode 0: packed reduced system (Sbuf) + damped solve + trial shared parameters; 1: Sbuf only; 2: solve only
@@ -160,8 +163,7 @@ void launch_cam_sq(const DevView& v, double* out /*n_cams x 2: sum sq, count*/, 
 void launch_outlier_mask(const DevView& v, int state, const double* thresh /*device, n_cams*/, unsigned char* mask, hipStream_t s);
 
 // inertial path (vc_imu_kernels.hip)
-void launch_imu_jac(const DevView& v, int wr, hipStream_t s);               // wr: weight buffer to read
-void launch_imu_res(const DevView& v, int state_sel, int wr, hipStream_t s);        // 2: accepted -> seg_cost-like eval into seg_trial, 3: trial
+void launch_imu_jac(const DevView& v, int wr, hipStream_t s, int trial = 0);   // wr: weight buffer to read; trial as for launch_reproj_jac
 void launch_imu_weights(const DevView& v, int wr, hipStream_t s);          // reads wsqrtb[wr], writes wsqrtb[1 - wr];                   // weight_sqrt_ from the accepted state
 void launch_chain_solve_a(const DevView& v, hipStream_t s);                 // assemble + cyclic-reduction elimination + Gram partials
 void launch_chain_solve_b(const DevView& v, hipStream_t s);                 // back-substitution + trial frame state

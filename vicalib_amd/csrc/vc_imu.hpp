@@ -73,15 +73,23 @@ template <class T> VC_HD void tq_matvec(const T* q, const T* v, T* o) {   // toR
   const T c = (txz - twy) * v[0] + (tyz + twx) * v[1] + (1.0 - (txx + tyy)) * v[2];
   o[0] = a; o[1] = b; o[2] = c;
 }
+// SO3::exp as a unit quaternion [sin(th/2) w/th, cos(th/2)].  Within th/2 <= pi/4 -- the RK4 increments are
+// gyro rate x a few milliseconds -- both factors are polynomials in z = th^2/4 (the fdlibm kernel forms, < 1 ulp; Sophus'
+// own small-angle series is their leading part): no square root, no division, no sin / cos call, and under dual numbers
+// the derivative comes from the same polynomial.  Larger angles take the closed form.
 template <class T> VC_HD void tso3_exp(const T* w, T* q) {
   const T th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-  const T th = sqrt(th2);
   T imag, real;
-  if (th < kSophusEps) {
-    const T th4 = th2 * th2;
-    imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
-    real = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
+  if (val(th2) <= 2.4) {
+    const T z = 0.25 * th2;
+    const T S = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const T Cc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                 z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    imag = 0.5 + 0.5 * (z * S);                  // sin(th/2) / th
+    real = (1.0 - 0.5 * z) + (z * z) * Cc;
   } else {
+    const T th = sqrt(th2);
     const T half = 0.5 * th;
     imag = sin(half) / th;
     real = cos(half);

@@ -8,15 +8,14 @@
 //                  parameters through the RK4 preintegration (vc_imu.hpp) -- the lane-parallel form of
 //                  ceres::Jet<double,35>; then local-parameterisation Jacobians, Cauchy(100) weight and
 //                  the 33 x 33 weighted J^T J / J^T r of the block
-//  k_imu_res       thread per block: residual cost at a state (trial-point evaluation)
 //  k_imu_weights   thread per block: UpdateImuWeights (vicalibrator.h:723-799, vc_imu_weights.hpp)
 //  k_chain_init    wavefront per frame: 9 x 9 diagonal block (visual tiles + two IMU blocks), coupling to the
 //                  next frame, dense border row W (9 x D) and gradient; damping; per-chunk sums of the
 //                  camera Gram blocks and of the IMU shared-parameter block
-//  k_cr_elim / k_cr_update   one level of block cyclic reduction: odd frames are eliminated (L, P = L^-1 B_prev^T,
-//                  Q = L^-1 B_self, Y = L^-1 [W | g]), even frames absorb their two eliminated neighbours
+//  k_chain_fwd     one level of the partitioned chain elimination: a wavefront eliminates the interior frames of a group
+//                  of 8 (L, X_s = L^-1 C, X_n = L^-1 B, Y = L^-1 [W | g]); the group's first frame survives to the next level
 //  k_chain_gram    sum over all frames of [Y | z]^T [Y | z] on the matrix pipe (v_mfma_f64_16x16x4_f64)
-//  k_cr_back       back-substitution, one level per launch;  k_frame_update  trial poses / velocities
+//  k_chain_back    back-substitution, one level per launch; the bottom level also writes the trial poses / velocities
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include "vc_math.hpp"
@@ -34,17 +33,19 @@ constexpr int kImuJacLds = 35 * 9 + 33 * 9 + 16;
 // Two IMU blocks per wavefront: 32 lanes carry the 32 derivative directions that need the dual propagation (the three
 // directions of the later frame's velocity do not -- d r / d v2 = -W^T rows 6..8, written directly), so a block fits a
 // half wave and the kernel, bound by per-lane latency at one wave per SIMD, needs half the waves.
-__global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr) {
+// trial = 0: at the accepted state, when the control record asks for a linearisation; trial = 1: at the trial state into buffer
+// 1 - cur (cost = the block's trial cost; the blocks are the next linearisation if the step is accepted) -- see k_reproj_jac.
+__global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   __shared__ double sh[8 * kImuJacLds];
   const Ctrl* ct = v.ctrl;
-  if (ct->done || !ct->need_lin) return;
+  if (ct->done || (!trial && !ct->need_lin)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int half = lane >> 5, l = lane & 31;
   const int n_blocks = v.n_frames - 1;
   const int s_raw = (blockIdx.x * 4 + wave) * 2 + half;       // block s couples frames s -> s+1
   const bool exists = s_raw < n_blocks;
   const int s = exists ? s_raw : n_blocks - 1;                 // a half past the end shadows the last block and stores nothing
-  const int cur = ct->cur, j = s + 1;
+  const int cur = trial ? 1 - ct->cur : ct->cur, j = s + 1;
   double* Jg = sh + (wave * 2 + half) * kImuJacLds;            // [35][9] global-parameter partials
   double* Jl = Jg + 35 * 9;                                    // [33][9] local columns: cur9 | prev9 | imu15
   const double* T2 = v.poses[cur] + (size_t)j * kPoseStride;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr) {
   loss_cauchy100(ss, &rho, &rho1);
   const double w = ct->imu_mult * rho1;
   if (!exists) return;
-  double* H = v.segH + (size_t)s * (33 * 33);
+  double* H = v.segHb[cur] + (size_t)s * (33 * 33);
   for (int e = l; e < 33 * 33; e += 32) {
     const int a = e / 33, bb = e % 33;
     double acc = 0.0;
@@ -113,28 +114,9 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr) {
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc += Jl[col * 9 + k] * r[k];
-    v.segg[(size_t)s * 33 + col] = w * acc;
+    v.seggb[cur][(size_t)s * 33 + col] = w * acc;
   }
-  if (l == 0) v.seg_cost[s] = ct->imu_mult * rho;
-}
-
-// residual cost of every IMU block at a state: sel 2 = accepted buffer, 3 = trial buffer
-__global__ __launch_bounds__(64) void k_imu_res(DevView v, int sel, int wr) {
-  const Ctrl* ct = v.ctrl;
-  if (ct->done) return;
-  const int s = blockIdx.x * 64 + threadIdx.x;
-  if (s >= v.n_frames - 1) return;
-  const int st = (sel == 3) ? 1 - ct->cur : ct->cur, j = s + 1;
-  const double* im = v.imus[st];
-  double r[9];
-  imu_residual<double>(imu_view(v), v.frame_time[j - 1], v.frame_time[j], v.wsqrtb[wr] + (size_t)s * 81, v.rotation_only,
-                       v.poses[st] + (size_t)j * kPoseStride, v.poses[st] + (size_t)(j - 1) * kPoseStride, v.vel[st] + (size_t)j * 4,
-                       v.vel[st] + (size_t)(j - 1) * 4, im, im + 2, im + 8, im[14], r);
-  double ss = 0.0;
-  for (int k = 0; k < 9; ++k) ss += r[k] * r[k];
-  double rho, rho1;
-  loss_cauchy100(ss, &rho, &rho1);
-  v.seg_trial[s] = ct->imu_mult * rho;
+  if (l == 0) { v.seg_costb[cur][s] = ct->imu_mult * rho; if (trial) v.seg_trial[s] = ct->imu_mult * rho; }
 }
 
 // UpdateImuWeights from the accepted state (vicalibrator.h:723-799): covariance propagation along the block's samples
@@ -445,7 +427,7 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int C = v.n_cams, D = v.D, N = v.n_frames, ldw = v.ldw;
+  const int C = v.n_cams, D = v.D, N = v.n_frames, ldw = v.ldw, ldx = v.ldx;
   double* Gw = sh + wave * (C * kGStride + kInitPad);
   double* Hs = Gw + C * kGStride;
   const int cur = ct->cur;
@@ -465,13 +447,15 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
     const int f = fg + wave;
     if (f >= f1) continue;
     const int t0 = v.frame_tile_off[f], nt = v.frame_tile_off[f + 1] - t0;
-    double* Wf = v.cW + (size_t)f * 9 * ldw;
+    double* Wf = v.cW + (size_t)f * 9 * ldx;     // the frame's image: [W | g] in columns 0..D, then (from ldw) C (zero) | A | B
     // pinned frames (separator / ghost, see DevView): their rows go to sep_strip, the chain sees an isolated identity block
     const bool pin_f = (f == 0 && v.pin_first), pin_l = (f == N - 1 && v.pin_last), pin_self = pin_f || pin_l;
     const bool pin_prev = (f == 1 && v.pin_first), pin_next = (f + 1 == N - 1 && v.pin_last);
     double* Wt = pin_self ? v.sep_strip + (size_t)(pin_f ? 0 : 1) * 9 * ldw : Wf;
+    const int ldt = pin_self ? ldw : ldx;         // row stride of Wt
     const int sep_self = pin_f ? v.sep_col0 : v.sep_col1;
-    for (int i = lane; i < 9 * ldw; i += 64) { Wf[i] = 0.0; if (pin_self) Wt[i] = 0.0; }
+    for (int i = lane; i < 9 * ldx; i += 64) Wf[i] = 0.0;
+    if (pin_self) for (int i = lane; i < 9 * ldw; i += 64) Wt[i] = 0.0;
     if (lane < 42) Hs[lane] = 0.0;
     wave_lds_sync();
     if (nt > 0) {
@@ -535,18 +519,18 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
           const int col = v.cd[c].col0 + j;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            Wt[i * ldw + col] = -(Rm[i] * u[0] + Rm[3 + i] * u[1] + Rm[6 + i] * u[2]);
-            Wt[(3 + i) * ldw + col] = Rm[i] * u[3] + Rm[3 + i] * u[4] + Rm[6 + i] * u[5];
+            Wt[i * ldt + col] = -(Rm[i] * u[0] + Rm[3 + i] * u[1] + Rm[6 + i] * u[2]);
+            Wt[(3 + i) * ldt + col] = Rm[i] * u[3] + Rm[3 + i] * u[4] + Rm[6 + i] * u[5];
           }
         }
       }
     }
     wave_lds_sync();
     // IMU blocks: block f-1 has this frame as "cur" (rows/cols 0..8), block f as "prev" (9..17)
-    const double* Hc = (f >= 1) ? v.segH + (size_t)(f - 1) * (33 * 33) : nullptr;
-    const double* Hp = (f + 1 < N) ? v.segH + (size_t)f * (33 * 33) : nullptr;
-    const double* gc = (f >= 1) ? v.segg + (size_t)(f - 1) * 33 : nullptr;
-    const double* gp = (f + 1 < N) ? v.segg + (size_t)f * 33 : nullptr;
+    const double* Hc = (f >= 1) ? v.segHb[cur] + (size_t)(f - 1) * (33 * 33) : nullptr;
+    const double* Hp = (f + 1 < N) ? v.segHb[cur] + (size_t)f * (33 * 33) : nullptr;
+    const double* gc = (f >= 1) ? v.seggb[cur] + (size_t)(f - 1) * 33 : nullptr;
+    const double* gp = (f + 1 < N) ? v.seggb[cur] + (size_t)f * 33 : nullptr;
     double aval[2] = {0.0, 0.0};
     for (int q = 0; q < 2; ++q) {
       const int e = lane + 64 * q;
@@ -558,9 +542,9 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
         aval[q] = a;
         // rows: this frame (prev of block f), cols: frame f+1 (cur); a pinned end cuts the chain and couples through
         // the separator's columns of the border instead
-        v.cB[(size_t)f * 81 + e] = (Hp && !pin_self && !pin_next) ? Hp[(9 + i) * 33 + j] : 0.0;
-        if (pin_prev && Hc) Wf[i * ldw + v.sep_col0 + j] = Hc[i * 33 + 9 + j];
-        if (pin_next && Hp) Wf[i * ldw + v.sep_col1 + j] = Hp[(9 + i) * 33 + j];
+        Wf[i * ldx + ldw + 18 + j] = (Hp && !pin_self && !pin_next) ? Hp[(9 + i) * 33 + j] : 0.0;
+        if (pin_prev && Hc) Wf[i * ldx + v.sep_col0 + j] = Hc[i * 33 + 9 + j];
+        if (pin_next && Hp) Wf[i * ldx + v.sep_col1 + j] = Hp[(9 + i) * 33 + j];
       }
     }
     double gval = 0.0;
@@ -577,7 +561,7 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
         double w = 0.0;
         if (Hc) w += Hc[i * 33 + 18 + a];
         if (Hp) w += Hp[(9 + i) * 33 + 18 + a];
-        Wt[i * ldw + col] = w;
+        Wt[i * ldt + col] = w;
       }
     }
     // IMU shared block of block f-1 (every block counted once, by its "cur" frame)
@@ -604,7 +588,7 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
       lam = pin_self ? 0.0 : dg / (radius * sc2);
       v.clam[(size_t)f * 9 + lane] = lam;
       v.cg[(size_t)f * 9 + lane] = pin_self ? 0.0 : gval;
-      Wt[lane * ldw + D] = gval;                // right-hand side rides as column D
+      Wt[lane * ldt + D] = gval;                // right-hand side rides as column D
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -614,8 +598,8 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
         double a = aval[q];
         const double li = __shfl(lam, i, 64);
         if (i == j) a += li;
-        if (pin_self) { Wt[i * ldw + sep_self + j] = aval[q]; a = (i == j) ? 1.0 : 0.0; }
-        v.cA[(size_t)f * 81 + e] = a;
+        if (pin_self) { Wt[i * ldt + sep_self + j] = aval[q]; a = (i == j) ? 1.0 : 0.0; }
+        Wf[i * ldx + ldw + 9 + j] = a;
       }
     }
   }
@@ -636,176 +620,355 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
     part[D * D + D + e] = (sh[e] + sh[slot + e]) + (sh[2 * slot + e] + sh[3 * slot + e]);
 }
 
-// ------------------------------------------------------------------------------------------ cyclic reduction
-// Level `s` (s = 2^l): frames e = s (mod 2s) are eliminated. s = 0: the last remaining frame 0.
-__global__ __launch_bounds__(256) void k_cr_elim(DevView v, int s) {
+// ------------------------------------------------------------------------------------------ chain elimination
+// The frame unknowns (pose 6 + velocity 3) form a block-tridiagonal chain with a dense border (the shared parameters and
+// the right-hand side).  Every frame owns one IMAGE of 9 rows (cW, row stride ldx): columns 0..D the border [W | g], then
+// from column ldw the three 9 x 9 blocks [C | A | B] -- C the coupling to the left separator (fill-in; zero to start
+// with), A the frame's own block, B the coupling to the next active frame (rows = this frame).
+// The chain is factored by nested partitioning: at level l the active frames are those with index 0 (mod s), s = m^l;
+// they are cut into groups of m -- the first frame of a group is its LEFT SEPARATOR and stays active, the other m - 1 (the
+// interior) are eliminated by ONE wavefront, sequentially, left to right, with lane = image column throughout:
+//   * factor A = L L^T (nine lanes, lane = row, pivots through v_readlane; the factor goes to LDS);
+//   * every lane solves L x = (its column); the solved C and B columns [X_s | X_n] (18 columns) go to LDS, the solved
+//     image replaces the frame's image in HBM (the A columns receive L itself): that is all the back-substitution needs;
+//   * every lane forms out = [X_s | X_n]^T x: rows 9..17 update the lane's column of the NEXT frame's image (which the
+//     lane keeps in registers for the next elimination; A's columns go to LDS for the next factorisation), rows 0..8
+//     accumulate the group's update of the left separator.
+// The last interior's "next" is the right separator, which belongs to the neighbouring group: its update goes to a side
+// image (rX, double-buffered by level parity) and is folded in when that frame is loaded or written at the next level.
+// A few levels (N = 2000, m = 8: 2000 -> 250 -> 32 -> 4) and a top level that eliminates what is left replace the
+// 2 log2(N) launches of cyclic reduction by log_m(N) + 1, with (m - 1) log_m(N) dependent eliminations.
+constexpr int kChainM = 8;          // group size: 7 eliminations per wavefront and level
+constexpr int kXsLd = 20;           // row stride of the [X_s | X_n] LDS image
+// phase stamps of the first group of level 0 (profiling builds only, -DVC_CHAIN_STAMPS): 100 MHz s_memrealtime ticks in dbg[0..31]
+#ifdef VC_CHAIN_STAMPS
+#define CSTAMP(i) do { if (blockIdx.x == 0 && lvl == 0 && threadIdx.x == 0 && (i) < 32) v.dbg[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
+template <int CPL>                  // columns per lane: D + 1 + 27 <= 64 CPL
+__global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int top, int lvl) {
+  __shared__ __attribute__((aligned(16))) double XS[9 * kXsLd];
+  __shared__ double An[81];
+  __shared__ double Ls[81];
+  CSTAMP(0);
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int idx = blockIdx.x * 4 + wave;
-  const int N = v.n_frames, D = v.D, ldw = v.ldw;
-  const int e = (s == 0) ? 0 : s + 2 * s * idx;
-  if (e >= N || (s == 0 && idx > 0)) return;
-  double L[81];
-  const double* A = v.cA + (size_t)e * 81;
+  CSTAMP(1);
+  const int lane = threadIdx.x;
+  const int N = v.n_frames, D = v.D, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
+  const long gs = (long)m * s;
+  const int a = top ? -1 : (int)(blockIdx.x * gs);
+  const int first = top ? 0 : a + s;
+  const bool pend = lvl > 0;                                   // right contributions of level lvl - 1 are waiting
+  const double* rp = v.rX[(lvl + 1) & 1];
+  double* rw = v.rX[lvl & 1];
+  const size_t isz = (size_t)9 * ldx;
+  // role of each of the lane's columns: 0 border (W | g), 1 C, 2 A, 3 B, 4 none
+  int role[CPL], pc[CPL], sub[CPL];
 #pragma unroll
-  for (int i = 0; i < 81; ++i) L[i] = A[i];
-  double dinv[9];
-  if (!chol_small<9>(L, dinv)) {
-    if (lane == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
-#pragma unroll
-    for (int i = 0; i < 81; ++i) L[i] = (i % 10 == 0) ? 1.0 : 0.0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) dinv[i] = 1.0;
+  for (int ci = 0; ci < CPL; ++ci) {
+    const int c = lane + 64 * ci, e = c - nW;
+    role[ci] = c < nW ? 0 : (e < 9 ? 1 : e < 18 ? 2 : e < 27 ? 3 : 4);
+    pc[ci] = c < nW ? c : (c < ncol ? ldw + e : 0);
+    sub[ci] = e < 9 ? e : e < 18 ? e - 9 : e - 18;            // column inside the 9 x 9 block
   }
-  if (lane < 45) {      // store the factor (lower triangle) over A
-    int r = 0, acc = 0;
-    while (acc + r + 1 <= lane) { acc += r + 1; ++r; }
-    const int c = lane - acc;
-    double val = 0.0;
+  if (first >= N) {            // a separator without interior frames: only its pending right contribution is folded in
+    if (!top && a < N) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i)
+      for (int ci = 0; ci < CPL; ++ci) {
+        double* img = v.cW + (size_t)a * isz + pc[ci];
+        if ((role[ci] == 0 || role[ci] == 2) && pend && a > 0) {
 #pragma unroll
-      for (int j = 0; j <= i; ++j) val = (i == r && j == c) ? L[i * 9 + j] : val;
-    v.cA[(size_t)e * 81 + r * 9 + c] = val;
-  }
-  const bool has_p = (s > 0) && (e - s >= 0), has_n = (s > 0) && (e + s < N);
-  const double* Bp = v.cB + (size_t)(has_p ? e - s : 0) * 81;
-  const double* Be = v.cB + (size_t)e * 81;
-  double* Wf = v.cW + (size_t)e * 9 * ldw;
-  // columns: 0..8 -> P (rhs = row c of B_prev), 9..17 -> Q (rhs = column of B_self), 18.. -> Y | z
-  for (int c = lane; c < 18 + D + 1; c += 64) {
-    double x[9];
-    if (c < 9) {
+          for (int k = 0; k < 9; ++k) img[k * ldx] += rp[(size_t)(a / s) * isz + k * ldx + pc[ci]];
+        } else if (role[ci] == 3) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) x[k] = has_p ? Bp[c * 9 + k] : 0.0;
-    } else if (c < 18) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) x[k] = has_n ? Be[k * 9 + (c - 9)] : 0.0;
-    } else {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) x[k] = Wf[k * ldw + (c - 18)];
+          for (int k = 0; k < 9; ++k) img[k * ldx] = 0.0;
+        }
+      }
     }
-    fwd_solve_inv<9>(L, dinv, x);
-    if (c < 9) {
+    return;
+  }
+  const int q = top ? (N - 1) / s + 1 : min(m - 1, (N - 1 - first) / s + 1);      // frames this wavefront eliminates
+  double xin[CPL][9], dacc[CPL][9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) v.cP[(size_t)e * 81 + k * 9 + c] = x[k];
-    } else if (c < 18) {
+  for (int ci = 0; ci < CPL; ++ci)
 #pragma unroll
-      for (int k = 0; k < 9; ++k) v.cQ[(size_t)e * 81 + k * 9 + (c - 9)] = x[k];
-    } else {
+    for (int k = 0; k < 9; ++k) dacc[ci][k] = 0.0;
+  // ---- the first frame: its image columns to the lanes (C = B_a^T, a row of the separator's B block), A to LDS; the
+  // second frame's columns are requested in the same breath (o / op: the next frame's image and its pending update)
+  double o[CPL][9], op[CPL][9];
+  auto request_next = [&](int e, int i) {
+    const int n = e + s;
+    const bool load_n = (n < N) && !(!top && (i == m - 2));
+    const double* img = v.cW + (size_t)(load_n ? n : e) * isz;
+    const double* rpn = rp + (size_t)((load_n ? n : e) / s) * isz;
+    const bool pn = pend && load_n;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Wf[k * ldw + (c - 18)] = x[k];
+    for (int ci = 0; ci < CPL; ++ci)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        o[ci][k] = (load_n && role[ci] < 4) ? img[k * ldx + pc[ci]] : 0.0;
+        op[ci][k] = (pn && role[ci] < 4) ? rpn[k * ldx + pc[ci]] : 0.0;
+      }
+  };
+  {
+    const bool pe = pend && first > 0;
+    const double* img = v.cW + (size_t)first * isz;
+    const double* rpe = rp + (size_t)(first / s) * isz;
+    double x0[CPL][9], xp[CPL][9];
+#pragma unroll
+    for (int ci = 0; ci < CPL; ++ci) {
+      if (role[ci] == 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { x0[ci][k] = (a >= 0) ? v.cW[(size_t)a * isz + sub[ci] * ldx + ldw + 18 + k] : 0.0; xp[ci][k] = 0.0; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { x0[ci][k] = (role[ci] < 4) ? img[k * ldx + pc[ci]] : 0.0; xp[ci][k] = (pe && role[ci] < 4) ? rpe[k * ldx + pc[ci]] : 0.0; }
+      }
+    }
+    request_next(first, 0);
+#pragma unroll
+    for (int ci = 0; ci < CPL; ++ci) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) xin[ci][k] = x0[ci][k] + xp[ci][k];
+      if (role[ci] == 2) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) An[k * 9 + sub[ci]] = xin[ci][k];
+      }
+    }
+  }
+  for (int i = 0; i < q; ++i) {
+    const int e = first + i * s, n = e + s;
+    const bool has_n = n < N;
+    const bool n_sep = !top && (i == m - 2);                   // the next frame is the right separator (another group's)
+    if (i > 0) request_next(e, i);       // the next frame's columns: requested now, used after the factorisation and the solve
+    wave_lds_sync();
+    CSTAMP(2 + 4 * i);
+    // ---- A = L L^T: lane = row (lanes 0..8), pivots and pivot columns through v_readlane
+    double dinv[9];
+    {
+      const int rr = lane < 9 ? lane : 8;
+      double row[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) row[k] = An[rr * 9 + k];
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        double d = readlane_f64(row[j], j);
+        const bool ok = d > 0.0;
+        bad |= !ok;
+        d = ok ? d : 1.0;
+        const double ip = fast_rsqrt(d);
+        const double lij = (lane == j) ? d * ip : row[j] * ip;
+        row[j] = lij;
+        dinv[j] = ip;
+#pragma unroll
+        for (int k = j + 1; k < 9; ++k) row[k] -= lij * readlane_f64(lij, k);
+      }
+      if (bad) {               // wave-uniform (the pivots are): the frame gets an identity block, the pass is flagged
+        if (lane == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { row[k] = (k == lane) ? 1.0 : 0.0; dinv[k] = 1.0; }
+      }
+      if (lane < 9) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ls[lane * 9 + k] = (k <= lane) ? row[k] : 0.0;
+      }
+    }
+    wave_lds_sync();
+    CSTAMP(3 + 4 * i);
+    // ---- forward solves, lane = column; the image of e becomes [Y | z | X_s | L | X_n]
+    double x[CPL][9];
+#pragma unroll
+    for (int ci = 0; ci < CPL; ++ci) {
+      // column-oriented: x_k is final after k updates, the updates of one column are independent of each other
+#pragma unroll
+      for (int r = 0; r < 9; ++r) x[ci][r] = xin[ci][r];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        x[ci][k] *= dinv[k];
+#pragma unroll
+        for (int r = k + 1; r < 9; ++r) x[ci][r] -= Ls[r * 9 + k] * x[ci][k];
+      }
+      if (role[ci] == 2) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) x[ci][k] = Ls[k * 9 + sub[ci]];
+      }
+      if (role[ci] < 4) {
+        double* img = v.cW + (size_t)e * isz + pc[ci];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) img[k * ldx] = x[ci][k];
+      }
+      if (role[ci] == 1 || role[ci] == 3) {
+        const int xc = sub[ci] + (role[ci] == 3 ? 9 : 0);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) XS[k * kXsLd + xc] = x[ci][k];
+      }
+    }
+    wave_lds_sync();
+    CSTAMP(4 + 4 * i);
+    // ---- Schur updates: out[r] = sum_k [X_s | X_n][k][r] * (column)[k]; the A columns are driven by X_n's columns
+#pragma unroll
+    for (int ci = 0; ci < CPL; ++ci) {
+      if (role[ci] == 2) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) x[ci][k] = XS[k * kXsLd + 9 + sub[ci]];
+      }
+      double out[18];
+#pragma unroll
+      for (int r = 0; r < 18; ++r) out[r] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const double xk = x[ci][k];
+#pragma unroll
+        for (int r = 0; r < 18; ++r) out[r] += XS[k * kXsLd + r] * xk;
+      }
+#pragma unroll
+      for (int r = 0; r < 9; ++r) dacc[ci][r] += out[r];
+      if (has_n) {
+        if (n_sep) {
+          if (role[ci] < 4) {
+            double* ri = rw + (size_t)(n / gs) * isz + pc[ci];
+            const bool keep = role[ci] == 0 || role[ci] == 2;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) ri[k * ldx] = keep ? -out[9 + k] : 0.0;
+          }
+          if (role[ci] == 3 && a >= 0) {                      // the separator's coupling to the right separator at the next level
+            double* img = v.cW + (size_t)a * isz + pc[ci];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) img[k * ldx] = -out[k];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) xin[ci][k] = (o[ci][k] + op[ci][k]) - (role[ci] == 3 ? 0.0 : out[9 + k]);
+          if (role[ci] == 2) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) An[k * 9 + sub[ci]] = xin[ci][k];
+          }
+        }
+      }
+    }
+    CSTAMP(5 + 4 * i);
+  }
+  CSTAMP(30);
+  // ---- the left separator absorbs its group (and the right contribution it received one level down)
+  if (a >= 0) {
+    const bool chain_ends = !(q == m - 1 && first + q * s < N);
+    const bool pa = pend && a > 0;
+    const double* rpa = rp + (size_t)(a / s) * isz;
+#pragma unroll
+    for (int ci = 0; ci < CPL; ++ci) {
+      if (role[ci] == 0 || role[ci] == 1) {                    // the C lanes carry the update of A's columns
+        const int pcd = role[ci] == 1 ? ldw + 9 + sub[ci] : pc[ci];
+        double* img = v.cW + (size_t)a * isz + pcd;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) img[k * ldx] += (pa ? rpa[k * ldx + pcd] : 0.0) - dacc[ci][k];
+      } else if (role[ci] == 3 && chain_ends) {
+        double* img = v.cW + (size_t)a * isz + pc[ci];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) img[k * ldx] = 0.0;
+      }
     }
   }
 }
-// Survivors p = 0 (mod 2s) absorb their eliminated neighbours el = p - s (as its "next") and er = p + s (as its "prev").
-__global__ __launch_bounds__(256) void k_cr_update(DevView v, int s) {
+
+// Back-substitution of one level: delta_e = -L^-T (z + Y delta_s + X_s delta_a + X_n delta_next), right to left inside
+// the group.  Everything that does not depend on the chain (z + Y delta_s + X_s delta_a, the rows of X_n, the columns of L)
+// is formed by lane (frame i, row k) beforehand; the dependent part is one 9 x 9 product and a triangular solve per frame,
+// exchanged through v_readlane.  At level 0 the wavefront also moves its frames (T <- T exp(delta), v <- v + dv) and
+// publishes their step terms.
+__global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int top, int lvl) {
+  __shared__ double ds[192 + 8];
+  __shared__ double dl[kChainM * 9];
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int idx = blockIdx.x * 4 + wave;
-  const int N = v.n_frames, D = v.D, ldw = v.ldw;
-  const int p = 2 * s * idx;
-  if (p >= N) return;
-  const int el = p - s, er = p + s;
-  const bool has_l = el >= 0, has_r = er < N;
-  const double* Pr = v.cP + (size_t)(has_r ? er : 0) * 81;
-  const double* Qr = v.cQ + (size_t)(has_r ? er : 0) * 81;
-  const double* Ql = v.cQ + (size_t)(has_l ? el : 0) * 81;
-  const bool r_has_next = has_r && (er + s < N);
-  for (int e = lane; e < 81; e += 64) {
-    const int i = e / 9, j = e % 9;
-    double a = v.cA[(size_t)p * 81 + e], b = 0.0;
-    if (has_r) {
-      double t = 0.0, u = 0.0;
+  const int lane = threadIdx.x;
+  const int N = v.n_frames, D = v.D, ldw = v.ldw, ldx = v.ldx;
+  const long gs = (long)m * s;
+  const int a = top ? -1 : (int)(blockIdx.x * gs);
+  const int first = top ? 0 : a + s;
+  const size_t isz = (size_t)9 * ldx;
+  for (int j = lane; j < D; j += 64) ds[j] = v.delta_s[j];
+  const int q = first < N ? (top ? (N - 1) / s + 1 : min(m - 1, (N - 1 - first) / s + 1)) : 0;
+  const int r = first + q * s;                                  // right separator (or past the end)
+  double da[9], dn[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) { t += Pr[k * 9 + i] * Pr[k * 9 + j]; u += Pr[k * 9 + i] * Qr[k * 9 + j]; }
-      a -= t;
-      if (r_has_next) b = -u;
-    }
-    if (has_l) {
-      double t = 0.0;
+  for (int k = 0; k < 9; ++k) { da[k] = (a >= 0 && a < N) ? v.cdelta[(size_t)a * 9 + k] : 0.0; dn[k] = (!top && q > 0 && r < N) ? v.cdelta[(size_t)r * 9 + k] : 0.0; }
+  const int fi = lane / 9, k = lane % 9;
+  const bool mine = fi < q;
+  const int e = first + (mine ? fi : 0) * s;
+  double t = 0.0, dinv = 1.0, Qrow[9], Lcol[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) t += Ql[k * 9 + i] * Ql[k * 9 + j];
-      a -= t;
+  for (int c = 0; c < 9; ++c) { Qrow[c] = 0.0; Lcol[c] = 0.0; }
+  wave_lds_sync();
+  if (mine) {
+    const double* img = v.cW + (size_t)e * isz;
+    const double* Wr = img + (size_t)k * ldx;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { Qrow[c] = Wr[ldw + 18 + c]; Lcol[c] = (c > k) ? img[c * ldx + ldw + 9 + k] : 0.0; }
+    dinv = 1.0 / Wr[ldw + 9 + k];
+    double acc = Wr[D];
+    for (int j = 0; j < D; ++j) acc += Wr[j] * ds[j];
+    if (a >= 0) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) acc += Wr[ldw + c] * da[c];
     }
-    v.cA[(size_t)p * 81 + e] = a;
-    v.cB[(size_t)p * 81 + e] = b;
+    t = acc;
   }
-  const double* Yr = v.cW + (size_t)(has_r ? er : 0) * 9 * ldw;
-  const double* Yl = v.cW + (size_t)(has_l ? el : 0) * 9 * ldw;
-  double* Wp = v.cW + (size_t)p * 9 * ldw;
-  for (int e = lane; e < 9 * (D + 1); e += 64) {
-    const int i = e / (D + 1), j = e % (D + 1);
-    double w = Wp[i * ldw + j];
-    if (has_r) {
-      double t = 0.0;
+  double my = 0.0;
+  for (int i = q - 1; i >= 0; --i) {
+    double y = t;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) t += Pr[k * 9 + i] * Yr[k * ldw + j];
-      w -= t;
+    for (int c = 0; c < 9; ++c) y += Qrow[c] * dn[c];
+#pragma unroll
+    for (int j = 8; j >= 0; --j) {
+      const double xj = readlane_f64(y * dinv, i * 9 + j);
+      dn[j] = -xj;
+      y -= Lcol[j] * xj;
     }
-    if (has_l) {
-      double t = 0.0;
+    if (fi == i) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) t += Ql[k * 9 + i] * Yl[k * ldw + j];
-      w -= t;
-    }
-    Wp[i * ldw + j] = w;
-  }
-}
-// delta_e = -L^-T (z + P delta_prev + Q delta_next + Y delta_s) for the frames eliminated at level s
-__global__ __launch_bounds__(256) void k_cr_back(DevView v, int s) {
-  const Ctrl* ct = v.ctrl;
-  if (ct->done) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int idx = blockIdx.x * 4 + wave;
-  const int N = v.n_frames, D = v.D, ldw = v.ldw;
-  const int e = (s == 0) ? 0 : s + 2 * s * idx;
-  if (e >= N || (s == 0 && idx > 0)) return;
-  const double* Wf = v.cW + (size_t)e * 9 * ldw;
-  double y[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) y[k] = 0.0;
-  for (int j = lane; j < D; j += 64) {
-    const double dj = v.delta_s[j];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) y[k] += Wf[k * ldw + j] * dj;
-  }
-#pragma unroll
-  for (int k = 0; k < 9; ++k) y[k] = wave_allsum(y[k]) + Wf[k * ldw + D];
-  if (s > 0) {
-    if (e - s >= 0) {
-      const double* P = v.cP + (size_t)e * 81;
-      const double* dp = v.cdelta + (size_t)(e - s) * 9;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) { double t = 0.0;
-#pragma unroll
-        for (int c = 0; c < 9; ++c) t += P[k * 9 + c] * dp[c];
-        y[k] += t; }
-    }
-    if (e + s < N) {
-      const double* Q = v.cQ + (size_t)e * 81;
-      const double* dn = v.cdelta + (size_t)(e + s) * 9;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) { double t = 0.0;
-#pragma unroll
-        for (int c = 0; c < 9; ++c) t += Q[k * 9 + c] * dn[c];
-        y[k] += t; }
+      for (int j = 0; j < 9; ++j) my = (j == k) ? dn[j] : my;
     }
   }
-  double L[81];
-  const double* A = v.cA + (size_t)e * 81;
+  if (mine) v.cdelta[(size_t)e * 9 + k] = my;
+  if (lvl != 0) return;
+  // ---- level 0: trial poses / velocities of the group's frames and their step terms
+  if (mine) dl[(fi + 1) * 9 + k] = my;
+  if (lane < 9) dl[lane] = da[lane];
+  wave_lds_sync();
+  const int base = top ? 0 : a, cnt = top ? q : (a < N ? q + 1 : 0), off = top ? 1 : 0;
+  if (lane < cnt) {
+    const int f = base + lane;
+    const int cur = ct->cur;
+    // pinned frames step with the reduced system's solution; their gradient / damping terms are counted there, and only the
+    // owner (not the rank that holds the ghost copy) counts the step and parameter norms
+    const bool pin_f = (f == 0 && v.pin_first), pin_l = (f == N - 1 && v.pin_last);
+    double d[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i)
-#pragma unroll
-    for (int j = 0; j < 9; ++j) L[i * 9 + j] = (j <= i) ? A[i * 9 + j] : 0.0;
-  bwd_solve<9>(L, y);
-  if (lane < 9) {
-    double d = 0.0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) d = (k == lane) ? -y[k] : d;
-    v.cdelta[(size_t)e * 9 + lane] = d;
+    for (int i = 0; i < 9; ++i) d[i] = pin_f ? ds[v.sep_col0 + i] : pin_l ? ds[v.sep_col1 + i] : dl[(lane + off) * 9 + i];
+    const double* pin = v.poses[cur] + (size_t)f * kPoseStride;
+    double* pout = v.poses[1 - cur] + (size_t)f * kPoseStride;
+    double Tin[7], Tout[7], dd[6];
+    for (int i = 0; i < 7; ++i) Tin[i] = pin[i];
+    for (int i = 0; i < 6; ++i) dd[i] = d[i];
+    se3_plus(Tin, dd, Tout);
+    double gd = 0, dld = 0, step2 = 0, x2 = 0, g2 = 0, gmax = 0;
+    for (int i = 0; i < 7; ++i) { pout[i] = Tout[i]; const double ee = Tout[i] - Tin[i]; step2 += ee * ee; x2 += Tin[i] * Tin[i]; }
+    pout[7] = 0.0;
+    const double* vin = v.vel[cur] + (size_t)f * 4;
+    double* vout = v.vel[1 - cur] + (size_t)f * 4;
+    for (int i = 0; i < 3; ++i) { const double dv = d[6 + i]; vout[i] = vin[i] + dv; step2 += dv * dv; x2 += vin[i] * vin[i]; }
+    vout[3] = 0.0;
+    for (int i = 0; i < 9; ++i) {
+      const double gi = v.cg[(size_t)f * 9 + i];
+      gd += gi * d[i]; dld += v.clam[(size_t)f * 9 + i] * d[i] * d[i]; g2 += gi * gi; gmax = fmax(gmax, fabs(gi));
+    }
+    if (pin_f || pin_l) { gd = 0; dld = 0; g2 = 0; gmax = 0; }
+    if (pin_l) { step2 = 0; x2 = 0; }
+    double* o = v.fpart + (size_t)f * kNumScal;
+    o[kScGd] = gd; o[kScDld] = dld; o[kScStep2] = step2; o[kScX2] = x2; o[kScG2] = g2; o[kScCost] = 0.0; o[kScGmax] = gmax; o[kScSq] = 0.0;
   }
 }
 
@@ -834,7 +997,7 @@ __global__ __launch_bounds__(256) void k_chain_gram(DevView v) {
       const int nf = min(4, f1 - fg);
       for (int i = tid; i < 36 * ld; i += 256) {
         const int row = i / ld;
-        R[i] = (row < nf * 9) ? v.cW[(size_t)fg * 9 * ld + i] : 0.0;
+        R[i] = (row < nf * 9) ? v.cW[((size_t)fg * 9 + row) * v.ldx + (i - row * ld)] : 0.0;
       }
       __syncthreads();
       int I = Ib, J = Jb, pi = 0;
@@ -873,48 +1036,10 @@ __global__ __launch_bounds__(256) void k_chain_gram(DevView v) {
   }
 }
 
-// trial poses / velocities of every frame and its step terms
-__global__ __launch_bounds__(64) void k_frame_update(DevView v) {
-  const Ctrl* ct = v.ctrl;
-  if (ct->done) return;
-  const int f = blockIdx.x * 64 + threadIdx.x;
-  if (f >= v.n_frames) return;
-  const int cur = ct->cur;
-  // pinned frames step with the reduced system's solution; their gradient / damping terms are counted there, and only the
-  // owner (not the rank that holds the ghost copy) counts the step and parameter norms
-  const bool pin_f = (f == 0 && v.pin_first), pin_l = (f == v.n_frames - 1 && v.pin_last);
-  const double* d = pin_f ? v.delta_s + v.sep_col0 : pin_l ? v.delta_s + v.sep_col1 : v.cdelta + (size_t)f * 9;
-  const double* pin = v.poses[cur] + (size_t)f * kPoseStride;
-  double* pout = v.poses[1 - cur] + (size_t)f * kPoseStride;
-  double Tin[7], Tout[7], dd[6];
-  for (int i = 0; i < 7; ++i) Tin[i] = pin[i];
-  for (int i = 0; i < 6; ++i) dd[i] = d[i];
-  se3_plus(Tin, dd, Tout);
-  double gd = 0, dld = 0, step2 = 0, x2 = 0, g2 = 0, gmax = 0;
-  for (int i = 0; i < 7; ++i) { pout[i] = Tout[i]; const double e = Tout[i] - Tin[i]; step2 += e * e; x2 += Tin[i] * Tin[i]; }
-  pout[7] = 0.0;
-  const double* vin = v.vel[cur] + (size_t)f * 4;
-  double* vout = v.vel[1 - cur] + (size_t)f * 4;
-  for (int i = 0; i < 3; ++i) { const double dv = d[6 + i]; vout[i] = vin[i] + dv; step2 += dv * dv; x2 += vin[i] * vin[i]; }
-  vout[3] = 0.0;
-  for (int i = 0; i < 9; ++i) {
-    const double gi = v.cg[(size_t)f * 9 + i];
-    gd += gi * d[i]; dld += v.clam[(size_t)f * 9 + i] * d[i] * d[i]; g2 += gi * gi; gmax = fmax(gmax, fabs(gi));
-  }
-  if (pin_f || pin_l) { gd = 0; dld = 0; g2 = 0; gmax = 0; }
-  if (pin_l) { step2 = 0; x2 = 0; }
-  double* o = v.fpart + (size_t)f * kNumScal;
-  o[kScGd] = gd; o[kScDld] = dld; o[kScStep2] = step2; o[kScX2] = x2; o[kScG2] = g2; o[kScCost] = 0.0; o[kScGmax] = gmax; o[kScSq] = 0.0;
-}
-
 // ------------------------------------------------------------------------------------------ launchers
-void launch_imu_jac(const DevView& v, int wr, hipStream_t s) {
+void launch_imu_jac(const DevView& v, int wr, hipStream_t s, int trial) {
   if (v.n_frames < 2) return;
-  hipLaunchKernelGGL(k_imu_jac, dim3((v.n_frames - 1 + 7) / 8), dim3(256), 0, s, v, wr);      // 8 blocks per workgroup
-}
-void launch_imu_res(const DevView& v, int sel, int wr, hipStream_t s) {
-  if (v.n_frames < 2) return;
-  hipLaunchKernelGGL(k_imu_res, dim3((v.n_frames - 1 + 63) / 64), dim3(64), 0, s, v, sel, wr);
+  hipLaunchKernelGGL(k_imu_jac, dim3((v.n_frames - 1 + 7) / 8), dim3(256), 0, s, v, wr, trial);      // 8 blocks per workgroup
 }
 void launch_imu_weights(const DevView& v, int wr, hipStream_t s) {
   if (v.n_frames < 2) return;
@@ -922,6 +1047,30 @@ void launch_imu_weights(const DevView& v, int wr, hipStream_t s) {
   static bool granted = false;
   if (!granted) { (void)hipFuncSetAttribute((const void*)k_imu_weights, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = true; }
   hipLaunchKernelGGL(k_imu_weights, dim3((v.n_frames - 1 + 15) / 16), dim3(256), lds, s, v, wr);
+}
+// Level schedule of the partitioned chain elimination: strides 1, m, m^2, ... while more than m - 1 frames are active, then
+// the top level (one wavefront eliminates the rest).  forward: bottom-up; backward: top-down.
+static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
+  const int N = v.n_frames, m = kChainM;
+  if (N < 1) return;
+  int strides[32], nl = 0;
+  long st = 1;
+  while ((N - 1) / st + 1 > m - 1) { strides[nl++] = (int)st; st *= m; }
+  const int top_stride = (int)st;
+  const int cpl = (v.D + 1 + 27 + 63) / 64;
+  auto fwd = [&](int groups, int stride, int top, int lvl) {
+    if (cpl <= 1) hipLaunchKernelGGL(k_chain_fwd<1>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
+    else if (cpl <= 2) hipLaunchKernelGGL(k_chain_fwd<2>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
+    else hipLaunchKernelGGL(k_chain_fwd<4>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
+  };
+  if (forward) {
+    for (int l = 0; l < nl; ++l) fwd((int)(((long)N - 1) / ((long)strides[l] * m) + 1), strides[l], 0, l);
+    fwd(1, top_stride, 1, nl);
+  } else {
+    hipLaunchKernelGGL(k_chain_back, dim3(1), dim3(64), 0, s, v, top_stride, m, 1, nl);
+    for (int l = nl - 1; l >= 0; --l)
+      hipLaunchKernelGGL(k_chain_back, dim3((int)(((long)N - 1) / ((long)strides[l] * m) + 1)), dim3(64), 0, s, v, strides[l], m, 0, l);
+  }
 }
 void launch_chain_solve_a(const DevView& v, hipStream_t s) {
   const int N = v.n_frames;
@@ -932,12 +1081,7 @@ void launch_chain_solve_a(const DevView& v, hipStream_t s) {
     if (lds > 65536 && lds > granted) { (void)hipFuncSetAttribute((const void*)k_chain_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
     hipLaunchKernelGGL(k_chain_init, dim3(v.n_chunks), dim3(256), lds, s, v);
   }
-  for (int st = 1; st < N; st *= 2) {
-    const int n_elim = (N - st + 2 * st - 1) / (2 * st), n_surv = (N + 2 * st - 1) / (2 * st);
-    hipLaunchKernelGGL(k_cr_elim, dim3((n_elim + 3) / 4), dim3(256), 0, s, v, st);
-    hipLaunchKernelGGL(k_cr_update, dim3((n_surv + 3) / 4), dim3(256), 0, s, v, st);
-  }
-  hipLaunchKernelGGL(k_cr_elim, dim3(1), dim3(256), 0, s, v, 0);
+  chain_levels(v, s, true);
   {
     const size_t lds = (size_t)36 * v.ldw * sizeof(double);
     static size_t granted = 0;
@@ -945,17 +1089,6 @@ void launch_chain_solve_a(const DevView& v, hipStream_t s) {
     hipLaunchKernelGGL(k_chain_gram, dim3(v.n_chunks), dim3(256), lds, s, v);
   }
 }
-void launch_chain_solve_b(const DevView& v, hipStream_t s) {
-  const int N = v.n_frames;
-  hipLaunchKernelGGL(k_cr_back, dim3(1), dim3(256), 0, s, v, 0);
-  int top = 1;
-  while (top * 2 < N) top *= 2;
-  for (int st = top; st >= 1; st /= 2) {
-    if (st >= N) continue;
-    const int n_elim = (N - st + 2 * st - 1) / (2 * st);
-    hipLaunchKernelGGL(k_cr_back, dim3((n_elim + 3) / 4), dim3(256), 0, s, v, st);
-  }
-  hipLaunchKernelGGL(k_frame_update, dim3((N + 63) / 64), dim3(64), 0, s, v);
-}
+void launch_chain_solve_b(const DevView& v, hipStream_t s) { chain_levels(v, s, false); }
 
 }  // namespace vc

@@ -176,22 +176,28 @@ __device__ __forceinline__ double jac_tile_dispatch(const DevView& v, int model,
   }
 }
 
-__global__ __launch_bounds__(256) void k_reproj_jac(DevView v) {
+// trial = 0: linearisation at the accepted state (only when the control record asks for one); trial = 1: the sweep runs at the
+// trial state and fills buffer 1 - cur -- its cost is the trial cost, its Gram blocks are the next linearisation if the step is
+// accepted (the decision flips `cur`), and a rejected step leaves buffer cur untouched.
+__global__ __launch_bounds__(256) void k_reproj_jac(DevView v, int trial) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const Ctrl* ct = v.ctrl;
 #ifdef VC_JAC_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0) v.dbg[7] = (long long)__builtin_readcyclecounter();
 #endif
-  if (ct->done || !ct->need_lin) return;
+  if (ct->done || (!trial && !ct->need_lin)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
   if (tile >= v.n_tiles) return;
   double* wl = lds + wave * 64 * kDotStride;
-  const int cur = ct->cur;
+  const int cur = trial ? 1 - ct->cur : ct->cur;
   const int f = v.tile_frame[tile], c = v.tile_cam[tile];
   const double cost = jac_tile_dispatch(v, v.cd[c].model, v.poses[cur] + (size_t)f * kPoseStride, v.cams[cur] + (size_t)c * kCamStride, ct->mult,
                                         tile, lane, wl, v.Gb[cur] + (size_t)tile * kGStride);
-  if (lane == 0) v.tile_costb[cur][tile] = cost;
+  if (lane == 0) {
+    v.tile_costb[cur][tile] = cost;
+    if (trial) { v.tile_trial[2 * tile] = cost; v.tile_trial[2 * tile + 1] = 0.0; }
+  }
 }
 
 // ------------------------------------------------------------------------------------------ residual sweeps
@@ -585,7 +591,7 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double
     double s = 0.0;
 #pragma unroll 4
     for (int t = tid; t < v.n_tiles; t += 256) s += v.tile_costb[cur][t];
-    for (int t = tid; t < v.n_frames - 1; t += 256) s += v.seg_cost[t];
+    for (int t = tid; t < v.n_frames - 1; t += 256) s += v.seg_costb[cur][t];
     L.red[tid] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) L.red[tid] += L.red[tid + o]; __syncthreads(); }
@@ -1464,10 +1470,10 @@ __global__ __launch_bounds__(256) void k_cam_sq(DevView v, double* out) {
 // ------------------------------------------------------------------------------------------ launchers
 static inline int tiles_grid(const DevView& v) { return (v.n_tiles + 3) / 4; }
 
-void launch_reproj_jac(const DevView& v, hipStream_t s) {
+void launch_reproj_jac(const DevView& v, hipStream_t s, int trial) {
   if (v.n_tiles == 0) return;
   const size_t lds = 4 * 64 * kDotStride * sizeof(double);
-  hipLaunchKernelGGL(k_reproj_jac, dim3(tiles_grid(v)), dim3(256), lds, s, v);
+  hipLaunchKernelGGL(k_reproj_jac, dim3(tiles_grid(v)), dim3(256), lds, s, v, trial);
 }
 void launch_part_sum(const DevView& v, hipStream_t s) {
   hipLaunchKernelGGL(k_part_sum, dim3((v.part_stride + 31) / 32, (v.n_chunks + kSlab - 1) / kSlab), dim3(256), 0, s, v);
