@@ -64,6 +64,8 @@ static void DefineFlags() {
   Define("models", "string", "", "Comma-separated list of camera model types: fov, poly2, poly3, kb4, linear.");
   Define("model_files", "string", "", "Comma-separated list of camera model files to initialise from.");
   Define("max_iters", "int32", "200", "Max iterations.");
+  Define("pnp_ransac_its", "int32", "0", "Minimal-sample iterations of the robust pose seed (0: plain PnP, as the reference calls PosePnPRansac).");
+  Define("pnp_ransac_tol", "double", "2.0", "Inlier threshold of the robust pose seed, pixels.");
   Define("gyro_sigma", "double", "5.3088444e-5", "Sigma of gyroscope measurements.");
   Define("accel_sigma", "double", "0.001883649", "Sigma of accel measurements.");
   Define("remove_outliers", "bool", "false", "Remove outliers and re-optimise.");
@@ -408,6 +410,7 @@ int main(int argc, char** argv) {
         n_obs += (long)kv.second.size();
       }
     }
+    cal.SetPnPRansac((int)FlagInt("pnp_ransac_its"), FlagDouble("pnp_ransac_tol"));
     seeded += cal.InitFramePosesPnP();
     // ---- VicalibTask::Start(has_initial_guess) (vicalib-task.cc:226-234) + flags read inside the calibrator ---------
     cal.SetOptimizationFlags(guess, guess && calibrate_imu, !guess, FlagBool("find_time_offset"));

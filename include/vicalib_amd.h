@@ -60,6 +60,13 @@ int vc_init_frame_poses_pnp(vc_calibrator* h, int* n_initialised);
 /* The same for one view, no handle: T_cw of a camera of `model`/`params` seeing n >= 4 corners of the planar grid. */
 int vc_pnp_planar(int model, const double* params, int nparams, int n, const double* p_w /* n x 3 */,
                   const double* p_c /* n x 2 */, double T_cw[7], double* rms_px);
+/* The robust branch of PosePnPRansac (robust_3pt_its > 0; the reference passes 0, 0 at vicalib-task.cc:323-325, which is
+   vc_pnp_planar): `iterations` minimal 4-corner samples, consensus at tol_px pixels of reprojection error on the full camera
+   model, refit on the consensus set.  inlier (n flags) and n_inliers are optional.  vc_set_pnp_ransac makes
+   vc_init_frame_poses_pnp use it (iterations = 0 restores the reference's call). */
+int vc_pnp_planar_ransac(int model, const double* params, int nparams, int n, const double* p_w, const double* p_c,
+                         int iterations, double tol_px, double T_cw[7], double* rms_px, int* n_inliers, char* inlier);
+int vc_set_pnp_ransac(vc_calibrator* h, int iterations, double tol_px);
 /* AddObservation(frame, cam, p_w, p_c, time) :385-468, in bulk: n corners of one (frame, camera) */
 int vc_add_observations(vc_calibrator* h, int frame, int camera, int n, const double* p_w /* n x 3 */,
                         const double* p_c /* n x 2 */);

@@ -68,6 +68,8 @@ class ViCalibrator {
     return vc_add_imu(h_, 1, gyro, accel, &time) == VC_OK;
   }
   int AddImuMeasurements(int n, const double* gyro, const double* accel, const double* time) { return vc_add_imu(h_, n, gyro, accel, time); }
+  // robust branch of calibu::PosePnPRansac (iterations = 0: the reference's own call, vicalib-task.cc:323-325)
+  void SetPnPRansac(int iterations, double tol_px) { vc_checked(vc_set_pnp_ransac(h_, iterations, tol_px), "SetPnPRansac"); }
   int InitFramePosesPnP() { int n = 0; vc_checked(vc_init_frame_poses_pnp(h_, &n), "InitFramePosesPnP"); return n; }      // vicalib-task.cc:335-348
 
   void SetOptimizationFlags(bool bias_active, bool inertial_active, bool rotation_only, bool optimize_imu_time_offset) {   // :252

@@ -95,3 +95,27 @@ def test_cli_visual_inertial_calibration(tmp_path):
     cams = _read_xml(str(out))
     assert cams[0][0] == "calibu_fu_fv_u0_v0_kb4"
     np.testing.assert_allclose(cams[0][1][:4], p.cam_K_gt[0][:4], rtol=3e-3)
+    # WriteCameraModels with the IMU (vicalibrator.h:214-219): RDF = RdfRobotics and the pose written is
+    # T_wc = T_ck^-1 * SE3(RdfRobotics^-1, 0)
+    from scipy.spatial.transform import Rotation as R
+    xml = open(out).read()
+    assert "<right> [ 0; 1; 0 ] </right>" in xml and "<down> [ 0; 0; 1 ] </down>" in xml and "<forward> [ 1; 0; 0 ] </forward>" in xml
+    T = p.cam_T_ck_gt[0]
+    R_ck = R.from_quat(T[:4]).as_matrix()
+    np.testing.assert_allclose(cams[0][2][:, :3], R_ck.T @ synth.RDF_ROBOTICS.T, atol=3e-3)
+    np.testing.assert_allclose(cams[0][2][:, 3], -R_ck.T @ T[4:], atol=3e-3)
+    # ... and exactly the solver's own T_ck, to the digits written: read the pose back and undo the RDF factor
+    m = re.search(r"T_ck \[qx qy qz qw tx ty tz\]:((?: [-0-9.e+]+){7})", r.stdout)      # PrintResults, 10 digits
+    Tck = np.array([float(x) for x in m.group(1).split()])
+    Rs = R.from_quat(Tck[:4]).as_matrix()
+    np.testing.assert_allclose(cams[0][2][:, :3] @ synth.RDF_ROBOTICS, Rs.T, atol=1e-8)
+    np.testing.assert_allclose(cams[0][2][:, 3], -Rs.T @ Tck[4:], atol=1e-8)
+    # round trip through -model_files (vicalib-engine.cc:186-199 reads the first camera of each rig file): with the intrinsics held
+    # fixed the second run must write back the very same model, digit for digit
+    out2 = tmp_path / "cameras2.xml"
+    r2 = _run(["-cam", "detections://" + files[0], "-model_files", str(out), "-nocalibrate_intrinsics", "-nocalibrate_imu", "-output", str(out2)])
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    cams2 = _read_xml(str(out2))
+    assert cams2[0][0] == cams[0][0]
+    np.testing.assert_array_equal(cams2[0][1], cams[0][1])
+    assert "<right> [ 1; 0; 0 ] </right>" in open(out2).read()          # no IMU: RdfVision (:221-225)

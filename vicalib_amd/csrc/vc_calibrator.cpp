@@ -168,6 +168,7 @@ struct vc_calibrator {
   bool fix_intrinsics = false, is_bias_active = false, is_scale_active = false, is_inertial_active = false,
        is_visual_active = true, rotation_only = true, optimize_time_offset = true, is_finished = false,
        gravity_initialized = false, outliers_removed = false;
+  int pnp_its = 0; double pnp_tol = 0.0;     // PosePnPRansac(..., robust_3pt_its = 0, robust_3pt_tol = 0, ...) at vicalib-task.cc:323-325
   int max_iters = 200;                       // FLAGS_max_iters
   double function_tolerance = 1e-6;          // vicalibrator.h:149
   double gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;   // Ceres defaults
@@ -970,6 +971,17 @@ int vc_pnp_planar(int model, const double* params, int nparams, int n, const dou
   if (!params || !p_w || !p_c || !T_cw || model_nk(model) < 0 || nparams != model_nk(model)) return VC_ERR_BAD_ARG;
   return pnp_planar(model, params, n, p_w, p_c, T_cw, rms) ? VC_OK : VC_ERR_BAD_ARG;
 }
+int vc_pnp_planar_ransac(int model, const double* params, int nparams, int n, const double* p_w, const double* p_c, int iterations,
+                         double tol_px, double T_cw[7], double* rms, int* n_inliers, char* inlier) {
+  if (!params || !p_w || !p_c || !T_cw || model_nk(model) < 0 || nparams != model_nk(model) || iterations < 0 || !(tol_px >= 0.0)) return VC_ERR_BAD_ARG;
+  return pnp_planar_ransac(model, params, n, p_w, p_c, iterations, tol_px, T_cw, rms, n_inliers, inlier) ? VC_OK : VC_ERR_BAD_ARG;
+}
+int vc_set_pnp_ransac(vc_calibrator* h, int iterations, double tol_px) {
+  NOT_RUNNING(h);
+  if (iterations < 0 || !(tol_px >= 0.0)) return VC_ERR_BAD_ARG;
+  h->pnp_its = iterations; h->pnp_tol = tol_px;
+  return VC_OK;
+}
 int vc_init_frame_poses_pnp(vc_calibrator* h, int* n_initialised) {
   NOT_RUNNING(h);
   const int N = (int)h->frames.size(), C = (int)h->cams.size();
@@ -990,7 +1002,7 @@ int vc_init_frame_poses_pnp(vc_calibrator* h, int* n_initialised) {
       }
       const HostCam& cm = h->cams[c];
       double T_cw[7], rms;
-      if (!pnp_planar(cm.model, cm.K, (int)ids.size(), pw.data(), pc.data(), T_cw, &rms)) continue;
+      if (!pnp_planar_ransac(cm.model, cm.K, (int)ids.size(), pw.data(), pc.data(), h->pnp_its, h->pnp_tol, T_cw, &rms, nullptr, nullptr)) continue;
       // T_wk = T_cw^-1 * T_ck  (vicalib-task.cc:344-348)
       const double qi[4] = {-T_cw[0], -T_cw[1], -T_cw[2], T_cw[3]};
       double ti[3], tr[3], T[7];

@@ -1,13 +1,18 @@
 // vc_pnp.hpp -- host-side pose initialisation of one (frame, camera) view of the planar calibration target.
 //
-// Stands in for calibu::PosePnPRansac at its call site vicalib-task.cc:335-337 (the reference then stores
-// T_wk = T_cw^-1 * T_ck, vicalib-task.cc:344-348).  The reference uses RANSAC over minimal P3P samples (a
-// random, unordered search inside Calibu, not vendored); its output only seeds the optimiser.  This is a
-// deterministic replacement for the same job: plane-to-image homography (normalised DLT, after undoing the
-// current distortion estimate) -> pose -> Levenberg-Marquardt refinement of the 6 pose parameters on the
-// full camera model.  Front-end code: runs once per view on the CPU before the solve, never inside the loop.
+// Stands in for calibu::PosePnPRansac at its call site vicalib-task.cc:323-325 (the reference then stores
+// T_wk = T_cw^-1 * T_ck, vicalib-task.cc:344-348); its output only seeds the optimiser.  The reference passes
+// robust_3pt_its = 0, robust_3pt_tol = 0 there, i.e. the plain (non-robust) branch of Calibu's routine (not vendored).
+//   pnp_planar         plane-to-image homography (normalised DLT, after undoing the current distortion estimate) -> pose ->
+//                      Levenberg-Marquardt refinement of the 6 pose parameters on the full camera model: the its = 0 case.
+//   pnp_planar_ransac  the robust branch (its > 0): minimal 4-point homographies from a deterministic counter-based
+//                      sampler, consensus by reprojection error <= tol pixels on the full model, refit on the consensus
+//                      set -- mismatched dots (a wrong grid association) no longer drag the seed pose.
+// Front-end code: runs once per view on the CPU before the solve, never inside the loop.
 #pragma once
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <vector>
 
@@ -77,7 +82,9 @@ inline bool pnp_unproject(int model, const double* K, double u, double v, double
 
 // T_cw from >= 4 corners of the plane z = const.  pw: n x 3 world, uv: n x 2 pixels.  Returns the RMS reprojection
 // error of the refined pose in *rms (pixels).  T = [qx qy qz qw tx ty tz].
-inline bool pnp_planar(int model, const double* K, int n, const double* pw, const double* uv, double* T_cw, double* rms) {
+// use: optional mask of the correspondences that take part (DLT and refinement); refine = false stops after the homography pose.
+inline bool pnp_planar_masked(int model, const double* K, int n, const double* pw, const double* uv, const char* use, bool refine,
+                              double* T_cw, double* rms) {
   if (n < 4) return false;
   const double z0 = pw[2];
   for (int i = 0; i < n; ++i) if (std::fabs(pw[3 * i + 2] - z0) > 1e-9) return false;     // the grid is planar (vicalib-task.cc:355-356)
@@ -86,7 +93,7 @@ inline bool pnp_planar(int model, const double* K, int n, const double* pw, cons
   int m = 0;
   double mX = 0, mY = 0, mx = 0, my = 0;
   for (int i = 0; i < n; ++i) {
-    ok[i] = pnp_unproject(model, K, uv[2 * i], uv[2 * i + 1], &xy[2 * (size_t)i]) ? 1 : 0;
+    ok[i] = ((!use || use[i]) && pnp_unproject(model, K, uv[2 * i], uv[2 * i + 1], &xy[2 * (size_t)i])) ? 1 : 0;
     if (ok[i]) { ++m; mX += pw[3 * i]; mY += pw[3 * i + 1]; mx += xy[2 * i]; my += xy[2 * i + 1]; }
   }
   if (m < 4) return false;
@@ -151,6 +158,7 @@ inline bool pnp_planar(int model, const double* K, int n, const double* pw, cons
     for (int i = 0; i < 4; ++i) q[i] /= nq;
   }
   double T[7] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2]};
+  if (!refine) { std::memcpy(T_cw, T, sizeof(T)); if (rms) *rms = 0.0; return std::isfinite(t[0] + t[1] + t[2]); }
   // ---- LM refinement of T_cw <- T_cw exp(delta) on the full model ---------------------------------------------
   ModelPre pre;
   model_precompute(model, K, &pre);
@@ -159,6 +167,7 @@ inline bool pnp_planar(int model, const double* K, int n, const double* pw, cons
     double cost = 0.0;
     if (Hm) { std::memset(Hm, 0, 36 * sizeof(double)); std::memset(g, 0, 6 * sizeof(double)); }
     for (int i = 0; i < n; ++i) {
+      if (use && !use[i]) continue;
       const double* p = pw + 3 * i;
       double pc[3];
       for (int a = 0; a < 3; ++a) pc[a] = Rc[3 * a] * p[0] + Rc[3 * a + 1] * p[1] + Rc[3 * a + 2] * p[2] + Tc[4 + a];
@@ -202,8 +211,75 @@ inline bool pnp_planar(int model, const double* K, int n, const double* pw, cons
     } else { lambda *= 10; if (lambda > 1e12) break; }
   }
   std::memcpy(T_cw, T, sizeof(T));
-  if (rms) *rms = std::sqrt(cost / n);
+  if (rms) *rms = std::sqrt(cost / m);
   return std::isfinite(cost);
+}
+inline bool pnp_planar(int model, const double* K, int n, const double* pw, const double* uv, double* T_cw, double* rms) {
+  return pnp_planar_masked(model, K, n, pw, uv, nullptr, true, T_cw, rms);
+}
+
+// reprojection error (pixels) of every correspondence under T_cw; points behind the camera get a huge error
+inline void pnp_errors(int model, const double* K, int n, const double* pw, const double* uv, const double* T, double* err) {
+  ModelPre pre;
+  model_precompute(model, K, &pre);
+  double Rc[9]; quat_to_R(T, Rc);
+  for (int i = 0; i < n; ++i) {
+    const double* p = pw + 3 * i;
+    double pc[3], pix[2];
+    for (int a = 0; a < 3; ++a) pc[a] = Rc[3 * a] * p[0] + Rc[3 * a + 1] * p[1] + Rc[3 * a + 2] * p[2] + T[4 + a];
+    if (pc[2] <= 1e-9) { err[i] = 1e30; continue; }
+    project_any<false>(model, pc, K, pre, pix, nullptr, nullptr);
+    const double e = std::hypot(pix[0] - uv[2 * i], pix[1] - uv[2 * i + 1]);
+    err[i] = std::isfinite(e) ? e : 1e30;
+  }
+}
+// Robust pose of one view: `its` minimal samples of 4 correspondences, consensus at `tol` pixels, refit on the consensus set.
+// rms: RMS reprojection error over the inliers; n_inliers / inlier (n flags) optional.
+inline bool pnp_planar_ransac(int model, const double* K, int n, const double* pw, const double* uv, int its, double tol,
+                              double* T_cw, double* rms, int* n_inliers, char* inlier) {
+  if (its <= 0 || n < 5) {
+    const bool ok = pnp_planar(model, K, n, pw, uv, T_cw, rms);
+    if (n_inliers) *n_inliers = ok ? n : 0;
+    if (inlier) std::memset(inlier, ok ? 1 : 0, (size_t)std::max(n, 0));
+    return ok;
+  }
+  std::vector<char> mask((size_t)n), best((size_t)n, 0);
+  std::vector<double> err((size_t)n);
+  int best_cnt = 0;
+  double best_sum = 0.0;
+  uint64_t state = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;          // deterministic: the same view gives the same pose
+  auto next = [&]() { state += 0x9E3779B97F4A7C15ull; uint64_t z = state; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+  for (int it = 0; it < its; ++it) {
+    int pick[4];
+    for (int k = 0; k < 4; ++k) {
+      bool again = true;
+      while (again) { pick[k] = (int)(next() % (uint64_t)n); again = false; for (int j = 0; j < k; ++j) if (pick[j] == pick[k]) again = true; }
+    }
+    std::fill(mask.begin(), mask.end(), 0);
+    for (int k = 0; k < 4; ++k) mask[pick[k]] = 1;
+    double T[7];
+    if (!pnp_planar_masked(model, K, n, pw, uv, mask.data(), false, T, nullptr)) continue;
+    pnp_errors(model, K, n, pw, uv, T, err.data());
+    int cnt = 0; double sum = 0.0;
+    for (int i = 0; i < n; ++i) if (err[i] <= tol) { ++cnt; sum += err[i]; }
+    if (cnt > best_cnt || (cnt == best_cnt && cnt > 0 && sum < best_sum)) {
+      best_cnt = cnt; best_sum = sum;
+      for (int i = 0; i < n; ++i) best[i] = err[i] <= tol;
+    }
+  }
+  if (best_cnt < 4) return false;
+  // refit on the consensus set, then let the refined pose re-vote once (a minimal sample's pose is rough)
+  double T[7], r = 0.0;
+  if (!pnp_planar_masked(model, K, n, pw, uv, best.data(), true, T, &r)) return false;
+  pnp_errors(model, K, n, pw, uv, T, err.data());
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) { mask[i] = err[i] <= tol; cnt += mask[i]; }
+  if (cnt >= 4 && cnt != best_cnt) { double T2[7], r2; if (pnp_planar_masked(model, K, n, pw, uv, mask.data(), true, T2, &r2)) { std::memcpy(T, T2, sizeof(T)); r = r2; best = mask; best_cnt = cnt; } }
+  std::memcpy(T_cw, T, sizeof(T));
+  if (rms) *rms = r;
+  if (n_inliers) *n_inliers = best_cnt;
+  if (inlier) std::memcpy(inlier, best.data(), (size_t)n);
+  return true;
 }
 
 }  // namespace vc

@@ -29,7 +29,7 @@ SYMBOLS = [
     "vc_get_biases", "vc_get_scale_factor", "vc_get_gravity", "vc_time_offset", "vc_mean_squared_error", "vc_get_camera_proj_rmse",
     "vc_get_num_iterations", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
     "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
-    "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_allreduce_calls", "vc_get_imu_weights",
+    "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_pnp_planar_ransac", "vc_set_pnp_ransac", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_allreduce_calls", "vc_get_imu_weights",
     "vc_solution_covariance_dim", "vc_get_solution_covariance", "vc_get_solution_covariance_names",
 ]
 
@@ -48,6 +48,19 @@ def pnp_planar(model, params, p_w, p_c):
     m = MODEL_IDS[model] if isinstance(model, str) else int(model)
     _check(L.vc_pnp_planar(m, _d(params), len(params), len(p_w), _d(p_w), _d(p_c), _d(T), C.byref(rms)), "pnp_planar")
     return T, rms.value
+
+
+def pnp_planar_ransac(model, params, p_w, p_c, iterations=64, tol_px=2.0):
+    """Robust pose of one view (vc_pnp_planar_ransac): T_cw, RMS over the inliers, inlier flags."""
+    L = load()
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    p_w = np.ascontiguousarray(p_w, dtype=np.float64); p_c = np.ascontiguousarray(p_c, dtype=np.float64)
+    T = np.zeros(7); rms = C.c_double(0); n_in = C.c_int(0); flags = np.zeros(len(p_w), dtype=np.int8)
+    from .synth import MODEL_IDS
+    m = MODEL_IDS[model] if isinstance(model, str) else int(model)
+    _check(L.vc_pnp_planar_ransac(m, _d(params), len(params), len(p_w), _d(p_w), _d(p_c), int(iterations), C.c_double(tol_px), _d(T),
+                                  C.byref(rms), C.byref(n_in), flags.ctypes.data_as(C.c_void_p)), "pnp_planar_ransac")
+    return T, rms.value, flags.astype(bool)
 
 
 def load():
@@ -121,6 +134,8 @@ class ViCalibrator:
         n = C.c_int(0)
         _check(self.L.vc_init_frame_poses_pnp(self.h, C.byref(n)), "InitFramePosesPnP")
         return n.value
+
+    def SetPnPRansac(self, iterations, tol_px): _check(self.L.vc_set_pnp_ransac(self.h, int(iterations), C.c_double(tol_px)), "SetPnPRansac")
 
     def AddObservations(self, frame, camera, p_w, p_c):
         p_w = np.ascontiguousarray(p_w, dtype=np.float64); p_c = np.ascontiguousarray(p_c, dtype=np.float64)
