@@ -135,6 +135,10 @@ int vc_get_solution_covariance(vc_calibrator* h, double* cov, int max_n, int* n)
 int vc_get_solution_covariance_names(vc_calibrator* h, char* buf, int len);
 
 /* ---- engine-level entry points (no counterpart in the reference: it has no GPU, no sharding) ---- */
+/* State the reference keeps inside the class with no setter (imu_.g_, VicalibFrame::v_w_): start values for tests and for a
+ * caller that resumes from a stored calibration.  vc_set_gravity also marks gravity as initialised (:927-949 is skipped). */
+int vc_set_gravity(vc_calibrator* h, const double g_dir[2]);
+int vc_set_frame_velocities(vc_calibrator* h, const double* v_w /* n x 3 */, int n);
 /* Per-iteration record of the trust-region loop = the columns of the reference's log line (:698-707).
  * rows of 10 doubles: iteration, cost, cost_change, gradient_max_norm, gradient_norm, step_norm,
  * relative_decrease, trust_region_radius, accepted, stage */

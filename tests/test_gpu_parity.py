@@ -7,6 +7,7 @@ import pytest
 
 import oracle_lib as ol
 from vicalib_amd import synth
+from vicalib_amd import lib
 from vicalib_amd.lib import ViCalibrator
 
 pytestmark = pytest.mark.gpu
@@ -242,6 +243,30 @@ def test_solver_matches_committed_lm_traces(name):
         assert abs(cal.time_offset() - e["imu"]["time_offset"]) < 1e-9
 
 
+def test_converged_optima_match_the_independent_optimiser_fixture():
+    """tests/golden/scipy_optima.json (make_golden_optima.py): optima found by scipy TRF on the oracle's residual functions.  The HIP
+    solver, run to the same tolerances, ends at the same intrinsics -- ALL of them, distortion included -- to 1e-6 relative
+    (north_star); nothing from oracle/ runs here."""
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scipy_optima.json")))
+    p = synth.generate(synth.BASELINE_CONFIGS["cfg1"])
+    cal = ViCalibrator(0).load_problem(p); cal.SetCalibrateImu(False)
+    cal.SetFunctionTolerance(1e-16); cal.SetTolerances(1e-14, 1e-14); cal.SetMaxIters(100)
+    cal.Solve()
+    np.testing.assert_allclose(cal.GetCamera(0)[0], fx["cfg1"]["K"], rtol=1e-6)
+    assert abs(cal.trace()[-1, 1] - fx["cfg1"]["cost"]) < 1e-9 * fx["cfg1"]["cost"]
+    vi = synth.generate(synth.Config(models=("kb4",), n_frames=60, imu=True, seed=5))
+    cal = ViCalibrator(0).load_problem(vi); cal.SetFunctionTolerance(1e-12)
+    cal.Solve()
+    f = fx["vi60"]
+    np.testing.assert_allclose(cal.GetCamera(0)[0], f["K"], rtol=1e-6)
+    np.testing.assert_allclose(cal.GetCamera(0)[1], f["T_ck"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(cal.GetBiases(), f["biases"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(cal.GetScaleFactor(), f["scale"], rtol=1e-6)
+    np.testing.assert_allclose(cal.GetGravity(), f["gravity"], rtol=1e-5, atol=1e-8)
+    assert abs(cal.time_offset() - f["time_offset"]) < 1e-8
+
+
 def test_per_frame_backsubstitution_kernel_gives_the_same_solve(monkeypatch):
     """Above 2048 tiles the back-substitution moves from k_trial (once per tile) to k_backsub (once per frame); forced on
     for a small problem it must reproduce the default path bit for bit."""
@@ -320,6 +345,33 @@ def test_imu_weight_update_matches_oracle():
         Cg = Wg[j] @ Wg[j].T; Co = Wo[j] @ Wo[j].T
         np.testing.assert_allclose(Cg, Co, rtol=1e-7, atol=1e-9 * np.abs(Co).max())
         assert np.allclose(np.tril(Wg[j], -1), 0.0)          # W = L^-T is upper triangular
+
+
+def test_imu_weight_update_against_numerically_propagated_covariance():
+    """The GPU's W W^T against an information matrix that shares nothing with it or with the oracle: covariance propagated with
+    central-difference step maps of a numpy RK4 integrator (tests/test_oracle_imu.py), projected with a central-difference
+    residual Jacobian.  Agreement is limited by the reference's own approximations in its hand Jacobians (low-order dqExp_dw,
+    scale factors ignored in dk_dx, types.h:417-422): 2e-4 on the standard deviations, 3e-4 on the correlations -- a transposed
+    block, a wrong sign or a wrong sigma shows at order one."""
+    import test_oracle_imu as num
+    p = synth.generate(synth.Config(models=("kb4",), n_frames=10, imu=True, seed=5))
+    gt = p.imu_gt
+    b = np.concatenate([gt["bg"], gt["ba"]]); s = np.concatenate([gt["sg"], gt["sa"]]); g = gt["g_dir"]; toff = gt["time_offset"]
+    cal = ViCalibrator(0)
+    cal.AddCamera(p.cam_model[0], p.cam_K_gt[0], p.cam_T_ck_gt[0], 640, 480)
+    for f in range(len(p.frame_time)):
+        cal.AddFrame(p.frame_T_wk_gt[f], p.frame_time[f])
+    for (f, c, ids, pix) in p.tiles:
+        cal.AddObservations(f, c, p.grid_points[ids], pix)
+    cal.AddImuMeasurements(p.imu_gyro, p.imu_accel, p.imu_t)
+    cal.SetOptimizationFlags(True, True, False, True); cal.SetBiases(b); cal.SetScaleFactor(s); cal.SetTimeOffset(toff)
+    L = lib.load()
+    assert L.vc_set_gravity(cal.h, lib._d(np.asarray(g, dtype=np.float64))) == 0
+    assert L.vc_set_frame_velocities(cal.h, lib._d(np.ascontiguousarray(p.frame_v_gt)), len(p.frame_time)) == 0
+    cal.linearize()                       # one pass on hold: the weight update runs at the state given
+    W = cal.imu_weights()
+    for j in (1, 4, 8):
+        num.compare_information(W[j - 1] @ W[j - 1].T, num.numeric_information(p, j, b, s, g, toff))
 
 
 def _compare_vi(p, cal, orc, rtol=1e-6):

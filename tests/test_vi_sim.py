@@ -1,0 +1,64 @@
+"""The reference's only end-to-end test, testing/vi_sim_test.cpp, restated: same configuration (vicalib_amd.synth.vi_sim_config:
+`-models linear`, 800 x 600, ground truth T_ck = [[0,1,0],[0,0,1],[1,0,0]], intrinsics (335.639853151, 335.639853151, 400, 300),
+no time offset, -nohas_initial_guess) and exactly its four assertions (vi_sim_test.cpp:76-92) with its own tolerances
+(:7-10).  These are the only numbers the reference holds for this path; they pin the conventions (T_ck direction, RDF rotation,
+pixel units of the reprojection error, sign of the time offset), not the arithmetic.  The oracle passes them on the CPU, the
+HIP solver on the GPU."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation as R
+
+import oracle_lib as ol
+from vicalib_amd import synth
+
+LOGDIFF_TOLERANCE = 1e-3          # vi_sim_test.cpp:7
+REPROJ_TOLERANCE = 1e-1           # :8
+CAMERA_TOLERANCE = 5              # :9
+TIMEOFFSET_TOLERANCE = 1e-4       # :10
+T_CK_GROUND_TRUTH = np.array([[0, 1, 0, 0], [0, 0, 1, 0], [1, 0, 0, 0], [0, 0, 0, 1.0]])      # :70-74
+CAM_INTRINSICS_GROUND_TRUTH = np.array([335.639853151, 335.639853151, 400, 300])            # :76-77
+
+
+def _se3_log_norm(M):
+    """|log(M)| of a 4 x 4 rigid transform, [upsilon, omega] as Sophus orders them."""
+    w = R.from_matrix(M[:3, :3]).as_rotvec()
+    th = np.linalg.norm(w)
+    W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    k = 1.0 / 12.0 if th < 1e-10 else (1.0 - th / (2.0 * np.tan(th / 2.0))) / (th * th)
+    Vinv = np.eye(3) - 0.5 * W + k * (W @ W)
+    return np.linalg.norm(np.concatenate([Vinv @ M[:3, 3], w]))
+
+
+def _assert_vi_sim(K, T_ck, rmse, ts):
+    M = np.eye(4); M[:3, :3] = R.from_quat(T_ck[:4]).as_matrix(); M[:3, 3] = T_ck[4:]
+    diff = T_CK_GROUND_TRUTH @ np.linalg.inv(M)                                               # :80-81
+    assert _se3_log_norm(diff) < LOGDIFF_TOLERANCE                                           # :82
+    assert rmse < REPROJ_TOLERANCE                                                           # :84
+    assert np.linalg.norm(K - CAM_INTRINSICS_GROUND_TRUTH) < CAMERA_TOLERANCE                # :86-87
+    assert ts < TIMEOFFSET_TOLERANCE                                                         # :91 (signed, as the reference writes it)
+    assert abs(ts) < TIMEOFFSET_TOLERANCE
+
+
+def test_vi_sim_oracle():
+    p = synth.generate(synth.vi_sim_config())
+    np.testing.assert_allclose(R.from_quat(p.cam_T_ck_gt[0][:4]).as_matrix(), T_CK_GROUND_TRUTH[:3, :3], atol=1e-15)
+    o = ol.Oracle().load(p); o.set_options(calibrate_imu=True, num_threads=4); o.solve()
+    K, T = o.camera(0)
+    _assert_vi_sim(K, T, o.rmse()[0], o.imu_state()[3])
+
+
+@pytest.mark.gpu
+def test_vi_sim_gpu():
+    from vicalib_amd.lib import ViCalibrator
+    p = synth.generate(synth.vi_sim_config())
+    cal = ViCalibrator(0).load_problem(p)
+    cal.SetOptimizationFlags(False, False, True, True)        # -nohas_initial_guess (vicalib-task.cc:226-234)
+    cal.Solve()
+    K, T = cal.GetCamera(0)
+    _assert_vi_sim(K, T, cal.GetCameraProjRMSE()[0], cal.time_offset())
+    # and the same run, iteration by iteration, against the oracle
+    o = ol.Oracle().load(p); o.set_options(calibrate_imu=True, num_threads=8); o.solve()
+    tg, to = cal.trace(), o.trace()
+    assert len(tg) == len(to)
+    np.testing.assert_allclose(tg[:, 1], to[:, 1], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(K, o.camera(0)[0], rtol=1e-6)

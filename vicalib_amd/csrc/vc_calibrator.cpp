@@ -1077,6 +1077,20 @@ int vc_set_optimization_flags(vc_calibrator* h, int bias, int inertial, int rot_
   h->rotation_only = rot_only != 0; h->optimize_time_offset = toff != 0; h->device_dirty = true;
   return VC_OK;
 }
+int vc_set_gravity(vc_calibrator* h, const double g_dir[2]) {
+  NOT_RUNNING(h);
+  if (!g_dir) return VC_ERR_BAD_ARG;
+  { std::lock_guard<std::mutex> lk(h->result_mutex); h->g_dir[0] = g_dir[0]; h->g_dir[1] = g_dir[1]; }
+  h->gravity_initialized = true; h->device_dirty = true;
+  return VC_OK;
+}
+int vc_set_frame_velocities(vc_calibrator* h, const double* v_w, int n) {
+  NOT_RUNNING(h);
+  if (!v_w || n != (int)h->frames.size()) return VC_ERR_BAD_ARG;
+  for (int f = 0; f < n; ++f) std::memcpy(h->frames[f].v, v_w + 3 * (size_t)f, 24);
+  h->device_dirty = true;
+  return VC_OK;
+}
 int vc_set_tolerances(vc_calibrator* h, double gradient_tolerance, double parameter_tolerance) {
   NOT_RUNNING(h);
   h->gradient_tolerance = gradient_tolerance; h->parameter_tolerance = parameter_tolerance;

@@ -161,6 +161,9 @@ class Config:
     pose_sigma_t: float = 0.01
     pose_sigma_r: float = np.deg2rad(1.5)
     first_frame: int = 0     # global index of the first frame generated (frame sharding)
+    gt_intrinsics: tuple = None      # ((k...), ...) per camera: exact ground-truth intrinsics instead of the jittered defaults
+    imu_truth: dict = None           # overrides of the IMU ground truth (bg, ba, sg, sa, g_dir, time_offset)
+    imu_noise: bool = True           # white noise on the IMU samples at the reference's default sigmas
     extrinsics_prior: bool = False   # start T_ck of cameras 1.. from a rough prior (GT o exp(1 cm, 0.5 deg)) instead of the
                                      # engine's identity (vicalib-engine.cc:211) -- a rig description from `-model_files`
 
@@ -255,7 +258,7 @@ def generate(cfg: Config) -> Problem:
     for c, m in enumerate(models):
         base = np.array(GT_INTRINSICS[m])
         jit = 1.0 + 0.02 * (2.0 * hash_uniform(seed + 17, c, np.arange(len(base))) - 1.0)
-        K_gt.append(base * jit)
+        K_gt.append(np.array(cfg.gt_intrinsics[c], dtype=np.float64) if cfg.gt_intrinsics is not None else base * jit)
         k0 = [300.0, 300.0, cfg.width / 2.0, cfg.height / 2.0] + ([0.2] if m == 0 else [0.0] * (MODEL_NK[m] - 4))
         K_init.append(np.array(k0))
         # body -> camera c: camera c sits 0.06*c along camera-0 x (the rig's lateral axis), small rotation
@@ -323,6 +326,8 @@ def _add_imu(prob: Problem, grid_w: float, grid_h: float, R_ck0: np.ndarray) -> 
     gt = dict(bg=np.array([0.002, -0.001, 0.0015]), ba=np.array([0.03, -0.02, 0.05]),
               sg=np.array([1.01, 0.99, 1.005]), sa=np.array([0.995, 1.01, 0.99]),
               g_dir=np.array([0.03, -0.02]), time_offset=0.003)
+    if cfg.imu_truth:
+        gt.update({k: (np.asarray(v, dtype=np.float64) if k != "time_offset" else float(v)) for k, v in cfg.imu_truth.items()})
     t0 = prob.frame_time[0] - 0.1
     t1 = prob.frame_time[-1] + 0.1
     k0 = int(np.floor(t0 * cfg.imu_rate)); k1 = int(np.ceil(t1 * cfg.imu_rate))
@@ -343,8 +348,9 @@ def _add_imu(prob: Problem, grid_w: float, grid_h: float, R_ck0: np.ndarray) -> 
     # k_w = R (z_g * s_g + b_g) ; k_a = R (z_a * s_a + b_a) - g_w   (ceres-cost-functions.h:98-102)
     zg = (np.einsum("nji,nj->ni", Rk0, w_w) - gt["bg"]) / gt["sg"]
     za = (np.einsum("nji,nj->ni", Rk0, a_w + g_w) - gt["ba"]) / gt["sa"]
-    zg = zg + 5.3088444e-5 * hash_normal(cfg.seed + 9001, k[:, None], np.arange(3)[None, :])
-    za = za + 0.001883649 * hash_normal(cfg.seed + 9002, k[:, None], np.arange(3)[None, :])
+    if cfg.imu_noise:
+        zg = zg + 5.3088444e-5 * hash_normal(cfg.seed + 9001, k[:, None], np.arange(3)[None, :])
+        za = za + 0.001883649 * hash_normal(cfg.seed + 9002, k[:, None], np.arange(3)[None, :])
     prob.imu_t, prob.imu_gyro, prob.imu_accel, prob.imu_gt = t_imu, zg, za, gt
 
 
@@ -369,7 +375,20 @@ def _native_lib():
     return _synth_lib
 
 
+def vi_sim_config(n_frames=120, seed=1234):
+    """The configuration of the reference's only end-to-end test, testing/vi_sim_test.cpp:18-23, :70-92: one `linear` camera, 800 x 600
+    images, ground truth T_ck = [[0,1,0],[0,0,1],[1,0,0]] (zero translation), intrinsics (335.639853151, 335.639853151, 400, 300),
+    no time offset, an ideal IMU (zero biases, unit scale factors), noise-free simulated detections.  Its image / IMU files are
+    not in the reference tree and the `medium` grid preset's dimensions live in Calibu: the large preset's grid and this
+    generator's trajectory stand in."""
+    return Config(models=("linear",), grid="large", n_frames=n_frames, imu=True, seed=seed, width=800, height=600, pixel_sigma=0.0,
+                  gt_intrinsics=((335.639853151, 335.639853151, 400.0, 300.0),), imu_noise=False,
+                  imu_truth=dict(bg=(0, 0, 0), ba=(0, 0, 0), sg=(1, 1, 1), sa=(1, 1, 1), g_dir=(0.0, 0.0), time_offset=0.0))
+
+
 def generate_native(cfg: Config, threads: int = 0) -> Problem:
+    if cfg.gt_intrinsics is not None or cfg.imu_truth is not None or not cfg.imu_noise:
+        raise ValueError("generate_native: gt_intrinsics / imu_truth / imu_noise are options of the numpy generator only")
     """The same problem as generate(cfg), produced by the C++ generator (all host cores): identical visible-dot sets,
     floating-point fields equal up to the last bits of the two math libraries.  BASELINE cfg4 / cfg5 take seconds."""
     import ctypes as C
