@@ -61,7 +61,7 @@ static void DefineFlags() {
   Define("output_log_file", "string", "vicalibrator.log", "Calibration result output log file.");
   Define("cam", "string", "", "Camera URI: detections://cam0.csv[,cam1.csv...]");
   Define("imu", "string", "", "IMU URI (if available): csv://directory");
-  Define("models", "string", "", "Comma-separated list of camera model types: fov, poly2, poly3, kb4, linear.");
+  Define("models", "string", "", "Comma-separated list of camera model types: fov, poly2, poly3, rational6, kb4, linear.");
   Define("model_files", "string", "", "Comma-separated list of camera model files to initialise from.");
   Define("max_iters", "int32", "200", "Max iterations.");
   Define("pnp_ransac_its", "int32", "0", "Minimal-sample iterations of the robust pose seed (0: plain PnP, as the reference calls PosePnPRansac).");
@@ -210,9 +210,10 @@ static int ModelId(const std::string& type) {     // -models strings (vicalib-en
   if (type == "poly3" || type == "poly" || type == "calibu_fu_fv_u0_v0_k1_k2_k3") return VC_MODEL_POLY3;
   if (type == "kb4" || type == "calibu_fu_fv_u0_v0_kb4") return VC_MODEL_KB4;
   if (type == "linear" || type == "calibu_fu_fv_u0_v0") return VC_MODEL_LINEAR;
+  if (type == "rational6" || type == "rational" || type == "calibu_fu_fv_u0_v0_rational6") return VC_MODEL_RATIONAL6;      // vicalib-engine.cc:233-240
   return -1;
 }
-static const char* ModelName(int id) { static const char* n[] = {"fov", "poly2", "poly3", "kb4", "linear"}; return (id >= 0 && id < 5) ? n[id] : "?"; }
+static const char* ModelName(int id) { static const char* n[] = {"fov", "poly2", "poly3", "kb4", "linear", "rational6"}; return (id >= 0 && id < 6) ? n[id] : "?"; }
 
 static std::string Between(const std::string& s, const std::string& a, const std::string& b, size_t from = 0) {
   const size_t p = s.find(a, from); if (p == std::string::npos) return "";
@@ -326,11 +327,11 @@ int main(int argc, char** argv) {
     for (const std::string& type : models) {
       vic::CameraAndPose cam;
       cam.model = ModelId(type);
-      if (cam.model < 0) { std::fprintf(stderr, "F camera model '%s' is not supported by this build (fov, poly2, poly3, kb4, linear)\n", type.c_str()); return 1; }
+      if (cam.model < 0) { std::fprintf(stderr, "F camera model '%s' is not supported by this build (fov, poly2, poly3, rational6, kb4, linear)\n", type.c_str()); return 1; }
       cam.width = W; cam.height = H;
       cam.params = {300, 300, W / 2.0, H / 2.0};
       if (cam.model == VC_MODEL_FOV) cam.params.push_back(0.2);
-      else cam.params.resize(cam.model == VC_MODEL_POLY2 ? 6 : cam.model == VC_MODEL_POLY3 ? 7 : cam.model == VC_MODEL_KB4 ? 8 : 4, 0.0);
+      else cam.params.resize(cam.model == VC_MODEL_POLY2 ? 6 : cam.model == VC_MODEL_POLY3 ? 7 : cam.model == VC_MODEL_KB4 ? 8 : cam.model == VC_MODEL_RATIONAL6 ? 10 : 4, 0.0);
       input_cameras.push_back(cam);
     }
   }

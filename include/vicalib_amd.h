@@ -38,7 +38,7 @@ enum {
 };
 
 /* -models strings of vicalib-engine.cc:203-253, in this order */
-enum { VC_MODEL_FOV = 0, VC_MODEL_POLY2 = 1, VC_MODEL_POLY3 = 2, VC_MODEL_KB4 = 3, VC_MODEL_LINEAR = 4 };
+enum { VC_MODEL_FOV = 0, VC_MODEL_POLY2 = 1, VC_MODEL_POLY3 = 2, VC_MODEL_KB4 = 3, VC_MODEL_LINEAR = 4, VC_MODEL_RATIONAL6 = 5 };
 
 /* ViCalibrator() vicalibrator.h:124-155 + Clear() :232-249.  device = HIP ordinal. */
 int vc_create(vc_calibrator** out, int device);

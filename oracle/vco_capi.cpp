@@ -48,7 +48,7 @@ void vco_destroy(void* h) { delete static_cast<Calibrator*>(h); }
 int vco_add_camera(void* h, int model, const double* params, int width, int height, const double* T_ck) {
   Camera c; std::memset(&c, 0, sizeof(c));
   c.model = model; c.nk = model_num_params(model);
-  if (c.nk < 0 || c.nk > 8) return -1;
+  if (c.nk < 0 || c.nk > 10) return -1;
   std::memcpy(c.K, params, c.nk * sizeof(double));
   std::memcpy(c.T_ck, T_ck, 7 * sizeof(double));
   c.width = width; c.height = height;

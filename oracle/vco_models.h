@@ -58,6 +58,16 @@ template <class T> inline void project_kb4(const T* ray, const T* k, T* pix) {
   pix[0] = k[0] * r * cos(psi) + k[2];
   pix[1] = k[1] * r * sin(psi) + k[3];
 }
+// calibu::Rational6Camera::Project (camera_models_rational.h; SURVEY 9.1: the OpenCV rational radial factor without tangential
+// terms -- the least certain of the reconstructed models): fac = (1 + k1 r^2 + k2 r^4 + k3 r^6) / (1 + k4 r^2 + k5 r^4 + k6 r^6).
+template <class T> inline void project_rational6(const T* ray, const T* k, T* pix) {
+  const T x = ray[0] / ray[2], y = ray[1] / ray[2];
+  const T r2 = x * x + y * y;
+  const T r4 = r2 * r2, r6 = r4 * r2;
+  const T fac = (1.0 + k[4] * r2 + k[5] * r4 + k[6] * r6) / (1.0 + k[7] * r2 + k[8] * r4 + k[9] * r6);
+  pix[0] = fac * k[0] * x + k[2];
+  pix[1] = fac * k[1] * y + k[3];
+}
 // calibu::LinearCamera::Project.
 template <class T> inline void project_linear(const T* ray, const T* k, T* pix) {
   pix[0] = k[0] * (ray[0] / ray[2]) + k[2];
@@ -69,6 +79,7 @@ template <class T> inline void project(int model, const T* ray, const T* k, T* p
     case kPoly2: project_poly(ray, k, 2, pix); break;
     case kPoly3: project_poly(ray, k, 3, pix); break;
     case kKb4: project_kb4(ray, k, pix); break;
+    case kRational6: project_rational6(ray, k, pix); break;
     default: project_linear(ray, k, pix); break;
   }
 }

@@ -155,6 +155,7 @@ class Calibrator {
       case 5: reproj_block<5>(o, r, Jf, Jr, Jt, Jk); break;
       case 6: reproj_block<6>(o, r, Jf, Jr, Jt, Jk); break;
       case 7: reproj_block<7>(o, r, Jf, Jr, Jt, Jk); break;
+      case 10: reproj_block<10>(o, r, Jf, Jr, Jt, Jk); break;
       default: reproj_block<8>(o, r, Jf, Jr, Jt, Jk); break;
     }
   }

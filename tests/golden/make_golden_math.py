@@ -46,6 +46,8 @@ def project(model, ray, k):
         fac = 1 + k[4] * r**2 + k[5] * r**4
     elif model == "poly3":
         fac = 1 + k[4] * r**2 + k[5] * r**4 + k[6] * r**6
+    elif model == "rational6":
+        fac = (1 + k[4] * r**2 + k[5] * r**4 + k[6] * r**6) / (1 + k[7] * r**2 + k[8] * r**4 + k[9] * r**6)
     else:
         fac = mp.mpf(1)
     return [fac * k[0] * x + k[2], fac * k[1] * y + k[3]]
@@ -137,6 +139,13 @@ def main():
         g = mp.mpf("9.8007")
         v = [-g * mp.cos(p) * mp.sin(q), g * mp.sin(p), -g * mp.cos(p) * mp.cos(q)]
         out["gravity"].append({"dir": [F(p), F(q)], "g": [F(x) for x in v]})
+    # rational6 (added later: its own random stream, so that every vector above keeps its value)
+    st2 = [987654321]
+    k = [mp.mpf(v) for v in [400, 401, 320.5, 240.25, "0.12", "0.05", "0.004", "0.40", "-0.04", "0.002"]]
+    rays = [[(rnd(st2) - 0.5) * 1.2, (rnd(st2) - 0.5) * 0.9, mp.mpf("0.2") + rnd(st2)] for _ in range(40)]
+    rays += [[mp.mpf(eps), mp.mpf(eps) / 3, mp.mpf(1)] for eps in ["3.0e-3", "1e-6"]]
+    for ray in rays:
+        out["project"].append({"model": 5, "ray": [F(v) for v in ray], "k": [F(v) for v in k], "pix": [F(v) for v in project("rational6", ray, k)]})
     with open(os.path.join(HERE, "math_kat.json"), "w") as f:
         json.dump(out, f, indent=0)
     print({k: len(v) for k, v in out.items()})

@@ -13,9 +13,10 @@ static double gram(const TileXf& x, const double* K, int n, const double* pw, co
   double cost = 0;
   ModelPre pre; model_precompute(MODEL, K, &pre);
   for (int d = 0; d < n; ++d) {
-    double r0[16], r1[16];
-    cost += corner_rows<MODEL>(x, K, pre, pw + 3 * d, uv[2 * d], uv[2 * d + 1], mult, r0, r1);
+    double r0[16], r1[16], rs[2];
+    cost += corner_rows<MODEL>(x, K, pre, pw + 3 * d, uv[2 * d], uv[2 * d + 1], mult, r0, r1, rs);
     for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) G[i * 16 + j] += r0[i] * r0[j] + r1[i] * r1[j];
+    if (MODEL == kRational6) for (int i = 0; i < 16; ++i) G[kGGrad + i] += r0[i] * rs[0] + r1[i] * rs[1];     // the side vector (see kGGrad)
   }
   return cost;
 }
@@ -32,12 +33,13 @@ void hh_project(int model, const double* pc, const double* K, double* pix, doubl
 double hh_tile_gram(int model, const double* T_wk, const double* T_ck, const double* K, int n, const double* pw, const double* uv,
                     double mult, double* G) {
   TileXf x; make_tile_xf(T_wk, T_ck, &x);
-  std::memset(G, 0, 256 * sizeof(double));
+  std::memset(G, 0, 272 * sizeof(double));       // the kernels' Gram record: 16 x 16 block + side vector
   switch (model) {
     case kFov: return gram<kFov>(x, K, n, pw, uv, mult, G);
     case kPoly2: return gram<kPoly2>(x, K, n, pw, uv, mult, G);
     case kPoly3: return gram<kPoly3>(x, K, n, pw, uv, mult, G);
     case kKb4: return gram<kKb4>(x, K, n, pw, uv, mult, G);
+    case kRational6: return gram<kRational6>(x, K, n, pw, uv, mult, G);
     default: return gram<kLinear>(x, K, n, pw, uv, mult, G);
   }
 }
@@ -48,6 +50,7 @@ double hh_tile_resid(int model, const double* T_wk, const double* T_ck, const do
     case kPoly2: return resid<kPoly2>(x, K, n, pw, uv, r);
     case kPoly3: return resid<kPoly3>(x, K, n, pw, uv, r);
     case kKb4: return resid<kKb4>(x, K, n, pw, uv, r);
+    case kRational6: return resid<kRational6>(x, K, n, pw, uv, r);
     default: return resid<kLinear>(x, K, n, pw, uv, r);
   }
 }

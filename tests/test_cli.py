@@ -119,3 +119,17 @@ def test_cli_visual_inertial_calibration(tmp_path):
     assert cams2[0][0] == cams[0][0]
     np.testing.assert_array_equal(cams2[0][1], cams[0][1])
     assert "<right> [ 1; 0; 0 ] </right>" in open(out2).read()          # no IMU: RdfVision (:221-225)
+
+
+@pytest.mark.gpu
+def test_cli_rational6_model(tmp_path):
+    """-models rational6 (vicalib-engine.cc:233-240): start values (300, 300, w/2, h/2, 0 x 6), type string calibu_fu_fv_u0_v0_rational6."""
+    p = synth.generate(synth.Config(models=("rational6",), n_frames=30, seed=7))
+    files, _ = synth.write_dataset(p, str(tmp_path))
+    out = tmp_path / "cameras.xml"
+    r = _run(["-cam", "detections://" + files[0], "-models", "rational6", "-nocalibrate_imu", "-output", str(out)])
+    assert r.returncode == 0, r.stdout + r.stderr
+    cams = _read_xml(str(out))
+    assert cams[0][0] == "calibu_fu_fv_u0_v0_rational6" and len(cams[0][1]) == 10
+    np.testing.assert_allclose(cams[0][1][:4], p.cam_K_gt[0][:4], rtol=5e-3)
+    assert "calibration succeeded" in r.stdout

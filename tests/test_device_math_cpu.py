@@ -30,7 +30,7 @@ def hh():
 
 
 d = ol._d
-NK = {0: 5, 1: 6, 2: 7, 3: 8, 4: 4}
+NK = {0: 5, 1: 6, 2: 7, 3: 8, 4: 4, 5: 10}
 
 
 def test_closed_form_projection_jacobians_match_duals():
@@ -49,7 +49,8 @@ def test_closed_form_projection_jacobians_match_duals():
         np.testing.assert_allclose(B, odk, rtol=1e-9, atol=1e-7)
 
 
-@pytest.mark.parametrize("models,fix_k", [(("fov", "fov"), False), (("poly3", "kb4", "poly2"), False), (("linear", "kb4"), True)])
+@pytest.mark.parametrize("models,fix_k", [(("fov", "fov"), False), (("poly3", "kb4", "poly2"), False), (("linear", "kb4"), True),
+                                          (("rational6", "fov"), False)])
 def test_tile_gram_algebra_matches_oracle_normal_equations(models, fix_k):
     p = synth.generate(synth.Config(models=models, n_frames=5, seed=11))
     o = ol.Oracle().load(p)
@@ -61,7 +62,7 @@ def test_tile_gram_algebra_matches_oracle_normal_equations(models, fix_k):
     H = hh()
     n = o.n_frames
     Aff = np.zeros((n, 6, 6)); gf = np.zeros((n, 6)); W = np.zeros((n, 6, max(D, 1))); Hss = np.zeros((D, D)); gs = np.zeros(D)
-    Gsum = {c: np.zeros(256) for c in range(len(models))}
+    Gsum = {c: np.zeros(272) for c in range(len(models))}
     cost = 0.0
     flags = {}
     for c in range(len(models)):
@@ -69,7 +70,7 @@ def test_tile_gram_algebra_matches_oracle_normal_equations(models, fix_k):
         flags[c] = fl
     for (f, c, ids, pix) in p.tiles:
         T, _ = o.frame(f); K, Tck = o.camera(c)
-        G = np.zeros(256)
+        G = np.zeros(272)
         pw = np.ascontiguousarray(p.grid_points[ids]); uv = np.ascontiguousarray(pix)
         cost += 0.5 * H.hh_tile_gram(p.cam_model[c], d(T), d(Tck), d(K), len(ids), d(pw), d(uv), C.c_double(1.0), d(G))
         Gsum[c] += G

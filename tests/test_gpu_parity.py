@@ -33,7 +33,7 @@ def _oracle_schur(lin):
     return S, g
 
 
-@pytest.mark.parametrize("models", [("fov", "fov"), ("poly3", "kb4", "poly2"), ("linear", "kb4"), ("poly3",)])
+@pytest.mark.parametrize("models", [("fov", "fov"), ("poly3", "kb4", "poly2"), ("linear", "kb4"), ("poly3",), ("rational6", "fov"), ("rational6",)])
 def test_linearisation_blocks_match_oracle(models):
     p, cal, orc = _pair(synth.Config(models=models, n_frames=9, seed=21))
     orc.prepare(vis_mult=1)
@@ -48,6 +48,34 @@ def test_linearisation_blocks_match_oracle(models):
     S, gr = _oracle_schur(lin)
     np.testing.assert_allclose(g["S"], S, rtol=1e-6, atol=1e-8 * np.abs(lin["Hss"]).max())
     np.testing.assert_allclose(g["g_red"], gr, rtol=1e-6, atol=1e-8 * np.abs(lin["gs"]).max())
+
+
+def test_rational6_calibration_matches_oracle():
+    """calibu::Rational6Camera (vicalibrator.h:434-443, -models rational6 vicalib-engine.cc:233-240): 10 parameters, 16 Jacobian
+    columns per corner -- the tile's 16 x 16 Gram block is full and J^T r travels in the record's side vector.  Complete solves
+    (mono and next to a poly3 camera) against the oracle: every iteration's cost, the accept / reject sequence, the RMSE and the
+    well-determined parameters at 1e-6.  The six distortion terms of a rational model are nearly redundant (the reduced system
+    is close to singular along them), so they are compared through what they mean -- the projection itself, at 1e-6 of a pixel
+    per focal length over the image -- not coefficient by coefficient."""
+    for models in (("rational6",), ("rational6", "poly3")):
+        p, cal, orc = _pair(synth.Config(models=models, n_frames=40, seed=7))
+        cal.Solve(); orc.solve()
+        tg, to = cal.trace(), orc.trace()
+        assert len(tg) == len(to)
+        np.testing.assert_allclose(tg[:, 1], to[:, 1], rtol=1e-6)
+        np.testing.assert_array_equal(tg[:, 8], to[:, 8])
+        np.testing.assert_allclose(cal.GetCameraProjRMSE(), orc.rmse(), rtol=1e-6)
+        assert np.all(np.abs(cal.GetCameraProjRMSE() - p.cfg.pixel_sigma) < 0.01)
+        Kg, Tg = cal.GetCamera(0); Ko, To = orc.camera(0)
+        assert len(Kg) == 10
+        np.testing.assert_allclose(Kg[:4], Ko[:4], rtol=1e-6)
+        np.testing.assert_allclose(Kg[:4], p.cam_K_gt[0][:4], rtol=3e-3)
+        rays = np.stack(np.meshgrid(np.linspace(-0.6, 0.6, 9), np.linspace(-0.45, 0.45, 7), [1.0]), -1).reshape(-1, 3)
+        pg = synth.project(5, Kg, rays); po = synth.project(5, Ko, rays)
+        assert np.abs(pg - po).max() < 1e-6 * Kg[0]
+        if len(models) == 2:
+            np.testing.assert_allclose(cal.GetCamera(1)[0], orc.camera(1)[0], rtol=1e-6, atol=1e-9)
+            np.testing.assert_allclose(cal.GetCamera(1)[1], orc.camera(1)[1], rtol=1e-6, atol=1e-8)
 
 
 def test_residual_sweep_matches_oracle():

@@ -19,7 +19,7 @@ def _mul(A, B):
     return np.concatenate([(ra * rb).as_quat(), ra.apply(B[4:]) + A[4:]])
 
 
-@pytest.mark.parametrize("model", ["fov", "poly2", "poly3", "kb4", "linear"])
+@pytest.mark.parametrize("model", ["fov", "poly2", "poly3", "kb4", "linear", "rational6"])
 def test_pnp_recovers_the_generating_pose(model):
     p = synth.generate(synth.Config(models=(model,), n_frames=12, seed=3, pixel_sigma=0.0))
     for (f, c, ids, pix) in p.tiles:

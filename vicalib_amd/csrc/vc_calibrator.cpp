@@ -1178,7 +1178,7 @@ int vc_write_camera_models(vc_calibrator* h, const char* filename) {
   FILE* f = std::fopen(filename, "w");
   if (!f) return VC_ERR_BAD_ARG;
   static const char* kType[] = {"calibu_fu_fv_u0_v0_w", "calibu_fu_fv_u0_v0_k1_k2", "calibu_fu_fv_u0_v0_k1_k2_k3",
-                                "calibu_fu_fv_u0_v0_kb4", "calibu_fu_fv_u0_v0"};   // vicalib-engine.cc:210-260
+                                "calibu_fu_fv_u0_v0_kb4", "calibu_fu_fv_u0_v0", "calibu_fu_fv_u0_v0_rational6"};   // vicalib-engine.cc:210-260
   std::lock_guard<std::mutex> lk(h->result_mutex);
   const bool robotics = h->calibrate_imu;     // FLAGS_calibrate_imu selects RdfRobotics (:214-219)
   const double rdf_rob[9] = {0, 1, 0, 0, 0, 1, 1, 0, 0}, rdf_vis[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};

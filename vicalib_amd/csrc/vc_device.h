@@ -16,7 +16,7 @@ constexpr int kMaxCams = 8;
 // obs_pt[i]: bits 0..14 = index into points[], bit 15 = this corner has one residual-block copy fewer than Ctrl::mult
 // (an outlier removed from the latest copy before SetupProblem re-added every block, vicalibrator.h:641-649, :911-914)
 constexpr int kObsPointMask = 0x7fff, kObsOneLess = 0x8000;
-constexpr int kGStride = 256;      // 16x16 Gram block per tile
+constexpr int kGStride = 272;      // Gram record per tile: the 16 x 16 block + the 16-entry side vector at kGGrad (vc_math.hpp)
 constexpr int kYStride = 96;       // 6 x 16 per tile
 constexpr int kFrStride = 48;      // per frame: L(21) z(6) g(6) lam(6) 1/diag(L)(6) pad
 constexpr int kFrL = 0, kFrZ = 21, kFrG = 27, kFrLam = 33, kFrDinv = 39;
@@ -73,7 +73,7 @@ struct DevView {
   // Linearisation of the vision terms, double-buffered like the state: Gb[b] / tile_costb[b] belong to state buffer b.
   // Vision-only passes evaluate the Jacobian sweep AT THE TRIAL POINT inside k_trial (one projection sweep per LM
   // iteration instead of two); accepting the step flips `cur` and the linearisation is already there.
-  double* Gb[2];                   // n_tiles x 256
+  double* Gb[2];                   // n_tiles x kGStride
   double* tile_costb[2];           // n_tiles   (Jacobian sweep: cost at the linearisation point)
   int fused;                       // 1: the trial point is evaluated by the Jacobian sweeps themselves (k_trial on vision-only passes,
                                    // k_reproj_jac / k_imu_jac in trial mode with the IMU), which leave the next linearisation in buffer 1-cur

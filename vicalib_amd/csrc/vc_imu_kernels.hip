@@ -436,12 +436,12 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
   const double* cams = v.cams[cur];
   const int chunk = blockIdx.x;
   const int f0 = chunk * v.chunk_frames, f1 = min(f0 + v.chunk_frames, N);
-  double gsum[kMaxCams][4];
+  double gsum[kMaxCams][5];     // [4]: the Gram record's side vector (lanes < 16)
   double isum[4] = {0.0, 0.0, 0.0, 0.0};      // IMU shared block: Hii[a][b] at a*16+b (a,b<15), g_i[a] at a*16+15
 #pragma unroll
   for (int c = 0; c < kMaxCams; ++c)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gsum[c][q] = 0.0;
+    for (int q = 0; q < 5; ++q) gsum[c][q] = 0.0;
 
   for (int fg = f0; fg < f1; fg += 4) {
     const int f = fg + wave;
@@ -459,15 +459,16 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
     if (lane < 42) Hs[lane] = 0.0;
     wave_lds_sync();
     if (nt > 0) {
-      for (int m = 0; m < nt * 4; ++m) {
-        const int t = m >> 2, q = m & 3;
-        const double val = v.Gb[cur][(size_t)(t0 + t) * kGStride + q * 64 + lane];
-        Gw[t * kGStride + q * 64 + lane] = val;
+      for (int m = 0; m < nt * 5; ++m) {
+        const int t = m / 5, q = m % 5;
+        const int o = (q < 4) ? q * 64 + lane : kGGrad + (lane & 15);
+        const double val = (q < 4 || lane < 16) ? v.Gb[cur][(size_t)(t0 + t) * kGStride + o] : 0.0;
+        if (q < 4 || lane < 16) Gw[t * kGStride + o] = val;
         const int c = v.tile_cam[t0 + t];
 #pragma unroll
         for (int k = 0; k < kMaxCams; ++k)
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq) gsum[k][qq] += (k == c && qq == q) ? val : 0.0;
+          for (int qq = 0; qq < 5; ++qq) gsum[k][qq] += (k == c && qq == q) ? val : 0.0;
       }
       wave_lds_sync();
       if (lane < 42) {
@@ -487,10 +488,10 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
             hval += (a == b) ? s : -s;
           } else {
             const int i = lane - 36, a = i / 3, ii = i % 3;
-            const int rc = 6 + model_nk(v.cd[c].model);
+            const int nk = model_nk(v.cd[c].model);
             double s = 0.0;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) s += Rm[3 * p + ii] * g[(3 * a + p) * 16 + rc];
+            for (int p = 0; p < 3; ++p) s += Rm[3 * p + ii] * gram_grad(g, 3 * a + p, nk);
             hval += (a == 0) ? -s : s;
           }
         }
@@ -611,6 +612,7 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
     if (c < C) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) sh[wave * slot + c * kGStride + q * 64 + lane] = gsum[c][q];
+      if (lane < 16) sh[wave * slot + c * kGStride + kGGrad + lane] = gsum[c][4];
     }
 #pragma unroll
   for (int q = 0; q < 4; ++q) sh[wave * slot + C * kGStride + q * 64 + lane] = isum[q];

@@ -45,8 +45,9 @@ __device__ void merged_control(const DevView& v, Ctrl* out, double* red, bool wr
 template <int MODEL>
 __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* pose, const double* cam, double mult, int tile, int lane,
                                                 double* wl, double* G, int off_in, int cnt_in /* corner range if known (cnt_in >= 0) */) {
-  constexpr int nk = MODEL == kFov ? 5 : MODEL == kPoly2 ? 6 : MODEL == kPoly3 ? 7 : MODEL == kKb4 ? 8 : 4;
+  constexpr int nk = MODEL == kFov ? 5 : MODEL == kPoly2 ? 6 : MODEL == kPoly3 ? 7 : MODEL == kKb4 ? 8 : MODEL == kRational6 ? 10 : 4;
   constexpr bool kThreeCols = (7 + nk) <= 12;
+  constexpr bool kSideGrad = nk >= 10;         // 16 Jacobian columns: J^T r is accumulated beside the matrix pipe (kGGrad)
   const int off = cnt_in >= 0 ? off_in : __builtin_amdgcn_readfirstlane(v.tile_off[tile]);
   const int cnt = cnt_in >= 0 ? cnt_in : __builtin_amdgcn_readfirstlane(v.tile_off[tile + 1]) - off;
   const int b = (lane >> 2) & 3, i4 = lane & 3;
@@ -56,6 +57,9 @@ __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* 
   const int xc = kThreeCols ? (b == 0 ? 1 : b == 1 ? 2 : b == 2 ? 2 : 3) : ((b + 2) & 3);
   double acc[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
   double cost = 0.0;
+  double gacc[kSideGrad ? 16 : 1];
+#pragma unroll
+  for (int i = 0; i < (kSideGrad ? 16 : 1); ++i) gacc[i] = 0.0;
 #ifdef VC_JAC_STAMPS
 #define JSTAMP(i) do { if (tile == 0 && lane == 0) v.dbg[8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
@@ -65,9 +69,9 @@ __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* 
   if (cnt > 0) {
     TileXf x;
     make_tile_xf(pose, cam, &x);
-    double K[8];
+    double K[nk > 8 ? nk : 8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) K[i] = cam[kCamK + i];
+    for (int i = 0; i < (nk > 8 ? nk : 8); ++i) K[i] = cam[kCamK + i];
     ModelPre pre;
     model_precompute(MODEL, K, &pre);
     double* mine = wl + lane * kDotStride;
@@ -99,7 +103,14 @@ __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* 
       }
       if (base == 0) JSTAMP(1);
       if (d < cnt) {
-        cost += corner_rows<MODEL>(x, K, pre, pw, uv.x, uv.y, mult_d, mine, mine + 16);
+        if (kSideGrad) {
+          double rs[2];
+          cost += corner_rows<MODEL>(x, K, pre, pw, uv.x, uv.y, mult_d, mine, mine + 16, rs);
+#pragma unroll
+          for (int i = 0; i < (kSideGrad ? 16 : 1); ++i) gacc[i] += mine[i] * rs[0] + mine[16 + i] * rs[1];
+        } else {
+          cost += corner_rows<MODEL>(x, K, pre, pw, uv.x, uv.y, mult_d, mine, mine + 16);
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < 32; ++i) mine[i] = 0.0;
@@ -162,6 +173,13 @@ __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* 
       G[r2 * 16 + c2] = d2; G[c2 * 16 + r2] = d2;
     }
   }
+  if (kSideGrad) {
+#pragma unroll
+    for (int i = 0; i < (kSideGrad ? 16 : 1); ++i) {
+      const double t = wave_sum(gacc[i]);
+      if (lane == 0) G[kGGrad + i] = t;
+    }
+  }
   JSTAMP(5);
   return wave_sum(cost);          // valid in lane 0
 }
@@ -172,6 +190,7 @@ __device__ __forceinline__ double jac_tile_dispatch(const DevView& v, int model,
     case kPoly2: return jac_tile_body<kPoly2>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
     case kPoly3: return jac_tile_body<kPoly3>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
     case kKb4: return jac_tile_body<kKb4>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
+    case kRational6: return jac_tile_body<kRational6>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
     default: return jac_tile_body<kLinear>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
   }
 }
@@ -225,6 +244,7 @@ __device__ __forceinline__ void res_tile_dispatch(const DevView& v, int model, c
     case kPoly2: res_tile_sweep<kPoly2>(v, x, K, off, cnt, lane, mult, cost, sq); break;
     case kPoly3: res_tile_sweep<kPoly3>(v, x, K, off, cnt, lane, mult, cost, sq); break;
     case kKb4: res_tile_sweep<kKb4>(v, x, K, off, cnt, lane, mult, cost, sq); break;
+    case kRational6: res_tile_sweep<kRational6>(v, x, K, off, cnt, lane, mult, cost, sq); break;
     default: res_tile_sweep<kLinear>(v, x, K, off, cnt, lane, mult, cost, sq); break;
   }
 }
@@ -243,9 +263,9 @@ __global__ __launch_bounds__(256) void k_reproj_res(DevView v, int state, double
   const double* cam = v.cams[state] + (size_t)c * kCamStride;
   TileXf x;
   make_tile_xf(v.poses[state] + (size_t)f * kPoseStride, cam, &x);
-  double K[8];
+  double K[10];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) K[i] = cam[kCamK + i];
+  for (int i = 0; i < 10; ++i) K[i] = cam[kCamK + i];
   double cost, sq;
   res_tile_dispatch(v, v.cd[c].model, x, K, v.tile_off[tile], v.tile_off[tile + 1] - v.tile_off[tile], lane, mult, &cost, &sq);
   if (lane == 0) { v.tile_trial[2 * tile] = cost; v.tile_trial[2 * tile + 1] = sq; }
@@ -273,15 +293,16 @@ __global__ __launch_bounds__(256) void k_outlier_mask(DevView v, int state, cons
   const double* cam = v.cams[state] + (size_t)c * kCamStride;
   TileXf x;
   make_tile_xf(v.poses[state] + (size_t)f * kPoseStride, cam, &x);
-  double K[8];
+  double K[10];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) K[i] = cam[kCamK + i];
+  for (int i = 0; i < 10; ++i) K[i] = cam[kCamK + i];
   const double th = thresh[c];
   switch (v.cd[c].model) {
     case kFov: mask_tile_body<kFov>(v, x, K, off, cnt, lane, th, mask); break;
     case kPoly2: mask_tile_body<kPoly2>(v, x, K, off, cnt, lane, th, mask); break;
     case kPoly3: mask_tile_body<kPoly3>(v, x, K, off, cnt, lane, th, mask); break;
     case kKb4: mask_tile_body<kKb4>(v, x, K, off, cnt, lane, th, mask); break;
+    case kRational6: mask_tile_body<kRational6>(v, x, K, off, cnt, lane, th, mask); break;
     default: mask_tile_body<kLinear>(v, x, K, off, cnt, lane, th, mask); break;
   }
 }
@@ -323,11 +344,11 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
   v4d acc[MAXP];
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
-  double gsum[MAXC][4];
+  double gsum[MAXC][5];      // [4]: the record's side vector (lanes < 16)
 #pragma unroll
   for (int c = 0; c < MAXC; ++c)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gsum[c][q] = 0.0;
+    for (int q = 0; q < 5; ++q) gsum[c][q] = 0.0;
   double csum = 0.0;      // lane t: cost of tile t of this wave's frames (the chunk's cost rides in the partials)
   double x2_noobs = 0.0;  // lane 0: parameter norm of this wave's frames that have no observations
 
@@ -356,17 +377,19 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
     }
     if (nt > 0) {
       for (int t = 0; t < nt; ++t) {           // full 16x16 Gram block of every tile of the frame
-        double val[4];
+        double val[5];
 #pragma unroll
         for (int q = 0; q < 4; ++q) val[q] = v.Gb[cur][(size_t)(t0 + t) * kGStride + q * 64 + lane];
+        val[4] = (lane < 16) ? v.Gb[cur][(size_t)(t0 + t) * kGStride + kGGrad + lane] : 0.0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) Gw[t * kGStride + q * 64 + lane] = val[q];
+        if (lane < 16) Gw[t * kGStride + kGGrad + lane] = val[4];
         const int c = __builtin_amdgcn_readlane(my_cam, t);      // wave-uniform: scalar branch, one camera's accumulators touched
 #pragma unroll
         for (int k = 0; k < MAXC; ++k)
           if (k == c) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) gsum[k][q] += val[q];
+            for (int q = 0; q < 5; ++q) gsum[k][q] += val[q];
           }
       }
       wave_lds_sync();
@@ -387,10 +410,10 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
             hval += (a == b) ? s : -s;
           } else {
             const int i = lane - 36, a = i / 3, ii = i % 3;
-            const int rc = 6 + model_nk(s_cd[c].model);
+            const int nk = model_nk(s_cd[c].model);
             double s = 0.0;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) s += Rm[3 * p + ii] * g[(3 * a + p) * 16 + rc];
+            for (int p = 0; p < 3; ++p) s += Rm[3 * p + ii] * gram_grad(g, 3 * a + p, nk);
             hval += (a == 0) ? -s : s;
           }
         }
@@ -516,6 +539,7 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
     if (c < C) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) sh[wave * (C * kGStride) + c * kGStride + q * 64 + lane] = gsum[c][q];
+      if (lane < 16) sh[wave * (C * kGStride) + c * kGStride + kGGrad + lane] = gsum[c][4];
     }
   __syncthreads();
   for (int e = tid; e < C * kGStride; e += 256)
@@ -556,7 +580,7 @@ __global__ __launch_bounds__(256) void k_part_sum(DevView v) {
 
 // Phase A of the reduced system (one workgroup):
 // Sbuf = [ S = H_ss - sum Y^T Y (full symmetric, undamped) | g_red | diag(H_ss) | g_s | cost, 0 ]
-struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[kMaxCams * 256]; double T1[kMaxCams * 256]; double red[256]; double camq[kMaxCams * 4]; };
+struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[kMaxCams * 256]; double T1[kMaxCams * 256]; double red[256]; double camq[kMaxCams * 4]; double gc[kMaxCams * 16]; };
 // shader-clock stamps of k_reduced's phases (tools/dbg_stamps.py): profiling builds only (-DVC_REDUCED_STAMPS) -- each stamp is
 // a global store whose acknowledgement the next barrier waits for (~1.5k cycles apiece)
 #ifdef VC_REDUCED_STAMPS
@@ -623,20 +647,20 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double
   }
   __syncthreads();
   for (int c = 0; c < C; ++c) {
-    const int nu = 6 + model_nk(cd[c].model);
+    const int nk = model_nk(cd[c].model), nu = 6 + nk;
     const double* G = L.gsum + c * kGStride;
     const double* P = L.P + c * 256;
-    const int i = tid >> 4, a = tid & 15;     // T1[i][a] = sum_k G[i][k] P[k][a]; row 15 := g_c = sum_k P[k][a] G[k][nu]
+    const int i = tid >> 4, a = tid & 15;     // T1[i][a] = sum_k G[i][k] P[k][a] (rows i >= nu: zero)
     double s = 0.0;
-    if (i == 15) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) s += P[k * 16 + a] * G[k * 16 + nu];
-    } else {
+    for (int k = 0; k < 16; ++k) s += G[i * 16 + k] * P[k * 16 + a];
+    L.T1[c * 256 + tid] = (i < nu) ? s : 0.0;
+    if (tid < 16) {                           // g_c[a] = sum_k P[k][a] (J^T r)[k]
+      double gca = 0.0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) s += G[i * 16 + k] * P[k * 16 + a];
-      if (i >= nu) s = 0.0;
+      for (int k = 0; k < 16; ++k) gca += (k < nu) ? P[k * 16 + tid] * gram_grad(G, k, nk) : 0.0;
+      L.gc[c * 16 + tid] = gca;
     }
-    L.T1[c * 256 + tid] = s;
   }
   __syncthreads();
   for (int c = 0; c < C; ++c) {
@@ -644,15 +668,15 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double
     const int nc = cam_ncols(flags, nk), c0 = cd[c].col0;
     const double* P = L.P + c * 256;
     const double* T1 = L.T1 + c * 256;
-    const int b = tid >> 4, a = tid & 15;     // Hcc[b][a] = sum_i P[i][b] T1[i][a]  (rows i >= nu of P are zero; row 15 of T1 is g_c)
+    const int b = tid >> 4, a = tid & 15;     // Hcc[b][a] = sum_i P[i][b] T1[i][a]  (rows i >= nu of P and T1 are zero)
     if (a < nc && b < nc && a >= b) {
       double s = 0.0;
 #pragma unroll
-      for (int i = 0; i < 15; ++i) s += P[i * 16 + b] * T1[i * 16 + a];
+      for (int i = 0; i < 16; ++i) s += P[i * 16 + b] * T1[i * 16 + a];
       S[(c0 + b) * D + c0 + a] += s;
       if (a == b) hd[c0 + a] = s;
     }
-    if (b == 15 && a < nc) { gred[c0 + a] += T1[15 * 16 + a]; gs[c0 + a] = T1[15 * 16 + a]; }
+    if (b == 15 && a < nc) { gred[c0 + a] += L.gc[c * 16 + a]; gs[c0 + a] = L.gc[c * 16 + a]; }
   }
   __syncthreads();
   VC_STAMP(3);
@@ -1147,9 +1171,9 @@ __device__ __forceinline__ void trial_tile(const DevView& v, int cur, double mul
   const int f = h.frame, c = h.cam;
   const int t0 = h.t0;
   const double* cam = cams_trial + (size_t)c * kCamStride;
-  double camr[16];
+  double camr[kCamK + 10];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) camr[i] = cam[i];
+  for (int i = 0; i < kCamK + 10; ++i) camr[i] = cam[i];
   double Tout[7];
   if (v.pre_backsub) {            // k_backsub has been here: take the frame's trial pose and (first tile) its step terms
     const double* pt = v.poses[1 - cur] + (size_t)f * kPoseStride;
@@ -1173,9 +1197,9 @@ __device__ __forceinline__ void trial_tile(const DevView& v, int cur, double mul
   } else {
     TileXf x;
     make_tile_xf(Tout, camr, &x);
-    double K[8];
+    double K[10];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) K[i] = camr[kCamK + i];
+    for (int i = 0; i < 10; ++i) K[i] = camr[kCamK + i];
     res_tile_dispatch(v, h.model, x, K, h.off, h.cnt, lane, mult, &cost, &sq);
   }
   if (lane == 0) {

@@ -22,13 +22,18 @@
 namespace vc {
 
 // model ids = order of the -models strings (vicalib-engine.cc:203-253)
-enum Model { kFov = 0, kPoly2 = 1, kPoly3 = 2, kKb4 = 3, kLinear = 4 };
-VC_HD int model_nk(int m) { return m == kFov ? 5 : m == kPoly2 ? 6 : m == kPoly3 ? 7 : m == kKb4 ? 8 : m == kLinear ? 4 : -1; }
+enum Model { kFov = 0, kPoly2 = 1, kPoly3 = 2, kKb4 = 3, kLinear = 4, kRational6 = 5 };
+VC_HD int model_nk(int m) { return m == kFov ? 5 : m == kPoly2 ? 6 : m == kPoly3 ? 7 : m == kKb4 ? 8 : m == kLinear ? 4 : m == kRational6 ? 10 : -1; }
 
 constexpr int kPoseStride = 8;    // [qx qy qz qw tx ty tz pad] = 64 B per frame
 constexpr int kCamStride = 24;    // [T_ck(7) pad | K(<=10) pad..]
 constexpr int kCamK = 8;          // offset of K inside a camera record
 constexpr int kUCols = 16;        // padded width of a unique-column row
+// A tile's Gram record: the 16 x 16 block over u = [A (3) | A x q (3) | B (nk) | r] at 0, and 16 more doubles at kGGrad.  With
+// nk <= 9 the residual column r sits inside the block (column 6 + nk).  rational6 has nk = 10: its 16 Jacobian columns fill the
+// block and the products with r (J^T r, 16 values) live in the side vector at kGGrad.
+constexpr int kGGrad = 256;
+VC_HD double gram_grad(const double* G, int row, int nk) { return nk < 10 ? G[row * kUCols + 6 + nk] : G[kGGrad + row]; }
 constexpr int kSoftL1A = 0;       // loss ids
 constexpr double kSophusEps = 1e-10;
 
@@ -183,7 +188,7 @@ VC_HD void project_radial(int model, const double* pc, const double* K, const Mo
   const double x = pc[0] * iz, y = pc[1] * iz;
   const double r2 = x * x + y * y;
   double fac = 1.0, h = 0.0;           // h = fac'(r) / r
-  double dk0 = 0.0, dk1 = 0.0, dk2 = 0.0;
+  double dk0 = 0.0, dk1 = 0.0, dk2 = 0.0, dk3 = 0.0, dk4 = 0.0, dk5 = 0.0;
   if (model == kFov) {
     // Branch-free (selects, not jumps): on the GPU this arithmetic runs in the shadow of the previous pass's MFMAs and a
     // jump would cut the scheduling region.  The discarded alternatives may hold inf/nan; they are never blended in.
@@ -208,6 +213,17 @@ VC_HD void project_radial(int model, const double* pc, const double* K, const Mo
   } else if (model == kPoly3) {
     fac = 1.0 + r2 * (K[4] + r2 * (K[5] + r2 * K[6]));
     if (JAC) { h = 2.0 * K[4] + r2 * (4.0 * K[5] + 6.0 * K[6] * r2); dk0 = r2; dk1 = r2 * r2; dk2 = dk1 * r2; }
+  } else if (model == kRational6) {
+    // fac = N / Dn, N = 1 + k1 r^2 + k2 r^4 + k3 r^6, Dn = 1 + k4 r^2 + k5 r^4 + k6 r^6
+    const double N = 1.0 + r2 * (K[4] + r2 * (K[5] + r2 * K[6])), Dn = 1.0 + r2 * (K[7] + r2 * (K[8] + r2 * K[9]));
+    const double iD = 1.0 / Dn;
+    fac = N * iD;
+    if (JAC) {
+      const double dN = K[4] + r2 * (2.0 * K[5] + 3.0 * K[6] * r2), dD = K[7] + r2 * (2.0 * K[8] + 3.0 * K[9] * r2);
+      h = 2.0 * (dN - fac * dD) * iD;                 // d fac / d r^2 = (N' Dn - N Dn') / Dn^2, times 2
+      const double r4 = r2 * r2, r6 = r4 * r2, q = -fac * iD;
+      dk0 = r2 * iD; dk1 = r4 * iD; dk2 = r6 * iD; dk3 = q * r2; dk4 = q * r4; dk5 = q * r6;
+    }
   }
   const double fu = K[0], fv = K[1];
   pix[0] = fu * x * fac + K[2];
@@ -223,6 +239,7 @@ VC_HD void project_radial(int model, const double* pc, const double* K, const Mo
     if (nk > 4) { B[4] = fu * x * dk0; B[nk + 4] = fv * y * dk0; }
     if (nk > 5) { B[5] = fu * x * dk1; B[nk + 5] = fv * y * dk1; }
     if (nk > 6) { B[6] = fu * x * dk2; B[nk + 6] = fv * y * dk2; }
+    if (nk > 7) { B[7] = fu * x * dk3; B[nk + 7] = fv * y * dk3; B[8] = fu * x * dk4; B[nk + 8] = fv * y * dk4; B[9] = fu * x * dk5; B[nk + 9] = fv * y * dk5; }
   }
 }
 template <bool JAC>
@@ -284,12 +301,13 @@ VC_HD void tile_point(const TileXf& x, const double* pw, double* pc) {
 }
 
 // Robustified unique-column rows of one corner: row[i] = sqrt(w) [A_i | A_i x q | B_i | r_i | 0..],
-// w = mult * rho'(|r|^2); returns mult * rho(|r|^2) (twice the block's cost).
+// w = mult * rho'(|r|^2); returns mult * rho(|r|^2) (twice the block's cost).  rs (optional): sqrt(w) r, the residual as it is
+// scaled in the rows -- rational6's 16 Jacobian columns leave no room for it in the row (see kGGrad).
 template <int MODEL>
 VC_HD double corner_rows(const TileXf& x, const double* K, const ModelPre& pre, const double* pw, double u, double v, double mult,
-                         double* row0 /*16*/, double* row1 /*16*/) {
+                         double* row0 /*16*/, double* row1 /*16*/, double* rs = nullptr /*2*/) {
   constexpr int model = MODEL;
-  double pc[3], pix[2], A[6], B[16];
+  double pc[3], pix[2], A[6], B[20];
   tile_point(x, pw, pc);
   project_any<true>(model, pc, K, pre, pix, A, B);
   const double r0 = pix[0] - u, r1 = pix[1] - v;
@@ -297,8 +315,9 @@ VC_HD double corner_rows(const TileXf& x, const double* K, const ModelPre& pre, 
   loss_soft_l1(r0 * r0 + r1 * r1, &rho, &rho1);
   const double sw = sqrt(mult * rho1);
   const double q0 = pc[0] - x.tck[0], q1 = pc[1] - x.tck[1], q2 = pc[2] - x.tck[2];
-  constexpr int nk = MODEL == kFov ? 5 : MODEL == kPoly2 ? 6 : MODEL == kPoly3 ? 7 : MODEL == kKb4 ? 8 : 4;
+  constexpr int nk = MODEL == kFov ? 5 : MODEL == kPoly2 ? 6 : MODEL == kPoly3 ? 7 : MODEL == kKb4 ? 8 : MODEL == kRational6 ? 10 : 4;
   for (int i = 7 + nk; i < kUCols; ++i) { row0[i] = 0.0; row1[i] = 0.0; }
+  if (rs) { rs[0] = sw * r0; rs[1] = sw * r1; }
   for (int i = 0; i < 2; ++i) {
     double* row = i ? row1 : row0;
     const double* a = A + 3 * i;
@@ -307,7 +326,7 @@ VC_HD double corner_rows(const TileXf& x, const double* K, const ModelPre& pre, 
     row[4] = sw * (a[2] * q0 - a[0] * q2);
     row[5] = sw * (a[0] * q1 - a[1] * q0);
     for (int k = 0; k < nk; ++k) row[6 + k] = sw * B[i * nk + k];
-    row[6 + nk] = sw * (i ? r1 : r0);
+    if (6 + nk < kUCols) row[6 + nk] = sw * (i ? r1 : r0);
   }
   return mult * rho;
 }
@@ -343,7 +362,6 @@ VC_HD void tile_to_frame_blocks(const double* G, const double* Rck, int nk, int 
       T[i * 6 + 3 + j] = g[3] * Rck[j] + g[4] * Rck[3 + j] + g[5] * Rck[6 + j];
     }
   }
-  const int rc = 6 + nk;   // column of r
   if (Hff) {
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 6; ++j) {
@@ -351,8 +369,8 @@ VC_HD void tile_to_frame_blocks(const double* G, const double* Rck, int nk, int 
         Hff[(3 + i) * 6 + j] += Rck[i] * T[3 * 6 + j] + Rck[3 + i] * T[4 * 6 + j] + Rck[6 + i] * T[5 * 6 + j];
       }
     for (int i = 0; i < 3; ++i) {
-      gf[i] += -(Rck[i] * G[0 * kUCols + rc] + Rck[3 + i] * G[1 * kUCols + rc] + Rck[6 + i] * G[2 * kUCols + rc]);
-      gf[3 + i] += Rck[i] * G[3 * kUCols + rc] + Rck[3 + i] * G[4 * kUCols + rc] + Rck[6 + i] * G[5 * kUCols + rc];
+      gf[i] += -(Rck[i] * gram_grad(G, 0, nk) + Rck[3 + i] * gram_grad(G, 1, nk) + Rck[6 + i] * gram_grad(G, 2, nk));
+      gf[3 + i] += Rck[i] * gram_grad(G, 3, nk) + Rck[3 + i] * gram_grad(G, 4, nk) + Rck[6 + i] * gram_grad(G, 5, nk);
     }
   }
   if (W) {
@@ -386,7 +404,7 @@ VC_HD void tile_to_frame_blocks(const double* G, const double* Rck, int nk, int 
 // Camera c's own block from the sum of its tiles' Gram blocks: Hcc (ncols x ncols, ld 16) and gc (ncols).
 // P maps u -> columns: rot: rows V * (-R); trans: rows A * I; K: rows B * I.
 VC_HD void cam_block_from_gsum(const double* G, const double* Rck, int nk, int flags, double* Hcc /*16x16*/, double* gc /*16*/) {
-  double P[15 * 16];   // (6+nk) x ncols
+  double P[16 * 16];   // (6+nk) x ncols
   const int nu = 6 + nk;
   const int nc = cam_ncols(flags, nk);
   for (int i = 0; i < nu * 16; ++i) P[i] = 0.0;
@@ -396,11 +414,11 @@ VC_HD void cam_block_from_gsum(const double* G, const double* Rck, int nk, int f
   if (flags & kCamKFree) { for (int p = 0; p < nk; ++p) P[(6 + p) * 16 + col + p] = 1.0; col += nk; }
   for (int a = 0; a < nc; ++a) {
     // t = G[u,u] P[:,a]
-    double t[15];
+    double t[16];
     for (int i = 0; i < nu; ++i) { double s = 0; for (int k = 0; k < nu; ++k) s += G[i * kUCols + k] * P[k * 16 + a]; t[i] = s; }
     for (int b = 0; b < nc; ++b) { double s = 0; for (int i = 0; i < nu; ++i) s += P[i * 16 + b] * t[i]; Hcc[b * 16 + a] = s; }
     double s = 0;
-    for (int i = 0; i < nu; ++i) s += P[i * 16 + a] * G[i * kUCols + nu];
+    for (int i = 0; i < nu; ++i) s += P[i * 16 + a] * gram_grad(G, i, nk);
     gc[a] = s;
   }
 }

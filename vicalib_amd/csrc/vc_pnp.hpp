@@ -172,7 +172,7 @@ inline bool pnp_planar_masked(int model, const double* K, int n, const double* p
       double pc[3];
       for (int a = 0; a < 3; ++a) pc[a] = Rc[3 * a] * p[0] + Rc[3 * a + 1] * p[1] + Rc[3 * a + 2] * p[2] + Tc[4 + a];
       if (pc[2] <= 1e-9) { cost += 1e6; continue; }
-      double pix[2], A[6], B[16];
+      double pix[2], A[6], B[20];
       project_any<true>(model, pc, K, pre, pix, A, B);
       const double r[2] = {pix[0] - uv[2 * i], pix[1] - uv[2 * i + 1]};
       if (!std::isfinite(r[0]) || !std::isfinite(r[1])) { cost += 1e6; continue; }
