@@ -2,7 +2,9 @@
 """HBM traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately, as
 MI355X_MICROARCH.md prescribes).  Launches that exit early (converged solve, queued passes) are excluded:
 "active" = launches whose counter exceeds 5 % of the kernel's maximum.
-Usage: python tools/pmc_traffic.py fetch_results.db write_results.db"""
+Usage: python tools/pmc_traffic.py fetch_results.db write_results.db [workload out.json]
+With the two extra arguments the per-kernel byte counts are merged into out.json under `workload` (what bench.py reads as
+profiles/pmc_traffic_latest.json)."""
 import re
 import sqlite3
 import sys
@@ -26,7 +28,7 @@ def short(name):
     return m.group(1) if m else name[:24]
 
 
-def main(fetch_db, write_db):
+def main(fetch_db, write_db, workload=None, out_json=None):
     F = per_kernel(fetch_db, "FETCH_SIZE"); W = per_kernel(write_db, "WRITE_SIZE")
     print("# FETCH_SIZE / WRITE_SIZE in KB as reported; gfx950 correction: FETCH_SIZE counts 64 B per 128-B request -> x2")
     print("%-20s %9s %9s %14s %14s %16s" % ("kernel", "launches", "active", "FETCH_KB", "WRITE_KB", "bytes(2F+W)"))
@@ -39,7 +41,15 @@ def main(fetch_db, write_db):
         rows.append((2048.0 * favg + 1024.0 * wavg, short(name), len(f), len(fa), favg, wavg))
     for b, n, nl, na, fa, wa in sorted(rows, reverse=True):
         print("%-20s %9d %9d %14.1f %14.1f %16.0f" % (n, nl, na, fa, wa, b))
+    if workload and out_json:
+        import json
+        import os
+        d = {}
+        if os.path.exists(out_json):
+            d = json.load(open(out_json))
+        d[workload] = {n: b for b, n, nl, na, fa, wa in rows}
+        json.dump(d, open(out_json, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:5])

@@ -1,0 +1,20 @@
+"""Phase timeline of k_reduced on BASELINE cfg3 (final stage): build the library with -DVC_REDUCED_STAMPS and point VICALIB_AMD_LIB
+at it.  Stamps are s_memtime ticks (100 MHz on gfx950): differences in microseconds."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vicalib_amd import synth
+from vicalib_amd.lib import ViCalibrator
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+p = synth.generate_native(synth.BASELINE_CONFIGS[name])
+cal = ViCalibrator(0).load_problem(p)
+if p.imu_t is not None:
+    cal.SetStageLimit(3); cal.Solve()
+else:
+    cal.SetCalibrateImu(False)
+cal.prepare()
+cal.run_iterations(5)
+st = cal.debug_stamps().astype(float)
+names = ["entry", "partials summed", "costs summed", "camera blocks", "S complete / solve starts", "solve done", "tail done"]
+for i in range(1, 7):
+    print("%-28s +%.2f us" % (names[i], (st[i] - st[i - 1]) / 100.0))
+print("total %.2f us" % ((st[6] - st[0]) / 100.0))

@@ -75,14 +75,22 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
     if (col < 6 || (col >= 9 && col < 15)) {
       const bool is_cur = col < 6;
       const int c = is_cur ? col : col - 9;
-      double P[42];
+      double P[42], pcol[7];
       local_jac_se3(is_cur ? T2 : T1, P);
+      // column c of P by selects over static indices (a dynamically indexed local array would live in scratch memory)
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        double sel = P[i * 6];
+#pragma unroll
+        for (int cc = 1; cc < 6; ++cc) sel = (c == cc) ? P[i * 6 + cc] : sel;
+        pcol[i] = sel;
+      }
       const double* src = Jg + (is_cur ? 0 : 7) * 9;
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         double a = 0.0;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) a += src[i * 9 + k] * P[i * 6 + c];
+        for (int i = 0; i < 7; ++i) a += src[i * 9 + k] * pcol[i];
         cv[k] = a;
       }
     } else {
@@ -702,18 +710,26 @@ __global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int t
   double o[CPL][9], op[CPL][9];
   auto request_next = [&](int e, int i) {
     const int n = e + s;
-    const bool load_n = (n < N) && !(!top && (i == m - 2));
-    const double* img = v.cW + (size_t)(load_n ? n : e) * isz;
-    const double* rpn = rp + (size_t)((load_n ? n : e) / s) * isz;
-    const bool pn = pend && load_n;
+    const bool load_n = (n < N) && !(!top && (i == m - 2));        // wave-uniform
+    if (!load_n) return;                                            // (o / op are not read then)
+    const double* img = v.cW + (size_t)n * isz;
+    // unconditional loads: idle lanes (role 4) read column 0, their values are never used
 #pragma unroll
     for (int ci = 0; ci < CPL; ++ci)
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        o[ci][k] = (load_n && role[ci] < 4) ? img[k * ldx + pc[ci]] : 0.0;
-        op[ci][k] = (pn && role[ci] < 4) ? rpn[k * ldx + pc[ci]] : 0.0;
-      }
+      for (int k = 0; k < 9; ++k) o[ci][k] = img[k * ldx + pc[ci]];
+    if (pend) {
+      const double* rpn = rp + (size_t)(n / s) * isz;
+#pragma unroll
+      for (int ci = 0; ci < CPL; ++ci)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) op[ci][k] = rpn[k * ldx + pc[ci]];
+    }
   };
+#pragma unroll
+  for (int ci = 0; ci < CPL; ++ci)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { o[ci][k] = 0.0; op[ci][k] = 0.0; }
   {
     const bool pe = pend && first > 0;
     const double* img = v.cW + (size_t)first * isz;
