@@ -120,20 +120,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- one complete calibration: the metric's "final RMS reproj err" and the wall time of the whole schedule ---------
-    cal2 = ViCalibrator(local_rank).load_problem(prob)
-    cal2.SetCalibrateImu(vi)
-    attach(cal2)
-    barrier(); t0 = time.perf_counter()
-    cal2.Solve()
-    barrier(); t_full = time.perf_counter() - t0
-    rmse = [float(x) for x in cal2.GetCameraProjRMSE()]
-    full_trace = cal2.trace()
-    full = {"seconds": t_full, "lm_iterations": int(np.sum(full_trace[:, 0] > 0)), "stages": int(full_trace[-1, 9]) + 1 if len(full_trace) else 0}
-    if vi:
-        gt = prob.imu_gt
-        full["time_offset_error_s"] = abs(cal2.time_offset() - gt["time_offset"])
-        full["gyro_bias_error"] = float(np.abs(cal2.GetBiases()[:3] - gt["bg"]).max())
+    # ---- complete calibrations: the metric's "final RMS reproj err" and the wall time of the whole schedule.  The first solve of a
+    # process also pays for code-object loading and first-touch allocations (~20 ms); the second one is what a caller sees from
+    # then on.
+    full = None
+    for rep in range(2):
+        cal2 = ViCalibrator(local_rank).load_problem(prob)
+        cal2.SetCalibrateImu(vi)
+        attach(cal2)
+        barrier(); t0 = time.perf_counter()
+        cal2.Solve()
+        barrier(); t_full = time.perf_counter() - t0
+        if rep == 0:
+            t_first = t_full
+            continue
+        rmse = [float(x) for x in cal2.GetCameraProjRMSE()]
+        full_trace = cal2.trace()
+        full = {"seconds": t_full, "seconds_first_in_process": t_first, "lm_iterations": int(np.sum(full_trace[:, 0] > 0)),
+                "stages": int(full_trace[-1, 9]) + 1 if len(full_trace) else 0}
+        if vi:
+            gt = prob.imu_gt
+            full["time_offset_error_s"] = abs(cal2.time_offset() - gt["time_offset"])
+            full["gyro_bias_error"] = float(np.abs(cal2.GetBiases()[:3] - gt["bg"]).max())
     del cal2
 
     # ---- the timed loop: LM iterations of the final stage --------------------------------------------------------
@@ -319,11 +327,16 @@ def cpu_baseline(wl, prob):
     orc, nobs = build(threads)
     iters, t = run(orc, 12.0)
     ncpu = os.cpu_count() or threads
-    all_cores = None
+    all_cores = best = None
     if ncpu > threads:
-        orc2, _ = build(min(ncpu, 64))
+        nt = min(ncpu, 64)
+        orc2, _ = build(nt)
         it2, t2 = run(orc2, 5.0)
-        all_cores = {"value": nobs * it2 / t2, "cores": min(ncpu, 64)}
+        all_cores = {"value": nobs * it2 / t2, "cores": nt}
+        # the same work with closed-form reprojection Jacobians (oracle/vco_fast.h) instead of forward duals
+        orc3, _ = build(nt); orc3.set_closed_form(True)
+        it3, t3 = run(orc3, 5.0)
+        best = {"value": nobs * it3 / t3, "cores": nt, "what": "closed-form reprojection Jacobians, dual-number IMU blocks, block elimination; threads over frames / IMU blocks"}
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -336,7 +349,7 @@ def cpu_baseline(wl, prob):
             "sample": "%d LM-iteration work units of the %s (IMU weight update, dual-number Jacobian sweep, IMU blocks, block solve, cost sweep) on the "
                       "first %d of %d frames (%d corners) of %s, %.1f s" % (iters, "final stage" if vi else "vision-only solve", n_sub, len(prob.frame_time), nobs, wl, t),
             "lm_iters_per_sec_extrapolated_to_full": (nobs * iters / t) / prob.n_obs,
-            "all_cores": all_cores, "host": {"nproc": ncpu, "cpu": cpu_model}}
+            "all_cores": all_cores, "best_cpu": best, "host": {"nproc": ncpu, "cpu": cpu_model}}
 
 
 if __name__ == "__main__":

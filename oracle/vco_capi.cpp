@@ -5,6 +5,7 @@
 #include <vector>
 #include <chrono>
 #include "vco_solver.h"
+#include "vco_fast.h"
 
 using namespace vco;
 
@@ -86,6 +87,7 @@ void vco_set_options(void* h, int max_iters, double function_tolerance, int cali
   CAL->fix_intrinsics = fix_intrinsics; CAL->opt.remove_outliers = remove_outliers; CAL->opt.outlier_threshold = outlier_threshold;
   CAL->opt.num_threads = num_threads; CAL->opt.dense_check = dense_check;
 }
+void vco_set_closed_form(void* h, int on) { CAL->opt.closed_form = on != 0; }
 void vco_set_tolerances(void* h, double gradient_tolerance, double parameter_tolerance) {
   CAL->opt.gradient_tolerance = gradient_tolerance; CAL->opt.parameter_tolerance = parameter_tolerance;
 }

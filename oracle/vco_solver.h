@@ -49,7 +49,12 @@ struct Options {
   double outlier_threshold = 2.0;    // vicalib-engine.cc:102
   int num_threads = 1;
   bool dense_check = false;          // solve with a dense Cholesky instead of the block elimination
+  bool closed_form = false;          // bench.py's "best CPU" leg only (never a parity test): reprojection Jacobians in closed form
+                                     // instead of forward duals -- the work shape of a hand-optimised CPU path, not of Ceres' AutoDiff
 };
+
+class Calibrator;
+void reproj_block_closed_form(const Calibrator& c, const Obs& o, double* r, double* Jf, double* Jr, double* Jt, double* Jk);   // vco_fast.h
 
 class Calibrator {
  public:
@@ -150,6 +155,7 @@ class Calibrator {
     }
   }
   void reproj_block_any(const Obs& o, double* r, double* Jf, double* Jr, double* Jt, double* Jk) const {
+    if (opt.closed_form) { reproj_block_closed_form(*this, o, r, Jf, Jr, Jt, Jk); return; }
     switch (cams[o.cam].nk) {
       case 4: reproj_block<4>(o, r, Jf, Jr, Jt, Jk); break;
       case 5: reproj_block<5>(o, r, Jf, Jr, Jt, Jk); break;

@@ -91,6 +91,10 @@ class Oracle:
         self.L.vco_set_options(self.h, int(max_iters), C.c_double(function_tolerance), int(calibrate_imu), int(fix_intrinsics),
                                int(remove_outliers), C.c_double(outlier_threshold), int(num_threads), int(dense_check))
 
+    def set_closed_form(self, on=True):
+        """bench.py's best-CPU leg: closed-form reprojection Jacobians (oracle/vco_fast.h); never used by a parity test."""
+        self.L.vco_set_closed_form(self.h, int(on))
+
     def set_tolerances(self, gradient_tolerance=1e-10, parameter_tolerance=1e-8):
         self.L.vco_set_tolerances(self.h, C.c_double(gradient_tolerance), C.c_double(parameter_tolerance))
 

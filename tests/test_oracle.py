@@ -182,3 +182,16 @@ def test_oracle_reproduces_committed_lm_trace(name):
     np.testing.assert_allclose(tr[:, 4], want[:, 4], rtol=1e-9)          # trust-region radius
     for c, cam in enumerate(e["cameras"]):
         np.testing.assert_allclose(orc.camera(c)[0], cam["K"], rtol=1e-9)
+
+
+def test_closed_form_cpu_mode_reproduces_the_dual_number_blocks():
+    """oracle/vco_fast.h (bench.py's "best CPU" baseline: closed-form reprojection Jacobians) yields the normal equations of the
+    forward-dual path it is timed against."""
+    p = _small_problem(("fov", "kb4", "rational6"), n=6)
+    lins = []
+    for closed in (False, True):
+        o = ol.Oracle().load(p); o.set_options(calibrate_imu=False); o.set_closed_form(closed); o.prepare()
+        lins.append(o.linearize())
+    for k in ("A", "W", "Hss", "gf", "gs"):
+        np.testing.assert_allclose(lins[1][k], lins[0][k], rtol=1e-9, atol=1e-9 * np.abs(lins[0][k]).max())
+    assert abs(lins[1]["cost"] - lins[0]["cost"]) <= 1e-13 * lins[0]["cost"]

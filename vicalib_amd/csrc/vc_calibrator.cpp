@@ -209,8 +209,8 @@ struct vc_calibrator {
   DBuf<double> d_pose[2], d_cam[2], d_G[2], d_tile_cost[2], d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_sdiag,
       d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total;
   DBuf<Ctrl> d_ctrl;
-  DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_segH[2], d_segg[2], d_seg_cost[2], d_seg_trial,
-      d_cW, d_cdelta, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init, d_rX[2];
+  DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_segH[2], d_segg[2], d_seg_cost[2],
+      d_cW, d_cdelta, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init, d_rX[2], d_grp_part, d_wg_trial, d_wg_imu_trial;
   size_t wsqrt_frames = 0;       // number of frames the device weight_sqrt_ array was initialised for
   int trace_cap = 0;
   struct Pinned { Ctrl up; Ctrl down; double trace[64 * kTraceCols]; };
@@ -440,6 +440,13 @@ struct vc_calibrator {
     dv.fpart = d_fpart.p; dv.scal = d_scal.p; dv.flags = d_flags.p;
     dv.pre_backsub = (T > 2048) ? 1 : 0;
     { const char* e = std::getenv("VICALIB_AMD_PRE_BACKSUB"); if (e && (e[0] == '0' || e[0] == '1')) dv.pre_backsub = e[0] - '0'; }   // test hook     // 1024 SIMDs x 2 resident waves: beyond that the per-tile repeat of the back-substitution is pure cost
+    {
+      // bottom-level groups of the chain elimination (launch_chain_solve_*: groups of 8 while more than 7 frames are active)
+      const int groups = (N > 7) ? (N - 1) / 8 + 1 : 1;
+      HIP_OK(d_grp_part.alloc((size_t)groups * kNumScal)); HIP_OK(d_wg_trial.alloc((size_t)std::max(1, (T + 3) / 4)));
+      HIP_OK(d_wg_imu_trial.alloc((size_t)std::max(1, (N + 6) / 8)));
+      dv.grp_part = d_grp_part.p; dv.wg_trial = d_wg_trial.p; dv.wg_imu_trial = d_wg_imu_trial.p; dv.n_chain_groups = groups;
+    }
     dv.wgpart = d_wgpart.p; dv.merged = 0; dv.par = 0; dv.ctrl_prev = d_ctrl.p + 1;
     dv.part_stride = part_stride; dv.ctrl = d_ctrl.p; dv.trace = d_trace.p; dv.dbg = (long long*)(d_tmp.p + 64);
     HIP_OK(d_pose_init.upload(poses, stream)); HIP_OK(d_cam_init.upload(camrec, stream));
@@ -473,7 +480,6 @@ struct vc_calibrator {
         HIP_OK(hipStreamSynchronize(stream));
       }
       for (int b = 0; b < 2; ++b) { HIP_OK(d_segH[b].alloc(ns * 33 * 33)); HIP_OK(d_segg[b].alloc(ns * 33)); HIP_OK(d_seg_cost[b].alloc(ns)); }
-      HIP_OK(d_seg_trial.alloc(ns));
       const size_t nf = (size_t)std::max(N, 1);
       HIP_OK(d_cW.alloc(nf * 9 * dv.ldx)); HIP_OK(d_cdelta.alloc(nf * 9)); HIP_OK(d_cg.alloc(nf * 9)); HIP_OK(d_clam.alloc(nf * 9));
       HIP_OK(d_cdiag.alloc(nf * 9)); HIP_OK(d_cscale2.alloc(nf * 9));
@@ -481,7 +487,7 @@ struct vc_calibrator {
     }
     dv.imu_t = d_imu_t.p; dv.imu_w = d_imu_w.p; dv.imu_a = d_imu_a.p; dv.frame_time = d_frame_time.p;
     dv.vel[0] = d_vel[0].p; dv.vel[1] = d_vel[1].p; dv.imus[0] = d_imus[0].p; dv.imus[1] = d_imus[1].p;
-    dv.wsqrtb[0] = d_wsqrt[0].p; dv.wsqrtb[1] = d_wsqrt[1].p; dv.seg_trial = d_seg_trial.p;
+    dv.wsqrtb[0] = d_wsqrt[0].p; dv.wsqrtb[1] = d_wsqrt[1].p;
     for (int b = 0; b < 2; ++b) { dv.segHb[b] = d_segH[b].p; dv.seggb[b] = d_segg[b].p; dv.seg_costb[b] = d_seg_cost[b].p; }
     dv.cW = d_cW.p; dv.cdelta = d_cdelta.p; dv.cg = d_cg.p;
     dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p;
@@ -881,9 +887,17 @@ struct vc_calibrator {
         if (inner++ >= kMaxRepeats) { status = VC_ERR_NO_CONVERGENCE; break; }
         if (o_frame.empty()) { is_finished = true; break; }
         Termination t; double fc = 0; long nr = 1;
+        const bool timing = std::getenv("VICALIB_AMD_TIMING") != nullptr;
+        auto now = []() { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto t0 = now();
+        if (device_dirty) { status = upload(); if (status) break; }
+        const auto t1 = now();
         status = solve_once(&t, &fc, &nr); if (status) break;
+        const auto t2 = now();
         status = compute_rmse(); if (status) break;
         status = download_state(); if (status) break;
+        if (timing) std::fprintf(stderr, "[vicalib_amd] stage %d: upload %.3f ms, solve %.3f ms (%d iterations), rmse + download %.3f ms\n", stage, ms(t0, t1), ms(t1, t2), last_iters, ms(t2, now()));
         { std::lock_guard<std::mutex> lk(result_mutex); mse = fc / (double)std::max(1L, nr); }
         ++stage;
         if (t != kNoConvergence && calibrate_imu) {

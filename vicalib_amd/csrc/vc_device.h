@@ -89,7 +89,13 @@ struct DevView {
   double* sscale2;                 // D
   double* slam;                    // D
   double* delta_s;                 // D
-  double* fpart;                   // n_frames x kNumScal: per-frame step terms
+  double* fpart;                   // n_frames x kNumScal: per-frame step terms (vision-only passes)
+  // visual-inertial passes pre-reduce what the decision needs where it is produced, so that the single workgroup of k_final
+  // adds a few hundred records instead of one per tile / block / frame:
+  double* grp_part;                // n_chain_groups x kNumScal: step terms of the 8 frames of a bottom-level chain group (k_chain_back)
+  double* wg_trial;                // (n_tiles + 3) / 4: trial cost of the 4 tiles of a k_reproj_jac workgroup
+  double* wg_imu_trial;            // (n_frames - 1 + 7) / 8: trial cost of the 8 blocks of a k_imu_jac workgroup
+  int n_chain_groups;
   double* scal;                    // kNumScal (frame sums) + kNumScal (shared-parameter terms)
   int* flags;                      // [0]: frame Cholesky failures, [1]: reduced Cholesky failure (per pass)
   Ctrl* ctrl;
@@ -115,7 +121,6 @@ struct DevView {
   double* segHb[2];                // (n_frames-1) x 33 x 33  weighted J^T J, columns [frame j (9) | frame j-1 (9) | imu (15)]
   double* seggb[2];                // (n_frames-1) x 33       weighted J^T r
   double* seg_costb[2];            // (n_frames-1)  imu_mult * rho at the linearisation point
-  double* seg_trial;               // (n_frames-1)  same at the trial point
   // ---- block-tridiagonal frame chain (9 x 9 blocks: pose 6 + velocity 3), cyclic reduction ----------------
   double* cW;                      // n_frames x 9 x ldx, one image per frame: columns 0..D-1 W -> Y = L^-1 W, column D: g -> z, then
                                    // from column ldw three 9 x 9 blocks: C (coupling to the group's left separator) -> X_s = L^-1 C,

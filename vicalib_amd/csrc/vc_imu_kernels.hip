@@ -109,6 +109,12 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   double rho, rho1;
   loss_cauchy100(ss, &rho, &rho1);
   const double w = ct->imu_mult * rho1;
+  if (trial) {                 // the workgroup's share of the trial cost (8 blocks, fixed order); all threads reach this barrier
+    __shared__ double s_cost[8];
+    if (l == 0) s_cost[wave * 2 + half] = exists ? ct->imu_mult * rho : 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) v.wg_imu_trial[blockIdx.x] = ((s_cost[0] + s_cost[1]) + (s_cost[2] + s_cost[3])) + ((s_cost[4] + s_cost[5]) + (s_cost[6] + s_cost[7]));
+  }
   if (!exists) return;
   double* H = v.segHb[cur] + (size_t)s * (33 * 33);
   for (int e = l; e < 33 * 33; e += 32) {
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
     for (int k = 0; k < 9; ++k) acc += Jl[col * 9 + k] * r[k];
     v.seggb[cur][(size_t)s * 33 + col] = w * acc;
   }
-  if (l == 0) { v.seg_costb[cur][s] = ct->imu_mult * rho; if (trial) v.seg_trial[s] = ct->imu_mult * rho; }
+  if (l == 0) v.seg_costb[cur][s] = ct->imu_mult * rho;
 }
 
 // UpdateImuWeights from the accepted state (vicalibrator.h:723-799): covariance propagation along the block's samples
@@ -957,6 +963,7 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
   if (lane < 9) dl[lane] = da[lane];
   wave_lds_sync();
   const int base = top ? 0 : a, cnt = top ? q : (a < N ? q + 1 : 0), off = top ? 1 : 0;
+  double gd = 0, dld = 0, step2 = 0, x2 = 0, g2 = 0, gmax = 0;
   if (lane < cnt) {
     const int f = base + lane;
     const int cur = ct->cur;
@@ -972,7 +979,6 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
     for (int i = 0; i < 7; ++i) Tin[i] = pin[i];
     for (int i = 0; i < 6; ++i) dd[i] = d[i];
     se3_plus(Tin, dd, Tout);
-    double gd = 0, dld = 0, step2 = 0, x2 = 0, g2 = 0, gmax = 0;
     for (int i = 0; i < 7; ++i) { pout[i] = Tout[i]; const double ee = Tout[i] - Tin[i]; step2 += ee * ee; x2 += Tin[i] * Tin[i]; }
     pout[7] = 0.0;
     const double* vin = v.vel[cur] + (size_t)f * 4;
@@ -985,7 +991,13 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
     }
     if (pin_f || pin_l) { gd = 0; dld = 0; g2 = 0; gmax = 0; }
     if (pin_l) { step2 = 0; x2 = 0; }
-    double* o = v.fpart + (size_t)f * kNumScal;
+  }
+  // the group's step terms in one record (lanes >= cnt hold zeros; fixed summation order)
+  gd = wave_sum(gd); dld = wave_sum(dld); step2 = wave_sum(step2); x2 = wave_sum(x2); g2 = wave_sum(g2);
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) gmax = fmax(gmax, __shfl_down(gmax, o2, 64));
+  if (lane == 0) {
+    double* o = v.grp_part + (size_t)blockIdx.x * kNumScal;
     o[kScGd] = gd; o[kScDld] = dld; o[kScStep2] = step2; o[kScX2] = x2; o[kScG2] = g2; o[kScCost] = 0.0; o[kScGmax] = gmax; o[kScSq] = 0.0;
   }
 }

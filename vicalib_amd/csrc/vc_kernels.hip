@@ -204,18 +204,23 @@ __global__ __launch_bounds__(256) void k_reproj_jac(DevView v, int trial) {
 #ifdef VC_JAC_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0) v.dbg[7] = (long long)__builtin_readcyclecounter();
 #endif
+  __shared__ double s_cost[4];
   if (ct->done || (!trial && !ct->need_lin)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
-  if (tile >= v.n_tiles) return;
-  double* wl = lds + wave * 64 * kDotStride;
-  const int cur = trial ? 1 - ct->cur : ct->cur;
-  const int f = v.tile_frame[tile], c = v.tile_cam[tile];
-  const double cost = jac_tile_dispatch(v, v.cd[c].model, v.poses[cur] + (size_t)f * kPoseStride, v.cams[cur] + (size_t)c * kCamStride, ct->mult,
-                                        tile, lane, wl, v.Gb[cur] + (size_t)tile * kGStride);
-  if (lane == 0) {
-    v.tile_costb[cur][tile] = cost;
-    if (trial) { v.tile_trial[2 * tile] = cost; v.tile_trial[2 * tile + 1] = 0.0; }
+  double cost = 0.0;
+  if (tile < v.n_tiles) {
+    double* wl = lds + wave * 64 * kDotStride;
+    const int cur = trial ? 1 - ct->cur : ct->cur;
+    const int f = v.tile_frame[tile], c = v.tile_cam[tile];
+    cost = jac_tile_dispatch(v, v.cd[c].model, v.poses[cur] + (size_t)f * kPoseStride, v.cams[cur] + (size_t)c * kCamStride, ct->mult,
+                             tile, lane, wl, v.Gb[cur] + (size_t)tile * kGStride);
+    if (lane == 0) v.tile_costb[cur][tile] = cost;
+  }
+  if (trial) {               // the workgroup's share of the trial cost, in fixed order
+    if (lane == 0) s_cost[wave] = cost;
+    __syncthreads();
+    if (threadIdx.x == 0) v.wg_trial[blockIdx.x] = (s_cost[0] + s_cost[1]) + (s_cost[2] + s_cost[3]);
   }
 }
 
@@ -1415,13 +1420,22 @@ __device__ void final_phase(const DevView& v, int mode, double* red) {
   const int tid = threadIdx.x;
   if (mode != 2) {
     double s[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (int f = tid; f < v.n_frames; f += 256) {
-      const double* p = v.fpart + (size_t)f * kNumScal;
-      s[0] += p[kScGd]; s[1] += p[kScDld]; s[2] += p[kScStep2]; s[3] += p[kScX2]; s[4] += p[kScG2];
-      s[6] = fmax(s[6], p[kScGmax]);
+    if (v.imu_on) {      // pre-reduced where they are produced (k_chain_back, k_reproj_jac / k_imu_jac in trial mode)
+      for (int g = tid; g < v.n_chain_groups; g += 256) {
+        const double* p = v.grp_part + (size_t)g * kNumScal;
+        s[0] += p[kScGd]; s[1] += p[kScDld]; s[2] += p[kScStep2]; s[3] += p[kScX2]; s[4] += p[kScG2];
+        s[6] = fmax(s[6], p[kScGmax]);
+      }
+      for (int t = tid; t < (v.n_tiles + 3) / 4; t += 256) s[5] += v.wg_trial[t];
+      for (int t = tid; t < (v.n_frames - 1 + 7) / 8; t += 256) s[5] += v.wg_imu_trial[t];
+    } else {
+      for (int f = tid; f < v.n_frames; f += 256) {
+        const double* p = v.fpart + (size_t)f * kNumScal;
+        s[0] += p[kScGd]; s[1] += p[kScDld]; s[2] += p[kScStep2]; s[3] += p[kScX2]; s[4] += p[kScG2];
+        s[6] = fmax(s[6], p[kScGmax]);
+      }
+      for (int t = tid; t < v.n_tiles; t += 256) s[5] += v.tile_trial[2 * t];
     }
-    for (int t = tid; t < v.n_tiles; t += 256) s[5] += v.tile_trial[2 * t];
-    if (v.imu_on) for (int t = tid; t < v.n_frames - 1; t += 256) s[5] += v.seg_trial[t];
     for (int k = 0; k < 7; ++k) red[k * 256 + tid] = s[k];
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
