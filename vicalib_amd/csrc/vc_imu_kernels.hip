@@ -713,7 +713,9 @@ __global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int t
     for (int k = 0; k < 9; ++k) dacc[ci][k] = 0.0;
   // ---- the first frame: its image columns to the lanes (C = B_a^T, a row of the separator's B block), A to LDS; the
   // second frame's columns are requested in the same breath (o / op: the next frame's image and its pending update)
-  double o[CPL][9], op[CPL][9];
+  // four columns per lane (D > 164) do not leave registers for the pending values as well: they are read where they are used
+  constexpr bool kLateOp = CPL >= 4;
+  double o[CPL][9], op[kLateOp ? 1 : CPL][9];
   auto request_next = [&](int e, int i) {
     const int n = e + s;
     const bool load_n = (n < N) && !(!top && (i == m - 2));        // wave-uniform
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int t
     for (int ci = 0; ci < CPL; ++ci)
 #pragma unroll
       for (int k = 0; k < 9; ++k) o[ci][k] = img[k * ldx + pc[ci]];
-    if (pend) {
+    if (pend && !kLateOp) {
       const double* rpn = rp + (size_t)(n / s) * isz;
 #pragma unroll
       for (int ci = 0; ci < CPL; ++ci)
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int t
 #pragma unroll
   for (int ci = 0; ci < CPL; ++ci)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { o[ci][k] = 0.0; op[ci][k] = 0.0; }
+    for (int k = 0; k < 9; ++k) { o[ci][k] = 0.0; if (!kLateOp) op[ci][k] = 0.0; }
   {
     const bool pe = pend && first > 0;
     const double* img = v.cW + (size_t)first * isz;
@@ -864,8 +866,14 @@ __global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int t
             for (int k = 0; k < 9; ++k) img[k * ldx] = -out[k];
           }
         } else {
+          if (kLateOp) {
+            const double* rpn = rp + (size_t)(n / s) * isz + pc[ci];
 #pragma unroll
-          for (int k = 0; k < 9; ++k) xin[ci][k] = (o[ci][k] + op[ci][k]) - (role[ci] == 3 ? 0.0 : out[9 + k]);
+            for (int k = 0; k < 9; ++k) xin[ci][k] = (o[ci][k] + (pend ? rpn[k * ldx] : 0.0)) - (role[ci] == 3 ? 0.0 : out[9 + k]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) xin[ci][k] = (o[ci][k] + op[ci][k]) - (role[ci] == 3 ? 0.0 : out[9 + k]);
+          }
           if (role[ci] == 2) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) An[k * 9 + sub[ci]] = xin[ci][k];
@@ -1091,6 +1099,7 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
   auto fwd = [&](int groups, int stride, int top, int lvl) {
     if (cpl <= 1) hipLaunchKernelGGL(k_chain_fwd<1>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
     else if (cpl <= 2) hipLaunchKernelGGL(k_chain_fwd<2>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
+    else if (cpl <= 3) hipLaunchKernelGGL(k_chain_fwd<3>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
     else hipLaunchKernelGGL(k_chain_fwd<4>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
   };
   if (forward) {
