@@ -122,6 +122,15 @@ double vc_time_offset(vc_calibrator* h);                                        
 double vc_mean_squared_error(vc_calibrator* h);                                    /* MeanSquaredError :506 */
 int vc_get_camera_proj_rmse(vc_calibrator* h, double* rmse /* n_cameras */);       /* GetCameraProjRMSE :160 */
 unsigned vc_get_num_iterations(vc_calibrator* h);                                  /* GetNumIterations :283 */
+/* imu_buffer() :487: the stored measurements in time order (any pointer may be NULL); returns the number copied */
+int vc_num_imu_measurements(vc_calibrator* h);
+int vc_get_imu_measurements(vc_calibrator* h, double* gyro, double* accel, double* time, int max_n);
+/* GetIntegrationPoses(id) :508-533: the poses the IMU integration passes through between frame id and id + 1 -- the start pose,
+ * then one per measurement of the range; rows of 11 doubles [q(4) t(3) v_w(3) time].  Returns the count (0 unless the inertial
+ * terms are fully active, :510), which may exceed max_poses. */
+int vc_get_integration_poses(vc_calibrator* h, int id, double* poses, int max_poses);
+/* PrintResults() :536-544 into buf: per camera its parameters and T_ck as a 4 x 4 matrix; returns the length */
+int vc_print_results(vc_calibrator* h, char* buf, int len);
 /* WriteCameraModels(filename) :208-229 (calibu rig XML) */
 int vc_write_camera_models(vc_calibrator* h, const char* filename);
 

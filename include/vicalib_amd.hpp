@@ -7,6 +7,7 @@
 #pragma once
 #include <vicalib_amd.h>
 
+#include <algorithm>
 #include <array>
 #include <stdexcept>
 #include <string>
@@ -111,6 +112,28 @@ class ViCalibrator {
     VicalibFrame f;
     if (vc_get_frame(h_, (int)id, f.t_wp_.data(), f.v_w_.data(), &f.time) != VC_OK) throw std::out_of_range("GetFrame");
     return f;
+  }
+  // imu_buffer() :487 (a copy: [gyro(3) accel(3) time] per measurement), GetIntegrationPoses(id) :508 (rows of 11: q t v time),
+  // PrintResults() :536 (returned instead of logged)
+  std::vector<std::array<double, 7>> imu_buffer() {
+    const int n = vc_num_imu_measurements(h_);
+    std::vector<double> g(3 * (size_t)std::max(n, 0)), a(g.size()), t((size_t)std::max(n, 0));
+    std::vector<std::array<double, 7>> out((size_t)std::max(n, 0));
+    if (n > 0) vc_checked(vc_get_imu_measurements(h_, g.data(), a.data(), t.data(), n), "imu_buffer");
+    for (int i = 0; i < n; ++i) out[i] = {{g[3 * i], g[3 * i + 1], g[3 * i + 2], a[3 * i], a[3 * i + 1], a[3 * i + 2], t[i]}};
+    return out;
+  }
+  std::vector<std::array<double, 11>> GetIntegrationPoses(unsigned id) {
+    std::vector<std::array<double, 11>> out(64);
+    const int n = vc_checked(vc_get_integration_poses(h_, (int)id, out[0].data(), 64), "GetIntegrationPoses");
+    out.resize((size_t)std::min(n, 64));
+    return out;
+  }
+  std::string PrintResults() {
+    std::string s(4096, '\0');
+    const int n = vc_checked(vc_print_results(h_, &s[0], (int)s.size()), "PrintResults");
+    s.resize((size_t)n);
+    return s;
   }
   void WriteCameraModels(const std::string& filename) { vc_checked(vc_write_camera_models(h_, filename.c_str()), "WriteCameraModels"); }   // :208
   // GetSolutionCovariance(problem) :802-857: row-major n x n over the blocks named by covariance_names

@@ -295,6 +295,28 @@ def test_converged_optima_match_the_independent_optimiser_fixture():
     assert abs(cal.time_offset() - f["time_offset"]) < 1e-8
 
 
+def test_gui_readers_imu_buffer_integration_poses_print_results():
+    """imu_buffer() (vicalibrator.h:487), GetIntegrationPoses(id) (:508-533), PrintResults() (:536-544): what vicalib's GUI polls."""
+    p = synth.generate(synth.Config(models=("kb4",), n_frames=60, imu=True, seed=5))
+    cal = ViCalibrator(0).load_problem(p)
+    g, a, t = cal.imu_buffer()
+    np.testing.assert_array_equal(t, p.imu_t); np.testing.assert_array_equal(g, p.imu_gyro); np.testing.assert_array_equal(a, p.imu_accel)
+    assert len(cal.GetIntegrationPoses(3)) == 0                  # inertial terms not active yet (:510)
+    cal.SetMaxIters(100); cal.Solve()
+    for j in (0, 17, 58):
+        P = cal.GetIntegrationPoses(j)
+        T1, v1, t1 = cal.GetFrame(j); T2, v2, t2 = cal.GetFrame(j + 1)
+        assert 10 <= len(P) <= 14                                # 50 ms of 200 Hz samples + the two interpolated ends
+        np.testing.assert_array_equal(P[0, :7], T1); np.testing.assert_array_equal(P[0, 7:10], v1)
+        assert P[0, 10] == t1 and abs(P[-1, 10] - t2) < 1e-12 and np.all(np.diff(P[:, 10]) > 0)
+        # the integration ends at the next frame up to the block's residual (calibrated IMU: millimetres, mrad, mm/s)
+        assert np.linalg.norm(P[-1, 4:7] - T2[4:]) < 2e-3 and abs(abs(P[-1, :4] @ T2[:4]) - 1) < 1e-6 and np.linalg.norm(P[-1, 7:10] - v2) < 2e-2
+    assert len(cal.GetIntegrationPoses(59)) == 0                 # no next frame
+    txt = cal.PrintResults()
+    assert txt.startswith("-----") and "Camera: 0" in txt and txt.rstrip().endswith("0 0 0 1")
+    assert ("%.10g" % cal.GetCamera(0)[0][0]) in txt
+
+
 def test_per_frame_backsubstitution_kernel_gives_the_same_solve(monkeypatch):
     """Above 2048 tiles the back-substitution moves from k_trial (once per tile) to k_backsub (once per frame); forced on
     for a small problem it must reproduce the default path bit for bit."""

@@ -27,6 +27,7 @@
 #include "vc_device.h"
 #include "vc_math.hpp"
 #include "vc_pnp.hpp"
+#include "vc_imu.hpp"
 
 using namespace vc;
 
@@ -942,7 +943,7 @@ int vc_create(vc_calibrator** out, int device) {
   *out = h;
   return VC_OK;
 }
-void vc_destroy(vc_calibrator* h) { delete h; }
+void vc_destroy(vc_calibrator* h) { if (h) (void)hipSetDevice(h->device); delete h; }
 
 int vc_clear(vc_calibrator* h) {
   if (!h) return VC_ERR_BAD_ARG;
@@ -955,6 +956,9 @@ int vc_clear(vc_calibrator* h) {
 }
 
 #define NOT_RUNNING(h) do { if (!(h)) return VC_ERR_BAD_ARG; if ((h)->is_running) return VC_ERR_RUNNING; } while (0)
+// every entry point that touches HIP binds the calibrator's device first (several calibrators, one per device, may live in one
+// process and be driven from any thread: the CLI's -gpus N)
+#define BIND_DEVICE(h) do { if (hipSetDevice((h)->device) != hipSuccess) return VC_ERR_NO_DEVICE; } while (0)
 
 int vc_add_camera(vc_calibrator* h, int model, const double* params, int nparams, int width, int height, const double T_ck[7]) {
   NOT_RUNNING(h);
@@ -1185,6 +1189,71 @@ int vc_get_camera_proj_rmse(vc_calibrator* h, double* rmse) {
   return VC_OK;
 }
 unsigned vc_get_num_iterations(vc_calibrator* h) { return h ? h->num_iterations.load() : 0u; }
+// imu_buffer() :487 -- the stored measurements, in time order
+int vc_num_imu_measurements(vc_calibrator* h) { return h ? (int)h->imu_t.size() : VC_ERR_BAD_ARG; }
+int vc_get_imu_measurements(vc_calibrator* h, double* gyro, double* accel, double* time, int max_n) {
+  if (!h || max_n < 0) return VC_ERR_BAD_ARG;
+  const int n = std::min<int>(max_n, (int)h->imu_t.size());
+  if (gyro) std::memcpy(gyro, h->imu_w.data(), (size_t)n * 24);
+  if (accel) std::memcpy(accel, h->imu_a.data(), (size_t)n * 24);
+  if (time) std::memcpy(time, h->imu_t.data(), (size_t)n * 8);
+  return n;
+}
+// GetIntegrationPoses(id) :508-533: the poses the IMU integration passes through between frame id and frame id + 1 (the GUI draws
+// them): the start pose, then one pose per measurement of the range (ceres-cost-functions.h:200-227).  Rows of 11 doubles
+// [q(4) t(3) v_w(3) time]; empty unless the inertial terms are fully active (:510).  Host arithmetic (vc_imu.hpp).
+int vc_get_integration_poses(vc_calibrator* h, int id, double* poses, int max_poses) {
+  if (!h || id < 0 || (max_poses > 0 && !poses)) return VC_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(h->result_mutex);
+  if (!(h->is_inertial_active && !h->rotation_only)) return 0;
+  if (id + 1 >= (int)h->frames.size()) return 0;
+  const ImuView buf = {h->imu_t.data(), h->imu_w.data(), h->imu_a.data(), (int)h->imu_t.size()};
+  const HostFrame& f1 = h->frames[id];
+  const HostFrame& f2 = h->frames[id + 1];
+  const ImuRange rg = imu_range(buf, f1.time, f2.time, h->time_offset);
+  if (!rg.valid) return 0;
+  double gw[3];
+  imu_gravity<double>(h->g_dir, gw);
+  PoseV<double> s;
+  for (int i = 0; i < 4; ++i) s.q[i] = f1.T[i];
+  for (int i = 0; i < 3; ++i) { s.p[i] = f1.T[4 + i]; s.v[i] = f1.v[i]; }
+  const int n_meas = (rg.k1 - rg.k0 + 1) + 2;
+  int n = 0;
+  auto push = [&](double time) {
+    if (n < max_poses) { double* o = poses + 11 * (size_t)n; std::memcpy(o, s.q, 32); std::memcpy(o + 4, s.p, 24); std::memcpy(o + 7, s.v, 24); o[10] = time; }
+    ++n;
+  };
+  push(f1.time);
+  Meas<double> z0, z1;
+  imu_range_get<double>(buf, rg, h->time_offset, f1.time, f2.time, 0, &z0);
+  for (int m = 1; m < n_meas; ++m) {
+    imu_range_get<double>(buf, rg, h->time_offset, f1.time, f2.time, m, &z1);
+    imu_rk4_step<double>(&s, z0, z1, h->biases, h->scale, gw);
+    push(z1.time);
+    z0 = z1;
+  }
+  return n;
+}
+// PrintResults() :536-544 into a caller's buffer: per camera its parameters and T_ck as a 4 x 4 matrix
+int vc_print_results(vc_calibrator* h, char* buf, int len) {
+  if (!h || !buf || len <= 0) return VC_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(h->result_mutex);
+  std::string out = "------------------------------------------\n";
+  char line[512];
+  for (size_t c = 0; c < h->cams.size(); ++c) {
+    const HostCam& cm = h->cams[c];
+    std::snprintf(line, sizeof(line), "Camera: %zu\n", c); out += line;
+    for (int i = 0; i < cm.nk; ++i) { std::snprintf(line, sizeof(line), "%s%.10g", i ? " " : "", cm.K[i]); out += line; }
+    out += "\n";
+    double R[9];
+    quat_to_R(cm.T_ck, R);
+    for (int i = 0; i < 3; ++i) { std::snprintf(line, sizeof(line), "%.10g %.10g %.10g %.10g\n", R[3 * i], R[3 * i + 1], R[3 * i + 2], cm.T_ck[4 + i]); out += line; }
+    out += "0 0 0 1\n\n";
+  }
+  if ((int)out.size() + 1 > len) return VC_ERR_BAD_ARG;
+  std::memcpy(buf, out.c_str(), out.size() + 1);
+  return (int)out.size();
+}
 
 // WriteCameraModels, vicalibrator.h:208-229 + calibu WriteXmlRig layout
 int vc_write_camera_models(vc_calibrator* h, const char* filename) {
@@ -1275,6 +1344,7 @@ int vc_prepare(vc_calibrator* h) {
 int vc_shared_dim(vc_calibrator* h) { return h ? h->dv.D : VC_ERR_BAD_ARG; }
 int vc_linearize(vc_calibrator* h, double* cost, double* Hpp, double* gp, double* S, double* g_red, double* hss_diag, double* g_s) {
   NOT_RUNNING(h);
+  BIND_DEVICE(h);
   if (h->device_dirty) { int rc = vc_prepare(h); if (rc) return rc; }
   double lin_cost = 0;
   // radius = +inf-like: lambda -> ~0 so that L L^T = H_pp to rounding; S is stored undamped anyway
@@ -1307,6 +1377,7 @@ int vc_linearize(vc_calibrator* h, double* cost, double* Hpp, double* gp, double
 }
 int vc_evaluate(vc_calibrator* h, double* cost, double* sum_sq) {
   NOT_RUNNING(h);
+  BIND_DEVICE(h);
   if (h->device_dirty) { int rc = vc_prepare(h); if (rc) return rc; }
   launch_reproj_res(h->dv, h->cur, (double)h->vis_mult, h->stream);
   launch_sum_tile_cost(h->dv, h->d_tmp.p, h->stream);
@@ -1319,6 +1390,7 @@ int vc_evaluate(vc_calibrator* h, double* cost, double* sum_sq) {
 }
 int vc_run_iterations(vc_calibrator* h, int iters, int* jac_sweeps, int* res_sweeps) {
   NOT_RUNNING(h);
+  BIND_DEVICE(h);
   if (h->device_dirty) { int rc = vc_prepare(h); if (rc) return rc; }
   // Exactly `iters` LM iterations of the real solver: complete solves (termination tests on) run back to
   // back from the uploaded initial state; the last one is cut by max_iters so the total is exact.
@@ -1342,6 +1414,7 @@ int vc_run_iterations(vc_calibrator* h, int iters, int* jac_sweeps, int* res_swe
 }
 int vc_time_kernels(vc_calibrator* h, int reps, double* jac_ms, double* res_ms) {
   NOT_RUNNING(h);
+  BIND_DEVICE(h);
   if (h->device_dirty) { int rc = vc_prepare(h); if (rc) return rc; }
   EventSet<3> evs;
   if (!evs.create()) return VC_ERR_NO_DEVICE;
@@ -1367,6 +1440,7 @@ int vc_time_kernels(vc_calibrator* h, int reps, double* jac_ms, double* res_ms) 
 // decision logic on hold (state does not change).  out[0..5]: jac, frame_prep, schur_reduce, reduced, trial, final
 int vc_time_stages(vc_calibrator* h, int reps, double* out) {
   NOT_RUNNING(h);
+  BIND_DEVICE(h);
   if (!out) return VC_ERR_BAD_ARG;
   if (h->device_dirty) { int rc = vc_prepare(h); if (rc) return rc; }
   Ctrl c; h->init_ctrl(&c); c.hold = 1; c.first = 0; if (c.mult < 1) c.mult = 1;
@@ -1398,6 +1472,7 @@ int vc_time_stages(vc_calibrator* h, int reps, double* out) {
 // [frame j: pose 6, velocity 3 | frame j-1: pose 6, velocity 3 | g 2, b 6, sf 6, time offset 1]
 int vc_get_imu_blocks(vc_calibrator* h, double* H, double* g, double* cost) {
   NOT_RUNNING(h);
+  BIND_DEVICE(h);
   if (!h->dv.imu_on) return VC_ERR_BAD_ARG;
   const size_t ns = (size_t)std::max(h->dv.n_frames - 1, 0);
   const int b = h->cur;
@@ -1408,6 +1483,7 @@ int vc_get_imu_blocks(vc_calibrator* h, double* H, double* g, double* cost) {
 }
 int vc_get_imu_weights(vc_calibrator* h, double* out) {
   NOT_RUNNING(h);
+  BIND_DEVICE(h);
   if (!out || !h->dv.imu_on) return VC_ERR_BAD_ARG;
   const size_t n = (size_t)std::max(0, h->dv.n_frames - 1) * 81;
   if (n == 0) return VC_OK;
@@ -1447,6 +1523,7 @@ int vc_get_solution_covariance_names(vc_calibrator* h, char* buf, int len) {
 }
 int vc_get_solution_covariance(vc_calibrator* h, double* cov, int max_n, int* n_out) {
   NOT_RUNNING(h);
+  BIND_DEVICE(h);
   if (!cov) return VC_ERR_BAD_ARG;
   std::vector<int> first, size;
   const int n = covariance_layout(h, &first, &size);

@@ -27,7 +27,7 @@ SYMBOLS = [
     "vc_set_function_tolerance", "vc_set_optimization_flags", "vc_set_max_iters", "vc_set_tolerances", "vc_set_gravity", "vc_set_frame_velocities", "vc_set_calibrate_imu", "vc_set_remove_outliers",
     "vc_solve", "vc_start", "vc_resume", "vc_set_stage_limit", "vc_set_kernel_timing", "vc_get_kernel_timing", "vc_is_running", "vc_stop", "vc_num_frames", "vc_num_cameras", "vc_get_camera", "vc_get_frame",
     "vc_get_biases", "vc_get_scale_factor", "vc_get_gravity", "vc_time_offset", "vc_mean_squared_error", "vc_get_camera_proj_rmse",
-    "vc_get_num_iterations", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
+    "vc_get_num_iterations", "vc_num_imu_measurements", "vc_get_imu_measurements", "vc_get_integration_poses", "vc_print_results", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
     "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
     "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_pnp_planar_ransac", "vc_set_pnp_ransac", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_allreduce_calls", "vc_get_imu_weights",
     "vc_solution_covariance_dim", "vc_get_solution_covariance", "vc_get_solution_covariance_names",
@@ -219,6 +219,22 @@ class ViCalibrator:
         return r[:self.NumCameras()]
 
     def GetNumIterations(self): return self.L.vc_get_num_iterations(self.h)
+
+    def imu_buffer(self):
+        n = _check(self.L.vc_num_imu_measurements(self.h), "imu_buffer")
+        g = np.zeros((n, 3)); a = np.zeros((n, 3)); t = np.zeros(n)
+        _check(self.L.vc_get_imu_measurements(self.h, _d(g), _d(a), _d(t), n), "imu_buffer")
+        return g, a, t
+
+    def GetIntegrationPoses(self, frame_id):
+        out = np.zeros((64, 11))
+        n = _check(self.L.vc_get_integration_poses(self.h, int(frame_id), _d(out), 64), "GetIntegrationPoses")
+        return out[:min(n, 64)]
+
+    def PrintResults(self):
+        buf = C.create_string_buffer(4096)
+        _check(self.L.vc_print_results(self.h, buf, len(buf)), "PrintResults")
+        return buf.value.decode()
     def WriteCameraModels(self, path): _check(self.L.vc_write_camera_models(self.h, path.encode()), "WriteCameraModels")
 
     # ---- engine-level ------------------------------------------------------------------------
