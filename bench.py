@@ -264,11 +264,27 @@ def main():
 
 
 def secondary(device):
-    """Last round's vision-only headline (cfg2) and the same rig with 10x the frames, measured the same way (complete solves back
-    to back, in-loop kernel timing): informational, `value` above is the N = 1 workload's number."""
+    """(a) BASELINE cfg4 at full size on this one GPU (4 x poly3 + IMU, 900-dot grid, 10 000 frames, 21.7 M corners): the same loop
+    where the chip is filled -- what the per-kernel roofline fractions look like away from cfg3's launch-latency regime;
+    (b) last round's vision-only headline (cfg2) and the same rig with 10x the frames.  Measured the same way (complete solves
+    back to back, in-loop kernel timing).  Informational: `value` above is the N = 1 workload's number."""
     from vicalib_amd import synth
     from vicalib_amd.lib import ViCalibrator
     out = {}
+    base = synth.BASELINE_CONFIGS["cfg4"]
+    p = synth.generate_native(base)
+    cal = ViCalibrator(device).load_problem(p)
+    cal.SetStageLimit(3); cal.Solve(); cal.prepare()
+    n = cal.num_observations()
+    cal.run_iterations(3)
+    t0 = time.perf_counter(); done, _, _ = cal.run_iterations(12); dt = time.perf_counter() - t0
+    cal.set_kernel_timing(True); cal.run_iterations(12); kt = cal.kernel_timing(); cal.set_kernel_timing(False)
+    jac = kt.get("k_reproj_jac(trial)", (0, float("nan")))[1]
+    out["cfg4_one_gpu"] = {"frames": len(p.frame_time), "corners": n, "reduced_dim": cal.shared_dim(), "ms_per_lm_iteration": 1e3 * dt / done,
+                           "corner_residuals_per_sec": n * done / dt, "kernels_in_loop_us": {k: 1e3 * v[1] for k, v in kt.items()},
+                           "jacobian_sweep_tflops": 1050.0 * n / (jac * 1e-3) / 1e12, "jacobian_sweep_fp64_frac": 1050.0 * n / (jac * 1e-3) / 78.6e12,
+                           "jacobian_sweep_hbm_frac": 18.0 * n / (jac * 1e-3) / 8e12}
+    del cal, p
     for tag, frames in (("cfg2", 500), ("cfg2_x10", 5000)):
         p = synth.generate_native(synth.Config(models=("fov", "fov"), grid="small", n_frames=frames, imu=False))
         cal = ViCalibrator(device).load_problem(p); cal.SetCalibrateImu(False); cal.prepare()
