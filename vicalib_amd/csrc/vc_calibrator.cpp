@@ -208,7 +208,7 @@ struct vc_calibrator {
   DBuf<double> d_wgpart;
   int kpass = 0;                  // passes enqueued since init_ctrl (merged mode: selects the control record and flag parity)
   DBuf<double> d_pose[2], d_cam[2], d_G[2], d_tile_cost[2], d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_sdiag,
-      d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total;
+      d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total, d_part_total2;
   DBuf<Ctrl> d_ctrl;
   DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_segH[2], d_segg[2], d_seg_cost[2],
       d_cW, d_cdelta, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init, d_rX[2], d_grp_part, d_wg_trial, d_wg_imu_trial;
@@ -437,6 +437,13 @@ struct vc_calibrator {
     dv.fused = 1;
  dv.tile_trial = d_tile_trial.p; dv.Y = d_Y.p; dv.fr = d_fr.p;
     dv.fdiag = d_fdiag.p; dv.fscale2 = d_fscale2.p; dv.part = d_part.p; dv.part_total = d_part_total.p; dv.Sbuf = d_Sbuf.p;
+    {
+      // k_reduced is one workgroup: above ~0.5 MB of slab totals a second reduction level on many CUs is cheaper than its own loop
+      const int nslab = (n_chunks + 63) / 64;
+      dv.two_level_sum = (nslab > 1 && (size_t)nslab * part_stride * sizeof(double) > (512u << 10)) ? 1 : 0;
+      dv.n_slab = dv.two_level_sum ? 1 : nslab;
+      HIP_OK(d_part_total2.alloc((size_t)part_stride)); dv.part_total2 = d_part_total2.p;
+    }
     dv.sdiag = d_sdiag.p; dv.sscale2 = d_sscale2.p; dv.slam = d_slam.p; dv.delta_s = d_delta_s.p;
     dv.fpart = d_fpart.p; dv.scal = d_scal.p; dv.flags = d_flags.p;
     dv.pre_backsub = (T > 2048) ? 1 : 0;

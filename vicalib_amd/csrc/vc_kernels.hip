@@ -562,16 +562,21 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
 // sums the slab's partials k = slice (mod 8), the 8 slices are then added in order:
 //   part_total[y][e] = sum_{k in slab y} part[k][e];   the slabs are added by the consumer (k_reduced).
 constexpr int kSlab = 64;
-__global__ __launch_bounds__(256) void k_part_sum(DevView v) {
+// second = 1: the same over the slab totals of a first launch (large problems: the consumer then adds one record instead of up to
+// 32 slabs of D^2 + ... entries -- 7 MB through one workgroup at cfg5's 8-way shard size)
+__global__ __launch_bounds__(256) void k_part_sum(DevView v, int second) {
   __shared__ double sl[256];
   if (v.ctrl->done) return;
   const int tid = threadIdx.x, e = blockIdx.x * 32 + (tid & 31), ks = tid >> 5;
   const int stride = v.part_stride;
-  const int k0 = blockIdx.y * kSlab, k1 = min(k0 + kSlab, v.n_chunks);
+  const double* src = second ? v.part_total : v.part;
+  double* dst = second ? v.part_total2 : v.part_total;
+  const int n_src = second ? (v.n_chunks + kSlab - 1) / kSlab : v.n_chunks;
+  const int k0 = blockIdx.y * kSlab, k1 = min(k0 + kSlab, n_src);
   double s = 0.0;
   if (e < stride) {
 #pragma unroll 8
-    for (int k = k0 + ks; k < k1; k += 8) s += v.part[(size_t)k * stride + e];
+    for (int k = k0 + ks; k < k1; k += 8) s += src[(size_t)k * stride + e];
   }
   sl[tid] = s;
   __syncthreads();
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(256) void k_part_sum(DevView v) {
     double t = sl[tid];
 #pragma unroll
     for (int q = 1; q < 8; ++q) t += sl[q * 32 + tid];
-    v.part_total[(size_t)blockIdx.y * stride + e] = t;
+    dst[(size_t)blockIdx.y * stride + e] = t;
   }
 }
 
@@ -602,13 +607,14 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double
   double* gs = hd + D;
   double* sc = gs + D;
   const int stride = v.part_stride;
-  const int nslab = (v.n_chunks + kSlab - 1) / kSlab;
+  const int nslab = v.n_slab;
+  const double* ptot = v.n_slab == 1 && v.two_level_sum ? v.part_total2 : v.part_total;
   // camera rotations: fetched now, under the partial sums' latency, instead of one dependent global load per camera later
   if (tid < C * 4) L.camq[tid] = v.cams[cur][(size_t)(tid >> 2) * kCamStride + (tid & 3)];
   for (int e = tid; e < stride; e += 256) {
     double t = 0.0;
 #pragma unroll 8
-    for (int k = 0; k < nslab; ++k) t += v.part_total[(size_t)k * stride + e];
+    for (int k = 0; k < nslab; ++k) t += ptot[(size_t)k * stride + e];
     if (e < D * D) S[e] = -t;
     else if (e < D * D + D) gred[e - D * D] = -t;
     else if (e < stride - 2) L.gsum[e - D * D - D] = t;      // (the last two slots: x2 of observation-less frames, chunk cost)
@@ -627,7 +633,7 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double
     if (tid == 0) { sc[0] = 0.5 * L.red[0]; sc[1] = 0.0; }
   } else if (tid == 0) {
     double t = 0.0;
-    for (int k = 0; k < nslab; ++k) t += v.part_total[(size_t)k * stride + stride - 1];
+    for (int k = 0; k < nslab; ++k) t += ptot[(size_t)k * stride + stride - 1];
     sc[0] = 0.5 * t; sc[1] = 0.0;
   }
   __syncthreads();
@@ -1039,8 +1045,9 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
       double x2 = 0.0;
       if (x2_noobs) x2 = *x2_noobs;
       else {
-        const int stride = v.part_stride, nslab = (v.n_chunks + kSlab - 1) / kSlab;
-        for (int k = 0; k < nslab; ++k) x2 += v.part_total[(size_t)k * stride + stride - 2];
+        const int stride = v.part_stride, nslab = v.n_slab;
+        const double* ptot = v.n_slab == 1 && v.two_level_sum ? v.part_total2 : v.part_total;
+        for (int k = 0; k < nslab; ++k) x2 += ptot[(size_t)k * stride + stride - 2];
       }
       h[kScX2] += x2;
       v.ctrl->needs_decision = 1;
@@ -1514,7 +1521,9 @@ void launch_reproj_jac(const DevView& v, hipStream_t s, int trial) {
   hipLaunchKernelGGL(k_reproj_jac, dim3(tiles_grid(v)), dim3(256), lds, s, v, trial);
 }
 void launch_part_sum(const DevView& v, hipStream_t s) {
-  hipLaunchKernelGGL(k_part_sum, dim3((v.part_stride + 31) / 32, (v.n_chunks + kSlab - 1) / kSlab), dim3(256), 0, s, v);
+  const int nslab = (v.n_chunks + kSlab - 1) / kSlab;
+  hipLaunchKernelGGL(k_part_sum, dim3((v.part_stride + 31) / 32, nslab), dim3(256), 0, s, v, 0);
+  if (v.two_level_sum) hipLaunchKernelGGL(k_part_sum, dim3((v.part_stride + 31) / 32, 1), dim3(256), 0, s, v, 1);
 }
 void launch_frame_schur(const DevView& v, hipStream_t s) {
   const int D = v.D;
