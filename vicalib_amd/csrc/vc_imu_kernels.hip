@@ -180,20 +180,27 @@ __device__ void w_step_cols(WLds& L, WState* st, const Meas<double>& z0, const M
       // dk_dx: rows 0-2 = d/dv, rows 3-5 = (dqx_dq(q, zg) + dqx_dq(q, bg)) on the quaternion, rows 6-8 likewise with za, ba
 #pragma unroll
       for (int i = 0; i < 3; ++i) kcol[i] = Yc[7 + i];
-      w_dqx_dq(cur.q, zg, m1); w_dqx_dq(cur.q, b, m2);
+      // (dqx_dq is linear in its vector argument: one evaluation at z + b stands for the reference's sum of two)
+      {
+        const double zb[3] = {zg[0] + b[0], zg[1] + b[1], zg[2] + b[2]};
+        w_dqx_dq(cur.q, zb, m1);
+      }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         double a = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a += (m1[i * 4 + q] + m2[i * 4 + q]) * Yc[3 + q];
+        for (int q = 0; q < 4; ++q) a += m1[i * 4 + q] * Yc[3 + q];
         kcol[3 + i] = a;
       }
-      w_dqx_dq(cur.q, za, m1); w_dqx_dq(cur.q, b + 3, m2);
+      {
+        const double zb[3] = {za[0] + b[3], za[1] + b[4], za[2] + b[5]};
+        w_dqx_dq(cur.q, zb, m2);
+      }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         double a = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a += (m1[i * 4 + q] + m2[i * 4 + q]) * Yc[3 + q];
+        for (int q = 0; q < 4; ++q) a += m2[i * 4 + q] * Yc[3 + q];
         kcol[6 + i] = a;
       }
       // dk_db: R in rows 3-5 for the gyro bias columns (10..12), in rows 6-8 for the accelerometer bias columns (13..15)
