@@ -942,11 +942,15 @@ int vc_create(vc_calibrator** out, int device) {
   { const char* e = std::getenv("VICALIB_AMD_GRAPHS"); if (e && e[0] == '1') h->use_graphs = true; }
   { const char* e = std::getenv("VICALIB_AMD_NO_MERGED_DECISION"); if (e && e[0] == '1') h->merged_enabled = false; }
   { const char* e = std::getenv("VICALIB_AMD_OVERLAP_WEIGHTS"); if (e && e[0] == '0') h->serial_weights = true; }
+  // the hand-over events between the calibrator's two streams order work on ONE device: no system-scope fence at the record
+  // (VICALIB_AMD_EVENT_SYSTEM_FENCE=1 restores the default, for A/B measurements)
+  unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+  { const char* e = std::getenv("VICALIB_AMD_EVENT_SYSTEM_FENCE"); if (e && e[0] == '1') evf = hipEventDisableTiming; }
   if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_weights, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_imujac, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_back, hipEventDisableTiming) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }
+      hipEventCreateWithFlags(&h->ev_state, evf) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_weights, evf) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_imujac, evf) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_back, evf) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }
   *out = h;
   return VC_OK;
 }
