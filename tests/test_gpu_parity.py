@@ -376,6 +376,39 @@ def test_imu_blocks_match_oracle(rot_only):
         np.testing.assert_allclose(g[j - 1], go, rtol=1e-7, atol=1e-9 * np.abs(go).max())
 
 
+@pytest.mark.parametrize("n_frames,models", [(n, ("kb4",)) for n in (2, 3, 7, 8, 9, 15, 16, 17, 57, 63, 64, 65, 130)] +
+                         [(17, ("poly3",) * 4), (9, ("fov", "kb4") * 4), (66, ("fov", "kb4") * 4)])
+def test_chain_elimination_matches_dense_schur_complement(n_frames, models):
+    """The partitioned elimination of the frame chain (groups of 8, levels, top level; vc_imu_kernels.hip) for frame counts on
+    every side of its group boundaries, and for one, two and three image columns per lane (D = 29, 67, 115): the reduced system
+    it leaves on the shared parameters -- S = H_ss - W^T M^-1 W, g_red = g_s - W^T M^-1 g_f with M the block-tridiagonal frame
+    matrix -- against a dense solve of the oracle's normal equations (visual + inertial blocks, all parameters free)."""
+    p = synth.generate(synth.Config(models=models, n_frames=n_frames, imu=True, seed=5))
+    gt = p.imu_gt
+    cal = ViCalibrator(0).load_problem(p, init=False)
+    orc = ol.Oracle().load(p, init=False); orc.set_options(calibrate_imu=True)
+    b0 = np.concatenate([gt["bg"], gt["ba"]]) * 0.8; s0 = np.concatenate([gt["sg"], gt["sa"]])
+    orc.set_flags(True, True, False, True); orc.set_imu_state(b0, s0, np.zeros(2), 0.002)
+    cal.SetOptimizationFlags(True, True, False, True); cal.SetBiases(b0); cal.SetScaleFactor(s0); cal.SetTimeOffset(0.002)
+    orc.prepare(vis_mult=1, imu_mult=1)
+    lin = orc.linearize()
+    g = cal.linearize()
+    n, D = n_frames, lin["Hss"].shape[0]
+    assert cal.shared_dim() == D
+    M = np.zeros((9 * n, 9 * n))
+    for f in range(n):
+        M[9 * f:9 * f + 9, 9 * f:9 * f + 9] = lin["A"][f]
+        if f + 1 < n:
+            M[9 * f:9 * f + 9, 9 * f + 9:9 * f + 18] = lin["C"][f]
+            M[9 * f + 9:9 * f + 18, 9 * f:9 * f + 9] = lin["C"][f].T
+    W = lin["W"].reshape(9 * n, D); gf = lin["gf"].reshape(9 * n)
+    X = np.linalg.solve(M, np.column_stack([W, gf]))
+    S = lin["Hss"] - W.T @ X[:, :D]; gr = lin["gs"] - W.T @ X[:, D]
+    assert abs(g["cost"] - lin["cost"]) <= 1e-10 * abs(lin["cost"]) + 1e-12
+    np.testing.assert_allclose(g["S"], S, rtol=1e-6, atol=1e-8 * np.abs(lin["Hss"]).max())
+    np.testing.assert_allclose(g["g_red"], gr, rtol=1e-6, atol=1e-8 * np.abs(lin["gs"]).max())
+
+
 def test_imu_weight_update_matches_oracle():
     """UpdateImuWeights (vicalibrator.h:723-799) on the GPU: covariance propagation with the reference's hand Jacobians,
     information matrix W W^T = (J Sigma J^T)^-1.  The GPU keeps the Cholesky-form factor, the oracle the symmetric square
