@@ -2,7 +2,8 @@
 """Per-iteration traces of the CPU oracle's LM loop on small seeded problems: cost, gradient max-norm,
 accepted flag, radius, stage for every iteration, and the converged shared parameters.  The fixture pins (a) the oracle
 against its own regressions (tests/test_oracle.py, no GPU) and (b) the GPU solver at iteration level
-(tests/test_gpu_parity.py).  Run from the repo root:  python tests/golden/make_golden_traces.py"""
+(tests/test_gpu_parity.py).  Run from the repo root:  python tests/golden/make_golden_traces.py
+(adds missing cases; --all regenerates the committed ones too)."""
 import json
 import os
 import sys
@@ -19,6 +20,9 @@ CASES = {
     "cfg1_poly3_50": (dict(models=("poly3",), n_frames=50), dict(calibrate_imu=False)),
     "stereo_fov_kb4_30": (dict(models=("fov", "kb4"), n_frames=30, seed=7), dict(calibrate_imu=False)),
     "mono_kb4_imu_60": (dict(models=("kb4",), n_frames=60, imu=True, seed=5), dict(calibrate_imu=True, max_iters=100)),
+    "mono_rational6_40": (dict(models=("rational6",), n_frames=40, seed=9), dict(calibrate_imu=False)),
+    "rig4_mixed_imu_80": (dict(models=("fov", "poly3", "kb4", "rational6"), n_frames=80, imu=True, seed=13, extrinsics_prior=True),
+                          dict(calibrate_imu=True, max_iters=100)),
 }
 
 
@@ -40,8 +44,10 @@ def run(cfg_kw, opt):
 
 
 if __name__ == "__main__":
-    data = {name: run(*spec) for name, spec in CASES.items()}
-    with open(os.path.join(HERE, "lm_traces.json"), "w") as f:
+    path = os.path.join(HERE, "lm_traces.json")
+    data = json.load(open(path)) if os.path.exists(path) and "--all" not in sys.argv else {}
+    data.update({name: run(*spec) for name, spec in CASES.items() if name not in data})      # committed entries stay as they are
+    with open(path, "w") as f:
         json.dump(data, f, indent=0)
     for k, v in data.items():
         print(k, len(v["trace"]), "trace rows, final cost", v["trace"][-1][1])

@@ -240,7 +240,7 @@ def test_cfg4_rig_reduced_frame_count_visual_inertial():
         np.testing.assert_allclose(cal.GetCamera(c)[0][:4], p.cam_K_gt[c][:4], rtol=2e-3)
 
 
-@pytest.mark.parametrize("name", ["cfg1_poly3_50", "stereo_fov_kb4_30", "mono_kb4_imu_60"])
+@pytest.mark.parametrize("name", ["cfg1_poly3_50", "stereo_fov_kb4_30", "mono_kb4_imu_60", "mono_rational6_40", "rig4_mixed_imu_80"])
 def test_solver_matches_committed_lm_traces(name):
     """Iteration-level agreement with the fixture tests/golden/lm_traces.json (the oracle's LM loop, generated by
     tests/golden/make_golden_traces.py): cost of every iteration, accept/reject sequence, radius, final parameters."""

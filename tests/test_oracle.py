@@ -167,7 +167,7 @@ def test_cfg1_optimum_matches_scipy():
 TRACES = json.load(open(os.path.join(HERE, "golden", "lm_traces.json")))
 
 
-@pytest.mark.parametrize("name", ["cfg1_poly3_50", "stereo_fov_kb4_30"])
+@pytest.mark.parametrize("name", ["cfg1_poly3_50", "stereo_fov_kb4_30", "mono_rational6_40"])
 def test_oracle_reproduces_committed_lm_trace(name):
     """tests/golden/lm_traces.json (make_golden_traces.py): the oracle's per-iteration record is stable."""
     e = TRACES[name]
@@ -181,7 +181,8 @@ def test_oracle_reproduces_committed_lm_trace(name):
     np.testing.assert_array_equal(tr[:, 3], want[:, 3])                   # accept / reject
     np.testing.assert_allclose(tr[:, 4], want[:, 4], rtol=1e-9)          # trust-region radius
     for c, cam in enumerate(e["cameras"]):
-        np.testing.assert_allclose(orc.camera(c)[0], cam["K"], rtol=1e-9)
+        # rational6's numerator / denominator coefficients nearly cancel: the thread count's summation order shows at 1e-9 there
+        np.testing.assert_allclose(orc.camera(c)[0], cam["K"], rtol=1e-7 if "rational6" in name else 1e-9)
 
 
 def test_closed_form_cpu_mode_reproduces_the_dual_number_blocks():
