@@ -20,8 +20,9 @@ def hh():
     if _hh is None:
         src = os.path.join(HERE, "host_harness", "harness.cpp")
         so = os.path.join(HERE, "host_harness", "libvc_host_harness.so")
-        hdr = os.path.join(HERE, "..", "vicalib_amd", "csrc", "vc_math.hpp")
-        if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
+        csrc = os.path.join(HERE, "..", "vicalib_amd", "csrc")
+        deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".h"))]
+        if not os.path.exists(so) or max(os.path.getmtime(f) for f in deps) > os.path.getmtime(so):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
         _hh = C.CDLL(so)
         _hh.hh_tile_gram.restype = C.c_double
@@ -142,6 +143,26 @@ def test_imu_block_lane_duals_match_oracle():
                            d(W[j - 1]), rot_only, d(T2), d(T1), d(v2), d(v1), d(g), d(b), d(sfac), C.c_double(toff), d(r), d(J))
             np.testing.assert_allclose(r, r0, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(r0).max()))
             np.testing.assert_allclose(J, J0, rtol=1e-8, atol=1e-8 * np.abs(J0).max())
+            # the delta form the kernels run (per-interval RK4 from the identity state, composed along the block)
+            r2 = np.zeros(9); J2 = np.zeros((9, 33))
+            H.hh_imu_block_deltas(len(p.imu_t), d(p.imu_t), d(p.imu_gyro), d(p.imu_accel), C.c_double(p.frame_time[j - 1]), C.c_double(p.frame_time[j]),
+                                  d(W[j - 1]), rot_only, d(T2), d(T1), d(v2), d(v1), d(g), d(b), d(sfac), C.c_double(toff), d(r2), d(J2))
+            np.testing.assert_allclose(r2, r, rtol=1e-11, atol=1e-11 * max(1.0, np.abs(r).max()))
+            np.testing.assert_allclose(J2, J, rtol=1e-10, atol=1e-10 * np.abs(J).max())
+            np.testing.assert_allclose(J2, J0, rtol=1e-8, atol=1e-8 * np.abs(J0).max())
+    # delta form against the lane duals for every block under time offsets that move the sample ranges (clamped ends included)
+    W9 = np.ascontiguousarray(np.eye(9) * 3.0 + 0.1 * np.arange(81).reshape(9, 9) / 81.0)
+    for toff_x in (-0.031, -0.0007, 0.0, 0.0123, 0.0449, 0.2):
+        for j in range(1, o.n_frames):
+            T2, v2 = o.frame(j); T1, v1 = o.frame(j - 1)
+            out = []
+            for fn in (H.hh_imu_block, H.hh_imu_block_deltas):
+                r = np.zeros(9); J = np.zeros((9, 33))
+                fn(len(p.imu_t), d(p.imu_t), d(p.imu_gyro), d(p.imu_accel), C.c_double(p.frame_time[j - 1]), C.c_double(p.frame_time[j]),
+                   d(W9), 0, d(T2), d(T1), d(v2), d(v1), d(g), d(b), d(sfac), C.c_double(toff_x), d(r), d(J))
+                out.append((r, J))
+            np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-11, atol=1e-11 * max(1.0, np.abs(out[0][0]).max()))
+            np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-10, atol=1e-10 * max(1.0, np.abs(out[0][1]).max()))
 
 
 def test_imu_covariance_weights_match_oracle():

@@ -143,7 +143,7 @@ struct vc_calibrator {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;        // the IMU weight update of a pass runs here, under the pass's Jacobian sweeps and chain solve
-  hipEvent_t ev_state = nullptr, ev_weights = nullptr, ev_imujac = nullptr, ev_back = nullptr;
+  hipEvent_t ev_state = nullptr, ev_weights = nullptr, ev_imujac = nullptr, ev_back = nullptr, ev_reduced = nullptr;
   int wcur = 0;                         // weight buffer holding the current weight_sqrt_
   bool serial_weights = false;          // false: IMU Jacobians + weight update on the second stream (VICALIB_AMD_OVERLAP_WEIGHTS=0: in line); was: VICALIB_AMD_OVERLAP_WEIGHTS=1 moves it to a second
                                         // stream under the Jacobian sweeps / chain solve (measured: the two latency-bound kernels then
@@ -211,7 +211,8 @@ struct vc_calibrator {
       d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total, d_part_total2;
   DBuf<Ctrl> d_ctrl;
   DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_segH[2], d_segg[2], d_seg_cost[2],
-      d_cW, d_cdelta, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init, d_rX[2], d_grp_part, d_wg_trial, d_wg_imu_trial;
+      d_cW, d_cdelta, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init, d_rX[2], d_grp_part, d_wg_trial, d_wg_imu_trial,
+      d_imu_delta, d_imu_delta_ab, d_imu_delta_blk;
   size_t wsqrt_frames = 0;       // number of frames the device weight_sqrt_ array was initialised for
   int trace_cap = 0;
   struct Pinned { Ctrl up; Ctrl down; double trace[64 * kTraceCols]; };
@@ -231,6 +232,7 @@ struct vc_calibrator {
     if (ev_weights) (void)hipEventDestroy(ev_weights);
     if (ev_imujac) (void)hipEventDestroy(ev_imujac);
     if (ev_back) (void)hipEventDestroy(ev_back);
+    if (ev_reduced) (void)hipEventDestroy(ev_reduced);
     if (stream) (void)hipStreamDestroy(stream);
     if (pin) (void)hipHostFree(pin);
   }
@@ -488,6 +490,8 @@ struct vc_calibrator {
         HIP_OK(hipStreamSynchronize(stream));
       }
       for (int b = 0; b < 2; ++b) { HIP_OK(d_segH[b].alloc(ns * 33 * 33)); HIP_OK(d_segg[b].alloc(ns * 33)); HIP_OK(d_seg_cost[b].alloc(ns)); }
+      HIP_OK(d_imu_delta.alloc((size_t)std::max<size_t>(imu_t.size(), 2) * kDeltaStride)); HIP_OK(d_imu_delta_ab.alloc(ns * 2 * kDeltaStride));
+      HIP_OK(d_imu_delta_blk.alloc(ns * kBlockDeltaStride));
       const size_t nf = (size_t)std::max(N, 1);
       HIP_OK(d_cW.alloc(nf * 9 * dv.ldx)); HIP_OK(d_cdelta.alloc(nf * 9)); HIP_OK(d_cg.alloc(nf * 9)); HIP_OK(d_clam.alloc(nf * 9));
       HIP_OK(d_cdiag.alloc(nf * 9)); HIP_OK(d_cscale2.alloc(nf * 9));
@@ -496,6 +500,7 @@ struct vc_calibrator {
     dv.imu_t = d_imu_t.p; dv.imu_w = d_imu_w.p; dv.imu_a = d_imu_a.p; dv.frame_time = d_frame_time.p;
     dv.vel[0] = d_vel[0].p; dv.vel[1] = d_vel[1].p; dv.imus[0] = d_imus[0].p; dv.imus[1] = d_imus[1].p;
     dv.wsqrtb[0] = d_wsqrt[0].p; dv.wsqrtb[1] = d_wsqrt[1].p;
+    dv.imu_delta = d_imu_delta.p; dv.imu_delta_ab = d_imu_delta_ab.p; dv.imu_delta_blk = d_imu_delta_blk.p;
     for (int b = 0; b < 2; ++b) { dv.segHb[b] = d_segH[b].p; dv.seggb[b] = d_segg[b].p; dv.seg_costb[b] = d_seg_cost[b].p; }
     dv.cW = d_cW.p; dv.cdelta = d_cdelta.p; dv.cg = d_cg.p;
     dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p;
@@ -621,16 +626,21 @@ struct vc_calibrator {
       if (!serial_weights) {
         HIP_OK(hipEventRecord(ev_state, stream));
         HIP_OK(hipStreamWaitEvent(stream2, ev_state, 0));
-        if (first_pass) KT2("k_imu_jac", launch_imu_jac(dv, wcur, stream2, 0));
+        if (first_pass) {
+          KT2("k_imu_delta", launch_imu_delta(dv, stream2, 0)); KT2("k_imu_jac", launch_imu_jac(dv, wcur, stream2, 0));
+          HIP_OK(hipEventRecord(ev_imujac, stream2));       // ahead of the weight update: the chain does not read the weights
+        }
         if (upd) KT2("k_imu_weights", launch_imu_weights(dv, wcur, stream2));
         if (first_pass) {
           KT("k_reproj_jac", launch_reproj_jac(dv, stream, 0));
-          HIP_OK(hipEventRecord(ev_imujac, stream2));       // (recorded behind the weight update: first pass only)
           HIP_OK(hipStreamWaitEvent(stream, ev_imujac, 0));
         }
       } else {
         if (upd) KT("k_imu_weights", launch_imu_weights(dv, wcur, stream));
-        if (first_pass) { KT("k_reproj_jac", launch_reproj_jac(dv, stream, 0)); KT("k_imu_jac", launch_imu_jac(dv, wcur, stream, 0)); }
+        if (first_pass) {
+          KT("k_reproj_jac", launch_reproj_jac(dv, stream, 0));
+          KT("k_imu_delta", launch_imu_delta(dv, stream, 0)); KT("k_imu_jac", launch_imu_jac(dv, wcur, stream, 0));
+        }
       }
       KT("chain_forward", launch_chain_solve_a(dv, stream));
       KT("k_part_sum", launch_part_sum(dv, stream));
@@ -642,21 +652,23 @@ struct vc_calibrator {
       } else {
         KT("k_reduced", launch_reduced(dv, 0, stream));
       }
-      KT("chain_backward", launch_chain_solve_b(dv, stream));
-      // trial point: both sweeps in trial mode, the IMU blocks with the weights this pass has just updated -- on the second
-      // stream behind the weight update, next to the vision sweep on the main one
-      if (upd) wcur = 1 - wcur;
+      // the trial IMU parameters exist: the interval deltas of the trial point run on the second stream next to the chain's
+      // back-substitution (they depend on no pose)
       if (!serial_weights) {
-        HIP_OK(hipEventRecord(ev_back, stream));
-        HIP_OK(hipStreamWaitEvent(stream2, ev_back, 0));
-        KT2("k_imu_jac(trial)", launch_imu_jac(dv, wcur, stream2, 1));
-        HIP_OK(hipEventRecord(ev_weights, stream2));
-        KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
-        HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0));
-      } else {
-        KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
-        KT("k_imu_jac(trial)", launch_imu_jac(dv, wcur, stream, 1));
+        HIP_OK(hipEventRecord(ev_reduced, stream));
+        HIP_OK(hipStreamWaitEvent(stream2, ev_reduced, 0));
+        KT2("k_imu_delta(trial)", launch_imu_delta(dv, stream2, 1));
       }
+      KT("chain_backward", launch_chain_solve_b(dv, stream));
+      // trial point: both sweeps in trial mode on the main stream, the IMU blocks with the weights this pass has just updated
+      // (second stream: weight update, then the deltas -- ev_weights covers both); the decision follows without another
+      // cross-stream hop (each costs 6-13 us on the device's timeline)
+      if (upd) wcur = 1 - wcur;
+      if (!serial_weights) HIP_OK(hipEventRecord(ev_weights, stream2));
+      KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
+      if (!serial_weights) HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0));
+      else KT("k_imu_delta(trial)", launch_imu_delta(dv, stream, 1));
+      KT("k_imu_jac(trial)", launch_imu_jac(dv, wcur, stream, 1));
       if (sharded()) {
         launch_final(dv, 1, stream);
         rc = do_allreduce(dv.gath, world * kNumScal, 0); if (rc) return rc;
@@ -950,7 +962,8 @@ int vc_create(vc_calibrator** out, int device) {
       hipEventCreateWithFlags(&h->ev_state, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_weights, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_imujac, evf) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_back, evf) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }
+      hipEventCreateWithFlags(&h->ev_back, evf) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_reduced, evf) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }
   *out = h;
   return VC_OK;
 }

@@ -123,6 +123,11 @@ struct DevView {
   double* segHb[2];                // (n_frames-1) x 33 x 33  weighted J^T J, columns [frame j (9) | frame j-1 (9) | imu (15)]
   double* seggb[2];                // (n_frames-1) x 33       weighted J^T r
   double* seg_costb[2];            // (n_frames-1)  imu_mult * rho at the linearisation point
+  // delta form of the sample intervals (vc_imu.hpp, kDeltaStride doubles each): the stored intervals i -> i + 1 and the two partial
+  // intervals at the ends of every block; written by k_imu_delta, composed along the blocks by k_imu_jac
+  double* imu_delta;               // (n_imu - 1) x kDeltaStride
+  double* imu_delta_ab;            // (n_frames - 1) x 2 x kDeltaStride
+  double* imu_delta_blk;           // (n_frames - 1) x kBlockDeltaStride: the intervals of a block appended (k_imu_block); T = -1: empty range
   // ---- block-tridiagonal frame chain (9 x 9 blocks: pose 6 + velocity 3), cyclic reduction ----------------
   double* cW;                      // n_frames x 9 x ldx, one image per frame: columns 0..D-1 W -> Y = L^-1 W, column D: g -> z, then
                                    // from column ldw three 9 x 9 blocks: C (coupling to the group's left separator) -> X_s = L^-1 C,
@@ -170,7 +175,8 @@ void launch_cam_sq(const DevView& v, double* out /*n_cams x 2: sum sq, count*/, 
 void launch_outlier_mask(const DevView& v, int state, const double* thresh /*device, n_cams*/, unsigned char* mask, hipStream_t s);
 
 // inertial path (vc_imu_kernels.hip)
-void launch_imu_jac(const DevView& v, int wr, hipStream_t s, int trial = 0);   // wr: weight buffer to read; trial as for launch_reproj_jac
+void launch_imu_delta(const DevView& v, hipStream_t s, int trial = 0);         // interval and block deltas under the IMU parameters of the accepted (0) / trial (1) state (two launches)
+void launch_imu_jac(const DevView& v, int wr, hipStream_t s, int trial = 0);   // wr: weight buffer to read; trial as for launch_reproj_jac; needs launch_imu_delta
 void launch_imu_weights(const DevView& v, int wr, hipStream_t s);          // reads wsqrtb[wr], writes wsqrtb[1 - wr];                   // weight_sqrt_ from the accepted state
 void launch_chain_solve_a(const DevView& v, hipStream_t s);                 // assemble + cyclic-reduction elimination + Gram partials
 void launch_chain_solve_b(const DevView& v, hipStream_t s);                 // back-substitution + trial frame state

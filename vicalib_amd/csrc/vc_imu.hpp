@@ -232,6 +232,31 @@ template <class T> VC_HD void imu_gravity(const T* dir, T* out) {
   out[2] = (cp * cq) * (-g);
 }
 
+// Tail of the residual: the predicted state against frame j -- [log(T_pred T_j^-1); v_pred - v_j] times weight_sqrt, then the
+// rotation-only switch (ceres-cost-functions.h:468-482).
+template <class T>
+VC_HD void imu_residual_tail(const PoseV<T>& s, const double* w_sqrt, int rotation_only, const T* T2, const T* v2, T* r) {
+  // rel = T_pred * T2^-1 (SE3 product: SO3 part renormalised), then log
+  T qc[4] = {-T2[0], -T2[1], -T2[2], T2[3]};
+  T nt[3] = {T2[4] * -1.0, T2[5] * -1.0, T2[6] * -1.0}, ti[3];
+  tq_rotate(qc, nt, ti);
+  T rel[7], tr[3];
+  tq_mul(s.q, qc, rel);
+  const T nrm = sqrt(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2] + rel[3] * rel[3]);
+  for (int i = 0; i < 4; ++i) rel[i] = rel[i] / nrm;
+  tq_rotate(s.q, ti, tr);
+  for (int i = 0; i < 3; ++i) rel[4 + i] = s.p[i] + tr[i];
+  T raw[9];
+  tse3_log(rel, raw);
+  for (int i = 0; i < 3; ++i) raw[6 + i] = s.v[i] - v2[i];
+  for (int j = 0; j < 9; ++j) {
+    T acc = cst<T>(0.0);
+    for (int i = 0; i < 9; ++i) acc = acc + raw[i] * w_sqrt[i * 9 + j];
+    r[j] = acc;
+  }
+  if (rotation_only) for (int i = 0; i < 3; ++i) { r[i] = cst<T>(0.0); r[6 + i] = cst<T>(0.0); }
+}
+
 // The residual. Parameters: T2 = frame j [q t], T1 = frame j-1, v2, v1, gdir(2), b(6), sf(6), toff.
 // w_sqrt 9x9 row-major; r <- (r^T W)^T; rotation-only zeroes rows 0-2, 6-8. Empty range -> r = 0.
 template <class T>
@@ -252,25 +277,7 @@ VC_HD void imu_residual(const ImuView& buf, double t_start, double t_end, const 
     imu_rk4_step(&s, z0, z1, b, sf, gw);
     z0 = z1;
   }
-  // rel = T_pred * T2^-1 (SE3 product: SO3 part renormalised), then log
-  T qc[4] = {-T2[0], -T2[1], -T2[2], T2[3]};
-  T nt[3] = {T2[4] * -1.0, T2[5] * -1.0, T2[6] * -1.0}, ti[3];
-  tq_rotate(qc, nt, ti);
-  T rel[7], tr[3];
-  tq_mul(s.q, qc, rel);
-  const T nrm = sqrt(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2] + rel[3] * rel[3]);
-  for (int i = 0; i < 4; ++i) rel[i] = rel[i] / nrm;
-  tq_rotate(s.q, ti, tr);
-  for (int i = 0; i < 3; ++i) rel[4 + i] = s.p[i] + tr[i];
-  T raw[9];
-  tse3_log(rel, raw);
-  for (int i = 0; i < 3; ++i) raw[6 + i] = s.v[i] - v2[i];
-  for (int j = 0; j < 9; ++j) {
-    T acc = cst<T>(0.0);
-    for (int i = 0; i < 9; ++i) acc = acc + raw[i] * w_sqrt[i * 9 + j];
-    r[j] = acc;
-  }
-  if (rotation_only) for (int i = 0; i < 3; ++i) { r[i] = cst<T>(0.0); r[6 + i] = cst<T>(0.0); }
+  imu_residual_tail(s, w_sqrt, rotation_only, T2, v2, r);
 }
 
 // LocalParamSe3::ComputeJacobian (local-param-se3.h:28-91): 7x6 row-major d(T exp(delta))/d(delta) at 0,
@@ -301,6 +308,177 @@ VC_HD void imu_block_direction(const ImuView& buf, double t_start, double t_end,
   for (int i = 0; i < 35; ++i) P[i].v = (i == dir) ? 1.0 : 0.0;
   D1 res[9];
   imu_residual<D1>(buf, t_start, t_end, w_sqrt, rotation_only, P, P + 7, P + 14, P + 17, P + 20, P + 22, P + 28, P[34], res);
+  for (int i = 0; i < 9; ++i) { r[i] = res[i].a; dr[i] = res[i].v; }
+}
+
+// ---- delta form of the block: what the device's Jacobian sweep runs --------------------------------------------------
+// The RK4 map of one sample interval commutes with the state it starts from.  With (dq, dp, dv) the step taken from the
+// identity state without gravity,
+//     q+ = q dq,     p+ = p + v dt - g dt^2 / 2 + R(q) dp,     v+ = v - g dt + R(q) dv :
+// the left-multiplied exponential of the world-frame rate is exp(R(q) u h) q = q exp(u h), Runge-Kutta schemes are
+// affine-equivariant, and the contributions of v and g are polynomials of degree <= 2 in time, which RK4 integrates exactly.
+// The deltas depend on the samples, biases and scale factors and -- the two partial intervals at the ends of a block -- on the
+// time offset, not on any pose: they are formed for all intervals in parallel (k_imu_delta), and a block then costs one
+// composition per interval (k_imu_jac) instead of a dependent RK4 step under dual numbers.  Equal to imu_residual up to
+// rounding (tests/test_device_math_cpu.py compares the two and the oracle).
+constexpr int kDeltaCols = 14;                    // value | d/db (6) | d/dsf (6) | d/dtoff
+constexpr int kDeltaStride = kDeltaCols * 10;     // one interval: [column][dq 4, dp 3, dv 3]
+
+// Interval kinds: 0 = stored samples i -> i + 1; 1 = first interval of a block (range elements 0 -> 1); 2 = its last interval
+// (elements n_meas - 2 -> n_meas - 1; only when n_meas >= 3).  dd: 0 = values only, 1..6 bias, 7..12 scale factor, 13 time offset.
+VC_HD void imu_delta_direction(const ImuView& buf, int kind, int i, const ImuRange& rg, double t_start, double t_end, const double* b,
+                               const double* sf, double toff, int dd, double* value /* 10 */, double* deriv /* 10 */) {
+  D1 bD[6], sD[6];
+  for (int k = 0; k < 6; ++k) { bD[k] = mk(b[k], dd == 1 + k ? 1.0 : 0.0); sD[k] = mk(sf[k], dd == 7 + k ? 1.0 : 0.0); }
+  const D1 offD = mk(toff, dd == 13 ? 1.0 : 0.0);
+  Meas<D1> z0, z1;
+  if (kind == 0) { imu_shift(buf, i, offD, &z0); imu_shift(buf, i + 1, offD, &z1); }
+  else {
+    const int m = (kind == 1) ? 1 : (rg.k1 - rg.k0 + 1) + 1;
+    imu_range_get(buf, rg, offD, t_start, t_end, m - 1, &z0);
+    imu_range_get(buf, rg, offD, t_start, t_end, m, &z1);
+  }
+  PoseV<D1> d;
+  for (int k = 0; k < 3; ++k) { d.q[k] = mk(0.0); d.p[k] = mk(0.0); d.v[k] = mk(0.0); }
+  d.q[3] = mk(1.0);
+  const D1 g0[3] = {mk(0.0), mk(0.0), mk(0.0)};
+  imu_rk4_step(&d, z0, z1, bD, sD, g0);
+  for (int k = 0; k < 4; ++k) { value[k] = d.q[k].a; deriv[k] = d.q[k].v; }
+  for (int k = 0; k < 3; ++k) { value[4 + k] = d.p[k].a; deriv[4 + k] = d.p[k].v; value[7 + k] = d.v[k].a; deriv[7 + k] = d.v[k].v; }
+}
+
+// Deltas accumulate without reference to a pose: appending the interval (dq, dp, dv; dt) to the block's running delta (Q, P, V; T),
+//     P <- P + V dt + R(Q) dp,   V <- V + R(Q) dv,   Q <- Q dq,   T <- T + dt,
+// and the block's end state from its start state (q, p, v) is  q Q,  p + v T - g T^2 / 2 + R(q) P,  v - g T + R(q) V.
+template <class T> struct DeltaAcc { T q[4], p[3], v[3], t; };
+template <class T> VC_HD void imu_delta_append(DeltaAcc<T>* A, const PoseV<T>& d, T dt) {
+  T rp[3], rv[3], q[4];
+  tq_rotate(A->q, d.p, rp);
+  tq_rotate(A->q, d.v, rv);
+  tq_mul(A->q, d.q, q);
+  for (int i = 0; i < 3; ++i) {
+    A->p[i] = (A->p[i] + A->v[i] * dt) + rp[i];
+    A->v[i] = A->v[i] + rv[i];
+  }
+  for (int i = 0; i < 4; ++i) A->q[i] = q[i];
+  A->t = A->t + dt;
+}
+constexpr int kBlockDeltaStride = kDeltaCols * 11;     // one block: [column][Q 4, P 3, V 3, T]
+
+struct DeltaRec { double v[10], d[10]; };
+VC_HD void imu_delta_load(const double* rec, int dcol, DeltaRec* o) {
+  for (int k = 0; k < 10; ++k) { o->v[k] = rec[k]; o->d[k] = (dcol > 0) ? rec[dcol * 10 + k] : 0.0; }
+}
+// Part `part` of `n_parts` of the block's delta along direction dd (as imu_delta_direction): the block's intervals cut into
+// n_parts contiguous runs, the run's intervals appended in order from the identity (appending is associative; the kernel runs
+// one part -- splitting a block over lane groups bought nothing, the kernel waits on dependent loads, not on the appends).
+// The records are requested three intervals ahead of their use (registers A, B, C in rotation).  Returns 0 for an empty range.
+VC_HD int imu_block_delta_part(const ImuView& buf, double t_start, double t_end, double toff, const double* delta_samples,
+                               const double* delta_ab, int dd, int part, int n_parts, DeltaAcc<D1>* acc_out) {
+  const ImuRange rg = imu_range(buf, t_start, t_end, toff);
+  if (!rg.valid) return 0;
+  const D1 offD = mk(toff, dd == 13 ? 1.0 : 0.0);
+  const int dcol_s = (dd < 13) ? dd : 0;               // stored intervals do not move with the offset
+  const int n_meas = (rg.k1 - rg.k0 + 1) + 2, n_steps = n_meas - 1;
+  // interval m (1 .. n_meas - 1) runs from range element m - 1 to m: the first is the block's record 0, the last (when there are
+  // interior samples) its record 1, those in between the stored intervals k0 + m - 2
+  const int m_lo = 1 + (part * n_steps) / n_parts, m_hi = 1 + ((part + 1) * n_steps) / n_parts;      // [m_lo, m_hi)
+  auto request = [&](int m, DeltaRec* o) {
+    if (m >= m_hi) return;
+    if (m == 1) imu_delta_load(delta_ab, dd, o);
+    else if (m == n_meas - 1) imu_delta_load(delta_ab + kDeltaStride, dd, o);
+    else imu_delta_load(delta_samples + (size_t)(rg.k0 + m - 2) * kDeltaStride, dcol_s, o);
+  };
+  DeltaRec A, B, C;
+  for (int k = 0; k < 10; ++k) { A.v[k] = A.d[k] = B.v[k] = B.d[k] = C.v[k] = C.d[k] = 0.0; }
+  request(m_lo, &A); request(m_lo + 1, &B); request(m_lo + 2, &C);
+  DeltaAcc<D1> acc;
+  for (int k = 0; k < 3; ++k) { acc.q[k] = mk(0.0); acc.p[k] = mk(0.0); acc.v[k] = mk(0.0); }
+  acc.q[3] = mk(1.0); acc.t = mk(0.0);
+  Meas<D1> zt;
+  D1 t_prev;
+  if (m_lo == 1) { imu_range_get(buf, rg, offD, t_start, t_end, 0, &zt); t_prev = zt.time; }
+  else t_prev = buf.t[rg.k0 + m_lo - 2] + offD;                 // element m_lo - 1 is an interior sample
+  auto step = [&](int m, DeltaRec* X) {
+    if (m >= m_hi) return;
+    D1 t_now;
+    if (m == n_meas - 1) { imu_range_get(buf, rg, offD, t_start, t_end, m, &zt); t_now = zt.time; }
+    else t_now = buf.t[rg.k0 + m - 1] + offD;
+    const D1 dt = t_now - t_prev;
+    if (dt.a != 0.0) {           // (a zero-length interval is skipped, imu_rk4_step)
+      PoseV<D1> d;
+      for (int k = 0; k < 4; ++k) d.q[k] = mk(X->v[k], X->d[k]);
+      for (int k = 0; k < 3; ++k) { d.p[k] = mk(X->v[4 + k], X->d[4 + k]); d.v[k] = mk(X->v[7 + k], X->d[7 + k]); }
+      imu_delta_append(&acc, d, dt);
+    }
+    t_prev = t_now;
+    request(m + 3, X);
+  };
+  for (int m = m_lo; m < m_hi; m += 3) { step(m, &A); step(m + 1, &B); step(m + 2, &C); }
+  *acc_out = acc;
+  return 1;
+}
+VC_HD void imu_delta_unpack(const DeltaAcc<D1>& acc, double* value /* 11 */, double* deriv /* 11 */) {
+  for (int k = 0; k < 4; ++k) { value[k] = acc.q[k].a; deriv[k] = acc.q[k].v; }
+  for (int k = 0; k < 3; ++k) { value[4 + k] = acc.p[k].a; deriv[4 + k] = acc.p[k].v; value[7 + k] = acc.v[k].a; deriv[7 + k] = acc.v[k].v; }
+  value[10] = acc.t.a; deriv[10] = acc.t.v;
+}
+// The whole block along direction dd: values and partials of (Q, P, V, T).
+VC_HD int imu_block_delta_direction(const ImuView& buf, double t_start, double t_end, double toff, const double* delta_samples,
+                                    const double* delta_ab, int dd, double* value /* 11 */, double* deriv /* 11 */) {
+  DeltaAcc<D1> a;
+  if (!imu_block_delta_part(buf, t_start, t_end, toff, delta_samples, delta_ab, dd, 0, 1, &a)) return 0;
+  imu_delta_unpack(a, value, deriv);
+  return 1;
+}
+
+// Local columns of the block (k_imu_jac's order): frame j pose 6 | its velocity 3 | frame j-1 pose 6 | its velocity 3 | gravity 2 |
+// biases 6 | scale factors 6 | time offset.  One lane's share: residual values r[9] and their partials along local column `col`
+// (col < 0: values only), from the block's delta record.  `valid`: the block's sample range is not empty.
+VC_HD void imu_block_final_direction(int valid, const double* block_rec, const double* w_sqrt, int rotation_only, const double* T2,
+                                     const double* T1, const double* v2, const double* v1, const double* gdir, int col, double* r,
+                                     double* dr) {
+  if (!valid) { for (int i = 0; i < 9; ++i) { r[i] = 0.0; dr[i] = 0.0; } return; }
+  const int dcol = (col >= 20) ? col - 19 : 0;                 // biases 1..6, scale factors 7..12, time offset 13
+  D1 Q[4], P[3], V[3];
+  for (int k = 0; k < 4; ++k) Q[k] = mk(block_rec[k], dcol ? block_rec[dcol * 11 + k] : 0.0);
+  for (int k = 0; k < 3; ++k) {
+    P[k] = mk(block_rec[4 + k], dcol ? block_rec[dcol * 11 + 4 + k] : 0.0);
+    V[k] = mk(block_rec[7 + k], dcol ? block_rec[dcol * 11 + 7 + k] : 0.0);
+  }
+  const D1 Tt = mk(block_rec[10], dcol ? block_rec[dcol * 11 + 10] : 0.0);
+  // seeds: poses move along T exp(delta) (local_jac_se3), everything else is a plain coordinate
+  D1 T2D[7], v2D[3], gD[2], gw[3], q0[4], p0[3], v0[3];
+  {
+    double J[42];
+    local_jac_se3(T2, J);
+    for (int i = 0; i < 7; ++i) {
+      double sel = 0.0;
+      for (int c = 0; c < 6; ++c) sel = (col == c) ? J[i * 6 + c] : sel;
+      T2D[i] = mk(T2[i], sel);
+    }
+    local_jac_se3(T1, J);
+    for (int i = 0; i < 7; ++i) {
+      double sel = 0.0;
+      for (int c = 0; c < 6; ++c) sel = (col == 9 + c) ? J[i * 6 + c] : sel;
+      if (i < 4) q0[i] = mk(T1[i], sel); else p0[i - 4] = mk(T1[i], sel);
+    }
+  }
+  for (int k = 0; k < 3; ++k) { v2D[k] = mk(v2[k], col == 6 + k ? 1.0 : 0.0); v0[k] = mk(v1[k], col == 15 + k ? 1.0 : 0.0); }
+  gD[0] = mk(gdir[0], col == 18 ? 1.0 : 0.0); gD[1] = mk(gdir[1], col == 19 ? 1.0 : 0.0);
+  imu_gravity(gD, gw);
+  PoseV<D1> x;
+  D1 rp[3], rv[3];
+  tq_rotate(q0, P, rp);
+  tq_rotate(q0, V, rv);
+  tq_mul(q0, Q, x.q);
+  const D1 ht2 = 0.5 * (Tt * Tt);
+  for (int i = 0; i < 3; ++i) {
+    x.p[i] = ((p0[i] + v0[i] * Tt) - gw[i] * ht2) + rp[i];
+    x.v[i] = (v0[i] - gw[i] * Tt) + rv[i];
+  }
+  D1 res[9];
+  imu_residual_tail(x, w_sqrt, rotation_only, T2D, v2D, res);
   for (int i = 0; i < 9; ++i) { r[i] = res[i].a; dr[i] = res[i].v; }
 }
 

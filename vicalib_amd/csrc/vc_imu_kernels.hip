@@ -4,10 +4,13 @@
 // coupled, so the per-frame elimination of the vision-only path becomes the factorisation of a
 // block-tridiagonal chain (9 x 9 blocks: pose 6 + velocity 3) bordered by the shared parameters.
 //
-//  k_imu_jac       one wavefront per IMU block; lane d carries derivative direction d of the 35 global
-//                  parameters through the RK4 preintegration (vc_imu.hpp) -- the lane-parallel form of
-//                  ceres::Jet<double,35>; then local-parameterisation Jacobians, Cauchy(100) weight and
-//                  the 33 x 33 weighted J^T J / J^T r of the block
+//  k_imu_delta     one RK4 step from the identity state per sample interval, 14 lanes each (values + 13 dual directions of the
+//                  biases / scale factors / time offset): the part of the preintegration that does not depend on any pose
+//  k_imu_block     the intervals of every block appended into the block's delta, 14 lanes per block
+//  k_imu_jac       half a wavefront per IMU block; lane = local column of the block, carried as a dual number through the
+//                  application of the block's delta to the start state and the residual's tail -- the lane-parallel form of
+//                  ceres::Jet<double,35> (vc_imu.hpp, "delta form"); then Cauchy(100) weight and the 33 x 33 weighted
+//                  J^T J / J^T r of the block
 //  k_imu_weights   thread per block: UpdateImuWeights (vicalibrator.h:723-799, vc_imu_weights.hpp)
 //  k_chain_init    wavefront per frame: 9 x 9 diagonal block (visual tiles + two IMU blocks), coupling to the
 //                  next frame, dense border row W (9 x D) and gradient; damping; per-chunk sums of the
@@ -29,10 +32,68 @@ namespace vc {
 __device__ __forceinline__ ImuView imu_view(const DevView& v) { ImuView b = {v.imu_t, v.imu_w, v.imu_a, v.n_imu}; return b; }
 
 // ------------------------------------------------------------------------------------------ IMU Jacobian
-constexpr int kImuJacLds = 35 * 9 + 33 * 9 + 16;
-// Two IMU blocks per wavefront: 32 lanes carry the 32 derivative directions that need the dual propagation (the three
-// directions of the later frame's velocity do not -- d r / d v2 = -W^T rows 6..8, written directly), so a block fits a
-// half wave and the kernel, bound by per-lane latency at one wave per SIMD, needs half the waves.
+// Interval deltas (vc_imu.hpp, "delta form"): 16 lanes per interval, lane dd carries the values (dd = 0) or one derivative
+// direction (biases, scale factors, time offset) through one RK4 step from the identity state.  Intervals: the stored sample
+// intervals that fall inside the frames' time span, then two partial intervals per block.  Depends on the shared IMU parameters
+// only -- in a solve it runs behind the reduced solve, next to the chain's back-substitution.
+__global__ __launch_bounds__(256) void k_imu_delta(DevView v, int trial) {
+  const Ctrl* ct = v.ctrl;
+  if (ct->done || (!trial && !ct->need_lin)) return;
+  const int dd = threadIdx.x & 15;
+  const int g = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int n_s = v.n_imu - 1, n_blocks = v.n_frames - 1;
+  if (g >= n_s + 2 * n_blocks || dd >= kDeltaCols) return;
+  const int cur = trial ? 1 - ct->cur : ct->cur;
+  const double* im = v.imus[cur];
+  const double toff = im[14];
+  const ImuView buf = imu_view(v);
+  ImuRange rg; rg.valid = 0; rg.k0 = 0; rg.k1 = -1; rg.i0 = rg.i1 = 0; rg.first_end = rg.last_end = 0;
+  int kind = 0, i = g;
+  double t_start = 0.0, t_end = 0.0;
+  double* rec;
+  if (g < n_s) {
+    // a stored interval outside the span of the frames belongs to no block
+    if (dd == 13 || v.imu_t[g + 1] + toff < v.frame_time[0] || v.imu_t[g] + toff > v.frame_time[v.n_frames - 1]) return;
+    rec = v.imu_delta + (size_t)g * kDeltaStride;
+  } else {
+    const int e = g - n_s, s = e >> 1;
+    kind = 1 + (e & 1); i = 0;
+    t_start = v.frame_time[s]; t_end = v.frame_time[s + 1];
+    rg = imu_range(buf, t_start, t_end, toff);
+    if (!rg.valid || (kind == 2 && rg.k1 - rg.k0 + 1 < 1)) return;
+    rec = v.imu_delta_ab + (size_t)e * kDeltaStride;
+  }
+  double val[10], der[10];
+  imu_delta_direction(buf, kind, i, rg, t_start, t_end, im + 2, im + 8, toff, dd, val, der);
+#pragma unroll
+  for (int k = 0; k < 10; ++k) rec[dd * 10 + k] = dd ? der[k] : val[k];
+}
+
+// The blocks' deltas: 16 lanes per block (values + 13 dual directions), the block's interval records appended in order.  Poses
+// play no part here either: in a solve this runs behind k_imu_delta, still next to the back-substitution, and leaves one record
+// per block for the sweep.  An empty sample range is flagged by T = -1 in the record.
+__global__ __launch_bounds__(256) void k_imu_block(DevView v, int trial) {
+  const Ctrl* ct = v.ctrl;
+  if (ct->done || (!trial && !ct->need_lin)) return;
+  const int dd = threadIdx.x & 15;
+  const int s = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (s >= v.n_frames - 1 || dd >= kDeltaCols) return;
+  const int cur = trial ? 1 - ct->cur : ct->cur;
+  const double toff = v.imus[cur][14];
+  double val[11], der[11];
+  const int valid = imu_block_delta_direction(imu_view(v), v.frame_time[s], v.frame_time[s + 1], toff, v.imu_delta,
+                                              v.imu_delta_ab + (size_t)s * 2 * kDeltaStride, dd, val, der);
+  double* rec = v.imu_delta_blk + (size_t)s * kBlockDeltaStride;
+  if (!valid) { if (dd == 0) rec[10] = -1.0; return; }
+#pragma unroll
+  for (int k = 0; k < 11; ++k) rec[dd * 11 + k] = dd ? der[k] : val[k];
+}
+
+constexpr int kImuJacLds = 33 * 9 + 7;
+// The sweep proper.  Two IMU blocks per wavefront, lane = local column of the block: frame j's pose (6), frame j-1's pose (6) and
+// velocity (3), gravity (2), biases (6), scale factors (6), time offset -- 30 lanes put the block's delta on the start state and
+// run the residual's tail under one dual direction each (vc_imu.hpp: imu_block_final_direction); the three columns of frame j's
+// velocity are -W^T rows 6..8, written directly.  Then Cauchy(100) weight and the 33 x 33 weighted J^T J / J^T r of the block.
 // trial = 0: at the accepted state, when the control record asks for a linearisation; trial = 1: at the trial state into buffer
 // 1 - cur (cost = the block's trial cost; the blocks are the next linearisation if the step is accepted) -- see k_reproj_jac.
 __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
@@ -46,61 +107,28 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   const bool exists = s_raw < n_blocks;
   const int s = exists ? s_raw : n_blocks - 1;                 // a half past the end shadows the last block and stores nothing
   const int cur = trial ? 1 - ct->cur : ct->cur, j = s + 1;
-  double* Jg = sh + (wave * 2 + half) * kImuJacLds;            // [35][9] global-parameter partials
-  double* Jl = Jg + 35 * 9;                                    // [33][9] local columns: cur9 | prev9 | imu15
+  double* Jl = sh + (wave * 2 + half) * kImuJacLds;            // [33][9] local columns: cur9 | prev9 | imu15
   const double* T2 = v.poses[cur] + (size_t)j * kPoseStride;
   const double* T1 = v.poses[cur] + (size_t)(j - 1) * kPoseStride;
   const double* v2 = v.vel[cur] + (size_t)j * 4;
   const double* v1 = v.vel[cur] + (size_t)(j - 1) * 4;
   const double* im = v.imus[cur];
   const double* wq = v.wsqrtb[wr] + (size_t)s * 81;
+  const double* brec = v.imu_delta_blk + (size_t)s * kBlockDeltaStride;
   double r[9], dr[9];
-  const ImuView buf = imu_view(v);
-  const int dir = (l < 14) ? l : l + 3;                        // global directions 0..13 and 17..34
-  imu_block_direction(buf, v.frame_time[j - 1], v.frame_time[j], wq, v.rotation_only, T2, T1, v2, v1, im, im + 2,
-                      im + 8, im[14], dir, r, dr);
+  const int col = (l < 6) ? l : (l < 30 ? l + 3 : -1);         // lanes 30, 31 carry the values only
+  const bool valid = brec[10] >= 0.0;
+  imu_block_final_direction(valid, brec, wq, v.rotation_only, T2, T1, v2, v1, im, col, r, dr);
+  if (col >= 0) {
 #pragma unroll
-  for (int k = 0; k < 9; ++k) Jg[dir * 9 + k] = dr[k];
-  if (l < 3) {                                                 // later frame's velocity: r = W^T raw, raw[6 + l] = v_pred - v2
-    const bool valid = imu_range(buf, v.frame_time[j - 1], v.frame_time[j], im[14]).valid;
+    for (int k = 0; k < 9; ++k) Jl[col * 9 + k] = dr[k];
+  }
+  if (l < 3) {                                                 // frame j's velocity: r = W^T raw, raw[6 + l] = v_pred - v2
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const bool zeroed = v.rotation_only && (k < 3 || k >= 6);
-      Jg[(14 + l) * 9 + k] = (valid && !zeroed) ? -wq[(6 + l) * 9 + k] : 0.0;
+      Jl[(6 + l) * 9 + k] = (valid && !zeroed) ? -wq[(6 + l) * 9 + k] : 0.0;
     }
-  }
-  wave_lds_sync();
-  for (int col = l; col < 33; col += 32) {
-    double cv[9];
-    if (col < 6 || (col >= 9 && col < 15)) {
-      const bool is_cur = col < 6;
-      const int c = is_cur ? col : col - 9;
-      double P[42], pcol[7];
-      local_jac_se3(is_cur ? T2 : T1, P);
-      // column c of P by selects over static indices (a dynamically indexed local array would live in scratch memory)
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        double sel = P[i * 6];
-#pragma unroll
-        for (int cc = 1; cc < 6; ++cc) sel = (c == cc) ? P[i * 6 + cc] : sel;
-        pcol[i] = sel;
-      }
-      const double* src = Jg + (is_cur ? 0 : 7) * 9;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        double a = 0.0;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) a += src[i * 9 + k] * pcol[i];
-        cv[k] = a;
-      }
-    } else {
-      // cur velocity 6..8 <- global 14..16 ; prev velocity 15..17 <- global 17..19 ; imu 18..32 <- global 20..34
-      const int gidx = (col < 9) ? 14 + (col - 6) : (col < 18) ? 17 + (col - 15) : 20 + (col - 18);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) cv[k] = Jg[gidx * 9 + k];
-    }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Jl[col * 9 + k] = cv[k];
   }
   wave_lds_sync();
   double ss = 0.0;
@@ -1082,6 +1110,12 @@ __global__ __launch_bounds__(256) void k_chain_gram(DevView v) {
 }
 
 // ------------------------------------------------------------------------------------------ launchers
+void launch_imu_delta(const DevView& v, hipStream_t s, int trial) {
+  const int n = (v.n_imu - 1) + 2 * (v.n_frames - 1);
+  if (n <= 0 || v.n_frames < 2) return;
+  hipLaunchKernelGGL(k_imu_delta, dim3((n + 15) / 16), dim3(256), 0, s, v, trial);
+  hipLaunchKernelGGL(k_imu_block, dim3((v.n_frames - 1 + 15) / 16), dim3(256), 0, s, v, trial);
+}
 void launch_imu_jac(const DevView& v, int wr, hipStream_t s, int trial) {
   if (v.n_frames < 2) return;
   hipLaunchKernelGGL(k_imu_jac, dim3((v.n_frames - 1 + 7) / 8), dim3(256), 0, s, v, wr, trial);      // 8 blocks per workgroup

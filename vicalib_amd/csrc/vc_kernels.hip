@@ -1001,11 +1001,19 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
   if (v.imu_on && tid == (one_wave ? 63 : 64)) {     // g(2) b(6) sf(6) toff(1): plain additive parameters
     const double* iin = v.imus[cur];
     double* iout = v.imus[1 - cur];
-    for (int a = 0; a < 16; ++a) iout[a] = iin[a];
+    // all loads first, then the arithmetic, then the stores: interleaved, every store would hold back the next element's loads
+    // (the compiler cannot tell the two buffers apart) -- 15 dependent memory round trips in the tail of a critical-path kernel
+    double o[16], dlt[15];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) o[a] = iin[a];
+#pragma unroll
+    for (int a = 0; a < 15; ++a) { const int col = v.imu_param_col[a]; dlt[a] = (col >= 0) ? x[col >= 0 ? col : 0] : 0.0; }
+#pragma unroll
     for (int a = 0; a < 15; ++a) {
-      const int col = v.imu_param_col[a];
-      if (col >= 0) { const double d = x[col], o = iin[a]; step2 += d * d; x2 += o * o; iout[a] = o + d; }
+      if (v.imu_param_col[a] >= 0) { step2 += dlt[a] * dlt[a]; x2 += o[a] * o[a]; }
+      iout[a] = o[a] + dlt[a];
     }
+    iout[15] = o[15];
   }
   double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;      // totals, valid in thread 0
   if (one_wave) {
