@@ -215,9 +215,10 @@ struct vc_calibrator {
       d_imu_delta, d_imu_delta_ab, d_imu_delta_blk;
   size_t wsqrt_frames = 0;       // number of frames the device weight_sqrt_ array was initialised for
   int trace_cap = 0;
-  struct Pinned { Ctrl up; Ctrl down; double trace[64 * kTraceCols]; };
+  struct Pinned { Ctrl up; Ctrl down; double trace[64 * kTraceCols]; unsigned long long progress; };
   Pinned* pin = nullptr;        // page-locked staging (async copies without a bounce buffer)
-  int expected_passes = 8;       // passes the previous solve needed: size of the first batch of the next one
+  int expected_passes = 8;       // passes the previous solve needed: size of the first batch of the next one (batched schedule)
+  bool feed_passes = std::getenv("VICALIB_AMD_BATCHED") == nullptr;   // single process: feed passes against the device's progress word
   DBuf<unsigned char> d_mask;
   std::vector<int> h_tile_frame, h_tile_cam, h_tile_off, h_obs_index;   // h_obs_index: device corner -> host observation
   std::vector<int> cam_flags, cam_col0;
@@ -452,7 +453,8 @@ struct vc_calibrator {
     { const char* e = std::getenv("VICALIB_AMD_PRE_BACKSUB"); if (e && (e[0] == '0' || e[0] == '1')) dv.pre_backsub = e[0] - '0'; }   // test hook     // 1024 SIMDs x 2 resident waves: beyond that the per-tile repeat of the back-substitution is pure cost
     {
       // bottom-level groups of the chain elimination (launch_chain_solve_*: groups of 8 while more than 7 frames are active)
-      const int groups = (N > 7) ? (N - 1) / 8 + 1 : 1;
+      const int cm = chain_group_size();
+      const int groups = (N > cm - 1) ? (N - 1) / cm + 1 : 1;
       HIP_OK(d_grp_part.alloc((size_t)groups * kNumScal)); HIP_OK(d_wg_trial.alloc((size_t)std::max(1, (T + 3) / 4)));
       HIP_OK(d_wg_imu_trial.alloc((size_t)std::max(1, (N + 6) / 8)));
       dv.grp_part = d_grp_part.p; dv.wg_trial = d_wg_trial.p; dv.wg_imu_trial = d_wg_imu_trial.p; dv.n_chain_groups = groups;
@@ -495,7 +497,7 @@ struct vc_calibrator {
       const size_t nf = (size_t)std::max(N, 1);
       HIP_OK(d_cW.alloc(nf * 9 * dv.ldx)); HIP_OK(d_cdelta.alloc(nf * 9)); HIP_OK(d_cg.alloc(nf * 9)); HIP_OK(d_clam.alloc(nf * 9));
       HIP_OK(d_cdiag.alloc(nf * 9)); HIP_OK(d_cscale2.alloc(nf * 9));
-      for (int b = 0; b < 2; ++b) HIP_OK(d_rX[b].alloc((nf / 8 + 2) * 9 * dv.ldx));
+      for (int b = 0; b < 2; ++b) HIP_OK(d_rX[b].alloc((nf / chain_group_size() + 2) * 9 * dv.ldx));
     }
     dv.imu_t = d_imu_t.p; dv.imu_w = d_imu_w.p; dv.imu_a = d_imu_a.p; dv.frame_time = d_frame_time.p;
     dv.vel[0] = d_vel[0].p; dv.vel[1] = d_vel[1].p; dv.imus[0] = d_imus[0].p; dv.imus[1] = d_imus[1].p;
@@ -741,11 +743,45 @@ struct vc_calibrator {
     init_ctrl(&pin->up);
     { int rcu = upload_ctrl(&pin->up); if (rcu) return rcu; }
     if (dv.imu_on && dv.weights_on) { launch_imu_weights(dv, wcur, stream); wcur = 1 - wcur; }     // UpdateImuWeights() before ceres::Solve (vicalibrator.h:955)
-    // First batch = what the previous solve needed (repeated solves of similar problems: no wasted launches,
-    // one host sync per solve); then small top-up batches until the device reports `done`.
-    int batch = std::max(1, std::min(expected_passes, max_iters + 1)), guard = 0, n_enq = 0;
     const size_t trace_bytes = (size_t)std::min(trace_cap, 64) * kTraceCols * 8;
-    while (true) {
+    int guard = 0, n_enq = 0;
+    if (!sharded() && !use_graphs && feed_passes) {
+      // Single process: the deciding thread publishes (decisions << 32 | done) to a page-locked word after every decision and
+      // the host keeps kAhead passes queued beyond the last decision it has seen -- no stream synchronisation inside the
+      // solve (each one drains the queue: ~40 us of idle device), at most kAhead passes enqueued past the end (they return at
+      // their first instruction).  Enqueueing a pass takes the host a fraction of the pass's run time.
+      const int kAhead = dv.imu_on ? 1 : 2;      // vision-only passes are short and their decision is taken at the head of the next pass
+      volatile unsigned long long* prog = &pin->progress;
+      *prog = 0ull;
+      dv.host_progress = &pin->progress;
+      auto t_seen = std::chrono::steady_clock::now();
+      unsigned long long last = 0ull;
+      while (should_run) {
+        const unsigned long long f = *prog;
+        if ((unsigned)(f & 0xffffffffull) != 0u) break;                       // Ctrl::done
+        if (f != last) { last = f; t_seen = std::chrono::steady_clock::now(); }
+        const int decided = (int)(f >> 32);
+        if (n_enq >= max_iters + 8) break;
+        if (n_enq - decided <= kAhead) {
+          int rc = enqueue_pass(n_enq == 0); if (rc) { dv.host_progress = nullptr; return rc; }
+          ++n_enq; t_seen = std::chrono::steady_clock::now();
+        } else {
+          __builtin_ia32_pause();
+          if (std::chrono::steady_clock::now() - t_seen > std::chrono::seconds(30)) break;      // a stuck device: fall through to the synchronising read
+        }
+      }
+      dv.host_progress = nullptr;
+      finish_batch();
+      HIP_OK(hipMemcpyAsync(&pin->down, ctrl_result(), sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipMemcpyAsync(pin->trace, d_trace.p, trace_bytes, hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+      if (ktime_on) kt_collect();
+    }
+    // Sharded (every rank must run the same schedule: the passes contain collectives) and graph replay: batches.  First batch =
+    // what the previous solve needed (repeated solves of similar problems: no wasted launches, one host sync per solve); then
+    // small top-up batches until the device reports `done`.
+    int batch = std::max(1, std::min(expected_passes, max_iters + 1));
+    while (sharded() || use_graphs || !feed_passes || (!pin->down.done && should_run && n_enq < max_iters + 8)) {
       for (int b = 0; b < batch; ++b) {
         const bool first = (n_enq++ == 0);
         int rc = (first || sharded() || !use_graphs) ? enqueue_pass(first) : launch_pass_graph();

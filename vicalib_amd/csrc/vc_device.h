@@ -99,6 +99,8 @@ struct DevView {
   double* wg_imu_trial;            // (n_frames - 1 + 7) / 8: trial cost of the 8 blocks of a k_imu_jac workgroup
   int n_chain_groups;
   double* scal;                    // kNumScal (frame sums) + kNumScal (shared-parameter terms)
+  unsigned long long* host_progress;   // page-locked host word, (decisions taken << 32) | Ctrl::done, stored by the deciding thread after
+                                   // every decision: the host feeds passes against it without synchronising the stream (null: off)
   int* flags;                      // [0]: frame Cholesky failures, [1]: reduced Cholesky failure (per pass)
   Ctrl* ctrl;
   long long* dbg;                  // 32 cycle-counter stamps (profiling aid)
@@ -175,6 +177,7 @@ void launch_cam_sq(const DevView& v, double* out /*n_cams x 2: sum sq, count*/, 
 void launch_outlier_mask(const DevView& v, int state, const double* thresh /*device, n_cams*/, unsigned char* mask, hipStream_t s);
 
 // inertial path (vc_imu_kernels.hip)
+int chain_group_size();          // frames per group of the partitioned chain elimination (test hook: VICALIB_AMD_CHAIN_M)
 void launch_imu_delta(const DevView& v, hipStream_t s, int trial = 0);         // interval and block deltas under the IMU parameters of the accepted (0) / trial (1) state (two launches)
 void launch_imu_jac(const DevView& v, int wr, hipStream_t s, int trial = 0);   // wr: weight buffer to read; trial as for launch_reproj_jac; needs launch_imu_delta
 void launch_imu_weights(const DevView& v, int wr, hipStream_t s);          // reads wsqrtb[wr], writes wsqrtb[1 - wr];                   // weight_sqrt_ from the accepted state

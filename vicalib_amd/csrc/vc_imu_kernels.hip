@@ -21,6 +21,7 @@
 //  k_chain_back    back-substitution, one level per launch; the bottom level also writes the trial poses / velocities
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include "vc_math.hpp"
 #include "vc_imu.hpp"
 #include "vc_imu_weights.hpp"
@@ -1129,8 +1130,13 @@ void launch_imu_weights(const DevView& v, int wr, hipStream_t s) {
 }
 // Level schedule of the partitioned chain elimination: strides 1, m, m^2, ... while more than m - 1 frames are active, then
 // the top level (one wavefront eliminates the rest).  forward: bottom-up; backward: top-down.
+int chain_group_size() {
+  static int m = 0;
+  if (!m) { const char* e = std::getenv("VICALIB_AMD_CHAIN_M"); m = e ? std::max(2, std::min(kChainM, std::atoi(e))) : kChainM; }
+  return m;
+}
 static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
-  const int N = v.n_frames, m = kChainM;
+  const int N = v.n_frames, m = chain_group_size();
   if (N < 1) return;
   int strides[32], nl = 0;
   long st = 1;

@@ -1349,12 +1349,18 @@ __device__ void lm_decide_local(const DevView& v, Ctrl* c, const double* s, bool
   }
 }
 
+// the host's view of the loop: one system-scope store per decision (vc_calibrator.cpp: solve_once feeds passes against it)
+__device__ __forceinline__ void publish_progress(const DevView& v, const Ctrl& c) {
+  if (v.host_progress)
+    __hip_atomic_store(v.host_progress, ((unsigned long long)(unsigned)c.passes << 32) | (unsigned)c.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ void lm_decide(const DevView& v) {
   Ctrl local = *v.ctrl;          // one burst of loads, one burst of stores
   const bool fail = (v.flags[4 + 2 * v.par] != 0) || (v.flags[5 + 2 * v.par] != 0);
   v.flags[4 + 2 * v.par] = 0; v.flags[5 + 2 * v.par] = 0;
   lm_decide_local(v, &local, v.scal, fail, true);
   *v.ctrl = local;
+  publish_progress(v, local);
 }
 // ---- merged decision --------------------------------------------------------------------------------------------
 // The control record of the current pass from the previous pass's record: judge the pending trial point, or carry a finished
@@ -1414,7 +1420,7 @@ __device__ void merged_control(const DevView& v, Ctrl* out, double* red, bool wr
       lm_decide_local(v, &c, s, fail, writer);
       c.needs_decision = 0;
       *out = c;
-      if (writer) *v.ctrl = c;
+      if (writer) { *v.ctrl = c; publish_progress(v, c); }
     }
   } else if (tid == 0) {
     if (pdone) { *out = c; if (writer) *v.ctrl = c; }
