@@ -704,9 +704,9 @@ __global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int t
   __shared__ double An[81];
   __shared__ double Ls[81];
   CSTAMP(0);
-  const Ctrl* ct = v.ctrl;
-  if (ct->done) return;
-  CSTAMP(1);
+  // the control record is requested here and looked at after the first frame's image has been requested as well: a finished
+  // solve costs a few wasted loads, a running one saves the record's round trip at the head of every level
+  const int done = v.ctrl->done;
   const int lane = threadIdx.x;
   const int N = v.n_frames, D = v.D, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
   const long gs = (long)m * s;
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int t
     sub[ci] = e < 9 ? e : e < 18 ? e - 9 : e - 18;            // column inside the 9 x 9 block
   }
   if (first >= N) {            // a separator without interior frames: only its pending right contribution is folded in
-    if (!top && a < N) {
+    if (!done && !top && a < N) {
 #pragma unroll
       for (int ci = 0; ci < CPL; ++ci) {
         double* img = v.cW + (size_t)a * isz + pc[ci];
@@ -790,6 +790,8 @@ __global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int t
       }
     }
     request_next(first, 0);
+    if (done) return;
+    CSTAMP(1);
 #pragma unroll
     for (int ci = 0; ci < CPL; ++ci) {
 #pragma unroll
@@ -949,8 +951,7 @@ __global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int t
 __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int top, int lvl) {
   __shared__ double ds[192 + 8];
   __shared__ double dl[kChainM * 9];
-  const Ctrl* ct = v.ctrl;
-  if (ct->done) return;
+  const int done = v.ctrl->done;        // looked at once the level's inputs have been requested (see k_chain_fwd)
   const int lane = threadIdx.x;
   const int N = v.n_frames, D = v.D, ldw = v.ldw, ldx = v.ldx;
   const long gs = (long)m * s;
@@ -984,6 +985,7 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
     }
     t = acc;
   }
+  if (done) return;
   double my = 0.0;
   for (int i = q - 1; i >= 0; --i) {
     double y = t;
@@ -1010,7 +1012,7 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
   double gd = 0, dld = 0, step2 = 0, x2 = 0, g2 = 0, gmax = 0;
   if (lane < cnt) {
     const int f = base + lane;
-    const int cur = ct->cur;
+    const int cur = v.ctrl->cur;
     // pinned frames step with the reduced system's solution; their gradient / damping terms are counted there, and only the
     // owner (not the rank that holds the ghost copy) counts the step and parameter norms
     const bool pin_f = (f == 0 && v.pin_first), pin_l = (f == N - 1 && v.pin_last);
