@@ -185,15 +185,24 @@ def main():
     flops_jac = 1050.0 * n_obs_local
     bytes_res = 18.0 * n_obs_local + n_tiles * (64 + 8)
     imu_samples = len(prob.imu_t) if vi else 0
-    # IMU block (SURVEY 8(d) "IMU segment"): n_meas * 56 B in + 2 * 80 B states, out 9 + 9 x 35; ~n_meas * 4 stages * 36 lanes * 400 flop
+    # IMU sweep in delta form, counted as the kernels run it (dual number = value + one partial, ~2.5 flop per operation):
+    #   k_imu_delta: one RK4 step from the identity state per sample interval and lane (14 lanes: values + 13 directions), ~4 x 400 flop;
+    #                in 56 B of samples, out a 140-double record
+    #   k_imu_block: per block 14 lanes append its n_meas interval records (~265 flop each); in the records, out a 154-double record
+    #   k_imu_jac:   per block 30 lanes put the delta on the start state and run the residual's tail (~900 flop each), then the 33 x 33
+    #                weighted J^T J (9 x 33 x 33 x 2 flop); in the record, two states, the 9 x 9 weight; out 33 x 33 + 33 + 1 doubles
     n_meas = imu_samples / max(n_imu_blocks, 1) + 2
-    bytes_imu = n_imu_blocks * (n_meas * 56 + 160 + 8 * (9 + 9 * 35))
-    flops_imu = n_imu_blocks * n_meas * 4 * 36 * 400.0
+    n_int = max(imu_samples - 1, 0) + 2 * n_imu_blocks
+    flops_delta = n_int * 14 * 1600.0 + n_imu_blocks * 14 * n_meas * 265.0
+    bytes_delta = n_int * (56 + 1120.0) + n_imu_blocks * (n_meas * 1120.0 + 154 * 8)
+    flops_imu = n_imu_blocks * (30 * 900.0 + 9 * 33 * 33 * 2.0)
+    bytes_imu = n_imu_blocks * (154 * 8 + 2 * 12 * 8 + 81 * 8 + (33 * 33 + 34) * 8.0)
     # weight update: per RK4 step 16 sensitivity columns through 4 stages (~9 kflop) + Sigma <- F Sigma F^T + G R G^T (~5.2 kflop)
     flops_w = n_imu_blocks * n_meas * 14200.0
     bytes_w = n_imu_blocks * (n_meas * 56 + 160 + 2 * 81 * 8)
     algo = {"k_reproj_jac": ("mfma", flops_jac, bytes_jac), "k_trial": ("mfma", flops_jac, bytes_jac + n_tiles * 8 * 96 + n_frames_local * 8 * 48),
-            "k_imu_jac": ("mfma", flops_imu, bytes_imu), "k_imu_weights": ("mfma", flops_w, bytes_w)}
+            "k_imu_jac": ("mfma", flops_imu, bytes_imu), "k_imu_weights": ("mfma", flops_w, bytes_w),
+            "k_imu_delta+k_imu_block": ("mfma", flops_delta, bytes_delta)}
     kernels = {}
     for name, (cnt, avg_ms) in kt.items():
         e = {"launch_groups": cnt, "avg_ms": avg_ms, "ms_per_step": avg_ms * cnt / max(done, 1)}
@@ -204,7 +213,7 @@ def main():
                       "hbm_gbs": by / (avg_ms * 1e-3) / 1e9, "hbm_frac": by / (avg_ms * 1e-3) / 8e12})
         kernels[name] = e
     # the dominant kernel = the single kernel with the largest share of the step (launch groups of several kernels excluded)
-    single = [k for k in kernels if k.replace("(trial)", "") in algo]
+    single = [k for k in kernels if k.replace("(trial)", "") in algo and "+" not in k]
     dom = max(single, key=lambda k: kernels[k]["ms_per_step"]) if single else None
     roofline = None
     if dom:

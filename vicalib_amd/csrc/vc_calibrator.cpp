@@ -629,7 +629,7 @@ struct vc_calibrator {
         HIP_OK(hipEventRecord(ev_state, stream));
         HIP_OK(hipStreamWaitEvent(stream2, ev_state, 0));
         if (first_pass) {
-          KT2("k_imu_delta", launch_imu_delta(dv, stream2, 0)); KT2("k_imu_jac", launch_imu_jac(dv, wcur, stream2, 0));
+          KT2("k_imu_delta+k_imu_block", launch_imu_delta(dv, stream2, 0)); KT2("k_imu_jac", launch_imu_jac(dv, wcur, stream2, 0));
           HIP_OK(hipEventRecord(ev_imujac, stream2));       // ahead of the weight update: the chain does not read the weights
         }
         if (upd) KT2("k_imu_weights", launch_imu_weights(dv, wcur, stream2));
@@ -641,7 +641,7 @@ struct vc_calibrator {
         if (upd) KT("k_imu_weights", launch_imu_weights(dv, wcur, stream));
         if (first_pass) {
           KT("k_reproj_jac", launch_reproj_jac(dv, stream, 0));
-          KT("k_imu_delta", launch_imu_delta(dv, stream, 0)); KT("k_imu_jac", launch_imu_jac(dv, wcur, stream, 0));
+          KT("k_imu_delta+k_imu_block", launch_imu_delta(dv, stream, 0)); KT("k_imu_jac", launch_imu_jac(dv, wcur, stream, 0));
         }
       }
       KT("chain_forward", launch_chain_solve_a(dv, stream));
@@ -659,7 +659,7 @@ struct vc_calibrator {
       if (!serial_weights) {
         HIP_OK(hipEventRecord(ev_reduced, stream));
         HIP_OK(hipStreamWaitEvent(stream2, ev_reduced, 0));
-        KT2("k_imu_delta(trial)", launch_imu_delta(dv, stream2, 1));
+        KT2("k_imu_delta+k_imu_block(trial)", launch_imu_delta(dv, stream2, 1));
       }
       KT("chain_backward", launch_chain_solve_b(dv, stream));
       // trial point: both sweeps in trial mode on the main stream, the IMU blocks with the weights this pass has just updated
@@ -669,7 +669,7 @@ struct vc_calibrator {
       if (!serial_weights) HIP_OK(hipEventRecord(ev_weights, stream2));
       KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
       if (!serial_weights) HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0));
-      else KT("k_imu_delta(trial)", launch_imu_delta(dv, stream, 1));
+      else KT("k_imu_delta+k_imu_block(trial)", launch_imu_delta(dv, stream, 1));
       KT("k_imu_jac(trial)", launch_imu_jac(dv, wcur, stream, 1));
       if (sharded()) {
         launch_final(dv, 1, stream);
@@ -745,12 +745,13 @@ struct vc_calibrator {
     if (dv.imu_on && dv.weights_on) { launch_imu_weights(dv, wcur, stream); wcur = 1 - wcur; }     // UpdateImuWeights() before ceres::Solve (vicalibrator.h:955)
     const size_t trace_bytes = (size_t)std::min(trace_cap, 64) * kTraceCols * 8;
     int guard = 0, n_enq = 0;
-    if (!sharded() && !use_graphs && feed_passes) {
-      // Single process: the deciding thread publishes (decisions << 32 | done) to a page-locked word after every decision and
+    const bool feed = !sharded() && !use_graphs && feed_passes && dv.imu_on;
+    if (feed) {
+      // Single process, visual-inertial passes (19 launches, ~270 us): the deciding thread publishes (decisions << 32 | done) to a page-locked word after every decision and
       // the host keeps kAhead passes queued beyond the last decision it has seen -- no stream synchronisation inside the
       // solve (each one drains the queue: ~40 us of idle device), at most kAhead passes enqueued past the end (they return at
       // their first instruction).  Enqueueing a pass takes the host a fraction of the pass's run time.
-      const int kAhead = dv.imu_on ? 1 : 2;      // vision-only passes are short and their decision is taken at the head of the next pass
+      constexpr int kAhead = 1;
       volatile unsigned long long* prog = &pin->progress;
       *prog = 0ull;
       dv.host_progress = &pin->progress;
@@ -777,11 +778,13 @@ struct vc_calibrator {
       HIP_OK(hipStreamSynchronize(stream));
       if (ktime_on) kt_collect();
     }
-    // Sharded (every rank must run the same schedule: the passes contain collectives) and graph replay: batches.  First batch =
+    // Sharded (every rank must run the same schedule: the passes contain collectives), graph replay and the vision-only path
+    // (four launches of ~13 us per pass, a handful of passes per solve: measured 60 vs 63 us per iteration at cfg2 -- the
+    // passes fed past the end cost more there than one synchronisation): batches.  First batch =
     // what the previous solve needed (repeated solves of similar problems: no wasted launches, one host sync per solve); then
     // small top-up batches until the device reports `done`.
     int batch = std::max(1, std::min(expected_passes, max_iters + 1));
-    while (sharded() || use_graphs || !feed_passes || (!pin->down.done && should_run && n_enq < max_iters + 8)) {
+    while (!feed || (!pin->down.done && should_run && n_enq < max_iters + 8)) {
       for (int b = 0; b < batch; ++b) {
         const bool first = (n_enq++ == 0);
         int rc = (first || sharded() || !use_graphs) ? enqueue_pass(first) : launch_pass_graph();

@@ -366,8 +366,9 @@ template <class T> VC_HD void imu_delta_append(DeltaAcc<T>* A, const PoseV<T>& d
 constexpr int kBlockDeltaStride = kDeltaCols * 11;     // one block: [column][Q 4, P 3, V 3, T]
 
 struct DeltaRec { double v[10], d[10]; };
+// (unconditional loads, the partial selected afterwards: a conditional load is a branch around every element on the device)
 VC_HD void imu_delta_load(const double* rec, int dcol, DeltaRec* o) {
-  for (int k = 0; k < 10; ++k) { o->v[k] = rec[k]; o->d[k] = (dcol > 0) ? rec[dcol * 10 + k] : 0.0; }
+  for (int k = 0; k < 10; ++k) { o->v[k] = rec[k]; const double d = rec[dcol * 10 + k]; o->d[k] = (dcol > 0) ? d : 0.0; }
 }
 // Part `part` of `n_parts` of the block's delta along direction dd (as imu_delta_direction): the block's intervals cut into
 // n_parts contiguous runs, the run's intervals appended in order from the identity (appending is associative; the kernel runs
@@ -384,10 +385,12 @@ VC_HD int imu_block_delta_part(const ImuView& buf, double t_start, double t_end,
   // interior samples) its record 1, those in between the stored intervals k0 + m - 2
   const int m_lo = 1 + (part * n_steps) / n_parts, m_hi = 1 + ((part + 1) * n_steps) / n_parts;      // [m_lo, m_hi)
   auto request = [&](int m, DeltaRec* o) {
-    if (m >= m_hi) return;
-    if (m == 1) imu_delta_load(delta_ab, dd, o);
-    else if (m == n_meas - 1) imu_delta_load(delta_ab + kDeltaStride, dd, o);
-    else imu_delta_load(delta_samples + (size_t)(rg.k0 + m - 2) * kDeltaStride, dcol_s, o);
+    // one address, one column, no branch: a request past the run re-reads the block's last interval (never used)
+    const int mc = m < n_meas - 1 ? m : n_meas - 1;
+    const bool ends = (mc == 1) || (mc == n_meas - 1);
+    const double* rec = (mc == 1) ? delta_ab : (mc == n_meas - 1) ? delta_ab + kDeltaStride
+                                                                   : delta_samples + (size_t)(rg.k0 + mc - 2) * kDeltaStride;
+    imu_delta_load(rec, ends ? dd : dcol_s, o);
   };
   DeltaRec A, B, C;
   for (int k = 0; k < 10; ++k) { A.v[k] = A.d[k] = B.v[k] = B.d[k] = C.v[k] = C.d[k] = 0.0; }
@@ -441,12 +444,11 @@ VC_HD void imu_block_final_direction(int valid, const double* block_rec, const d
   if (!valid) { for (int i = 0; i < 9; ++i) { r[i] = 0.0; dr[i] = 0.0; } return; }
   const int dcol = (col >= 20) ? col - 19 : 0;                 // biases 1..6, scale factors 7..12, time offset 13
   D1 Q[4], P[3], V[3];
-  for (int k = 0; k < 4; ++k) Q[k] = mk(block_rec[k], dcol ? block_rec[dcol * 11 + k] : 0.0);
-  for (int k = 0; k < 3; ++k) {
-    P[k] = mk(block_rec[4 + k], dcol ? block_rec[dcol * 11 + 4 + k] : 0.0);
-    V[k] = mk(block_rec[7 + k], dcol ? block_rec[dcol * 11 + 7 + k] : 0.0);
-  }
-  const D1 Tt = mk(block_rec[10], dcol ? block_rec[dcol * 11 + 10] : 0.0);
+  double bd[11];
+  for (int k = 0; k < 11; ++k) { const double d = block_rec[dcol * 11 + k]; bd[k] = dcol ? d : 0.0; }      // (unconditional loads)
+  for (int k = 0; k < 4; ++k) Q[k] = mk(block_rec[k], bd[k]);
+  for (int k = 0; k < 3; ++k) { P[k] = mk(block_rec[4 + k], bd[4 + k]); V[k] = mk(block_rec[7 + k], bd[7 + k]); }
+  const D1 Tt = mk(block_rec[10], bd[10]);
   // seeds: poses move along T exp(delta) (local_jac_se3), everything else is a plain coordinate
   D1 T2D[7], v2D[3], gD[2], gw[3], q0[4], p0[3], v0[3];
   {
