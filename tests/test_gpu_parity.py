@@ -731,3 +731,22 @@ def test_solution_covariance_visual_inertial_and_fixed_intrinsics():
     assert names2 == ["c[0].q_ck:(4)", "c[0].p_ck:(3)"] and cov2.shape == (7, 7)
     assert np.all(np.diag(cov2)[4:] > 0)
     assert np.all(np.diag(cov2)[4:] < np.diag(cov)[4:7])     # fewer free parameters: tighter extrinsics
+
+
+def test_pass_feeding_and_batched_schedules_give_the_same_trace(monkeypatch):
+    """Visual-inertial solves feed passes against the progress word the deciding thread publishes; VICALIB_AMD_BATCHED=1
+    brings back the batch-and-synchronise schedule.  Same passes either way: identical traces and parameters, bit for bit."""
+    p = synth.generate(synth.Config(models=("kb4",), n_frames=60, imu=True, seed=5))
+    out = []
+    for batched in (False, True):
+        if batched:
+            monkeypatch.setenv("VICALIB_AMD_BATCHED", "1")
+        else:
+            monkeypatch.delenv("VICALIB_AMD_BATCHED", raising=False)
+        cal = ViCalibrator(0).load_problem(p)
+        cal.Solve()
+        out.append((cal.trace().copy(), cal.GetCamera(0)[0].copy(), cal.GetBiases().copy(), cal.time_offset()))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    assert out[0][3] == out[1][3]

@@ -214,6 +214,7 @@ struct vc_calibrator {
       d_cW, d_cdelta, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init, d_rX[2], d_grp_part, d_wg_trial, d_wg_imu_trial,
       d_imu_delta, d_imu_delta_ab, d_imu_delta_blk;
   size_t wsqrt_frames = 0;       // number of frames the device weight_sqrt_ array was initialised for
+  size_t imu_uploaded = 0; double imu_uploaded_last = 0.0;      // sample count / last time stamp of the device copy of the IMU samples
   int trace_cap = 0;
   struct Pinned { Ctrl up; Ctrl down; double trace[64 * kTraceCols]; unsigned long long progress; };
   Pinned* pin = nullptr;        // page-locked staging (async copies without a bounce buffer)
@@ -301,6 +302,10 @@ struct vc_calibrator {
   int upload() {
     HIP_OK(hipSetDevice(device));
     drop_graphs();
+    const bool up_timing = std::getenv("VICALIB_AMD_TIMING") != nullptr;
+    const auto up_t0 = std::chrono::steady_clock::now();
+    auto up_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - up_t0).count(); };
+    double up_a = 0, up_b = 0, up_c = 0;
     const int Nown = (int)frames.size(), C = (int)cams.size();
     if (C > kMaxCams) return VC_ERR_UNSUPPORTED;
     // ---- frame-sharded IMU chain: this rank's first frame is a separator of the reduced system (rank > 0) and the
@@ -357,6 +362,7 @@ struct vc_calibrator {
       HIP_OK(hipStreamSynchronize(stream));        // the staging vectors go out of scope
       obs_dirty = false;
     }
+    up_a = up_ms();
     const size_t n_active = h_obs_index.size();
     const int T = (int)h_tile_frame.size();
     std::vector<int> frame_tile_off(N + 1, T), frame_cam_tile((size_t)N * std::max(C, 1), -1);
@@ -369,9 +375,16 @@ struct vc_calibrator {
     const int D0 = build_layout(col_cam, col_local);
     const int D = D0 + (shard_imu ? 9 * (world - 1) : 0);          // + one 9-column separator per shard boundary
     col_cam.resize(D, -1); col_local.resize(D, 0);
+    // the widest column layout this problem can reach (every camera and IMU parameter free): the stage machine only widens the
+    // layout, and growing a multi-megabyte buffer is a free + malloc of a few hundred microseconds -- the big ones get their
+    // final capacity at the first upload
+    int Dmax = (imu_on() ? 15 : 0) + (shard_imu ? 9 * (world - 1) : 0);
+    for (int c = 0; c < C; ++c) Dmax += 6 + cams[c].nk;
+    Dmax = std::max(Dmax, D);
     // the reduced solve lives in LDS (packed lower triangle + 12 KB of staging), the chain Gram handles 12 column tiles
     if (((size_t)(D + 1) * (D + 2) / 2 + 3 * (D + 1) + 528) * sizeof(double) + 13 * 1024 > 160 * 1024 || D + 1 > 12 * 16) return VC_ERR_UNSUPPORTED;
     for (int c = 0; c < C; ++c) cam_model[c] = cams[c].model;
+    up_b = up_ms();
     // ---- upload ---------------------------------------------------------------------------------
     {   // tile headers: depend on the tile layout and on this stage's column layout
       std::vector<TileHdr> hdr((size_t)T);
@@ -411,6 +424,7 @@ struct vc_calibrator {
     } HIP_OK(d_tile_trial.alloc((size_t)std::max(T, 1) * 2));
     HIP_OK(d_Y.alloc((size_t)std::max(T, 1) * kYStride)); HIP_OK(d_fr.alloc((size_t)std::max(N, 1) * kFrStride));
     HIP_OK(d_fdiag.alloc((size_t)std::max(N, 1) * 6)); HIP_OK(d_fscale2.alloc((size_t)std::max(N, 1) * 6));
+    HIP_OK(d_part.alloc((size_t)n_chunks * ((size_t)Dmax * Dmax + Dmax + C * kGStride + kGStride + 2)));
     HIP_OK(d_part.alloc((size_t)n_chunks * part_stride)); HIP_OK(d_part_total.alloc((size_t)part_stride * ((n_chunks + 63) / 64))); HIP_OK(d_Sbuf.alloc((size_t)D * D + 3 * D + 2));
     HIP_OK(d_sdiag.alloc(D)); HIP_OK(d_sscale2.alloc(D)); HIP_OK(d_slam.alloc(D)); HIP_OK(d_delta_s.alloc(D));
     HIP_OK(d_fpart.alloc((size_t)std::max(N, 1) * kNumScal));
@@ -483,7 +497,10 @@ struct vc_calibrator {
     HIP_OK(d_sep_strip.alloc((size_t)2 * 9 * dv.ldw)); dv.sep_strip = d_sep_strip.p;
     HIP_OK(d_gath.alloc((size_t)world * kNumScal)); dv.gath = d_gath.p; dv.rank = rank; dv.world = world;
     if (dv.imu_on) {
-      HIP_OK(d_imu_t.upload(imu_t, stream)); HIP_OK(d_imu_w.upload(imu_w, stream)); HIP_OK(d_imu_a.upload(imu_a, stream));
+      if (imu_uploaded != imu_t.size() || imu_uploaded_last != (imu_t.empty() ? 0.0 : imu_t.back())) {      // the samples do not change from stage to stage
+        HIP_OK(d_imu_t.upload(imu_t, stream)); HIP_OK(d_imu_w.upload(imu_w, stream)); HIP_OK(d_imu_a.upload(imu_a, stream));
+        imu_uploaded = imu_t.size(); imu_uploaded_last = imu_t.empty() ? 0.0 : imu_t.back();
+      }
       const size_t ns = (size_t)std::max(N - 1, 1);
       if (wsqrt_frames != (size_t)N) {          // initial weight 500 * I (vicalibrator.h:616); later stages keep the current weights
         std::vector<double> w(ns * 81, 0.0);
@@ -495,6 +512,11 @@ struct vc_calibrator {
       HIP_OK(d_imu_delta.alloc((size_t)std::max<size_t>(imu_t.size(), 2) * kDeltaStride)); HIP_OK(d_imu_delta_ab.alloc(ns * 2 * kDeltaStride));
       HIP_OK(d_imu_delta_blk.alloc(ns * kBlockDeltaStride));
       const size_t nf = (size_t)std::max(N, 1);
+      {
+        const int ldw_max = (((Dmax + 1 + 15) / 16) * 16 % 32 == 0) ? ((Dmax + 1 + 15) / 16) * 16 + 16 : ((Dmax + 1 + 15) / 16) * 16;
+        HIP_OK(d_cW.alloc(nf * 9 * (ldw_max + 32)));
+        for (int b = 0; b < 2; ++b) HIP_OK(d_rX[b].alloc((nf / chain_group_size() + 2) * 9 * (ldw_max + 32)));
+      }
       HIP_OK(d_cW.alloc(nf * 9 * dv.ldx)); HIP_OK(d_cdelta.alloc(nf * 9)); HIP_OK(d_cg.alloc(nf * 9)); HIP_OK(d_clam.alloc(nf * 9));
       HIP_OK(d_cdiag.alloc(nf * 9)); HIP_OK(d_cscale2.alloc(nf * 9));
       for (int b = 0; b < 2; ++b) HIP_OK(d_rX[b].alloc((nf / chain_group_size() + 2) * 9 * dv.ldx));
@@ -507,7 +529,9 @@ struct vc_calibrator {
     dv.cW = d_cW.p; dv.cdelta = d_cdelta.p; dv.cg = d_cg.p;
     dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p;
     for (int b = 0; b < 2; ++b) dv.rX[b] = d_rX[b].p;
+    up_c = up_ms();
     HIP_OK(hipStreamSynchronize(stream));   // the staging vectors above go out of scope
+    if (up_timing) std::fprintf(stderr, "[vicalib_amd]   upload: observations %.3f, layout %.3f, copies + allocations %.3f, drain %.3f ms\n", up_a, up_b - up_a, up_c - up_b, up_ms() - up_c);
     device_dirty = false;
     return VC_OK;
   }
@@ -1014,7 +1038,7 @@ int vc_clear(vc_calibrator* h) {
   h->cams.clear(); h->frames.clear(); h->o_frame.clear(); h->o_cam.clear(); h->o_pid.clear(); h->pts.clear(); h->o_pc.clear(); h->o_removed.clear();
   h->mse = 0; h->num_iterations = 0; h->is_bias_active = false; h->is_scale_active = false; h->is_inertial_active = false;
   h->is_visual_active = true; h->rotation_only = true; h->is_finished = false; h->gravity_initialized = false;
-  h->outliers_removed = false; h->vis_mult = 0; h->imu_mult = 0; h->wsqrt_frames = 0; h->imu_w.clear(); h->imu_a.clear(); h->imu_t.clear(); h->imu_end_time = -1.0; h->trace.clear(); h->stage = 0; h->device_dirty = true; h->obs_dirty = true;
+  h->outliers_removed = false; h->vis_mult = 0; h->imu_mult = 0; h->wsqrt_frames = 0; h->imu_w.clear(); h->imu_a.clear(); h->imu_t.clear(); h->imu_uploaded = 0; h->imu_end_time = -1.0; h->trace.clear(); h->stage = 0; h->device_dirty = true; h->obs_dirty = true;
   return VC_OK;
 }
 
