@@ -71,7 +71,7 @@ void hh_so3_plus(const double* q, const double* w, double* o) { so3_plus(q, w, o
 void hh_imu_block(int n, const double* t, const double* w, const double* a, double t_start, double t_end, const double* w_sqrt,
                   int rotation_only, const double* T2, const double* T1, const double* v2, const double* v1, const double* gdir,
                   const double* b, const double* sf, double toff, double* r, double* J) {
-  ImuView buf = {t, w, a, n};
+  ImuView buf = {t, w, a, n, imu_average_dt(t, n)};
   double Jg[35][9];
   for (int d = 0; d < 35; ++d) imu_block_direction(buf, t_start, t_end, w_sqrt, rotation_only, T2, T1, v2, v1, gdir, b, sf, toff, d, r, Jg[d]);
   double P2[42], P1[42];
@@ -91,7 +91,7 @@ void hh_imu_block(int n, const double* t, const double* w, const double* a, doub
 void hh_imu_block_deltas(int n, const double* t, const double* w, const double* a, double t_start, double t_end, const double* w_sqrt,
                          int rotation_only, const double* T2, const double* T1, const double* v2, const double* v1, const double* gdir,
                          const double* b, const double* sf, double toff, double* r, double* J) {
-  ImuView buf = {t, w, a, n};
+  ImuView buf = {t, w, a, n, imu_average_dt(t, n)};
   std::vector<double> ds((size_t)(n - 1) * kDeltaStride, 0.0), dab(2 * kDeltaStride, 0.0);
   const ImuRange rg = imu_range(buf, t_start, t_end, toff);
   for (int i = 0; i + 1 < n; ++i)
@@ -128,7 +128,7 @@ void hh_imu_block_deltas(int n, const double* t, const double* w, const double* 
 void hh_imu_weight(int n, const double* t, const double* w, const double* a, double t_start, double t_end, double toff,
                    const double* T1, const double* v1, const double* T2, const double* b, const double* sf, const double* gdir,
                    double gs, double as, double* w_sqrt) {
-  ImuView buf = {t, w, a, n};
+  ImuView buf = {t, w, a, n, imu_average_dt(t, n)};
   imu_weight_sqrt(buf, t_start, t_end, toff, T1, v1, T2, b, sf, gdir, gs, as, w_sqrt);
 }
 int hh_chol6(double* M) { return chol_small<6>(M) ? 1 : 0; }

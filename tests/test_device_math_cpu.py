@@ -150,6 +150,21 @@ def test_imu_block_lane_duals_match_oracle():
             np.testing.assert_allclose(r2, r, rtol=1e-11, atol=1e-11 * max(1.0, np.abs(r).max()))
             np.testing.assert_allclose(J2, J, rtol=1e-10, atol=1e-10 * np.abs(J).max())
             np.testing.assert_allclose(J2, J0, rtol=1e-8, atol=1e-8 * np.abs(J0).max())
+    # frames exactly on shifted sample times (what synthetic sequences produce at offsets that are multiples of the sample period):
+    # the reference's look-up walks up to the sample from its index guess and brackets it with weight 1, the zero-length interval
+    # behind it is skipped, and the time offset loses its grip on that end (oracle: column 32 exactly zero when both ends coincide)
+    for toff_x in (-0.05, -0.26, 0.05, 0.1, -0.005):
+        o.set_imu_state(b, sfac, g, toff_x)
+        for j in (1, 4, o.n_frames - 1):
+            r0, J0 = o.imu_block(j)
+            T2, v2 = o.frame(j); T1, v1 = o.frame(j - 1)
+            for fn in (H.hh_imu_block, H.hh_imu_block_deltas):
+                r = np.zeros(9); J = np.zeros((9, 33))
+                fn(len(p.imu_t), d(p.imu_t), d(p.imu_gyro), d(p.imu_accel), C.c_double(p.frame_time[j - 1]), C.c_double(p.frame_time[j]),
+                   d(W[j - 1]), 0, d(T2), d(T1), d(v2), d(v1), d(g), d(b), d(sfac), C.c_double(toff_x), d(r), d(J))
+                np.testing.assert_allclose(r, r0, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(r0).max()))
+                np.testing.assert_allclose(J, J0, rtol=1e-8, atol=1e-8 * max(np.abs(J0).max(), 1e-300))
+    o.set_imu_state(b, sfac, g, toff)
     # delta form against the lane duals for every block under time offsets that move the sample ranges (clamped ends included)
     W9 = np.ascontiguousarray(np.eye(9) * 3.0 + 0.1 * np.arange(81).reshape(9, 9) / 81.0)
     for toff_x in (-0.031, -0.0007, 0.0, 0.0123, 0.0449, 0.2):

@@ -376,6 +376,42 @@ def test_imu_blocks_match_oracle(rot_only):
         np.testing.assert_allclose(g[j - 1], go, rtol=1e-7, atol=1e-9 * np.abs(go).max())
 
 
+@pytest.mark.parametrize("frame_rate,imu_rate,toff", [(30.0, 1000.0, 0.0031), (10.0, 25.0, -0.013), (20.0, 20.0, 0.0), (20.0, 21.0, 0.02),
+                                                      (20.0, 200.0, -0.26), (20.0, 200.0, 0.049999)])
+def test_imu_blocks_match_oracle_across_sample_rates_and_offsets(frame_rate, imu_rate, toff):
+    """The delta form of the IMU sweep (k_imu_delta / k_imu_block / k_imu_jac) against the oracle's integrated Dual<35>
+    block where the interval bookkeeping is stressed: 33 samples per frame, 2.5, one or fewer (blocks whose range holds no interior
+    sample: the single interval from the interpolated first to the interpolated last element), an offset that pushes the first
+    blocks off the start of the sample stream (empty ranges: zero blocks) and one that lands a frame on a sample time."""
+    p = synth.generate(synth.Config(models=("kb4",), n_frames=14, imu=True, seed=9, frame_rate=frame_rate, imu_rate=imu_rate))
+    gt = p.imu_gt
+    cal = ViCalibrator(0).load_problem(p, init=False)
+    orc = ol.Oracle().load(p, init=False)
+    orc.set_options(calibrate_imu=True)
+    b0 = np.concatenate([gt["bg"], gt["ba"]]) * 0.8; s0 = np.concatenate([gt["sg"], gt["sa"]]) * 1.01
+    orc.set_flags(True, True, False, True)
+    orc.set_imu_state(b0, s0, np.array([0.01, -0.02]), toff)
+    cal.SetOptimizationFlags(True, True, False, True)
+    cal.SetBiases(b0); cal.SetScaleFactor(s0); cal.SetTimeOffset(toff); cal.SetGravity(np.array([0.01, -0.02]))
+    orc.prepare(vis_mult=1, imu_mult=1)
+    cal.linearize()
+    H, g, c = cal.imu_blocks()
+    perm = list(range(0, 6)) + [12, 13, 14] + list(range(6, 12)) + [15, 16, 17] + list(range(18, 33))
+    n_zero = 0
+    for j in range(1, orc.n_frames):
+        r, J = orc.imu_block(j)
+        J = J[:, perm]
+        s = float(r @ r)
+        n_zero += s == 0.0
+        rho = 1e4 * np.log(1.0 + s / 1e4); w = 1.0 / (1.0 + s / 1e4)
+        np.testing.assert_allclose(c[j - 1], rho, rtol=1e-6, atol=1e-12)
+        Ho = w * J.T @ J; go = w * J.T @ r
+        np.testing.assert_allclose(H[j - 1], Ho, rtol=1e-7, atol=1e-9 * max(np.abs(Ho).max(), 1e-300))
+        np.testing.assert_allclose(g[j - 1], go, rtol=1e-7, atol=1e-9 * max(np.abs(go).max(), 1e-300))
+    if toff < -0.2:
+        assert n_zero >= 2          # the first blocks start before the first sample: no range, no residual (HasElement, interpolation-buffer.h:122)
+
+
 @pytest.mark.parametrize("n_frames,models", [(n, ("kb4",)) for n in (2, 3, 7, 8, 9, 15, 16, 17, 57, 63, 64, 65, 130)] +
                          [(17, ("poly3",) * 4), (9, ("fov", "kb4") * 4), (66, ("fov", "kb4") * 4)])
 def test_chain_elimination_matches_dense_schur_complement(n_frames, models):

@@ -488,6 +488,7 @@ struct vc_calibrator {
     dv.imu_on = imu_on() ? 1 : 0; dv.rotation_only = rotation_only ? 1 : 0;
     dv.weights_on = (is_inertial_active && !rotation_only) ? 1 : 0;
     dv.n_imu = (int)imu_t.size();
+    dv.imu_avg_dt = imu_average_dt(imu_t.data(), (int)imu_t.size());
     dv.gyro_sigma = gyro_sigma; dv.accel_sigma = accel_sigma;
     for (int a = 0; a < 15; ++a) dv.imu_param_col[a] = imu_param_col[a];
     dv.ldw = (((D + 1 + 15) / 16) * 16 % 32 == 0) ? ((D + 1 + 15) / 16) * 16 + 16 : ((D + 1 + 15) / 16) * 16;
@@ -1294,7 +1295,7 @@ int vc_get_integration_poses(vc_calibrator* h, int id, double* poses, int max_po
   std::lock_guard<std::mutex> lk(h->result_mutex);
   if (!(h->is_inertial_active && !h->rotation_only)) return 0;
   if (id + 1 >= (int)h->frames.size()) return 0;
-  const ImuView buf = {h->imu_t.data(), h->imu_w.data(), h->imu_a.data(), (int)h->imu_t.size()};
+  const ImuView buf = {h->imu_t.data(), h->imu_w.data(), h->imu_a.data(), (int)h->imu_t.size(), imu_average_dt(h->imu_t.data(), (int)h->imu_t.size())};
   const HostFrame& f1 = h->frames[id];
   const HostFrame& f2 = h->frames[id + 1];
   const ImuRange rg = imu_range(buf, f1.time, f2.time, h->time_offset);

@@ -115,6 +115,7 @@ struct DevView {
   const double* imu_w;             // n_imu x 3 gyro
   const double* imu_a;             // n_imu x 3 accel
   const double* frame_time;        // n_frames
+  double imu_avg_dt;               // InterpolationBufferT::average_dt_ of the sample stream (vc_imu.hpp: imu_average_dt)
   double* vel[2];                  // n_frames x 4, double-buffered like poses
   double* imus[2];                 // 16: g(2) b(6) sf(6) toff(1) pad
   int imu_param_col[15];           // shared column of g0 g1 b0..5 sf0..5 toff, -1 = constant

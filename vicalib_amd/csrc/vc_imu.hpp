@@ -121,7 +121,14 @@ template <class T> VC_HD void tse3_log(const T* X, T* d) {
 }
 
 // ---- sample range (interpolation-buffer.h:100-226) ----------------------------------------------------
-struct ImuView { const double* t; const double* w; const double* a; int n; };   // w, a: n x 3
+struct ImuView { const double* t; const double* w; const double* a; int n; double avg_dt; };   // w, a: n x 3; avg_dt: imu_average_dt
+// InterpolationBufferT::average_dt_ as AddElement accumulates it (interpolation-buffer.h:70-85): the running mean of the sample
+// spacings, the first sample counted with spacing 0.  GetElement's first guess of an index divides by it.
+inline double imu_average_dt(const double* t, int n) {
+  double avg = 0.0;
+  for (int i = 0; i < n; ++i) { const double dt = i ? t[i] - t[i - 1] : 0.0; avg = (avg * (double)i + dt) / (double)(i + 1); }
+  return avg;
+}
 template <class T> struct Meas { T w[3], a[3], time; };
 
 // bracketing interval [i, i+1] of image-clock time `time` under offset `off` (samples shifted by +off): the largest i <= n - 2
@@ -152,23 +159,43 @@ template <class T> VC_HD void imu_shift(const ImuView& b, int i, T off, Meas<T>*
 }
 // Range description: first = element(t0), interior samples k0 .. k1 (inclusive, may be empty), last = element(t1).
 struct ImuRange { int valid; int i0, first_end; int k0, k1; int i1, last_end; };   // *_end: 1 = clamp to an end sample
-VC_HD void imu_element_index(const ImuView& b, double time, double off, int* idx, int* end_clamp) {
-  // GetElement :160-204: clamp to the first / last sample outside the buffer, bracketing interval inside
-  if (b.t[0] + off > time) { *idx = 0; *end_clamp = 1; return; }
-  if (b.t[b.n - 1] + off <= time) { *idx = b.n - 1; *end_clamp = 1; return; }
-  *idx = imu_bracket(b, time, off); *end_clamp = 0;
+// GetElement :160-204 without its walk.  The reference guesses an index -- (time - start + offset) / average_dt, the offset with that
+// sign -- and walks from there to the bracketing pair; where it ends up is the pair [i, i + 1] with t[i] + off <= time < t[i + 1] + off
+// (i = imu_bracket), EXCEPT when `time` falls exactly on a shifted sample and the walk came from below: the forward walk stops one
+// pair early, at [i - 1, i] with interpolation weight 1.  Same measurement values, but the interval that follows has length zero
+// and is skipped (ceres-cost-functions.h:150-152), and with it the time offset's influence through that end -- frames that
+// sit exactly on shifted sample times are what synthetic sequences produce.  The clamps to the first / last sample follow the
+// reference as well.  last_le: the largest sample index with t + off <= time (-1: none) -- where GetNext :100-117 stops.
+VC_HD void imu_element_index(const ImuView& b, double time, double off, int* idx, int* end_clamp, int* last_le) {
+  const int n = b.n;
+  const double q = (time - b.t[0] + off) / b.avg_dt;
+  int g = (q > 0.0) ? (q < (double)(n - 1) ? (int)q : n - 1) : 0;         // (a negative quotient is cast to size_t in the reference: 0 here)
+  const bool below = b.t[0] + off > time, above = b.t[n - 1] + off <= time;
+  const int is = below ? -1 : (above ? n - 1 : imu_bracket(b, time, off));     // largest i with t[i] + off <= time
+  *last_le = is;
+  if (b.t[g] + off > time) {                           // the walk goes backwards
+    if (g == 0) { *idx = 0; *end_clamp = 1; return; }
+    *idx = is > 0 ? is : 0; *end_clamp = 0;            // [is, is + 1]  ([0, 1], extrapolating, when even the first sample is later)
+    if (*idx > n - 2) *idx = n - 2;
+    return;
+  }
+  if (g == n - 1) { *idx = n - 1; *end_clamp = 1; return; }      // forwards from the last sample: clamp
+  if (b.t[is] + off == time && g < is) { *idx = is - 1; *end_clamp = 0; return; }     // stopped one pair early, weight 1
+  if (is == n - 1) { *idx = n - 1; *end_clamp = 1; return; }     // walked off the end (the reference reads past it: clamp)
+  *idx = is; *end_clamp = 0;
 }
 VC_HD ImuRange imu_range(const ImuView& b, double t0, double t1, double off) {
   ImuRange r; r.valid = 0; r.k0 = 0; r.k1 = -1; r.i0 = r.i1 = 0; r.first_end = r.last_end = 0;
   if (b.n < 2) return r;
   if (!(t0 >= b.t[0] + off && t0 <= b.t[b.n - 1] + off)) return r;   // HasElement :122-125
   r.valid = 1;
-  imu_element_index(b, t0, off, &r.i0, &r.first_end);
-  imu_element_index(b, t1, off, &r.i1, &r.last_end);
-  // GetNext :100-117: interior samples are the stored samples idx + 1 .. with time + off <= t1, i.e. up to the last sample not
-  // after t1 -- which is what the element look-up of t1 has just found (no scan over the samples in between)
+  int le0, le1;
+  imu_element_index(b, t0, off, &r.i0, &r.first_end, &le0);
+  imu_element_index(b, t1, off, &r.i1, &r.last_end, &le1);
+  // GetNext :100-117: interior samples are the stored samples idx + 1 .. while time + off <= t1 -- up to the last sample not after
+  // t1, which the look-up of t1 has just found (no scan over the samples in between)
   r.k0 = r.i0 + 1;
-  r.k1 = (r.last_end && r.i1 == 0) ? -1 : r.i1;            // t1 before the first sample: nothing (cannot happen with t1 >= t0 >= t[0] + off)
+  r.k1 = le1;
   if (r.k1 < r.i0) r.k1 = r.i0;
   return r;
 }

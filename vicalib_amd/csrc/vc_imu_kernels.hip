@@ -30,7 +30,7 @@
 
 namespace vc {
 
-__device__ __forceinline__ ImuView imu_view(const DevView& v) { ImuView b = {v.imu_t, v.imu_w, v.imu_a, v.n_imu}; return b; }
+__device__ __forceinline__ ImuView imu_view(const DevView& v) { ImuView b = {v.imu_t, v.imu_w, v.imu_a, v.n_imu, v.imu_avg_dt}; return b; }
 
 // ------------------------------------------------------------------------------------------ IMU Jacobian
 // Interval deltas (vc_imu.hpp, "delta form"): 16 lanes per interval, lane dd carries the values (dd = 0) or one derivative

@@ -155,6 +155,7 @@ class ViCalibrator:
 
     def SetSigmas(self, g, a): _check(self.L.vc_set_sigmas(self.h, C.c_double(g), C.c_double(a)), "SetSigmas")
     def SetBiases(self, b): _check(self.L.vc_set_biases(self.h, _d(b)), "SetBiases")
+    def SetGravity(self, g): _check(self.L.vc_set_gravity(self.h, _d(np.asarray(g, dtype=np.float64))), "SetGravity")   # engine-level (the reference has no setter)
     def SetScaleFactor(self, s): _check(self.L.vc_set_scale_factor(self.h, _d(s)), "SetScaleFactor")
     def SetTimeOffset(self, o): _check(self.L.vc_set_time_offset(self.h, C.c_double(o)), "SetTimeOffset")
     def SetFunctionTolerance(self, t): _check(self.L.vc_set_function_tolerance(self.h, C.c_double(t)), "SetFunctionTolerance")
