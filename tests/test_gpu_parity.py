@@ -445,6 +445,42 @@ def test_chain_elimination_matches_dense_schur_complement(n_frames, models):
     np.testing.assert_allclose(g["g_red"], gr, rtol=1e-6, atol=1e-8 * np.abs(lin["gs"]).max())
 
 
+@pytest.mark.parametrize("flags", [(b, i, r, t) for b in (False, True) for i in (False, True) for r in (False, True) for t in (False, True)])
+def test_reduced_system_for_every_combination_of_optimisation_flags(flags):
+    """SetOptimizationFlags (vicalibrator.h:419-432) drives SetupProblem's constancy rules (:655-676): which of biases, scale factors,
+    gravity, time offset, velocities and camera extrinsics get columns.  For all 16 combinations: the reduced system the GPU pass
+    leaves (two cameras) against the dense Schur complement of
+    the oracle's normal equations, and the same column layout (weights: the initial 500 I on both sides)."""
+    bias_active, inertial_active, rot_only, toff_free = flags
+    p = synth.generate(synth.Config(models=("fov", "kb4"), n_frames=21, imu=True, seed=11))
+    gt = p.imu_gt
+    cal = ViCalibrator(0).load_problem(p, init=False)
+    orc = ol.Oracle().load(p, init=False); orc.set_options(calibrate_imu=True)
+    b0 = np.concatenate([gt["bg"], gt["ba"]]) * 0.7; s0 = np.concatenate([gt["sg"], gt["sa"]]) * 1.005
+    orc.set_flags(bias_active, inertial_active, rot_only, toff_free); orc.set_imu_state(b0, s0, np.array([0.02, 0.01]), 0.0013)
+    cal.SetOptimizationFlags(bias_active, inertial_active, rot_only, toff_free); cal.SetBiases(b0); cal.SetScaleFactor(s0)
+    cal.SetTimeOffset(0.0013); cal.SetGravity(np.array([0.02, 0.01]))
+    orc.prepare(vis_mult=1, imu_mult=1)
+    lin = orc.linearize()
+    g = cal.linearize()
+    n, D = 21, lin["Hss"].shape[0]
+    assert cal.shared_dim() == D
+    M = np.zeros((9 * n, 9 * n))
+    for f in range(n):
+        M[9 * f:9 * f + 9, 9 * f:9 * f + 9] = lin["A"][f]
+        if f + 1 < n:
+            M[9 * f:9 * f + 9, 9 * f + 9:9 * f + 18] = lin["C"][f]
+            M[9 * f + 9:9 * f + 18, 9 * f:9 * f + 9] = lin["C"][f].T
+    W = lin["W"].reshape(9 * n, D); gf = lin["gf"].reshape(9 * n)
+    act = np.abs(M).sum(axis=1) > 0                    # constant frame parameters (velocities without inertial terms) have no rows
+    M, W, gf = M[np.ix_(act, act)], W[act], gf[act]
+    X = np.linalg.solve(M, np.column_stack([W, gf]))
+    S = lin["Hss"] - W.T @ X[:, :D]; gr = lin["gs"] - W.T @ X[:, D]
+    assert abs(g["cost"] - lin["cost"]) <= 1e-10 * abs(lin["cost"]) + 1e-12
+    np.testing.assert_allclose(g["S"], S, rtol=1e-6, atol=1e-8 * np.abs(lin["Hss"]).max())
+    np.testing.assert_allclose(g["g_red"], gr, rtol=1e-6, atol=1e-8 * np.abs(lin["gs"]).max())
+
+
 def test_imu_weight_update_matches_oracle():
     """UpdateImuWeights (vicalibrator.h:723-799) on the GPU: covariance propagation with the reference's hand Jacobians,
     information matrix W W^T = (J Sigma J^T)^-1.  The GPU keeps the Cholesky-form factor, the oracle the symmetric square
