@@ -33,7 +33,9 @@ def _oracle_schur(lin):
     return S, g
 
 
-@pytest.mark.parametrize("models", [("fov", "fov"), ("poly3", "kb4", "poly2"), ("linear", "kb4"), ("poly3",), ("rational6", "fov"), ("rational6",)])
+@pytest.mark.parametrize("models", [("fov", "fov"), ("poly3", "kb4", "poly2"), ("linear", "kb4"), ("poly3",), ("rational6", "fov"), ("rational6",),
+                                    ("fov", "poly2", "poly3", "kb4", "linear", "rational6", "kb4", "rational6"),       # every model in one rig, D = 100
+                                    ("rational6",) * 5, ("linear",) * 7])
 def test_linearisation_blocks_match_oracle(models):
     p, cal, orc = _pair(synth.Config(models=models, n_frames=9, seed=21))
     orc.prepare(vis_mult=1)
