@@ -7,6 +7,8 @@ from vicalib_amd.lib import ViCalibrator
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 p = synth.generate_native(synth.BASELINE_CONFIGS[name])
 cal = ViCalibrator(0).load_problem(p)
+if os.environ.get("VICALIB_AMD_FORCE_SHARD_PATH") == "1":
+    cal.set_shard_rccl(0, 1)        # the sharded code path (split kernels, all-reduces) with one rank
 if p.imu_t is not None:
     cal.SetStageLimit(3); cal.Solve()
 else:

@@ -218,6 +218,7 @@ struct vc_calibrator {
   int trace_cap = 0;
   struct Pinned { Ctrl up; Ctrl down; double trace[64 * kTraceCols]; unsigned long long progress; };
   Pinned* pin = nullptr;        // page-locked staging (async copies without a bounce buffer)
+  long nres_global_cached = -1; int nres_mult_cached[2] = {-1, -1};      // sharded: the all-reduced residual count and the multiplicities it was formed with
   int expected_passes = 8;       // passes the previous solve needed: size of the first batch of the next one (batched schedule)
   bool feed_passes = std::getenv("VICALIB_AMD_BATCHED") == nullptr;   // single process: feed passes against the device's progress word
   DBuf<unsigned char> d_mask;
@@ -531,6 +532,7 @@ struct vc_calibrator {
     dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p;
     for (int b = 0; b < 2; ++b) dv.rX[b] = d_rX[b].p;
     up_c = up_ms();
+    nres_global_cached = -1;
     HIP_OK(hipStreamSynchronize(stream));   // the staging vectors above go out of scope
     if (up_timing) std::fprintf(stderr, "[vicalib_amd]   upload: observations %.3f, layout %.3f, copies + allocations %.3f, drain %.3f ms\n", up_a, up_b - up_a, up_c - up_b, up_ms() - up_c);
     device_dirty = false;
@@ -630,6 +632,8 @@ struct vc_calibrator {
 
   // ---- one pass of the device pipeline (all asynchronous; the decision is taken on the device) ------
   int do_allreduce(double* p, int n, int op) {
+    static const bool skip = std::getenv("VICALIB_AMD_DEBUG_SKIP_ALLREDUCE") != nullptr;     // (experiment: world == 1 only)
+    if (skip && world == 1) return VC_OK;
     if (sharded() && rccl_comm) {
       ++rccl_calls;
       if (g_rccl.AllReduce(p, p, (size_t)n, kNcclDouble, op == 1 ? kNcclMax : kNcclSum, rccl_comm, stream) != 0) return VC_ERR_NO_DEVICE;
@@ -673,9 +677,9 @@ struct vc_calibrator {
       KT("k_part_sum", launch_part_sum(dv, stream));
       int rc = VC_OK;
       if (sharded()) {
-        launch_reduced(dv, 1, stream);
-        rc = do_allreduce(dv.Sbuf, D * D + 3 * D + 2, 0); if (rc) return rc;
-        launch_reduced(dv, 2, stream);
+        KT("k_reduced(assemble)", launch_reduced(dv, 1, stream));
+        KT("allreduce(S)", rc = do_allreduce(dv.Sbuf, D * D + 3 * D + 2, 0)); if (rc) return rc;
+        KT("k_reduced(solve)", launch_reduced(dv, 2, stream));
       } else {
         KT("k_reduced", launch_reduced(dv, 0, stream));
       }
@@ -697,9 +701,9 @@ struct vc_calibrator {
       else KT("k_imu_delta+k_imu_block(trial)", launch_imu_delta(dv, stream, 1));
       KT("k_imu_jac(trial)", launch_imu_jac(dv, wcur, stream, 1));
       if (sharded()) {
-        launch_final(dv, 1, stream);
-        rc = do_allreduce(dv.gath, world * kNumScal, 0); if (rc) return rc;
-        launch_final(dv, 2, stream);
+        KT("k_final(reduce)", launch_final(dv, 1, stream));
+        KT("allreduce(step scalars)", rc = do_allreduce(dv.gath, world * kNumScal, 0)); if (rc) return rc;
+        KT("k_final(decide)", launch_final(dv, 2, stream));
       } else {
         KT("k_final", launch_final(dv, 0, stream));
       }
@@ -762,7 +766,17 @@ struct vc_calibrator {
   int solve_once(Termination* term, double* final_cost, long* nres) {
     if (device_dirty) { int rc = upload(); if (rc) return rc; }
     *nres = 2L * ((long)dv.n_obs * vis_mult - n_one_less) + (dv.imu_on ? 9L * imu_mult * std::max(0, dv.n_frames - 1) : 0L);
-    if (sharded()) { std::vector<double> v = {(double)*nres}; int rc = host_allreduce_sum(v); if (rc) return rc; *nres = (long)v[0]; }
+    if (sharded()) {
+      // The global residual count changes with the observation set (every rank re-uploads then: upload() drops the cached value) and
+      // with the multiplicities (bumped on all ranks together): one collective per change, not per solve.  The test must not depend
+      // on anything rank-local -- a rank that skipped the collective while another entered it would hang the job.
+      if (nres_global_cached < 0 || nres_mult_cached[0] != vis_mult || nres_mult_cached[1] != imu_mult) {
+        std::vector<double> v = {(double)*nres};
+        int rc = host_allreduce_sum(v); if (rc) return rc;
+        nres_global_cached = (long)v[0]; nres_mult_cached[0] = vis_mult; nres_mult_cached[1] = imu_mult;
+      }
+      *nres = nres_global_cached;
+    }
     if (trace_cap < max_iters + 8) { trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); dv.trace = d_trace.p; }
     if (!pin) HIP_OK(hipHostMalloc((void**)&pin, sizeof(Pinned), hipHostMallocDefault));
     init_ctrl(&pin->up);
@@ -770,6 +784,8 @@ struct vc_calibrator {
     if (dv.imu_on && dv.weights_on) { launch_imu_weights(dv, wcur, stream); wcur = 1 - wcur; }     // UpdateImuWeights() before ceres::Solve (vicalibrator.h:955)
     const size_t trace_bytes = (size_t)std::min(trace_cap, 64) * kTraceCols * 8;
     int guard = 0, n_enq = 0;
+    double enqueue_ms = 0.0, wait_ms = 0.0;
+    const auto tso0 = std::chrono::steady_clock::now();
     const bool feed = !sharded() && !use_graphs && feed_passes && dv.imu_on;
     if (feed) {
       // Single process, visual-inertial passes (19 launches, ~270 us): the deciding thread publishes (decisions << 32 | done) to a page-locked word after every decision and
@@ -810,27 +826,36 @@ struct vc_calibrator {
     // small top-up batches until the device reports `done`.
     int batch = std::max(1, std::min(expected_passes, max_iters + 1));
     while (!feed || (!pin->down.done && should_run && n_enq < max_iters + 8)) {
+      const auto tq0 = std::chrono::steady_clock::now();
       for (int b = 0; b < batch; ++b) {
         const bool first = (n_enq++ == 0);
         int rc = (first || sharded() || !use_graphs) ? enqueue_pass(first) : launch_pass_graph();
         if (rc) return rc;
       }
       finish_batch();
+      enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count();
       HIP_OK(hipMemcpyAsync(&pin->down, ctrl_result(), sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
       HIP_OK(hipMemcpyAsync(pin->trace, d_trace.p, trace_bytes, hipMemcpyDeviceToHost, stream));
+      const auto tw0 = std::chrono::steady_clock::now();
       HIP_OK(hipStreamSynchronize(stream));
+      wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
       if (ktime_on) kt_collect();
       // Stop() is a collective decision when the frames are sharded: a rank that left its enqueue loop alone would leave
       // its peers waiting in the next all-reduce (every rank runs the same batch schedule, so the counts line up)
+      // (every rank holds the same control record: a finished solve ends here on all of them without another collective)
+      if (pin->down.done) break;
       if (sharded()) {
         std::vector<double> v = {should_run ? 0.0 : 1.0};
         int rc = host_allreduce_sum(v); if (rc) return rc;
         if (v[0] > 0.0) should_run = false;
       }
-      if (pin->down.done || !should_run || ++guard > max_iters + 8) break;
+      if (!should_run || ++guard > max_iters + 8) break;
       batch = 2;
     }
     const Ctrl c = pin->down;
+    if (std::getenv("VICALIB_AMD_TIMING") && enqueue_ms > 0.0)
+      std::fprintf(stderr, "[vicalib_amd]   solve: %d passes enqueued in %.3f ms of host time (batched schedule), %d decided; waited %.3f ms for the device, %.3f ms in all\n",
+                   n_enq, enqueue_ms, c.passes, wait_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tso0).count());
     expected_passes = std::max(1, c.passes);
     const int n = std::min(c.trace_len, trace_cap);
     std::vector<double> rows((size_t)std::max(n, 1) * kTraceCols);
@@ -1022,7 +1047,17 @@ int vc_create(vc_calibrator** out, int device) {
   // (VICALIB_AMD_EVENT_SYSTEM_FENCE=1 restores the default, for A/B measurements)
   unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
   { const char* e = std::getenv("VICALIB_AMD_EVENT_SYSTEM_FENCE"); if (e && e[0] == '1') evf = hipEventDisableTiming; }
-  if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess ||
+  // The second stream carries the off-critical-path kernels of a visual-inertial pass (weight update, interval deltas).  It is
+  // created with the LOWEST priority: (a) its kernels yield to the chain solve they run beside, and (b) streams of a different
+  // priority live in their own pool of hardware queues -- with equal priorities HIP multiplexes all streams of the process onto
+  // GPU_MAX_HW_QUEUES (4) queues, and a host program with a few streams of its own (torch with an eagerly created NCCL
+  // communicator does it) can land both of ours on ONE queue, which serialises the pass: 0.30 -> 0.46 ms at cfg3, measured.
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  const char* prio_env = std::getenv("VICALIB_AMD_STREAM2_PRIORITY");      // "default": plain hipStreamCreate (A/B measurements)
+  const bool plain2 = prio_env && std::strcmp(prio_env, "default") == 0;
+  if (hipStreamCreate(&h->stream) != hipSuccess ||
+      (plain2 ? hipStreamCreate(&h->stream2) : hipStreamCreateWithPriority(&h->stream2, hipStreamDefault, prio_least)) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_state, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_weights, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_imujac, evf) != hipSuccess ||
@@ -1488,11 +1523,14 @@ int vc_run_iterations(vc_calibrator* h, int iters, int* jac_sweeps, int* res_swe
   int done = 0, rc = VC_OK, guard = 0;
   while (done < iters && guard++ < iters + 4) {
     h->max_iters = std::min(mi, iters - done);
+    const auto ts0 = std::chrono::steady_clock::now();
     rc = h->reset_state(); if (rc) break;
     Termination t; double fc; long nr;
     rc = h->solve_once(&t, &fc, &nr);
     if (rc) break;
     const int ran = h->last_iters;
+    if (std::getenv("VICALIB_AMD_TIMING"))
+      std::fprintf(stderr, "[vicalib_amd]   run_iterations: solve of %d iterations in %.3f ms\n", ran, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count());
     done += std::max(ran, 1);
   }
   h->max_iters = mi;
