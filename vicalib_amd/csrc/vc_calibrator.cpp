@@ -1056,8 +1056,12 @@ int vc_create(vc_calibrator** out, int device) {
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   const char* prio_env = std::getenv("VICALIB_AMD_STREAM2_PRIORITY");      // "default": plain hipStreamCreate (A/B measurements)
   const bool plain2 = prio_env && std::strcmp(prio_env, "default") == 0;
-  if (hipStreamCreate(&h->stream) != hipSuccess ||
-      (plain2 ? hipStreamCreate(&h->stream2) : hipStreamCreateWithPriority(&h->stream2, hipStreamDefault, prio_least)) != hipSuccess ||
+  auto make_stream2 = [&]() -> hipError_t {
+    if (!plain2 && hipStreamCreateWithPriority(&h->stream2, hipStreamDefault, prio_least) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+    return hipStreamCreate(&h->stream2);          // (a runtime without stream priorities: plain stream, same results)
+  };
+  if (hipStreamCreate(&h->stream) != hipSuccess || make_stream2() != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_state, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_weights, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_imujac, evf) != hipSuccess ||
