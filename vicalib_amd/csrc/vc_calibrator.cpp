@@ -143,7 +143,7 @@ struct vc_calibrator {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;        // the IMU weight update of a pass runs here, under the pass's Jacobian sweeps and chain solve
-  hipEvent_t ev_state = nullptr, ev_weights = nullptr, ev_imujac = nullptr, ev_back = nullptr, ev_reduced = nullptr;
+  hipEvent_t ev_state = nullptr, ev_weights = nullptr, ev_imujac = nullptr, ev_reduced = nullptr;
   int wcur = 0;                         // weight buffer holding the current weight_sqrt_
   bool serial_weights = false;          // false: IMU Jacobians + weight update on the second stream (VICALIB_AMD_OVERLAP_WEIGHTS=0: in line); was: VICALIB_AMD_OVERLAP_WEIGHTS=1 moves it to a second
                                         // stream under the Jacobian sweeps / chain solve (measured: the two latency-bound kernels then
@@ -234,7 +234,6 @@ struct vc_calibrator {
     if (ev_state) (void)hipEventDestroy(ev_state);
     if (ev_weights) (void)hipEventDestroy(ev_weights);
     if (ev_imujac) (void)hipEventDestroy(ev_imujac);
-    if (ev_back) (void)hipEventDestroy(ev_back);
     if (ev_reduced) (void)hipEventDestroy(ev_reduced);
     if (stream) (void)hipStreamDestroy(stream);
     if (pin) (void)hipHostFree(pin);
@@ -632,8 +631,6 @@ struct vc_calibrator {
 
   // ---- one pass of the device pipeline (all asynchronous; the decision is taken on the device) ------
   int do_allreduce(double* p, int n, int op) {
-    static const bool skip = std::getenv("VICALIB_AMD_DEBUG_SKIP_ALLREDUCE") != nullptr;     // (experiment: world == 1 only)
-    if (skip && world == 1) return VC_OK;
     if (sharded() && rccl_comm) {
       ++rccl_calls;
       if (g_rccl.AllReduce(p, p, (size_t)n, kNcclDouble, op == 1 ? kNcclMax : kNcclSum, rccl_comm, stream) != 0) return VC_ERR_NO_DEVICE;
@@ -646,10 +643,12 @@ struct vc_calibrator {
     dv.merged = 0; dv.par = 0; dv.ctrl = d_ctrl.p; dv.ctrl_prev = d_ctrl.p + 1;
     if (dv.imu_on) {
       // UpdateImuWeights of the iteration callback (vicalibrator.h:691): linearise with the current weights, evaluate the
-      // trial point with the updated ones.  The pass is a small graph over two streams: the IMU Jacobians and, behind them,
-      // the weight update (which only needs the accepted state and writes the other weight buffer) run on the second
-      // stream next to the vision sweep and the chain solve -- every one of these kernels is a few hundred latency-bound
-      // wavefronts, far from filling the chip on its own.
+      // trial point with the updated ones.  The pass is a small graph over two streams: the weight update (which only needs the
+      // accepted state and writes the other weight buffer) and the interval / block deltas of the trial point (which only need
+      // the trial IMU parameters) run on the second, low-priority stream next to the chain solve -- every one of these kernels
+      // is a few hundred latency-bound wavefronts, far from filling the chip on its own.  Everything on the critical path --
+      // chain, both trial sweeps, decision -- stays on the main stream: kernels of one stream follow each other without a gap,
+      // an event hand-over costs 5-13 us.
       const bool upd = dv.weights_on != 0;
       // The Jacobian sweeps at the head of the pass only run when the control record asks for a linearisation: the first pass
       // of a solve.  Afterwards the trial point is evaluated by the same sweeps in trial mode (below), which leave the next
@@ -1065,7 +1064,6 @@ int vc_create(vc_calibrator** out, int device) {
       hipEventCreateWithFlags(&h->ev_state, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_weights, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_imujac, evf) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_back, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_reduced, evf) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }
   *out = h;
   return VC_OK;

@@ -321,8 +321,10 @@ VC_HD void local_jac_se3(const double* x, double* J) {
   J[6 * 6 + 0] = 2.0 * (q1 * q3 - q0 * q2); J[6 * 6 + 1] = 2.0 * (q2 * q3 + q0 * q1); J[6 * 6 + 2] = 1.0 - 2.0 * (q1 * q1 + q2 * q2);
 }
 
-// One lane's share of the IMU block: residual values r[9] and the partials of all 9 rows with respect to
-// global parameter `dir` (0..34 in the block order of vicalibrator.h:628-632; dir < 0: values only).
+// One lane's share of the IMU block in the INTEGRATED form (the reference's own order of operations: RK4 along the block under a
+// dual number): residual values r[9] and the partials of all 9 rows with respect to global parameter `dir` (0..34 in the block
+// order of vicalibrator.h:628-632; dir < 0: values only).  The kernels run the delta form below; this one is what the delta form
+// is checked against (tests/host_harness, tests/test_device_math_cpu.py) and what vc_get_integration_poses' host arithmetic shares.
 VC_HD void imu_block_direction(const ImuView& buf, double t_start, double t_end, const double* w_sqrt, int rotation_only,
                                const double* T2, const double* T1, const double* v2, const double* v1, const double* gdir,
                                const double* b, const double* sf, double toff, int dir, double* r, double* dr) {
