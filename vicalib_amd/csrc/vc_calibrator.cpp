@@ -516,11 +516,11 @@ struct vc_calibrator {
       {
         const int ldw_max = (((Dmax + 1 + 15) / 16) * 16 % 32 == 0) ? ((Dmax + 1 + 15) / 16) * 16 + 16 : ((Dmax + 1 + 15) / 16) * 16;
         HIP_OK(d_cW.alloc(nf * 9 * (ldw_max + 32)));
-        for (int b = 0; b < 2; ++b) HIP_OK(d_rX[b].alloc((nf / chain_group_size() + 2) * 9 * (ldw_max + 32)));
+        for (int b = 0; b < 2; ++b) HIP_OK(d_rX[b].alloc((nf / std::min(chain_group_size(), chain_group_size_upper()) + 2) * 9 * (ldw_max + 32)));
       }
       HIP_OK(d_cW.alloc(nf * 9 * dv.ldx)); HIP_OK(d_cdelta.alloc(nf * 9)); HIP_OK(d_cg.alloc(nf * 9)); HIP_OK(d_clam.alloc(nf * 9));
       HIP_OK(d_cdiag.alloc(nf * 9)); HIP_OK(d_cscale2.alloc(nf * 9));
-      for (int b = 0; b < 2; ++b) HIP_OK(d_rX[b].alloc((nf / chain_group_size() + 2) * 9 * dv.ldx));
+      for (int b = 0; b < 2; ++b) HIP_OK(d_rX[b].alloc((nf / std::min(chain_group_size(), chain_group_size_upper()) + 2) * 9 * dv.ldx));
     }
     dv.imu_t = d_imu_t.p; dv.imu_w = d_imu_w.p; dv.imu_a = d_imu_a.p; dv.frame_time = d_frame_time.p;
     dv.vel[0] = d_vel[0].p; dv.vel[1] = d_vel[1].p; dv.imus[0] = d_imus[0].p; dv.imus[1] = d_imus[1].p;

@@ -178,6 +178,7 @@ void launch_cam_sq(const DevView& v, double* out /*n_cams x 2: sum sq, count*/, 
 void launch_outlier_mask(const DevView& v, int state, const double* thresh /*device, n_cams*/, unsigned char* mask, hipStream_t s);
 
 // inertial path (vc_imu_kernels.hip)
+int chain_group_size_upper();    // ... above the bottom level (VICALIB_AMD_CHAIN_M_UPPER)
 int chain_group_size();          // frames per group of the partitioned chain elimination (test hook: VICALIB_AMD_CHAIN_M)
 void launch_imu_delta(const DevView& v, hipStream_t s, int trial = 0);         // interval and block deltas under the IMU parameters of the accepted (0) / trial (1) state (two launches)
 void launch_imu_jac(const DevView& v, int wr, hipStream_t s, int trial = 0);   // wr: weight buffer to read; trial as for launch_reproj_jac; needs launch_imu_delta

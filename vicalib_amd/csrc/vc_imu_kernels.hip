@@ -1137,27 +1137,39 @@ int chain_group_size() {
   if (!m) { const char* e = std::getenv("VICALIB_AMD_CHAIN_M"); m = e ? std::max(2, std::min(kChainM, std::atoi(e))) : kChainM; }
   return m;
 }
+// group size above the bottom level (test hook VICALIB_AMD_CHAIN_M_UPPER; default: the same as the bottom level)
+int chain_group_size_upper() {
+  static int m = 0;
+  if (!m) { const char* e = std::getenv("VICALIB_AMD_CHAIN_M_UPPER"); m = e ? std::max(2, std::min(kChainM, std::atoi(e))) : chain_group_size(); }
+  return m;
+}
+// Level schedule of the partitioned chain elimination: strides 1, m0, m0 m1, ... while more than m - 1 frames are active, then
+// the top level (one wavefront eliminates the rest).  forward: bottom-up; backward: top-down.
 static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
-  const int N = v.n_frames, m = chain_group_size();
+  const int N = v.n_frames;
   if (N < 1) return;
-  int strides[32], nl = 0;
+  int strides[32], ms[32], nl = 0;
   long st = 1;
-  while ((N - 1) / st + 1 > m - 1) { strides[nl++] = (int)st; st *= m; }
-  const int top_stride = (int)st;
+  while (true) {
+    const int m = nl == 0 ? chain_group_size() : chain_group_size_upper();
+    if (!((N - 1) / st + 1 > m - 1)) break;
+    strides[nl] = (int)st; ms[nl] = m; ++nl; st *= m;
+  }
+  const int top_stride = (int)st, m_top = kChainM;      // the top level eliminates whatever is left (fewer than a group)
   const int cpl = (v.D + 1 + 27 + 63) / 64;
-  auto fwd = [&](int groups, int stride, int top, int lvl) {
+  auto fwd = [&](int groups, int stride, int m, int top, int lvl) {
     if (cpl <= 1) hipLaunchKernelGGL(k_chain_fwd<1>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
     else if (cpl <= 2) hipLaunchKernelGGL(k_chain_fwd<2>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
     else if (cpl <= 3) hipLaunchKernelGGL(k_chain_fwd<3>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
     else hipLaunchKernelGGL(k_chain_fwd<4>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
   };
   if (forward) {
-    for (int l = 0; l < nl; ++l) fwd((int)(((long)N - 1) / ((long)strides[l] * m) + 1), strides[l], 0, l);
-    fwd(1, top_stride, 1, nl);
+    for (int l = 0; l < nl; ++l) fwd((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1), strides[l], ms[l], 0, l);
+    fwd(1, top_stride, m_top, 1, nl);
   } else {
-    hipLaunchKernelGGL(k_chain_back, dim3(1), dim3(64), 0, s, v, top_stride, m, 1, nl);
+    hipLaunchKernelGGL(k_chain_back, dim3(1), dim3(64), 0, s, v, top_stride, m_top, 1, nl);
     for (int l = nl - 1; l >= 0; --l)
-      hipLaunchKernelGGL(k_chain_back, dim3((int)(((long)N - 1) / ((long)strides[l] * m) + 1)), dim3(64), 0, s, v, strides[l], m, 0, l);
+      hipLaunchKernelGGL(k_chain_back, dim3((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1)), dim3(64), 0, s, v, strides[l], ms[l], 0, l);
   }
 }
 void launch_chain_solve_a(const DevView& v, hipStream_t s) {
