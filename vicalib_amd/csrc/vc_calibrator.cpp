@@ -823,7 +823,9 @@ struct vc_calibrator {
     // passes fed past the end cost more there than one synchronisation): batches.  First batch =
     // what the previous solve needed (repeated solves of similar problems: no wasted launches, one host sync per solve); then
     // small top-up batches until the device reports `done`.
-    int batch = std::max(1, std::min(expected_passes, max_iters + 1));
+    // (visual-inertial: a first batch of at most 16 passes: a long previous solve -- stage C's 38 iterations ahead of stage D's 12 -- must not
+    //  queue dozens of passes past the end; then top-ups of 8: one synchronisation per ~2 ms of device work)
+    int batch = std::max(1, std::min(dv.imu_on ? std::min(expected_passes, 16) : expected_passes, max_iters + 1));
     while (!feed || (!pin->down.done && should_run && n_enq < max_iters + 8)) {
       const auto tq0 = std::chrono::steady_clock::now();
       for (int b = 0; b < batch; ++b) {
@@ -849,7 +851,7 @@ struct vc_calibrator {
         if (v[0] > 0.0) should_run = false;
       }
       if (!should_run || ++guard > max_iters + 8) break;
-      batch = 2;
+      batch = dv.imu_on ? 8 : 2;        // (vision-only passes are 50 us: a synchronisation every two of them was the better trade there)
     }
     const Ctrl c = pin->down;
     if (std::getenv("VICALIB_AMD_TIMING") && enqueue_ms > 0.0)
