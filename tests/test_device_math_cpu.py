@@ -180,14 +180,21 @@ def test_imu_block_lane_duals_match_oracle():
             np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-10, atol=1e-10 * max(1.0, np.abs(out[0][1]).max()))
 
 
-def test_imu_covariance_weights_match_oracle():
-    """UpdateImuWeights restated for the device (vc_imu_weights.hpp) against the oracle's version."""
+@pytest.mark.parametrize("toff0,jitter", [(0.0025, False), (-0.05, False), (0.013, True), (-0.26, False)])
+def test_imu_covariance_weights_match_oracle(toff0, jitter):
+    """UpdateImuWeights restated for the device (vc_imu_weights.hpp) against the oracle's version: a plain offset, one that puts
+    every frame exactly on a shifted sample, irregular time stamps, and one that runs the last blocks off the end of the stream."""
     p = synth.generate(synth.Config(models=("kb4",), n_frames=10, imu=True, seed=8))
+    if jitter:
+        rng = np.random.default_rng(3)
+        t = np.array(p.imu_t, dtype=np.float64); dt = np.diff(t) * (1.0 + 0.5 * (rng.random(len(t) - 1) - 0.5))
+        t2 = np.concatenate([[t[0]], t[0] + np.cumsum(dt)])
+        p.imu_t = np.ascontiguousarray(t[0] + (t2 - t[0]) * (t[-1] - t[0]) / (t2[-1] - t2[0]))
     o = ol.Oracle().load(p, init=False)
     o.set_options(calibrate_imu=True)
     gt = p.imu_gt
     o.set_flags(True, True, False, True)
-    o.set_imu_state(np.concatenate([gt["bg"], gt["ba"]]), np.concatenate([gt["sg"], gt["sa"]]), gt["g_dir"], 0.0025)
+    o.set_imu_state(np.concatenate([gt["bg"], gt["ba"]]), np.concatenate([gt["sg"], gt["sa"]]), gt["g_dir"], toff0)
     for f in range(o.n_frames):
         o.set_frame(f, p.frame_T_wk_gt[f], p.frame_v_gt[f])
     o.prepare(vis_mult=1, imu_mult=1)
@@ -197,7 +204,45 @@ def test_imu_covariance_weights_match_oracle():
     H = hh()
     for j in range(1, o.n_frames):
         T2, _ = o.frame(j); T1, v1 = o.frame(j - 1)
-        w = np.zeros((9, 9))
+        w = np.eye(9) * 500.0                 # a block without samples keeps the weight it has (vicalibrator.h:731-733)
         H.hh_imu_weight(len(p.imu_t), d(p.imu_t), d(p.imu_gyro), d(p.imu_accel), C.c_double(p.frame_time[j - 1]), C.c_double(p.frame_time[j]),
                         C.c_double(toff), d(T1), d(v1), d(T2), d(b), d(sfac), d(g), C.c_double(5.3088444e-5), C.c_double(0.001883649), d(w))
         np.testing.assert_allclose(w, W[j - 1], rtol=1e-7, atol=1e-9 * np.abs(W[j - 1]).max())
+
+
+def test_imu_block_forms_match_oracle_on_irregular_sample_times():
+    """Jittered, gappy IMU time stamps (the reference's index guess is then off by many samples and its walk does the work) and
+    random time offsets, some of them exact multiples of the nominal period: the integrated and the delta form of the device
+    code against the oracle's Dual<35> block, residual and all 33 Jacobian columns."""
+    rng = np.random.default_rng(17)
+    H = hh()
+    for trial in range(6):
+        p = synth.generate(synth.Config(models=("kb4",), n_frames=10, imu=True, seed=30 + trial, imu_rate=[200.0, 90.0, 400.0][trial % 3]))
+        t = np.array(p.imu_t, dtype=np.float64)
+        dt = np.diff(t)
+        jit = 1.0 + 0.6 * (rng.random(len(dt)) - 0.5)                    # +-30 % spacing jitter
+        if trial % 2:
+            jit[rng.integers(5, len(dt) - 5, size=3)] = 4.0             # a few dropped samples
+        t2 = np.concatenate([[t[0]], t[0] + np.cumsum(dt * jit)])
+        t2 = t[0] + (t2 - t[0]) * (t[-1] - t[0]) / (t2[-1] - t2[0])      # same span: the frames stay inside the stream
+        p.imu_t = np.ascontiguousarray(t2)
+        o = ol.Oracle().load(p, init=False)
+        o.set_options(calibrate_imu=True)
+        o.set_flags(True, True, False, True)
+        gt = p.imu_gt
+        b = np.concatenate([gt["bg"], gt["ba"]]) * 0.6; sfac = np.concatenate([gt["sg"], gt["sa"]]) * 0.99; g = np.array([0.03, -0.01])
+        for toff in [0.0, 1.0 / 200.0, -3.0 / 90.0] + list(rng.uniform(-0.04, 0.04, size=3)):
+            o.set_imu_state(b, sfac, g, toff)
+            for f in range(o.n_frames):
+                o.set_frame(f, p.frame_T_wk_gt[f], p.frame_v_gt[f] * 0.98)
+            o.prepare(vis_mult=1, imu_mult=1)
+            W = o.imu_weights()
+            for j in range(1, o.n_frames):
+                r0, J0 = o.imu_block(j)
+                T2, v2 = o.frame(j); T1, v1 = o.frame(j - 1)
+                for fn in (H.hh_imu_block, H.hh_imu_block_deltas):
+                    r = np.zeros(9); J = np.zeros((9, 33))
+                    fn(len(p.imu_t), d(p.imu_t), d(p.imu_gyro), d(p.imu_accel), C.c_double(p.frame_time[j - 1]), C.c_double(p.frame_time[j]),
+                       d(W[j - 1]), 0, d(T2), d(T1), d(v2), d(v1), d(g), d(b), d(sfac), C.c_double(toff), d(r), d(J))
+                    np.testing.assert_allclose(r, r0, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(r0).max()))
+                    np.testing.assert_allclose(J, J0, rtol=1e-8, atol=1e-8 * max(np.abs(J0).max(), 1e-300))
