@@ -18,7 +18,8 @@ def pytest_sessionstart(session):
     import subprocess
     lib = os.path.join(ROOT, "vicalib_amd", "libvicalib_amd.so")
     cli = os.path.join(ROOT, "vicalib_amd", "vicalib")
-    if os.path.exists(lib) and os.path.exists(cli):
+    gen = os.path.join(ROOT, "vicalib_amd", "libvicalib_synth.so")        # the C++ problem generator (test / bench infrastructure)
+    if os.path.exists(lib) and os.path.exists(cli) and os.path.exists(gen):
         return
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not (os.path.exists(hipcc) or shutil.which("hipcc")):
