@@ -1,5 +1,6 @@
 """Phase timeline of k_reduced on BASELINE cfg3 (final stage): build the library with -DVC_REDUCED_STAMPS and point VICALIB_AMD_LIB
-at it.  Stamps are s_memtime ticks (100 MHz on gfx950): differences in microseconds."""
+at it.  Stamps are shader-clock cycles (__builtin_readcyclecounter: the clock the wavefront runs at, ~2.4 GHz under load): printed as
+cycles and as shares of the kernel; scale by the kernel's duration from a trace for microseconds."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vicalib_amd import synth
@@ -15,6 +16,7 @@ cal.prepare()
 cal.run_iterations(5)
 st = cal.debug_stamps().astype(float)
 names = ["entry", "partials summed", "costs summed", "camera blocks", "S complete / solve starts", "solve done", "tail done"]
+tot = st[6] - st[0]
 for i in range(1, 7):
-    print("%-28s +%.2f us" % (names[i], (st[i] - st[i - 1]) / 100.0))
-print("total %.2f us" % ((st[6] - st[0]) / 100.0))
+    print("%-28s +%8.0f cycles  %5.1f %%" % (names[i], st[i] - st[i - 1], 100.0 * (st[i] - st[i - 1]) / tot))
+print("total %.0f cycles" % tot)
