@@ -1,6 +1,6 @@
 ROOT=$PWD; mkdir -p gpurun_out/tl
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $ROOT/gpurun_out/tl/trace -o t -- python $ROOT/tools/trace_pass.py ${1:-cfg3} > $ROOT/gpurun_out/tl/out.txt 2> $ROOT/gpurun_out/tl/err.txt
+rocprofv3 --kernel-trace -d $ROOT/gpurun_out/tl/trace -o t -- python $ROOT/tools/trace_pass.py ${1:-cfg3} ${3:-} > $ROOT/gpurun_out/tl/out.txt 2> $ROOT/gpurun_out/tl/err.txt
 cd $ROOT
 for b in 4 8 12; do python tools/pass_timeline.py $(ls gpurun_out/tl/trace/*results.db | head -1) $b ${2:-k_final}; done
 rm -rf gpurun_out/tl/trace
