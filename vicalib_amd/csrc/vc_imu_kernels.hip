@@ -698,16 +698,24 @@ constexpr int kXsLd = 20;           // row stride of the [X_s | X_n] LDS image
 #else
 #define CSTAMP(i) do { } while (0)
 #endif
-template <int CPL>                  // columns per lane: D + 1 + 27 <= 64 CPL
-__global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int top, int lvl) {
+// NW > 1: the group's columns are spread over NW wavefronts of one workgroup instead of several columns per lane (column
+// c = lane + 64 (wave + NW ci)).  Every wavefront factors A itself (its own copy of L in LDS: nine lanes, a microsecond), the
+// solved [X_s | X_n] columns and the next frame's A are exchanged through the shared LDS images behind workgroup barriers.  For
+// wide borders (D > 36) this replaces columns per lane, which cost 25 us per elimination at three columns (256 VGPR + AGPR
+// copies) against a few us here; the columns-per-lane instances stay for A/B runs (launcher below).
+template <int CPL, int NW>          // columns per lane x wavefronts: D + 1 + 27 <= 64 CPL NW
+__global__ __launch_bounds__(64 * NW) void k_chain_fwd(DevView v, int s, int m, int top, int lvl) {
   __shared__ __attribute__((aligned(16))) double XS[9 * kXsLd];
   __shared__ double An[81];
-  __shared__ double Ls[81];
+  __shared__ double Ls_all[NW * 81];
+  const int wave = threadIdx.x >> 6;
+  double* Ls = Ls_all + wave * 81;
+  auto group_sync = [&]() { if (NW > 1) __syncthreads(); else wave_lds_sync(); };
   CSTAMP(0);
   // the control record is requested here and looked at after the first frame's image has been requested as well: a finished
   // solve costs a few wasted loads, a running one saves the record's round trip at the head of every level
   const int done = v.ctrl->done;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int N = v.n_frames, D = v.D, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
   const long gs = (long)m * s;
   const int a = top ? -1 : (int)(blockIdx.x * gs);
@@ -720,7 +728,7 @@ __global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int t
   int role[CPL], pc[CPL], sub[CPL];
 #pragma unroll
   for (int ci = 0; ci < CPL; ++ci) {
-    const int c = lane + 64 * ci, e = c - nW;
+    const int c = lane + 64 * (wave + NW * ci), e = c - nW;
     role[ci] = c < nW ? 0 : (e < 9 ? 1 : e < 18 ? 2 : e < 27 ? 3 : 4);
     pc[ci] = c < nW ? c : (c < ncol ? ldw + e : 0);
     sub[ci] = e < 9 ? e : e < 18 ? e - 9 : e - 18;            // column inside the 9 x 9 block
@@ -807,7 +815,7 @@ __global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int t
     const bool has_n = n < N;
     const bool n_sep = !top && (i == m - 2);                   // the next frame is the right separator (another group's)
     if (i > 0) request_next(e, i);       // the next frame's columns: requested now, used after the factorisation and the solve
-    wave_lds_sync();
+    group_sync();                        // the frame's A block (LDS) is complete
     CSTAMP(2 + 4 * i);
     // ---- A = L L^T: lane = row (lanes 0..8), pivots and pivot columns through v_readlane
     double dinv[9];
@@ -831,7 +839,7 @@ __global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int t
         for (int k = j + 1; k < 9; ++k) row[k] -= lij * readlane_f64(lij, k);
       }
       if (bad) {               // wave-uniform (the pivots are): the frame gets an identity block, the pass is flagged
-        if (lane == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
+        if (threadIdx.x == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
 #pragma unroll
         for (int k = 0; k < 9; ++k) { row[k] = (k == lane) ? 1.0 : 0.0; dinv[k] = 1.0; }
       }
@@ -870,7 +878,7 @@ __global__ __launch_bounds__(64) void k_chain_fwd(DevView v, int s, int m, int t
         for (int k = 0; k < 9; ++k) XS[k * kXsLd + xc] = x[ci][k];
       }
     }
-    wave_lds_sync();
+    group_sync();                        // [X_s | X_n] is complete
     CSTAMP(4 + 4 * i);
     // ---- Schur updates: out[r] = sum_k [X_s | X_n][k][r] * (column)[k]; the A columns are driven by X_n's columns
 #pragma unroll
@@ -1157,11 +1165,20 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
   }
   const int top_stride = (int)st, m_top = kChainM;      // the top level eliminates whatever is left (fewer than a group)
   const int cpl = (v.D + 1 + 27 + 63) / 64;
+  // wide borders: wavefronts side by side (measured: 1.68 -> 1.51 ms per pass at cfg5's per-rank size, 8.74 -> 8.39 ms at its full
+  // size, where the chip is full either way); VICALIB_AMD_CHAIN_WAVES=0 selects columns per lane for A/B runs and the parity tests
+  static const bool columns_per_lane = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_WAVES"); return e && std::atoi(e) == 0; }();
   auto fwd = [&](int groups, int stride, int m, int top, int lvl) {
-    if (cpl <= 1) hipLaunchKernelGGL(k_chain_fwd<1>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
-    else if (cpl <= 2) hipLaunchKernelGGL(k_chain_fwd<2>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
-    else if (cpl <= 3) hipLaunchKernelGGL(k_chain_fwd<3>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
-    else hipLaunchKernelGGL(k_chain_fwd<4>, dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
+    const bool side_by_side = cpl > 1 && !columns_per_lane;
+    if (cpl <= 1) hipLaunchKernelGGL((k_chain_fwd<1, 1>), dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
+    else if (side_by_side) {
+      if (cpl <= 2) hipLaunchKernelGGL((k_chain_fwd<1, 2>), dim3(groups), dim3(128), 0, s, v, stride, m, top, lvl);
+      else if (cpl <= 3) hipLaunchKernelGGL((k_chain_fwd<1, 3>), dim3(groups), dim3(192), 0, s, v, stride, m, top, lvl);
+      else hipLaunchKernelGGL((k_chain_fwd<1, 4>), dim3(groups), dim3(256), 0, s, v, stride, m, top, lvl);
+    }
+    else if (cpl <= 2) hipLaunchKernelGGL((k_chain_fwd<2, 1>), dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
+    else if (cpl <= 3) hipLaunchKernelGGL((k_chain_fwd<3, 1>), dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
+    else hipLaunchKernelGGL((k_chain_fwd<4, 1>), dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
   };
   if (forward) {
     for (int l = 0; l < nl; ++l) fwd((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1), strides[l], ms[l], 0, l);
