@@ -220,6 +220,7 @@ struct vc_calibrator {
   Pinned* pin = nullptr;        // page-locked staging (async copies without a bounce buffer)
   long nres_global_cached = -1; int nres_mult_cached[2] = {-1, -1};      // sharded: the all-reduced residual count and the multiplicities it was formed with
   int expected_passes = 8;       // passes the previous solve needed: size of the first batch of the next one (batched schedule)
+  int feed_ahead = 1;            // passes kept queued beyond the last decision seen (grows when the host is found late)
   bool feed_passes = std::getenv("VICALIB_AMD_BATCHED") == nullptr;   // single process: feed passes against the device's progress word
   DBuf<unsigned char> d_mask;
   std::vector<int> h_tile_frame, h_tile_cam, h_tile_off, h_obs_index;   // h_obs_index: device corner -> host observation
@@ -791,7 +792,10 @@ struct vc_calibrator {
       // the host keeps kAhead passes queued beyond the last decision it has seen -- no stream synchronisation inside the
       // solve (each one drains the queue: ~40 us of idle device), at most kAhead passes enqueued past the end (they return at
       // their first instruction).  Enqueueing a pass takes the host a fraction of the pass's run time.
-      constexpr int kAhead = 1;
+      // kAhead starts at 1 and grows (up to 4, kept for the calibrator's lifetime) whenever the host finds every enqueued pass
+      // already decided -- it came back late (a busy host: one box of the pool ran cfg3 at 0.40 instead of 0.30 ms per pass, with
+      // the launch-ahead schedules unaffected) and the device has been idle; a longer queue rides such gaps out.
+      int& kAhead = feed_ahead;
       volatile unsigned long long* prog = &pin->progress;
       *prog = 0ull;
       dv.host_progress = &pin->progress;
@@ -803,6 +807,7 @@ struct vc_calibrator {
         if (f != last) { last = f; t_seen = std::chrono::steady_clock::now(); }
         const int decided = (int)(f >> 32);
         if (n_enq >= max_iters + 8) break;
+        if (n_enq > 0 && decided >= n_enq && kAhead < 4) ++kAhead;
         if (n_enq - decided <= kAhead) {
           int rc = enqueue_pass(n_enq == 0); if (rc) { dv.host_progress = nullptr; return rc; }
           ++n_enq; t_seen = std::chrono::steady_clock::now();
