@@ -788,7 +788,7 @@ struct vc_calibrator {
     const auto tso0 = std::chrono::steady_clock::now();
     const bool feed = !sharded() && !use_graphs && feed_passes && dv.imu_on;
     if (feed) {
-      // Single process, visual-inertial passes (19 launches, ~270 us): the deciding thread publishes (decisions << 32 | done) to a page-locked word after every decision and
+      // Single process, visual-inertial passes (18 launches at cfg3, ~270 us): the deciding thread publishes (decisions << 32 | done) to a page-locked word after every decision and
       // the host keeps kAhead passes queued beyond the last decision it has seen -- no stream synchronisation inside the
       // solve (each one drains the queue: ~40 us of idle device), at most kAhead passes enqueued past the end (they return at
       // their first instruction).  Enqueueing a pass takes the host a fraction of the pass's run time.
