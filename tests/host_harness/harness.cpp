@@ -131,5 +131,14 @@ void hh_imu_weight(int n, const double* t, const double* w, const double* a, dou
   ImuView buf = {t, w, a, n, imu_average_dt(t, n)};
   imu_weight_sqrt(buf, t_start, t_end, toff, T1, v1, T2, b, sf, gdir, gs, as, w_sqrt);
 }
+// The same weight in the interval-parallel form k_imu_weights runs (vc_imu_weights.hpp: maps per interval at the prefix state,
+// fold, Cholesky-form factor W = L^-T).  Returns 1 if W was written.
+int hh_imu_weight_intervals(int n, const double* t, const double* w, const double* a, double t_start, double t_end, double toff,
+                            const double* T1, const double* v1, const double* T2, const double* b, const double* sf, const double* gdir,
+                            double gs, double as, double* W) {
+  ImuView buf = {t, w, a, n, imu_average_dt(t, n)};
+  return imu_weight_factor_intervals(buf, t_start, t_end, toff, T1, v1, T2, b, sf, gdir, gs, as, W);
+}
+void hh_dlog_dse3(const double* T, double* full, double* lean) { w_dlog_dse3(T, full); w_dlog_dse3_lean(T, lean); }
 int hh_chol6(double* M) { return chol_small<6>(M) ? 1 : 0; }
 }

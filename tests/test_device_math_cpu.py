@@ -208,6 +208,37 @@ def test_imu_covariance_weights_match_oracle(toff0, jitter):
         H.hh_imu_weight(len(p.imu_t), d(p.imu_t), d(p.imu_gyro), d(p.imu_accel), C.c_double(p.frame_time[j - 1]), C.c_double(p.frame_time[j]),
                         C.c_double(toff), d(T1), d(v1), d(T2), d(b), d(sfac), d(g), C.c_double(5.3088444e-5), C.c_double(0.001883649), d(w))
         np.testing.assert_allclose(w, W[j - 1], rtol=1e-7, atol=1e-9 * np.abs(W[j - 1]).max())
+        # the interval-parallel form the kernel runs (maps per interval at the prefix state, fold, Cholesky-form factor):
+        # the same information matrix, to rounding level against the sequential device form and at 1e-7 against the oracle
+        Wf = np.eye(9) * 500.0
+        wrote = H.hh_imu_weight_intervals(len(p.imu_t), d(p.imu_t), d(p.imu_gyro), d(p.imu_accel), C.c_double(p.frame_time[j - 1]),
+                                          C.c_double(p.frame_time[j]), C.c_double(toff), d(T1), d(v1), d(T2), d(b), d(sfac), d(g),
+                                          C.c_double(5.3088444e-5), C.c_double(0.001883649), d(Wf))
+        info_o = W[j - 1] @ W[j - 1].T
+        if np.allclose(W[j - 1], np.eye(9) * 500.0):
+            assert not wrote and np.array_equal(Wf, np.eye(9) * 500.0)
+        else:
+            assert wrote
+            np.testing.assert_allclose(Wf @ Wf.T, info_o, rtol=1e-7, atol=1e-9 * np.abs(info_o).max())
+            np.testing.assert_allclose(Wf @ Wf.T, w @ w.T, rtol=2e-9, atol=1e-11 * np.abs(info_o).max())
+            assert np.allclose(np.tril(Wf, -1), 0.0)
+
+
+def test_lean_dlog_dse3_matches_the_transliterated_form():
+    """w_dlog_dse3_lean (one arctangent, tan(theta/2) = |q_v| / |q_w|, shared reciprocals) against the term-by-term form of
+    vicalibrator-utils.h:107-154, :308-434 -- over rotation angles from 1e-12 rad (the small-angle branches) to almost pi, both
+    signs of q_w.  The closed forms cancel like 1/theta^2 - 1/theta^2 for small angles, so the bound scales with 1e-16 / theta^2."""
+    rng = np.random.default_rng(5)
+    H = hh()
+    for ang in [0.0, 1e-12, 3e-10, 5e-9, 1e-6, 1e-4, 1e-3, 0.02, 0.3, 1.0, 2.5, 3.1]:
+        for sign in (1.0, -1.0):
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            q = np.concatenate([np.sin(ang / 2) * ax, [np.cos(ang / 2)]]) * sign
+            T = np.concatenate([q, rng.normal(size=3) * 0.2])
+            a = np.zeros(42); b = np.zeros(42)
+            H.hh_dlog_dse3(d(T), d(a), d(b))
+            tol = max(1e-12, 3e-15 / max(ang, 1e-9) ** 2) if ang >= 1e-9 else 1e-12
+            np.testing.assert_allclose(b, a, rtol=tol, atol=tol * max(1.0, np.abs(a).max()))
 
 
 def test_imu_block_forms_match_oracle_on_irregular_sample_times():

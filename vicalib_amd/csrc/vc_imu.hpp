@@ -135,13 +135,28 @@ template <class T> struct Meas { T w[3], a[3], time; };
 // with t[i] + off <= time.  IMU streams are (nearly) uniformly sampled, so the search starts at the interpolated position and
 // walks -- two or three dependent loads instead of the ~15 of a bisection over 20 000 samples, which every lane of every IMU
 // kernel used to wait for twice; the result is the bisection's.
-VC_HD int imu_bracket(const ImuView& b, double time, double off) {
+VC_HD int imu_bracket(const ImuView& b, double time, double off, double* t_at = nullptr) {
   const double t0 = b.t[0], span = b.t[b.n - 1] - t0;
   int g = (span > 0.0) ? (int)((((time - off) - t0) / span) * (double)(b.n - 1)) : 0;
   g = g < 0 ? 0 : (g > b.n - 2 ? b.n - 2 : g);
-  while (g > 0 && b.t[g] + off > time) --g;
-  while (g < b.n - 2 && b.t[g + 1] + off <= time) ++g;
-  return g;
+  // the guess and its neighbours in ONE round of loads (a dependent load is ~1 us on the device): with nearly uniform sampling
+  // the answer is among them; the walks below only run for gappy streams.  All four comparisons are taken before any branch, so
+  // that the loads cannot be deferred into the branches that use them.
+  const int gm = g > 0 ? g - 1 : 0, gpp = g + 2 < b.n ? g + 2 : b.n - 1;
+  const double tm = b.t[gm], tg = b.t[g], tp = b.t[g + 1], tpp = b.t[gpp];
+  const bool dn = tg + off > time, dn_m = tm + off > time, up_p = tp + off <= time, up_pp = tpp + off <= time;
+  const bool dn_stop = g == 0, dn_one = !dn_m || gm == 0;            // downwards: stays at 0 / one step
+  const bool up_stop = g >= b.n - 2 || !up_p, up_one = g + 1 >= b.n - 2 || !up_pp;
+  int is = dn ? (dn_stop ? 0 : gm) : (up_stop ? g : g + 1);
+  double tis = dn ? (dn_stop ? tg : tm) : (up_stop ? tg : tp);
+  const bool slow = dn ? !(dn_stop || dn_one) : !(up_stop || up_one);
+  if (slow) {
+    if (dn) { g = gm; while (g > 0 && b.t[g] + off > time) --g; }
+    else { g = g + 2; while (g < b.n - 2 && b.t[g + 1] + off <= time) ++g; }
+    is = g; tis = b.t[g];
+  }
+  if (t_at) *t_at = tis;
+  return is;
 }
 template <class T> VC_HD void imu_interp(const ImuView& b, int i, T off, double time, Meas<T>* m) {
   const T ta = b.t[i] + off, tb = b.t[i + 1] + off;
@@ -170,17 +185,23 @@ VC_HD void imu_element_index(const ImuView& b, double time, double off, int* idx
   const int n = b.n;
   const double q = (time - b.t[0] + off) / b.avg_dt;
   int g = (q > 0.0) ? (q < (double)(n - 1) ? (int)q : n - 1) : 0;         // (a negative quotient is cast to size_t in the reference: 0 here)
-  const bool below = b.t[0] + off > time, above = b.t[n - 1] + off <= time;
-  const int is = below ? -1 : (above ? n - 1 : imu_bracket(b, time, off));     // largest i with t[i] + off <= time
+  const double t_guess = b.t[g];                   // (requested with the bracket's loads: nothing below depends on it before they return)
+  const double t_first = b.t[0], t_last = b.t[n - 1];
+  double t_is;
+  const int ib = imu_bracket(b, time, off, &t_is);
+  const bool below = t_first + off > time, above = t_last + off <= time;
+  const int is = below ? -1 : (above ? n - 1 : ib);     // largest i with t[i] + off <= time
+  if (above) t_is = t_last;
   *last_le = is;
-  if (b.t[g] + off > time) {                           // the walk goes backwards
+  const bool back = t_guess + off > time, on_sample = t_is + off == time;     // (compared before the branches: see imu_bracket)
+  if (back) {                                          // the walk goes backwards
     if (g == 0) { *idx = 0; *end_clamp = 1; return; }
     *idx = is > 0 ? is : 0; *end_clamp = 0;            // [is, is + 1]  ([0, 1], extrapolating, when even the first sample is later)
     if (*idx > n - 2) *idx = n - 2;
     return;
   }
   if (g == n - 1) { *idx = n - 1; *end_clamp = 1; return; }      // forwards from the last sample: clamp
-  if (b.t[is] + off == time && g < is) { *idx = is - 1; *end_clamp = 0; return; }     // stopped one pair early, weight 1
+  if (on_sample && g < is) { *idx = is - 1; *end_clamp = 0; return; }     // stopped one pair early, weight 1
   if (is == n - 1) { *idx = n - 1; *end_clamp = 1; return; }     // walked off the end (the reference reads past it: clamp)
   *idx = is; *end_clamp = 0;
 }
@@ -205,6 +226,31 @@ template <class T> VC_HD void imu_range_get(const ImuView& b, const ImuRange& r,
   if (which == 0) { if (r.first_end) imu_shift(b, r.i0, off, m); else imu_interp(b, r.i0, off, t0, m); }
   else if (which <= n_int) imu_shift(b, r.k0 + which - 1, off, m);
   else { if (r.last_end) imu_shift(b, r.i1, off, m); else imu_interp(b, r.i1, off, t1, m); }
+}
+
+// The same element without control flow around the loads (what the device kernels call: a branch per element kind costs a round of
+// dependent loads per branch): one sample pair [idx, idx + 1] is read whatever the kind, an interpolated element blends it,
+// a shifted sample takes the first of the pair.  Bit-identical to imu_range_get.
+template <class T> VC_HD void imu_range_get_flat(const ImuView& b, const ImuRange& r, T off, double t0, double t1, int which, Meas<T>* m) {
+  const int n_int = r.k1 - r.k0 + 1;
+  const bool first = which == 0, last = which > n_int;
+  const int idx = first ? r.i0 : (last ? r.i1 : r.k0 + which - 1);
+  const bool interp = (first && !r.first_end) || (last && !r.last_end);
+  const int idn = idx + 1 < b.n ? idx + 1 : b.n - 1;
+  const double tq = first ? t0 : t1;
+  const double ta_ = b.t[idx], tb_ = b.t[idn];
+  double wa[3], wb[3], aa[3], ab[3];
+  for (int k = 0; k < 3; ++k) { wa[k] = b.w[3 * idx + k]; wb[k] = b.w[3 * idn + k]; aa[k] = b.a[3 * idx + k]; ab[k] = b.a[3 * idn + k]; }
+  const T ta = ta_ + off, tb = tb_ + off;
+  const T den = interp ? tb - ta : cst<T>(1.0);
+  const T f = (cst<T>(tq) - ta) / den;
+  const T omf = 1.0 - f;
+  for (int k = 0; k < 3; ++k) {
+    const T wi = wa[k] * omf + wb[k] * f, ai = aa[k] * omf + ab[k] * f;
+    m->w[k] = interp ? wi : cst<T>(wa[k]);
+    m->a[k] = interp ? ai : cst<T>(aa[k]);
+  }
+  m->time = interp ? cst<T>(tq) : ta;
 }
 
 // ---- RK4 (ceres-cost-functions.h:39-177) --------------------------------------------------------------

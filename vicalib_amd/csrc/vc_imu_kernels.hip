@@ -11,7 +11,7 @@
 //                  application of the block's delta to the start state and the residual's tail -- the lane-parallel form of
 //                  ceres::Jet<double,35> (vc_imu.hpp, "delta form"); then Cauchy(100) weight and the 33 x 33 weighted
 //                  J^T J / J^T r of the block
-//  k_imu_weights   thread per block: UpdateImuWeights (vicalibrator.h:723-799, vc_imu_weights.hpp)
+//  k_imu_weights   16 lanes per block: UpdateImuWeights (vicalibrator.h:723-799) interval-parallel (vc_imu_weights.hpp)
 //  k_chain_init    wavefront per frame: 9 x 9 diagonal block (visual tiles + two IMU blocks), coupling to the
 //                  next frame, dense border row W (9 x D) and gradient; damping; per-chunk sums of the
 //                  camera Gram blocks and of the IMU shared-parameter block
@@ -162,295 +162,311 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   if (l == 0) v.seg_costb[cur][s] = ct->imu_mult * rho;
 }
 
-// UpdateImuWeights from the accepted state (vicalibrator.h:723-799): covariance propagation along the block's samples
-// (w_step_cols below), projection through the residual's Jacobian, factorisation.
-// The weight is stored as W = L^-T with  J Sigma J^T = L L^T  (Cholesky): W W^T = (J Sigma J^T)^-1 exactly as
-// for the reference's symmetric square root (vicalibrator.h:783-796), and cost, gradient and Gauss-Newton
-// Hessian of the block depend on W only through W W^T -- same optimisation, no 9x9 eigen-decomposition.
-// Per-block LDS of the weight update: M / T are the 10 x 16 images used to transpose / broadcast the step's
-// sensitivity matrices (two round trips per IMU step), the rest serves the final 9 x 10 projection.
-struct WLds { double M[160], T[160], tmp[100], Sigma[100], J[90], P[81]; };
+// UpdateImuWeights from the accepted state (vicalibrator.h:723-799), interval-parallel (vc_imu_weights.hpp, second half).
+// 16 lanes per IMU block, four blocks per wavefront, one wavefront per workgroup.  A round handles 16 sample intervals of every
+// block (cfg3: 12 per block, one round), lane i = interval i:
+//   1. the interval's RK4 delta from the identity state (values only, vc_imu.hpp);
+//   2. inclusive scan of the deltas over the 16 lanes (composition is associative): lane i learns the state its interval starts
+//      from, q_start * Q_prefix, without walking the block;
+//   3. the interval's maps, formed ONCE -- F (41 structural entries) and Q = G R G^T (55) -- from that quaternion;
+//   4. the recurrence Sigma <- F Sigma F^T + Q unrolled: Sigma_end = sum_k P_k Q_k P_k^T with P_k the product of the maps after
+//      interval k.  A suffix scan over the lanes gives P_k (the block form of F is closed under products), every lane conjugates
+//      its own Q, a butterfly sums the 55 entries: no step of the recurrence waits for the one before it.
+// All lane exchanges are DPP row operations (rows of 16 lanes = the groups): no LDS round trip anywhere in 1-4.
+// Then the projection through the residual's Jacobian in registers (every lane holds Sigma), J Sigma J^T = L L^T by nine lanes
+// (lane = row, pivots and pivot columns by 16-lane shuffles) and the stored factor W = L^-T:  W W^T = (J Sigma J^T)^-1 exactly
+// as for the reference's symmetric square root (vicalibrator.h:783-796), and cost, gradient and Gauss-Newton Hessian of the
+// block depend on W only through W W^T -- same optimisation, no 9x9 eigen-decomposition.
+constexpr int kWLds = 128;                       // per block: the factor's rows for the inverse (81) | frame poses j-1, j (16) | v_{j-1} (4) | IMU parameters (15)
+constexpr int kWPose = 88, kWVel = 104, kWImu = 108;
 
-// One RK4 step of the covariance propagation (types.h:427-595) with lane = column: lane c (< 16) carries column c of
-// [dy_dy0 (10) | dy_db (6)] through the four stages in registers.  The stage matrices of the reference's hand-derived
-// chain (dk_dx 9 x 10, dk_db 9 x 6, dy_dk 10 x 9, dy_dy 10 x 10) are sparse with a handful of small dense blocks; every
-// lane forms those blocks from the (replicated) state and applies them to its own column, so the whole step needs no
-// communication until Sigma <- F Sigma F^T + G R G^T, which goes through two LDS images.  Sc: column c of Sigma (c < 10).
-__device__ void w_step_cols(WLds& L, WState* st, const Meas<double>& z0, const Meas<double>& z1, const double* b, const double* sf,
-                            const double* g, double sg2, double sa2, int c, double* Sc) {
-  const double dt = z1.time - z0.time;
-  if (dt == 0) return;
-  const double tau[4] = {0.0, dt / 2, dt / 2, dt}, hh[4] = {dt * 0.5, dt * 0.5, dt, dt / 6.0}, wgt[4] = {1.0, 2.0, 2.0, 1.0};
-  double Y0[10], Yc[10], kt[9], ksum[9];
+// DPP row operations on doubles (two 32-bit moves).  row_shr:n -- lane i of a row reads lane i - n; row_shl:n -- lane i + n;
+// lanes without a source keep `old`.
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double old, double x) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int N> __device__ __forceinline__ double row_shr(double old, double x) { return dpp_f64<0x110 + N>(old, x); }
+template <int N> __device__ __forceinline__ double row_shl(double old, double x) { return dpp_f64<0x100 + N>(old, x); }
+// row permutation of a double (every lane has a source: no `old` operand, no copy)
+template <int CTRL> __device__ __forceinline__ double dpp_perm(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// sums over the 16 lanes of a row of N values at once, the same bits in every lane (each level adds the partner's value to the
+// lane's own: commutative).  Level by level over all values: the N exchanges of a level are independent instructions.
+template <int CTRL, int N> __device__ __forceinline__ void row_add_level(double* x) {
+  double y[N];
 #pragma unroll
-  for (int i = 0; i < 10; ++i) { Y0[i] = (i == c) ? 1.0 : 0.0; Yc[i] = Y0[i]; }     // dy_dy0 = I, dy_db = 0 at the step start
+  for (int e = 0; e < N; ++e) y[e] = dpp_perm<CTRL>(x[e]);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { kt[i] = 0.0; ksum[i] = 0.0; }
-  WState cur = *st, y = *st;
-#pragma unroll 1
-  for (int stage = 0; stage < 5; ++stage) {
-    double kcol[9], kv[9];
-    if (stage < 4) {
-      // k = f(cur) (GetPoseDerivative, types.h:380-425) and this lane's column of dk/d[y0 | b]
-      const double alpha = (z1.time - (z0.time + tau[stage])) / (z1.time - z0.time);
-      double zg[3], za[3], u[3], o[3], R[9], m1[12], m2[12];
+  for (int e = 0; e < N; ++e) x[e] += y[e];
+}
+template <int N> __device__ __forceinline__ void row_allsum_n(double* x) {
+  row_add_level<0xB1, N>(x);                     // quad_perm [1 0 3 2]
+  row_add_level<0x4E, N>(x);                     // quad_perm [2 3 0 1]
+  row_add_level<0x141, N>(x);                    // row_half_mirror
+  row_add_level<0x140, N>(x);                    // row_mirror
+}
+__device__ __forceinline__ double shfl16(double x, int src) { return __shfl(x, src, 16); }
+__device__ __forceinline__ void delta_identity(DeltaAcc<double>* a) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { zg[i] = z0.w[i] * alpha + z1.w[i] * (1.0 - alpha); za[i] = z0.a[i] * alpha + z1.a[i] * (1.0 - alpha); }
-      quat_to_R(cur.q, R);
+  for (int k = 0; k < 3; ++k) { a->q[k] = 0.0; a->p[k] = 0.0; a->v[k] = 0.0; }
+  a->q[3] = 1.0; a->t = 0.0;
+}
+// a <- a followed by x
+__device__ __forceinline__ void delta_then(DeltaAcc<double>* a, const DeltaAcc<double>& x) {
+  PoseV<double> d;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { kv[i] = cur.v[i]; u[i] = zg[i] * sf[i] + b[i]; }
+  for (int k = 0; k < 4; ++k) d.q[k] = x.q[k];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) kv[3 + i] = R[3 * i] * u[0] + R[3 * i + 1] * u[1] + R[3 * i + 2] * u[2];
+  for (int k = 0; k < 3; ++k) { d.p[k] = x.p[k]; d.v[k] = x.v[k]; }
+  imu_delta_append(a, d, x.t);
+}
+// one level of the inclusive scan: lanes >= N of the row take (lane - N's value) followed by their own
+template <int N> __device__ __forceinline__ void delta_scan_level(DeltaAcc<double>* X, int c) {
+  DeltaAcc<double> A;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) u[i] = za[i] * sf[3 + i] + b[3 + i];
-      quat_rotate(cur.q, u, o);
+  for (int k = 0; k < 4; ++k) A.q[k] = row_shr<N>(X->q[k], X->q[k]);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) kv[6 + i] = o[i] - g[i];
-      // dk_dx: rows 0-2 = d/dv, rows 3-5 = (dqx_dq(q, zg) + dqx_dq(q, bg)) on the quaternion, rows 6-8 likewise with za, ba
+  for (int k = 0; k < 3; ++k) { A.p[k] = row_shr<N>(X->p[k], X->p[k]); A.v[k] = row_shr<N>(X->v[k], X->v[k]); }
+  A.t = row_shr<N>(X->t, X->t);
+  delta_then(&A, *X);
+  if (c >= N) *X = A;
+}
+// one level of the suffix scan of the maps: (lane + N's map) applied after the lane's own; the last N lanes of the row receive
+// the identity, whose product with their own map is that map bit for bit
+template <int N> __device__ __forceinline__ void map_scan_level(double* S) {
+  double B[kWMapF], O[kWMapF];
+  w_map_identity(B);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) kcol[i] = Yc[7 + i];
-      // (dqx_dq is linear in its vector argument: one evaluation at z + b stands for the reference's sum of two)
-      {
-        const double zb[3] = {zg[0] + b[0], zg[1] + b[1], zg[2] + b[2]};
-        w_dqx_dq(cur.q, zb, m1);
-      }
+  for (int e = 0; e < kWMapF; ++e) B[e] = row_shl<N>(B[e], S[e]);
+  w_map_compose(B, S, O);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        double a = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a += m1[i * 4 + q] * Yc[3 + q];
-        kcol[3 + i] = a;
-      }
-      {
-        const double zb[3] = {za[0] + b[3], za[1] + b[4], za[2] + b[5]};
-        w_dqx_dq(cur.q, zb, m2);
-      }
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        double a = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a += m2[i * 4 + q] * Yc[3 + q];
-        kcol[6 + i] = a;
-      }
-      // dk_db: R in rows 3-5 for the gyro bias columns (10..12), in rows 6-8 for the accelerometer bias columns (13..15)
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          kcol[3 + i] += (c == 10 + q) ? R[3 * i + q] : 0.0;
-          kcol[6 + i] += (c == 13 + q) ? R[3 * i + q] : 0.0;
-        }
-#pragma unroll
-      for (int i = 0; i < 9; ++i) { kt[i] += wgt[stage] * kcol[i]; ksum[i] += wgt[stage] * kv[i]; }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) { kcol[i] = kt[i]; kv[i] = ksum[i]; }      // final combination: k1 + 2 k2 + 2 k3 + k4, h = dt / 6
-    }
-    if (stage == 3) continue;                     // k4 only enters the sum
-    // y = IntegratePose(st, k, h) (types.h:330-378) and this lane's column of dy/d[y0 | b] = dy_dk kcol + dy_dy Y0
-    const double h = hh[stage == 4 ? 3 : stage];
-    const double wdt[3] = {kv[3] * h, kv[4] * h, kv[5] * h};
-    double rq[4], A[16], E[12], AE[12], D2[16];
-    so3_exp(wdt, rq);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { y.p[i] = st->p[i] + kv[i] * h; y.v[i] = st->v[i] + kv[6 + i] * h; }
-    quat_mul(rq, st->q, y.q);
-    w_dq1q2_dq1(st->q, A); w_dqexp_dw(wdt, E);
-    mm(A, E, AE, 4, 4, 3);
-    w_dq1q2_dq2(rq, D2);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { Yc[i] = h * kcol[i] + Y0[i]; Yc[7 + i] = h * kcol[6 + i] + Y0[7 + i]; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      double a = 0.0;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) a += AE[i * 3 + q] * kcol[3 + q];
-      a *= h;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) a += D2[i * 4 + q] * Y0[3 + q];
-      Yc[3 + i] = a;
-    }
-    cur = y;
-  }
-  // ---- Sigma <- F Sigma F^T + G R G^T:  F = columns 0..9, G = columns 10..15 of the lanes ------------------------------
-#pragma unroll
-  for (int i = 0; i < 10; ++i) L.M[i * 16 + c] = Yc[i];
-  wave_lds_sync();
-  double T[10], Frow[16];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) T[i] = 0.0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) Frow[r] = (c < 10) ? L.M[c * 16 + r] : 0.0;          // row c of [F | G]
-#pragma unroll
-  for (int q = 0; q < 10; ++q) {
-#pragma unroll
-    for (int i = 0; i < 10; ++i) T[i] += L.M[i * 16 + q] * Sc[q];                  // column c of F Sigma (broadcast reads)
-    __builtin_amdgcn_sched_barrier(0);          // ten loads in flight at a time, not a hundred (register pressure)
-  }
-#pragma unroll
-  for (int i = 0; i < 10; ++i) L.T[i * 16 + c] = T[i];
-  wave_lds_sync();
-  double Sn[10];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) Sn[i] = 0.0;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-#pragma unroll
-    for (int i = 0; i < 10; ++i) Sn[i] += L.T[i * 16 + r] * Frow[r];                // (F Sigma) F^T, column c
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    const double rw = (q < 3 ? sg2 : sa2) * Frow[10 + q];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) Sn[i] += L.M[i * 16 + 10 + q] * rw;                // G R G^T, column c
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  wave_lds_sync();
-#pragma unroll
-  for (int i = 0; i < 10; ++i) Sc[i] = (c < 10) ? Sn[i] : 0.0;
-  *st = y;
+  for (int e = 0; e < kWMapF; ++e) S[e] = O[e];
 }
 
-// Four IMU blocks per wavefront: the propagation only uses 16 lanes (one per column of [dy_dy0 | dy_db]), and the kernel is
-// bound by per-lane instruction latency at one wave per SIMD (it needs the whole register file), so packing four 16-lane
-// groups into a wave quarters the number of waves.  Everything below is per group: its own LDS record, 16-lane loops,
-// stores predicated on the group's state; no early return (the groups of a wave finish together).
-__global__ __launch_bounds__(256) void k_imu_weights(DevView v, int wr) {
-  extern __shared__ __attribute__((aligned(16))) double w_lds[];
+// imu_range (vc_imu.hpp) with its two look-ups side by side: even lanes find the element of t0, odd lanes that of t1 -- the same
+// dependent loads, once instead of twice in a row -- and neighbours swap results.  All lanes of the wavefront must be active.
+__device__ __forceinline__ ImuRange imu_range_lanes(const ImuView& b, double t0, double t1, double off, int lane) {
+  ImuRange r; r.valid = 0; r.k0 = 0; r.k1 = -1; r.i0 = r.i1 = 0; r.first_end = r.last_end = 0;
+  if (b.n < 2) return r;
+  const bool odd = lane & 1;
+  int idx, endc, le;
+  imu_element_index(b, odd ? t1 : t0, off, &idx, &endc, &le);
+  const int idx_o = __shfl_xor(idx, 1, 64), endc_o = __shfl_xor(endc, 1, 64), le_o = __shfl_xor(le, 1, 64);
+  r.valid = (t0 >= b.t[0] + off && t0 <= b.t[b.n - 1] + off) ? 1 : 0;      // HasElement :122-125
+  r.i0 = odd ? idx_o : idx; r.first_end = odd ? endc_o : endc;
+  r.i1 = odd ? idx : idx_o; r.last_end = odd ? endc : endc_o;
+  r.k0 = r.i0 + 1;
+  r.k1 = odd ? le : le_o;
+  if (r.k1 < r.i0) r.k1 = r.i0;
+  return r;
+}
+
+// phase stamps of the first wavefront (profiling builds only, -DVC_W_STAMPS): 100 MHz s_memrealtime ticks in dbg[0..15]
+#ifdef VC_W_STAMPS
+#define WSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) v.dbg[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WSTAMP(i) do { } while (0)
+#endif
+__global__ __launch_bounds__(64) void k_imu_weights(DevView v, int wr) {
+  __shared__ __attribute__((aligned(16))) double w_lds[4 * kWLds];
   const Ctrl* ct = v.ctrl;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int grp = lane >> 4, c = lane & 15;      // c: column of [dy_dy0 | dy_db] this lane carries within its group
+  const int lane = threadIdx.x;
+  const int grp = lane >> 4, c = lane & 15;      // c: interval of the round; row of the projection afterwards
   const int n_blocks = v.n_frames - 1;
-  const int s_raw = (blockIdx.x * 4 + wave) * 4 + grp;
+  const int s_raw = blockIdx.x * 4 + grp;
   const bool exists = s_raw < n_blocks;
   const int s = exists ? s_raw : n_blocks - 1;   // groups past the end shadow the last block and store nothing
-  WLds& L = *reinterpret_cast<WLds*>(w_lds + (size_t)(wave * 4 + grp) * (sizeof(WLds) / sizeof(double)));
+  double* L = w_lds + grp * kWLds;
   // the buffer being written starts as a copy of the current weights: blocks that keep their weight (no samples, singular
   // projection) and passes queued behind a finished solve leave a consistent buffer behind
   if (exists) for (int e = c; e < 81; e += 16) v.wsqrtb[1 - wr][(size_t)s * 81 + e] = v.wsqrtb[wr][(size_t)s * 81 + e];
   if (ct->done || !v.weights_on) return;        // wave-uniform
-  const int st = ct->cur, j = s + 1;
-  const double* im = v.imus[st];
-  double T1[7], T2[7], b[6], sf[6], g2[2], gw[3];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) { T1[i] = v.poses[st][(size_t)(j - 1) * kPoseStride + i]; T2[i] = v.poses[st][(size_t)j * kPoseStride + i]; }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { b[i] = im[2 + i]; sf[i] = im[8 + i]; }
-  g2[0] = im[0]; g2[1] = im[1];
-  const double toff = im[14];
+  WSTAMP(0);
+  const int j = s + 1;
+  // The block's state, one value per lane: frames j - 1 and j are 16 consecutive doubles, the IMU parameters 15; both state buffers
+  // are requested before the control record says which one is current (one round of loads less), the current one goes to LDS and
+  // every lane reads what it needs when it needs it -- nothing of this sits in registers across the phases below.
+  {
+    const double p0 = v.poses[0][(size_t)(j - 1) * kPoseStride + c], p1 = v.poses[1][(size_t)(j - 1) * kPoseStride + c];
+    const double u0 = v.vel[0][(size_t)(j - 1) * 4 + (c & 3)], u1 = v.vel[1][(size_t)(j - 1) * 4 + (c & 3)];
+    const int ci = c < 15 ? c : 14;
+    const double i0 = v.imus[0][ci], i1 = v.imus[1][ci];
+    const bool one = ct->cur != 0;
+    L[kWPose + c] = one ? p1 : p0;
+    if (c < 4) L[kWVel + c] = one ? u1 : u0;
+    if (c < 15) L[kWImu + c] = one ? i1 : i0;
+  }
   const double t_start = v.frame_time[j - 1], t_end = v.frame_time[j];
+  wave_lds_sync();
+  double b[6], sf[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { b[i] = L[kWImu + 2 + i]; sf[i] = L[kWImu + 8 + i]; }
+  const double toff = L[kWImu + 14];
   const ImuView buf = imu_view(v);
-  const ImuRange rg = imu_range(buf, t_start, t_end, toff);
-  bool live = exists && rg.valid;                // an empty range keeps its current weight (vicalibrator.h:731-733)
-  imu_gravity(g2, gw);
-  WState sx;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) sx.q[i] = T1[i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) { sx.p[i] = T1[4 + i]; sx.v[i] = v.vel[st][(size_t)(j - 1) * 4 + i]; }
+  const ImuRange rg = imu_range_lanes(buf, t_start, t_end, toff, lane);
+  const bool live = exists && rg.valid;          // an empty range keeps its current weight (vicalibrator.h:731-733)
   const double sg2 = v.gyro_sigma * v.gyro_sigma, sa2 = v.accel_sigma * v.accel_sigma;
-  const int n_meas = live ? (rg.k1 - rg.k0 + 1) + 2 : 0;
-  int n_max = n_meas;                            // the wave runs to its longest group
+  const int n_int = live ? (rg.k1 - rg.k0 + 1) + 1 : 0;      // intervals between the n_meas = n_int + 1 range elements
+  int n_max = n_int;                             // the wave runs to its longest group
 #pragma unroll
   for (int o = 32; o >= 16; o >>= 1) n_max = max(n_max, __shfl_xor(n_max, o, 64));
-  double Sc[10];
+  DeltaAcc<double> carry;                        // the block's delta up to the current round
+  delta_identity(&carry);
+  double Sp[kWMapQ];                             // Sigma (packed lower triangle), the same in all lanes of the group
 #pragma unroll
-  for (int i = 0; i < 10; ++i) Sc[i] = 0.0;
-  Meas<double> z0, z1;
-  if (live) imu_range_get(buf, rg, toff, t_start, t_end, 0, &z0);
-  for (int m = 1; m < n_max; ++m) {
-    if (m < n_meas) {
-      imu_range_get(buf, rg, toff, t_start, t_end, m, &z1);
-      w_step_cols(L, &sx, z0, z1, b, sf, gw, sg2, sa2, c, Sc);
-      z0 = z1;
+  for (int e = 0; e < kWMapQ; ++e) Sp[e] = 0.0;
+  const double g0[3] = {0.0, 0.0, 0.0};
+  WSTAMP(1);
+#pragma unroll 1
+  for (int base = 0; base < n_max; base += 16) {
+    const int m = base + c + 1;                  // interval m runs from range element m - 1 to m
+    Meas<double> z0, z1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { z0.w[k] = z0.a[k] = z1.w[k] = z1.a[k] = 0.0; }
+    z0.time = z1.time = 0.0;
+    if (m <= n_int) { imu_range_get_flat(buf, rg, toff, t_start, t_end, m - 1, &z0); imu_range_get_flat(buf, rg, toff, t_start, t_end, m, &z1); }
+    const bool act = z1.time != z0.time;         // a zero-length interval is skipped (types.h:150-152)
+    WSTAMP(2);
+    // 1. the interval's delta from the identity
+    DeltaAcc<double> X;
+    {
+      PoseV<double> d;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { d.q[k] = 0.0; d.p[k] = 0.0; d.v[k] = 0.0; }
+      d.q[3] = 1.0;
+      imu_rk4_step(&d, z0, z1, b, sf, g0);       // (returns at once for a skipped interval: the identity)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) X.q[k] = d.q[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { X.p[k] = d.p[k]; X.v[k] = d.v[k]; }
+      X.t = z1.time - z0.time;
     }
+    WSTAMP(3);
+    // 2. inclusive scan over the group's 16 lanes
+    delta_scan_level<1>(&X, c); delta_scan_level<2>(&X, c); delta_scan_level<4>(&X, c); delta_scan_level<8>(&X, c);
+    double q_st[4];
+    {
+      double qe[4], ident[4] = {0.0, 0.0, 0.0, 1.0};      // everything before this lane's interval: the carry, then lanes 0 .. c - 1
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ident[k] = row_shr<1>(ident[k], X.q[k]);
+      quat_mul(carry.q, ident, qe);
+      const double q1[4] = {L[kWPose + 0], L[kWPose + 1], L[kWPose + 2], L[kWPose + 3]};
+      quat_mul(q1, qe, q_st);
+      DeltaAcc<double> Tt;                       // the round's total (lane 15) joins the carry
+#pragma unroll
+      for (int k = 0; k < 4; ++k) Tt.q[k] = shfl16(X.q[k], 15);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { Tt.p[k] = shfl16(X.p[k], 15); Tt.v[k] = shfl16(X.v[k], 15); }
+      Tt.t = shfl16(X.t, 15);
+      delta_then(&carry, Tt);
+    }
+    WSTAMP(4);
+    // 3. the interval's maps (a skipped interval: the identity map and no noise)
+    double F[kWMapF], G[kWMapG];
+    if (act) w_interval_maps(q_st, z0, z1, b, sf, F, G);
+    else {
+      w_map_identity(F);
+#pragma unroll
+      for (int e = 0; e < kWMapG; ++e) G[e] = 0.0;
+    }
+    WSTAMP(5);
+    // 4. Sigma_out = S_0 Sigma_in S_0^T + sum_k P_k G_k R G_k^T P_k^T  (S_0: all maps of the round, P_k: those after interval k)
+    map_scan_level<1>(F); map_scan_level<2>(F); map_scan_level<4>(F); map_scan_level<8>(F);     // F: F_15 ... F_c
+    double term[kWMapQ];
+    {
+      double P[kWMapF];
+      w_map_identity(P);
+#pragma unroll
+      for (int e = 0; e < kWMapF; ++e) P[e] = row_shl<1>(P[e], F[e]);        // the maps after this lane's interval
+      WSTAMP(6);
+      w_noise_term(P, G, sg2, sa2, term);
+    }
+    if (base > 0) {                              // a later round: the first lane takes Sigma_in through the whole round
+      double Sin[kWMapQ];
+      w_conj(F, Sp, Sin);
+#pragma unroll
+      for (int e = 0; e < kWMapQ; ++e) term[e] += (c == 0) ? Sin[e] : 0.0;
+    }
+    WSTAMP(7);
+#pragma unroll
+    for (int e0 = 0; e0 < kWMapQ; e0 += 11) row_allsum_n<11>(term + e0);
+#pragma unroll
+    for (int e = 0; e < kWMapQ; ++e) Sp[e] = term[e];
   }
-  if (c < 10) {
-#pragma unroll
-    for (int i = 0; i < 10; ++i) L.Sigma[i * 10 + c] = Sc[i];
-  }
-  // J = dLog_dSE3(T_pred T2^-1) dt1t2_dt1(T_pred, T2^-1), velocity identity appended (9 x 10)
-  const double qc[4] = {-T2[0], -T2[1], -T2[2], T2[3]}, nt[3] = {-T2[4], -T2[5], -T2[6]};
-  double t2w[7], rel[7], tr[3];
-  quat_rotate(qc, nt, t2w + 4);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) t2w[i] = qc[i];
-  quat_mul(sx.q, qc, rel);
-  const double nrm = sqrt(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2] + rel[3] * rel[3]);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) rel[i] /= nrm;
-  quat_rotate(sx.q, t2w + 4, tr);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) rel[4 + i] = sx.p[i] + tr[i];
-  for (int e = c; e < 90; e += 16) L.J[e] = 0.0;
-  wave_lds_sync();
+  WSTAMP(8);
+  // the predicted state from the block's delta (vc_imu.hpp), then J = dLog_dSE3(T_pred T2^-1) dt1t2_dt1(T_pred, T2^-1) with
+  // the velocity identity appended (9 x 10); lane i (< 9) forms row i of P = J Sigma J^T
+  double a[9];
   {
-    // J67 = dLog_dSE3 * dt1t2_dt1 with dt1t2_dt1 = [I3, dqx_dq(q, t); 0, dq1q2_dq1] (sparse): row i of J67 in lane i of the group
-    double dl[42], m34[12], m44[16];
-    w_dlog_dse3(rel, dl);
-    w_dqx_dq(sx.q, t2w + 4, m34);
+    double T1[7], T2[7], v1[3], gw[3], q_end[4], p_end[3], rp[3];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { T1[i] = L[kWPose + i]; T2[i] = L[kWPose + 8 + i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v1[i] = L[kWVel + i];
+    { const double g2[2] = {L[kWImu + 0], L[kWImu + 1]}; imu_gravity(g2, gw); }
+    quat_mul(T1, carry.q, q_end);
+    tq_rotate(T1, carry.p, rp);
+    const double ht2 = 0.5 * (carry.t * carry.t);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p_end[i] = ((T1[4 + i] + v1[i] * carry.t) - gw[i] * ht2) + rp[i];
+    double rel[7], t2w[7], dl[42], m34[12], m44[16], Jr[6][7], mine[10];
+    w_projection_prepare(q_end, p_end, T2, rel, t2w);
+    w_dlog_dse3_lean(rel, dl);
+    w_dqx_dq(q_end, t2w + 4, m34);
     w_dq1q2_dq1(t2w, m44);
-    if (c < 6) {
-      double row[7];
 #pragma unroll
-      for (int jj = 0; jj < 7; ++jj) row[jj] = 0.0;
+    for (int i = 0; i < 6; ++i) w_projection_row(dl, m34, m44, i, Jr[i]);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        if (i == c) {
+    for (int q = 0; q < 10; ++q) {
+      double x = (q >= 7 && c == q - 1) ? 1.0 : 0.0;            // rows 6..8: the velocity identity
 #pragma unroll
-          for (int jj = 0; jj < 3; ++jj) row[jj] = dl[i * 7 + jj];
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            double a = 0.0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) a += dl[i * 7 + k] * m34[k * 4 + jj];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a += dl[i * 7 + 3 + k] * m44[k * 4 + jj];
-            row[3 + jj] = a;
-          }
-        }
-      }
-#pragma unroll
-      for (int jj = 0; jj < 7; ++jj) L.J[c * 10 + jj] = row[jj];
+      for (int i = 0; i < 6; ++i) x = (q < 7 && c == i) ? Jr[i][q] : x;
+      mine[q] = x;
     }
-    if (c == 0) L.J[6 * 10 + 7] = L.J[7 * 10 + 8] = L.J[8 * 10 + 9] = 1.0;
-  }
-  wave_lds_sync();
-  for (int e = c; e < 90; e += 16) {             // tmp = J Sigma (9 x 10)
-    const int i = e / 10, jj = e % 10;
-    double acc = 0.0;
+    double JS[10];
 #pragma unroll
-    for (int q = 0; q < 10; ++q) acc += L.J[i * 10 + q] * L.Sigma[q * 10 + jj];
-    L.tmp[e] = acc;
-  }
-  wave_lds_sync();
-  for (int e = c; e < 81; e += 16) {             // P = (J Sigma) J^T
-    const int i = e / 9, jj = e % 9;
-    double acc = 0.0;
+    for (int q = 0; q < 10; ++q) {
+      double acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < 10; ++q) acc += L.tmp[i * 10 + q] * L.J[jj * 10 + q];
-    L.P[e] = acc;
-  }
-  wave_lds_sync();
-  // Cholesky P = L L^T in place (lane 0 of the group; 9 columns), then X = L^-1 column per lane, W = X^T
-  if (c == 0) {
-    for (int cc = 0; cc < 9; ++cc) {
-      double d = L.P[cc * 9 + cc];
-      for (int k = 0; k < cc; ++k) d -= L.P[cc * 9 + k] * L.P[cc * 9 + k];
-      const double id = (d > 0.0) ? fast_rsqrt(d) : 0.0;
-      L.P[cc * 9 + cc] = d * id;
-      L.tmp[cc] = id;
-      for (int i = cc + 1; i < 9; ++i) {
-        double a = L.P[i * 9 + cc];
-        for (int k = 0; k < cc; ++k) a -= L.P[i * 9 + k] * L.P[cc * 9 + k];
-        L.P[i * 9 + cc] = a * id;
-      }
+      for (int r = 0; r < 10; ++r) acc += mine[r] * Sp[w_qidx(r, q)];
+      JS[q] = acc;
     }
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) {
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) acc += JS[q] * Jr[jj][q];
+      a[jj] = acc;
+    }
+#pragma unroll
+    for (int jj = 6; jj < 9; ++jj) a[jj] = JS[jj + 1];
   }
-  wave_lds_sync();
+  WSTAMP(9);
+  // Cholesky P = L L^T, lane i (< 9) = row i in registers: the pivot and the pivot column travel by 16-lane shuffles
+  double idg[9];
   bool ok = true;
-  for (int cc = 0; cc < 9; ++cc) ok = ok && (L.tmp[cc] > 0.0);
+#pragma unroll
+  for (int cc = 0; cc < 9; ++cc) {
+    const double d = shfl16(a[cc], cc);
+    ok = ok && (d > 0.0);
+    const double id = (d > 0.0) ? fast_rsqrt(d) : 0.0;
+    idg[cc] = id;
+    const double li = a[cc] * id;                // L[i][cc] for rows i >= cc (rows above: unused)
+#pragma unroll
+    for (int k = cc + 1; k < 9; ++k) a[k] -= li * shfl16(li, k);
+    a[cc] = li;
+  }
+  if (c < 9) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) L[c * 9 + k] = a[k];             // the factor's row c (entries k <= c)
+  }
+  wave_lds_sync();
+  WSTAMP(10);
   if (live && !ok && c == 0) atomicAdd((unsigned long long*)&v.dbg[20], 1ull);     // singular projection: keeps the previous weight (counted)
   if (live && ok && c < 9) {                     // column c of X = L^-1
     double x[9];
@@ -458,15 +474,16 @@ __global__ __launch_bounds__(256) void k_imu_weights(DevView v, int wr) {
     for (int i = 0; i < 9; ++i) x[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-      double a = (i == c) ? 1.0 : 0.0;
+      double acc = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) if (k < i) a -= L.P[i * 9 + k] * x[k];
-      x[i] = (i >= c) ? a * L.tmp[i] : 0.0;
+      for (int k = 0; k < 9; ++k) if (k < i) acc -= L[i * 9 + k] * x[k];
+      x[i] = (i >= c) ? acc * idg[i] : 0.0;
     }
     double* w = v.wsqrtb[1 - wr] + (size_t)s * 81;       // W[a][b] = X[b][a]
 #pragma unroll
     for (int i = 0; i < 9; ++i) w[c * 9 + i] = x[i];
   }
+  WSTAMP(11);
 }
 
 // ------------------------------------------------------------------------------------------ chain assembly
@@ -1133,10 +1150,7 @@ void launch_imu_jac(const DevView& v, int wr, hipStream_t s, int trial) {
 }
 void launch_imu_weights(const DevView& v, int wr, hipStream_t s) {
   if (v.n_frames < 2) return;
-  const size_t lds = 16 * sizeof(WLds);        // 16 blocks per workgroup (4 per wavefront)
-  static bool granted = false;
-  if (!granted) { (void)hipFuncSetAttribute((const void*)k_imu_weights, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = true; }
-  hipLaunchKernelGGL(k_imu_weights, dim3((v.n_frames - 1 + 15) / 16), dim3(256), lds, s, v, wr);
+  hipLaunchKernelGGL(k_imu_weights, dim3((v.n_frames - 1 + 3) / 4), dim3(64), 0, s, v, wr);      // four blocks per wavefront
 }
 // Level schedule of the partitioned chain elimination: strides 1, m, m^2, ... while more than m - 1 frames are active, then
 // the top level (one wavefront eliminates the rest).  forward: bottom-up; backward: top-down.
