@@ -72,6 +72,18 @@ static void DefineFlags() {
   Define("outlier_threshold", "double", "2.0", "Outlier threshold (x camera RMSE).");
   Define("paused", "bool", "false", "(GUI) ignored.");
   Define("use_only_when_static", "bool", "false", "(sensor front-end) ignored: the detections file already holds the chosen frames.");
+  // flags of the sensor / pattern front-end (vicalib-engine.cc:39, :65-77, :88-92, vicalib-task.cc:19): accepted so that an existing
+  // command line keeps working, without effect here -- the detections file is what that front-end would have produced
+  Define("device_serial", "string", "-1", "(sensor front-end) ignored: serial number of device.");
+  Define("scaled_ir_depth_cal", "bool", "false", "(sensor front-end) ignored: produce ir and depth calibration by rescaling RGB.");
+  Define("static_accel_threshold", "double", "0.08", "(sensor front-end) ignored: acceleration below which the device counts as static.");
+  Define("static_gyro_threshold", "double", "0.04", "(sensor front-end) ignored: angular velocity below which the device counts as static.");
+  Define("static_threshold_preset", "int32", "0", "(sensor front-end) ignored: a visual_inertial_calibration::StaticThresholdPreset.");
+  Define("use_static_threshold_preset", "bool", "false", "(sensor front-end) ignored: use one of the predefined static thresholds.");
+  Define("output_pattern_file", "string", "", "(pattern front-end) ignored: EPS or SVG file to save the calibration pattern.");
+  Define("grid_large_rad", "double", "0.00423", "(pattern front-end) ignored: radius of large dots (m).");
+  Define("grid_small_rad", "double", "0.00283", "(pattern front-end) ignored: radius of small dots (m).");
+  Define("clip_good", "bool", "false", "(sensor front-end) ignored: output proto file of only good tracked images.");
   // vicalib-task.cc:19-51
   Define("find_time_offset", "bool", "true", "Optimize for the time offset between the IMU and images.");
   Define("function_tolerance", "double", "1e-6", "Convergence criterion for the optimizer.");
@@ -85,6 +97,10 @@ static void DefineFlags() {
   Define("max_poly3_diff_k3", "double", "0.1", "Maximum poly3 k3 difference between calibrations.");
   Define("max_camera_trans_diff", "double", "0.1", "Maximum camera translation difference between calibrations.");
   Define("max_camera_angle_diff", "double", "0.1", "Maximum camera angle difference (rad) between calibrations.");
+  Define("max_imu_gyro_diff", "double", "0.1", "Maximum gyroscope bias difference between calibrations.");
+  Define("max_imu_accel_diff", "double", "0.1", "Maximum accelrometer bias difference between calibrations.");
+  Define("imu_diff_sense", "string", "reference", "IMUCalibrationDiffer with -has_initial_guess: 'reference' = the comparisons as the reference writes them "
+         "(vicalib-task.cc:811-826: a bias difference BELOW the limit counts as differing), 'corrected' = above the limit.");
   Define("use_system_time", "bool", "true", "Use the first (system) column of timestamp.txt; otherwise the second (device).");
   // new: what HAL would have told the reference
   Define("image_width", "int32", "640", "Image width of every channel (HAL reports it in the reference).");
@@ -243,6 +259,28 @@ static void RotationMatrix(const double* q, double* R) {
   R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
   R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
   R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// IMUCalibrationDiffer (vicalib-task.cc:807-829).  The reference compares with '<': it reports a difference when a bias moved by
+// LESS than the limit in any component -- with start biases of zero (vicalib-task.cc:129) that is nearly every calibration, so
+// -has_initial_guess makes its IsSuccessful() fail unless all six biases exceed the limits.  The exit status is part of the tool's
+// behaviour: 'reference' reproduces it (and says so), 'corrected' compares the way the message reads.
+static bool IMUCalibrationDiffer(const double* last, const double* current, bool reference_sense) {
+  double diff[6];
+  for (int i = 0; i < 6; ++i) diff[i] = last[i] - current[i];
+  const double lg = FlagDouble("max_imu_gyro_diff"), la = FlagDouble("max_imu_accel_diff");
+  auto out = [&](double d, double lim) { return reference_sense ? std::fabs(d) < lim : std::fabs(d) > lim; };
+  if (out(diff[0], lg) || out(diff[1], lg) || out(diff[2], lg)) {
+    std::fprintf(stderr, "E IMU bias(es) for gyroscope differ (%g, %g, %g ) more than expected (%g)%s\n", diff[0], diff[1], diff[2], lg,
+                 reference_sense ? " [reference comparison sense: '<', see -imu_diff_sense]" : "");
+    return true;
+  }
+  if (out(diff[3], la) || out(diff[4], la) || out(diff[5], la)) {
+    std::fprintf(stderr, "E IMU bias(es) for accelrometer differ (%g, %g, %g ) more than expected (%g)%s\n", diff[3], diff[4], diff[5], la,
+                 reference_sense ? " [reference comparison sense: '<', see -imu_diff_sense]" : "");
+    return true;
+  }
+  return false;
 }
 
 // CameraCalibrationsDiffer (vicalib-task.cc:722-806)
@@ -508,6 +546,11 @@ int main(int argc, char** argv) {
   if (success && guess) for (size_t c = 0; c < n_cam; ++c) {
     vic::CameraAndPose now = cal.GetCamera(c); now.model = input_cameras[c].model;
     if (CameraCalibrationsDiffer(input_cameras[c], now)) { success = false; break; }
+  }
+  if (success && guess) {                        // vicalib-task.cc:852-853 (input_imu_biases_: the calibrator's biases at construction, :129)
+    const double input_imu_biases[6] = {0, 0, 0, 0, 0, 0};
+    const auto bias_now = cal.GetBiases();
+    if (IMUCalibrationDiffer(input_imu_biases, bias_now.data(), FlagString("imu_diff_sense") != "corrected")) success = false;
   }
   std::printf("calibration %s -> %s\n", success ? "succeeded" : "FAILED", FlagString("output").c_str());
   return success ? 0 : 2;

@@ -320,8 +320,8 @@ def cpu_baseline(wl, prob):
     n_sub = min(200 if vi else 100, len(prob.frame_time))
     tf, tc, off, ids, pix = prob.flat
 
-    def build(nthreads):
-        orc = ol.Oracle()
+    def build(nthreads, fast=False):
+        orc = ol.Oracle(fast=fast)       # fast: libvco_fast.so (closed-form Jacobians borrowed from the product; timed only)
         for c, m in enumerate(prob.cam_model):
             orc.add_camera(m, prob.cam_K_gt[c], prob.cam_T_ck_gt[c])
         for n in range(n_sub):
@@ -359,7 +359,7 @@ def cpu_baseline(wl, prob):
         it2, t2 = run(orc2, 5.0)
         all_cores = {"value": nobs * it2 / t2, "cores": nt}
         # the same work with closed-form reprojection Jacobians (oracle/vco_fast.h) instead of forward duals
-        orc3, _ = build(nt); orc3.set_closed_form(True)
+        orc3, _ = build(nt, fast=True); orc3.set_closed_form(True)
         it3, t3 = run(orc3, 5.0)
         best = {"value": nobs * it3 / t3, "cores": nt, "what": "closed-form reprojection Jacobians, dual-number IMU blocks, block elimination; threads over frames / IMU blocks"}
     cpu_model = ""

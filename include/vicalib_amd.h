@@ -129,7 +129,8 @@ int vc_get_imu_measurements(vc_calibrator* h, double* gyro, double* accel, doubl
  * then one per measurement of the range; rows of 11 doubles [q(4) t(3) v_w(3) time].  Returns the count (0 unless the inertial
  * terms are fully active, :510), which may exceed max_poses. */
 int vc_get_integration_poses(vc_calibrator* h, int id, double* poses, int max_poses);
-/* PrintResults() :536-544 into buf: per camera its parameters and T_ck as a 4 x 4 matrix; returns the length */
+/* PrintResults() :536-544 into buf: per camera its parameters and T_ck as a 4 x 4 matrix; returns the length of the text.
+ * len = 0 (buf may be NULL): only the length is returned -- the text needs a buffer of that + 1 bytes; a buffer too small is VC_ERR_BAD_ARG */
 int vc_print_results(vc_calibrator* h, char* buf, int len);
 /* WriteCameraModels(filename) :208-229 (calibu rig XML) */
 int vc_write_camera_models(vc_calibrator* h, const char* filename);

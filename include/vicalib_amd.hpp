@@ -124,14 +124,15 @@ class ViCalibrator {
     return out;
   }
   std::vector<std::array<double, 11>> GetIntegrationPoses(unsigned id) {
-    std::vector<std::array<double, 11>> out(64);
-    const int n = vc_checked(vc_get_integration_poses(h_, (int)id, out[0].data(), 64), "GetIntegrationPoses");
-    out.resize((size_t)std::min(n, 64));
+    const int n = vc_checked(vc_get_integration_poses(h_, (int)id, nullptr, 0), "GetIntegrationPoses");      // the count first: all of them
+    std::vector<std::array<double, 11>> out((size_t)std::max(n, 0));
+    if (n > 0) vc_checked(vc_get_integration_poses(h_, (int)id, out[0].data(), n), "GetIntegrationPoses");
     return out;
   }
   std::string PrintResults() {
-    std::string s(4096, '\0');
-    const int n = vc_checked(vc_print_results(h_, &s[0], (int)s.size()), "PrintResults");
+    const int n = vc_checked(vc_print_results(h_, nullptr, 0), "PrintResults");          // the length first: any number of cameras
+    std::string s((size_t)n + 1, '\0');
+    vc_checked(vc_print_results(h_, &s[0], n + 1), "PrintResults");
     s.resize((size_t)n);
     return s;
   }

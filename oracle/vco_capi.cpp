@@ -5,7 +5,9 @@
 #include <vector>
 #include <chrono>
 #include "vco_solver.h"
-#include "vco_fast.h"
+#ifdef VCO_WITH_FAST
+#include "vco_fast.h"        // libvco_fast.so only (bench.py's closed-form CPU leg): borrows the product's arithmetic
+#endif
 
 using namespace vco;
 
@@ -87,7 +89,14 @@ void vco_set_options(void* h, int max_iters, double function_tolerance, int cali
   CAL->fix_intrinsics = fix_intrinsics; CAL->opt.remove_outliers = remove_outliers; CAL->opt.outlier_threshold = outlier_threshold;
   CAL->opt.num_threads = num_threads; CAL->opt.dense_check = dense_check;
 }
-void vco_set_closed_form(void* h, int on) { CAL->opt.closed_form = on != 0; }
+// 0 = done; -1 = this build has no closed-form path (libvco_oracle.so, the checker: it holds no product arithmetic)
+int vco_set_closed_form(void* h, int on) {
+#ifdef VCO_WITH_FAST
+  CAL->opt.closed_form = on != 0; return 0;
+#else
+  (void)h; return on ? -1 : 0;
+#endif
+}
 void vco_set_tolerances(void* h, double gradient_tolerance, double parameter_tolerance) {
   CAL->opt.gradient_tolerance = gradient_tolerance; CAL->opt.parameter_tolerance = parameter_tolerance;
 }

@@ -155,7 +155,9 @@ class Calibrator {
     }
   }
   void reproj_block_any(const Obs& o, double* r, double* Jf, double* Jr, double* Jt, double* Jk) const {
+#ifdef VCO_WITH_FAST
     if (opt.closed_form) { reproj_block_closed_form(*this, o, r, Jf, Jr, Jt, Jk); return; }
+#endif
     switch (cams[o.cam].nk) {
       case 4: reproj_block<4>(o, r, Jf, Jr, Jt, Jk); break;
       case 5: reproj_block<5>(o, r, Jf, Jr, Jt, Jk); break;

@@ -86,7 +86,7 @@ def load_slice(cal, prob, lo, hi):
     return cal
 
 
-def main_imu(models=("kb4",), n_total=80, max_iters=100, strict=True, oracle=False, prior=False):
+def main_imu(models=("kb4",), n_total=80, max_iters=100, oracle=False, prior=False):
     """Frame-sharded visual-inertial calibration: separators in the reduced system, interior chains per rank."""
     from vicalib_amd.lib import ViCalibrator
     rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
@@ -102,18 +102,6 @@ def main_imu(models=("kb4",), n_total=80, max_iters=100, strict=True, oracle=Fal
     np.set_printoptions(linewidth=200)
     if rank == 0:
         print('shared dims: sharded', cal.shared_dim(), 'single', ref.shared_dim(), 'iterations', len(tr))
-    if not strict:
-        # Ill-conditioned on purpose (8 cameras, few frames, every stage runs into max_iters): a 1e-7 difference from the
-        # different elimination order (separators vs one chain) grows over hundreds of iterations.  The first iterations
-        # of the schedule pin the arithmetic, the end state is compared loosely.
-        assert cal.shared_dim() == ref.shared_dim() + 9 * (world - 1)
-        k = min(30, len(tg), len(tr))
-        np.testing.assert_allclose(tg[:k, 1], tr[:k, 1], rtol=1e-5)
-        np.testing.assert_array_equal(tg[:k, 8], tr[:k, 8])
-        np.testing.assert_allclose(cal.GetCameraProjRMSE(), ref.GetCameraProjRMSE(), rtol=0.05)
-        dist.barrier(); dist.destroy_process_group()
-        print("rank", rank, "ok")
-        return
     assert len(tg) == len(tr), (tg[:, [0, 1, 8, 9]], tr[:, [0, 1, 8, 9]])
     np.testing.assert_allclose(tg[:, 1], tr[:, 1], rtol=1e-7)
     np.testing.assert_array_equal(tg[:, 8], tr[:, 8])
@@ -181,6 +169,6 @@ if __name__ == "__main__":
     if sys.argv[1] == "gpu_imu":
         _guarded(main_imu)
     elif sys.argv[1] == "gpu_imu8":      # cfg5's rig: 8 cameras + IMU, reduced dimension 115 + 9 per shard boundary; well conditioned
-        _guarded(main_imu, models=("fov", "kb4") * 4, n_total=240, max_iters=200, strict=True, oracle=True, prior=True)
+        _guarded(main_imu, models=("fov", "kb4") * 4, n_total=240, max_iters=200, oracle=True, prior=True)
     else:
         _guarded(main, sys.argv[1])

@@ -7,6 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 _lib = None
+_libs = {}
 
 dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -16,10 +17,12 @@ def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        so = os.path.join(ORACLE_DIR, "libvco_oracle.so")
+def lib(fast=False):
+    """libvco_oracle.so -- the checker; fast=True: libvco_fast.so, the same sources plus the closed-form Jacobians borrowed from the
+    product (bench.py's closed-form CPU leg; never a parity reference)."""
+    name = "libvco_fast.so" if fast else "libvco_oracle.so"
+    if name not in _libs:
+        so = os.path.join(ORACLE_DIR, name)
         srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".h", ".cpp"))]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s)):
             build()
@@ -30,8 +33,8 @@ def lib():
         L.vco_linearize.restype = C.c_double
         L.vco_time_iterations.restype = C.c_double
         L.vco_get_num_iterations.restype = C.c_uint
-        _lib = L
-    return _lib
+        _libs[name] = L
+    return _libs[name]
 
 
 def _d(a):
@@ -41,8 +44,8 @@ def _d(a):
 class Oracle:
     """Mirror of the reference ViCalibrator API over the CPU restatement."""
 
-    def __init__(self):
-        self.L = lib()
+    def __init__(self, fast=False):
+        self.L = lib(fast)
         self.h = C.c_void_p(self.L.vco_create())
         self.nk = []
 
@@ -92,8 +95,10 @@ class Oracle:
                                int(remove_outliers), C.c_double(outlier_threshold), int(num_threads), int(dense_check))
 
     def set_closed_form(self, on=True):
-        """bench.py's best-CPU leg: closed-form reprojection Jacobians (oracle/vco_fast.h); never used by a parity test."""
-        self.L.vco_set_closed_form(self.h, int(on))
+        """bench.py's closed-form CPU leg (oracle/vco_fast.h, in libvco_fast.so only: Oracle(fast=True)); never used by a parity test.
+        The checker library refuses."""
+        if self.L.vco_set_closed_form(self.h, int(on)) != 0:
+            raise RuntimeError("this oracle build has no closed-form path (libvco_oracle.so holds no product arithmetic); use Oracle(fast=True)")
 
     def set_tolerances(self, gradient_tolerance=1e-10, parameter_tolerance=1e-8):
         self.L.vco_set_tolerances(self.h, C.c_double(gradient_tolerance), C.c_double(parameter_tolerance))

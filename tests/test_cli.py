@@ -41,6 +41,24 @@ def test_help_and_flag_errors():
     r = _run(["-cam", "detections:///does/not/exist.csv"]); assert r.returncode == 1 and "cannot open" in r.stderr
 
 
+REFERENCE_FRONT_END_FLAGS = ["-device_serial", "abc123", "-scaled_ir_depth_cal", "-static_accel_threshold", "0.1", "-static_gyro_threshold=0.05",
+                             "-static_threshold_preset", "1", "-use_static_threshold_preset", "-output_pattern_file", "pattern.svg",
+                             "-grid_large_rad", "0.004", "-grid_small_rad", "0.003", "-noclip_good", "-max_imu_gyro_diff", "0.2",
+                             "-max_imu_accel_diff=0.3"]
+
+
+def test_every_reference_flag_is_accepted():
+    """The flags of the reference's sensor / pattern front-end (vicalib-engine.cc:39, :65-77, :88-92, vicalib-task.cc:19, :45-48) parse:
+    the command line gets as far as opening the detections (here: a file that does not exist), not 'unknown command line flag'."""
+    r = _run(REFERENCE_FRONT_END_FLAGS + ["-cam", "detections:///does/not/exist.csv"])
+    assert r.returncode == 1 and "cannot open" in r.stderr and "unknown command line flag" not in r.stderr
+    h = _run(["--help"]).stdout
+    for f in REFERENCE_FRONT_END_FLAGS:
+        if f.startswith("-") and not f[1:2].isdigit():
+            name = f.split("=")[0].replace("-no", "-", 1) if f.startswith("-noclip") else f.split("=")[0]
+            assert name + " " in h, name
+
+
 def test_no_gpu_is_a_loud_failure(tmp_path):
     import torch
     if torch.cuda.is_available():
@@ -133,3 +151,35 @@ def test_cli_rational6_model(tmp_path):
     assert cams[0][0] == "calibu_fu_fv_u0_v0_rational6" and len(cams[0][1]) == 10
     np.testing.assert_allclose(cams[0][1][:4], p.cam_K_gt[0][:4], rtol=5e-3)
     assert "calibration succeeded" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_initial_guess_reproduces_the_reference_exit_status(tmp_path):
+    """-has_initial_guess: IsSuccessful also runs IMUCalibrationDiffer (vicalib-task.cc:807-829, :852-853) against the biases the
+    calibrator was constructed with (zero, :129), and its comparisons are inverted in the reference ('<': a bias that moved by
+    LESS than the limit counts as differing).  The default reproduces that exit status -- a good calibration is reported as FAILED
+    whenever a bias stays below 0.1, i.e. always without an IMU -- and says so; -imu_diff_sense corrected judges it the way the
+    message reads."""
+    p = synth.generate(synth.Config(models=("kb4",), n_frames=80, imu=True, seed=5))
+    files, imu_dir = synth.write_dataset(p, str(tmp_path))
+    out = tmp_path / "cameras.xml"
+    r = _run(["-cam", "detections://" + files[0], "-imu", "csv://" + imu_dir, "-models", "kb4", "-max_iters", "100", "-output", str(out)])
+    assert r.returncode == 0, r.stdout + r.stderr
+    # vision only from the calibrated model: RMSE and the camera comparisons pass, the bias comparison decides
+    guess = ["-cam", "detections://" + files[0], "-model_files", str(out), "-has_initial_guess", "-nocalibrate_imu", "-output", str(tmp_path / "c2.xml")]
+    r_ref = _run(guess + REFERENCE_FRONT_END_FLAGS[:2])
+    assert r_ref.returncode == 2 and "calibration FAILED" in r_ref.stdout, r_ref.stdout + r_ref.stderr
+    assert "IMU bias(es) for gyroscope differ" in r_ref.stderr and "reference comparison sense" in r_ref.stderr
+    r_fix = _run(guess + ["-imu_diff_sense", "corrected"])
+    assert r_fix.returncode == 0 and "calibration succeeded" in r_fix.stdout, r_fix.stdout + r_fix.stderr
+    # with the IMU, Start(has_initial_guess) (vicalib-task.cc:226-234) goes straight to the stage with everything free, from the
+    # model file's intrinsics and an identity T_ck (vicalib-engine.cc:190-193): far from a good start, as in the reference.  With
+    # the earlier gates opened wide the run reaches the bias comparison in either sense.
+    wide = ["-max_reprojection_error", "1e3", "-max_fx_diff", "1e3", "-max_fy_diff", "1e3", "-max_cx_diff", "1e3", "-max_cy_diff", "1e3",
+            "-max_camera_trans_diff", "1e3", "-max_camera_angle_diff", "10"]
+    vi = ["-cam", "detections://" + files[0], "-imu", "csv://" + imu_dir, "-model_files", str(out), "-has_initial_guess", "-max_iters", "30",
+          "-output", str(tmp_path / "c3.xml")] + wide
+    r_vi = _run(vi + ["-max_imu_gyro_diff", "1e9", "-max_imu_accel_diff", "1e9"])
+    assert r_vi.returncode == 2 and "IMU bias(es) for gyroscope differ" in r_vi.stderr, r_vi.stdout + r_vi.stderr     # '<' 1e9: always
+    r_vi2 = _run(vi + ["-imu_diff_sense", "corrected", "-max_imu_gyro_diff", "1e9", "-max_imu_accel_diff", "1e9"])
+    assert r_vi2.returncode == 0, r_vi2.stdout + r_vi2.stderr

@@ -113,6 +113,42 @@ def test_cfg1_solve_matches_oracle():
     assert cal.GetCameraProjRMSE()[0] < 0.15       # vicalib-engine.cc:56
 
 
+@pytest.mark.parametrize("ransac", [False, True])
+def test_solve_from_the_pnp_seed_matches_oracle(ransac):
+    """The front-end's pose seed (calibu::PosePnPRansac + the pose write of vicalib-task.cc:323-325, :335-348) feeding the solver:
+    frames seeded by vc_init_frame_poses_pnp from the engine's start intrinsics -- plain fit, and the consensus fit with a fifth of
+    every view's dots carrying another dot's pixel -- then the same seed given to the oracle: same LM iterations, same optimum."""
+    import copy
+    p = synth.generate(synth.Config(models=("poly3",), n_frames=24, seed=21))
+    if ransac:
+        rng = np.random.default_rng(9)
+        tiles = []
+        for (f, c, ids, pix) in p.tiles:
+            n = len(ids)
+            bad = rng.choice(n, size=max(1, n // 5), replace=False)
+            pix2 = pix.copy()
+            pix2[bad] = pix[(bad + 7 + rng.integers(0, n - 14, size=len(bad))) % n]
+            tiles.append((f, c, ids, pix2))
+        p = copy.copy(p); p.tiles = tiles
+    cal = ViCalibrator(0).load_problem(p)
+    cal.SetCalibrateImu(False)
+    if ransac:
+        cal.SetPnPRansac(100, 1.5)
+    assert cal.InitFramePosesPnP() == len(p.frame_time)
+    seed = cal.GetFrames().copy()
+    # a usable seed: every frame within a few centimetres / degrees of the generating pose although the intrinsics are the
+    # engine's start values -- with mismatched dots only the consensus fit manages that
+    assert np.abs(seed[:, 4:] - p.frame_T_wk_gt[:, 4:]).max() < 0.25
+    orc = ol.Oracle().load(p)
+    orc.set_options(calibrate_imu=False, num_threads=4)
+    for f in range(len(seed)):
+        orc.set_frame(f, seed[f])
+    cal.Solve(); orc.solve()
+    _compare_solution(p, cal, orc)
+    if not ransac:
+        np.testing.assert_allclose(cal.GetCamera(0)[0][:4], p.cam_K_gt[0][:4], rtol=3e-3)
+
+
 def test_cfg2_solve_matches_oracle():
     """BASELINE config 2 (the benchmark workload): stereo fov,fov, small grid, 500 frames."""
     p, cal, orc = _pair(synth.BASELINE_CONFIGS["cfg2"], num_threads=8)
@@ -502,6 +538,30 @@ def test_imu_weight_update_matches_oracle():
         Cg = Wg[j] @ Wg[j].T; Co = Wo[j] @ Wo[j].T
         np.testing.assert_allclose(Cg, Co, rtol=1e-7, atol=1e-9 * np.abs(Co).max())
         assert np.allclose(np.tril(Wg[j], -1), 0.0)          # W = L^-T is upper triangular
+
+
+@pytest.mark.parametrize("imu_rate,toff", [(40.0, 0.004), (330.0, 0.0025), (345.0, -0.011), (1000.0, 0.0007), (700.0, 0.05)])
+def test_imu_weight_update_across_sample_rates(imu_rate, toff):
+    """The interval-parallel weight update over blocks of 1 to 51 sample intervals (the kernel handles 16 intervals of a block per
+    round: one to four rounds here, covariance carried from round to round; 330 Hz / 345 Hz put the round boundary inside some
+    blocks and not others of the same wavefront; 0.05 s of offset runs the last blocks off the stream): W W^T against the oracle."""
+    p = synth.generate(synth.Config(models=("kb4",), n_frames=14, imu=True, seed=12, imu_rate=imu_rate))
+    gt = p.imu_gt
+    cal = ViCalibrator(0).load_problem(p, init=False)
+    orc = ol.Oracle().load(p, init=False); orc.set_options(calibrate_imu=True)
+    b0 = np.concatenate([gt["bg"], gt["ba"]]) * 1.1; s0 = np.concatenate([gt["sg"], gt["sa"]]) * 0.995
+    orc.set_flags(True, True, False, True); orc.set_imu_state(b0, s0, np.zeros(2), toff)
+    cal.SetOptimizationFlags(True, True, False, True); cal.SetBiases(b0); cal.SetScaleFactor(s0); cal.SetTimeOffset(toff)
+    orc.prepare(vis_mult=1, imu_mult=1)
+    cal.linearize()
+    Wg = cal.imu_weights()
+    orc.update_imu_weights(); Wo = orc.imu_weights().reshape(-1, 9, 9)
+    n_new = 0
+    for j in range(len(Wg)):
+        Cg = Wg[j] @ Wg[j].T; Co = Wo[j] @ Wo[j].T
+        np.testing.assert_allclose(Cg, Co, rtol=1e-7, atol=1e-9 * np.abs(Co).max())
+        n_new += not np.allclose(Wo[j], np.eye(9) * Wo[j][0, 0])
+    assert n_new >= len(Wg) - 4            # the update ran (blocks without samples keep their start weight)
 
 
 def test_imu_weight_update_against_numerically_propagated_covariance():

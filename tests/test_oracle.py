@@ -191,8 +191,22 @@ def test_closed_form_cpu_mode_reproduces_the_dual_number_blocks():
     p = _small_problem(("fov", "kb4", "rational6"), n=6)
     lins = []
     for closed in (False, True):
-        o = ol.Oracle().load(p); o.set_options(calibrate_imu=False); o.set_closed_form(closed); o.prepare()
+        o = ol.Oracle(fast=closed).load(p); o.set_options(calibrate_imu=False); o.set_closed_form(closed); o.prepare()
         lins.append(o.linearize())
     for k in ("A", "W", "Hss", "gf", "gs"):
         np.testing.assert_allclose(lins[1][k], lins[0][k], rtol=1e-9, atol=1e-9 * np.abs(lins[0][k]).max())
     assert abs(lins[1]["cost"] - lins[0]["cost"]) <= 1e-13 * lins[0]["cost"]
+
+
+def test_checker_library_contains_no_product_arithmetic():
+    """libvco_oracle.so is the restatement alone: no symbol of the product's namespace (vc::, what vco_fast.h borrows for the bench's
+    closed-form CPU leg) is compiled into it, and it cannot be switched to that path; libvco_fast.so is where that lives."""
+    import subprocess
+    ol.lib(); ol.lib(fast=True)
+    syms = subprocess.run(["nm", "-C", "--defined-only", os.path.join(ol.ORACLE_DIR, "libvco_oracle.so")], capture_output=True, text=True).stdout
+    assert " vc::" not in syms and "vco::reproj_block_closed_form" not in syms
+    fast = subprocess.run(["nm", "-C", "--defined-only", os.path.join(ol.ORACLE_DIR, "libvco_fast.so")], capture_output=True, text=True).stdout
+    assert "vco::reproj_block_closed_form" in fast
+    with pytest.raises(RuntimeError):
+        ol.Oracle().set_closed_form(True)
+    ol.Oracle().set_closed_form(False)

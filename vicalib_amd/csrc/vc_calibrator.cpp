@@ -219,6 +219,7 @@ struct vc_calibrator {
   struct Pinned { Ctrl up; Ctrl down; double trace[64 * kTraceCols]; unsigned long long progress; };
   Pinned* pin = nullptr;        // page-locked staging (async copies without a bounce buffer)
   long nres_global_cached = -1; int nres_mult_cached[2] = {-1, -1};      // sharded: the all-reduced residual count and the multiplicities it was formed with
+  long solve_epoch = 0, nres_epoch_cached = -1;     // ... and the public solve call it was formed in (bumped by every rank at the same entry points)
   int expected_passes = 8;       // passes the previous solve needed: size of the first batch of the next one (batched schedule)
   int feed_ahead = 1;            // passes kept queued beyond the last decision seen (grows when the host is found late)
   bool feed_passes = std::getenv("VICALIB_AMD_BATCHED") == nullptr;   // single process: feed passes against the device's progress word
@@ -532,7 +533,6 @@ struct vc_calibrator {
     dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p;
     for (int b = 0; b < 2; ++b) dv.rX[b] = d_rX[b].p;
     up_c = up_ms();
-    nres_global_cached = -1;
     HIP_OK(hipStreamSynchronize(stream));   // the staging vectors above go out of scope
     if (up_timing) std::fprintf(stderr, "[vicalib_amd]   upload: observations %.3f, layout %.3f, copies + allocations %.3f, drain %.3f ms\n", up_a, up_b - up_a, up_c - up_b, up_ms() - up_c);
     device_dirty = false;
@@ -767,18 +767,22 @@ struct vc_calibrator {
     if (device_dirty) { int rc = upload(); if (rc) return rc; }
     *nres = 2L * ((long)dv.n_obs * vis_mult - n_one_less) + (dv.imu_on ? 9L * imu_mult * std::max(0, dv.n_frames - 1) : 0L);
     if (sharded()) {
-      // The global residual count changes with the observation set (every rank re-uploads then: upload() drops the cached value) and
-      // with the multiplicities (bumped on all ranks together): one collective per change, not per solve.  The test must not depend
-      // on anything rank-local -- a rank that skipped the collective while another entered it would hang the job.
-      if (nres_global_cached < 0 || nres_mult_cached[0] != vis_mult || nres_mult_cached[1] != imu_mult) {
+      // The global residual count changes with the observation set and with the multiplicities.  The test for a fresh collective
+      // must not depend on anything rank-local (a rank that skipped it while another entered would hang the job) -- not on
+      // device_dirty, which a mutator called on one rank only would set there alone: the key is the public solve call (every rank
+      // enters Solve() / vc_run_iterations together, they contain collectives anyway) and the multiplicities, which all ranks
+      // bump together, outlier removal included.  One collective per stage of a solve.
+      if (nres_epoch_cached != solve_epoch || nres_mult_cached[0] != vis_mult || nres_mult_cached[1] != imu_mult) {
         std::vector<double> v = {(double)*nres};
         int rc = host_allreduce_sum(v); if (rc) return rc;
-        nres_global_cached = (long)v[0]; nres_mult_cached[0] = vis_mult; nres_mult_cached[1] = imu_mult;
+        nres_global_cached = (long)v[0]; nres_mult_cached[0] = vis_mult; nres_mult_cached[1] = imu_mult; nres_epoch_cached = solve_epoch;
       }
       *nres = nres_global_cached;
     }
     if (trace_cap < max_iters + 8) { trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); dv.trace = d_trace.p; }
-    if (!pin) HIP_OK(hipHostMalloc((void**)&pin, sizeof(Pinned), hipHostMallocDefault));
+    // the progress word is written by the device and polled by the host: coherent (fine-grained), mapped memory whatever
+    // HIP_HOST_COHERENT says -- with a non-coherent allocation the host would never see the device's stores
+    if (!pin) HIP_OK(hipHostMalloc((void**)&pin, sizeof(Pinned), hipHostMallocCoherent | hipHostMallocMapped));
     init_ctrl(&pin->up);
     { int rcu = upload_ctrl(&pin->up); if (rcu) return rcu; }
     if (dv.imu_on && dv.weights_on) { launch_imu_weights(dv, wcur, stream); wcur = 1 - wcur; }     // UpdateImuWeights() before ceres::Solve (vicalibrator.h:955)
@@ -813,7 +817,14 @@ struct vc_calibrator {
           ++n_enq; t_seen = std::chrono::steady_clock::now();
         } else {
           __builtin_ia32_pause();
-          if (std::chrono::steady_clock::now() - t_seen > std::chrono::seconds(30)) break;      // a stuck device: fall through to the synchronising read
+          // the queue is full: nothing to do until the device decides a pass (~0.3 ms); past ~50 us without news, yield the core
+          const auto idle = std::chrono::steady_clock::now() - t_seen;
+          if (idle > std::chrono::microseconds(50)) std::this_thread::yield();
+          if (idle > std::chrono::seconds(5)) {          // a stuck device (or a progress word the host cannot see): say so, then
+            std::fprintf(stderr, "vicalib_amd: no progress from the device for 5 s (%d passes queued, %d decided) -- falling back to a "
+                                 "synchronising read\n", n_enq, decided);                     // fall through to the synchronising read
+            break;
+          }
         }
       }
       dv.host_progress = nullptr;
@@ -984,6 +995,7 @@ struct vc_calibrator {
   int solve() {
     // the worker thread of Start() (and any caller's thread) starts on device 0: bind this calibrator's device first
     HIP_OK(hipSetDevice(device));
+    ++solve_epoch;
     // is_finished_ is sticky until Clear() (vicalibrator.h:246, :922): a finished calibrator's Start()/Solve() returns at once
     int status = VC_OK;
     int stages_done = 0;
@@ -1189,6 +1201,7 @@ int vc_add_observation_tiles(vc_calibrator* h, int n_tiles, const int* tile_fram
   for (int t = 0; t < n_tiles; ++t)
     if (tile_frame[t] < 0 || tile_frame[t] >= N || tile_cam[t] < 0 || tile_cam[t] >= C || tile_off[t + 1] < tile_off[t]) return VC_ERR_BAD_ARG;
   if (n_tiles == 0) return VC_OK;
+  if (tile_off[0] < 0) return VC_ERR_BAD_ARG;       // (offsets are monotone: a negative first one would index before the arrays)
   const long long n0 = tile_off[0], n1 = tile_off[n_tiles];
   if ((long long)h->o_frame.size() + (n1 - n0) > 0x7fffffffLL) return VC_ERR_UNSUPPORTED;
   for (long long i = n0; i < n1; ++i) if (point_id[i] < 0 || point_id[i] >= n_points) return VC_ERR_BAD_ARG;
@@ -1368,7 +1381,7 @@ int vc_get_integration_poses(vc_calibrator* h, int id, double* poses, int max_po
 }
 // PrintResults() :536-544 into a caller's buffer: per camera its parameters and T_ck as a 4 x 4 matrix
 int vc_print_results(vc_calibrator* h, char* buf, int len) {
-  if (!h || !buf || len <= 0) return VC_ERR_BAD_ARG;
+  if (!h || len < 0 || (len > 0 && !buf)) return VC_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(h->result_mutex);
   std::string out = "------------------------------------------\n";
   char line[512];
@@ -1382,6 +1395,7 @@ int vc_print_results(vc_calibrator* h, char* buf, int len) {
     for (int i = 0; i < 3; ++i) { std::snprintf(line, sizeof(line), "%.10g %.10g %.10g %.10g\n", R[3 * i], R[3 * i + 1], R[3 * i + 2], cm.T_ck[4 + i]); out += line; }
     out += "0 0 0 1\n\n";
   }
+  if (len == 0) return (int)out.size();          // length query: the text needs a buffer of this + 1 bytes
   if ((int)out.size() + 1 > len) return VC_ERR_BAD_ARG;
   std::memcpy(buf, out.c_str(), out.size() + 1);
   return (int)out.size();
@@ -1529,6 +1543,7 @@ int vc_run_iterations(vc_calibrator* h, int iters, int* jac_sweeps, int* res_swe
   const int mi = h->max_iters;
   const long j0 = h->jac_sweeps, r0 = h->res_sweeps;
   h->should_run = true;
+  ++h->solve_epoch;
   int done = 0, rc = VC_OK, guard = 0;
   while (done < iters && guard++ < iters + 4) {
     h->max_iters = std::min(mi, iters - done);

@@ -282,10 +282,12 @@ __global__ __launch_bounds__(64) void k_imu_weights(DevView v, int wr) {
   const bool exists = s_raw < n_blocks;
   const int s = exists ? s_raw : n_blocks - 1;   // groups past the end shadow the last block and store nothing
   double* L = w_lds + grp * kWLds;
-  // the buffer being written starts as a copy of the current weights: blocks that keep their weight (no samples, singular
-  // projection) and passes queued behind a finished solve leave a consistent buffer behind
-  if (exists) for (int e = c; e < 81; e += 16) v.wsqrtb[1 - wr][(size_t)s * 81 + e] = v.wsqrtb[wr][(size_t)s * 81 + e];
-  if (ct->done || !v.weights_on) return;        // wave-uniform
+  // the buffer being written must end up complete: blocks that keep their weight (no samples, singular projection) and passes
+  // queued behind a finished solve copy the current one -- at the end, off the path of the blocks that get a new weight
+  if (ct->done || !v.weights_on) {               // wave-uniform
+    if (exists) for (int e = c; e < 81; e += 16) v.wsqrtb[1 - wr][(size_t)s * 81 + e] = v.wsqrtb[wr][(size_t)s * 81 + e];
+    return;
+  }
   WSTAMP(0);
   const int j = s + 1;
   // The block's state, one value per lane: frames j - 1 and j are 16 consecutive doubles, the IMU parameters 15; both state buffers
@@ -468,6 +470,7 @@ __global__ __launch_bounds__(64) void k_imu_weights(DevView v, int wr) {
   wave_lds_sync();
   WSTAMP(10);
   if (live && !ok && c == 0) atomicAdd((unsigned long long*)&v.dbg[20], 1ull);     // singular projection: keeps the previous weight (counted)
+  if (exists && !(live && ok)) for (int e = c; e < 81; e += 16) v.wsqrtb[1 - wr][(size_t)s * 81 + e] = v.wsqrtb[wr][(size_t)s * 81 + e];
   if (live && ok && c < 9) {                     // column c of X = L^-1
     double x[9];
 #pragma unroll

@@ -162,12 +162,15 @@ inline bool pnp_planar_masked(int model, const double* K, int n, const double* p
   // ---- LM refinement of T_cw <- T_cw exp(delta) on the full model ---------------------------------------------
   ModelPre pre;
   model_precompute(model, K, &pre);
+  int n_cost = 0;                                  // points the last cost_of call summed over (all used points, not only the m unprojectable ones)
   auto cost_of = [&](const double* Tc, double* Hm, double* g) {
     double Rc[9]; quat_to_R(Tc, Rc);
     double cost = 0.0;
+    n_cost = 0;
     if (Hm) { std::memset(Hm, 0, 36 * sizeof(double)); std::memset(g, 0, 6 * sizeof(double)); }
     for (int i = 0; i < n; ++i) {
       if (use && !use[i]) continue;
+      ++n_cost;
       const double* p = pw + 3 * i;
       double pc[3];
       for (int a = 0; a < 3; ++a) pc[a] = Rc[3 * a] * p[0] + Rc[3 * a + 1] * p[1] + Rc[3 * a + 2] * p[2] + Tc[4 + a];
@@ -211,7 +214,8 @@ inline bool pnp_planar_masked(int model, const double* K, int n, const double* p
     } else { lambda *= 10; if (lambda > 1e12) break; }
   }
   std::memcpy(T_cw, T, sizeof(T));
-  if (rms) *rms = std::sqrt(cost / m);
+  cost = cost_of(T, nullptr, nullptr);             // (sets n_cost for the accepted pose)
+  if (rms) *rms = std::sqrt(cost / (n_cost > 0 ? n_cost : 1));
   return std::isfinite(cost);
 }
 inline bool pnp_planar(int model, const double* K, int n, const double* pw, const double* uv, double* T_cw, double* rms) {

@@ -228,13 +228,16 @@ class ViCalibrator:
         return g, a, t
 
     def GetIntegrationPoses(self, frame_id):
-        out = np.zeros((64, 11))
-        n = _check(self.L.vc_get_integration_poses(self.h, int(frame_id), _d(out), 64), "GetIntegrationPoses")
-        return out[:min(n, 64)]
+        n = _check(self.L.vc_get_integration_poses(self.h, int(frame_id), None, 0), "GetIntegrationPoses")     # the count first
+        out = np.zeros((max(n, 1), 11))
+        if n > 0:
+            _check(self.L.vc_get_integration_poses(self.h, int(frame_id), _d(out), n), "GetIntegrationPoses")
+        return out[:n]
 
     def PrintResults(self):
-        buf = C.create_string_buffer(4096)
-        _check(self.L.vc_print_results(self.h, buf, len(buf)), "PrintResults")
+        n = _check(self.L.vc_print_results(self.h, None, 0), "PrintResults")           # the length first: any number of cameras
+        buf = C.create_string_buffer(n + 1)
+        _check(self.L.vc_print_results(self.h, buf, n + 1), "PrintResults")
         return buf.value.decode()
     def WriteCameraModels(self, path): _check(self.L.vc_write_camera_models(self.h, path.encode()), "WriteCameraModels")
 
