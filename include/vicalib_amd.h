@@ -167,6 +167,9 @@ void* vc_get_stream(vc_calibrator* h);    /* hipStream_t */
 int vc_rccl_unique_id(void* out128);
 int vc_set_shard_rccl(vc_calibrator* h, int rank, int world_size, const void* unique_id128);
 long long vc_allreduce_calls(vc_calibrator* h);    /* all-reduces issued through the library's own communicator */
+/* Text behind the last failing status of vc_set_shard_rccl on this thread (which library call failed, RCCL's error string and
+ * last-error text): what a launcher prints before it falls back to another transport.  Empty if nothing failed. */
+const char* vc_last_error(void);
 /* Upload the problem and linearise once at the current state (stage flags as set): fills the device
  * normal equations.  Used by the parity tests and the benchmark. */
 int vc_prepare(vc_calibrator* h);

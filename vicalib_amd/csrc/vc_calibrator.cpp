@@ -122,6 +122,8 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, RcclUniqueId, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;      // optional: diagnostics only
+  const char* (*GetLastError)(void*) = nullptr;
   bool load() {
     if (AllReduce) return true;
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
@@ -132,11 +134,15 @@ struct RcclApi {
     CommInitRank = (int (*)(void**, int, RcclUniqueId, int))dlsym(lib, "ncclCommInitRank");
     AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
     CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+    GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+    GetLastError = (const char* (*)(void*))dlsym(lib, "ncclGetLastError");
     if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) { AllReduce = nullptr; return false; }
     return true;
   }
 };
 static RcclApi g_rccl;
+// text of the last failure of an entry point that has more to say than its status code (vc_last_error; per thread)
+static thread_local std::string g_last_error;
 constexpr int kNcclDouble = 8, kNcclSum = 0, kNcclMax = 2;     // ncclDataType_t / ncclRedOp_t values of nccl.h
 
 struct vc_calibrator {
@@ -673,7 +679,9 @@ struct vc_calibrator {
           KT("k_imu_delta+k_imu_block", launch_imu_delta(dv, stream, 0)); KT("k_imu_jac", launch_imu_jac(dv, wcur, stream, 0));
         }
       }
-      KT("chain_forward", launch_chain_solve_a(dv, stream));
+      KT("k_chain_init", launch_chain_init(dv, stream));
+      KT("k_chain_fwd", launch_chain_fwd(dv, stream));
+      KT("k_chain_gram", launch_chain_gram(dv, stream));
       KT("k_part_sum", launch_part_sum(dv, stream));
       int rc = VC_OK;
       if (sharded()) {
@@ -690,7 +698,7 @@ struct vc_calibrator {
         HIP_OK(hipStreamWaitEvent(stream2, ev_reduced, 0));
         KT2("k_imu_delta+k_imu_block(trial)", launch_imu_delta(dv, stream2, 1));
       }
-      KT("chain_backward", launch_chain_solve_b(dv, stream));
+      KT("k_chain_back", launch_chain_solve_b(dv, stream));
       // trial point: both sweeps in trial mode on the main stream, the IMU blocks with the weights this pass has just updated
       // (second stream: weight update, then the deltas -- ev_weights covers both); the decision follows without another
       // cross-stream hop (each costs 6-13 us on the device's timeline)
@@ -1469,17 +1477,24 @@ int vc_rccl_unique_id(void* out128) {
 int vc_set_shard_rccl(vc_calibrator* h, int rank, int world_size, const void* unique_id128) {
   NOT_RUNNING(h);
   if (world_size < 1 || rank < 0 || rank >= world_size || !unique_id128) return VC_ERR_BAD_ARG;
-  if (!g_rccl.load()) return VC_ERR_UNSUPPORTED;
-  if (hipSetDevice(h->device) != hipSuccess) return VC_ERR_NO_DEVICE;
+  if (!g_rccl.load()) { g_last_error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy not all found"); return VC_ERR_UNSUPPORTED; }
+  if (hipSetDevice(h->device) != hipSuccess) { g_last_error = "hipSetDevice(" + std::to_string(h->device) + ") failed"; return VC_ERR_NO_DEVICE; }
   RcclUniqueId id;
   std::memcpy(&id, unique_id128, sizeof(id));
   if (h->rccl_comm) { (void)g_rccl.CommDestroy(h->rccl_comm); h->rccl_comm = nullptr; }
-  if (g_rccl.CommInitRank(&h->rccl_comm, world_size, id, rank) != 0) { h->rccl_comm = nullptr; return VC_ERR_NO_DEVICE; }
+  const int nrc = g_rccl.CommInitRank(&h->rccl_comm, world_size, id, rank);
+  if (nrc != 0) {
+    g_last_error = "ncclCommInitRank(rank " + std::to_string(rank) + " of " + std::to_string(world_size) + ", device " + std::to_string(h->device) + ") = " + std::to_string(nrc);
+    if (g_rccl.GetErrorString) g_last_error += std::string(" (") + g_rccl.GetErrorString(nrc) + ")";
+    if (g_rccl.GetLastError) { const char* le = g_rccl.GetLastError(nullptr); if (le && le[0]) g_last_error += std::string(": ") + le; }
+    h->rccl_comm = nullptr; return VC_ERR_NO_DEVICE;
+  }
   h->rank = rank; h->world = world_size; h->allreduce = nullptr; h->allreduce_ctx = nullptr; h->device_dirty = true;
   { const char* e = std::getenv("VICALIB_AMD_FORCE_SHARD_PATH"); h->force_shard_path = e && e[0] == '1'; }
   return VC_OK;
 }
 long long vc_allreduce_calls(vc_calibrator* h) { return h ? h->rccl_calls : 0; }
+const char* vc_last_error(void) { return g_last_error.c_str(); }
 void* vc_get_stream(vc_calibrator* h) { return h ? (void*)h->stream : nullptr; }
 int vc_prepare(vc_calibrator* h) {
   NOT_RUNNING(h);

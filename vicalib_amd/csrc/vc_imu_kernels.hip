@@ -1206,23 +1206,21 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
       hipLaunchKernelGGL(k_chain_back, dim3((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1)), dim3(64), 0, s, v, strides[l], ms[l], 0, l);
   }
 }
-void launch_chain_solve_a(const DevView& v, hipStream_t s) {
-  const int N = v.n_frames;
-  {
-    const size_t slot = (size_t)v.n_cams * kGStride + kGStride;
-    const size_t lds = std::max((size_t)4 * (v.n_cams * kGStride + kInitPad), 4 * slot) * sizeof(double);
-    static size_t granted = 0;
-    if (lds > 65536 && lds > granted) { (void)hipFuncSetAttribute((const void*)k_chain_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
-    hipLaunchKernelGGL(k_chain_init, dim3(v.n_chunks), dim3(256), lds, s, v);
-  }
-  chain_levels(v, s, true);
-  {
-    const size_t lds = (size_t)36 * v.ldw * sizeof(double);
-    static size_t granted = 0;
-    if (lds > 65536 && lds > granted) { (void)hipFuncSetAttribute((const void*)k_chain_gram, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
-    hipLaunchKernelGGL(k_chain_gram, dim3(v.n_chunks), dim3(256), lds, s, v);
-  }
+void launch_chain_init(const DevView& v, hipStream_t s) {
+  const size_t slot = (size_t)v.n_cams * kGStride + kGStride;
+  const size_t lds = std::max((size_t)4 * (v.n_cams * kGStride + kInitPad), 4 * slot) * sizeof(double);
+  static size_t granted = 0;
+  if (lds > 65536 && lds > granted) { (void)hipFuncSetAttribute((const void*)k_chain_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
+  hipLaunchKernelGGL(k_chain_init, dim3(v.n_chunks), dim3(256), lds, s, v);
 }
+void launch_chain_fwd(const DevView& v, hipStream_t s) { chain_levels(v, s, true); }
+void launch_chain_gram(const DevView& v, hipStream_t s) {
+  const size_t lds = (size_t)36 * v.ldw * sizeof(double);
+  static size_t granted = 0;
+  if (lds > 65536 && lds > granted) { (void)hipFuncSetAttribute((const void*)k_chain_gram, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
+  hipLaunchKernelGGL(k_chain_gram, dim3(v.n_chunks), dim3(256), lds, s, v);
+}
+void launch_chain_solve_a(const DevView& v, hipStream_t s) { launch_chain_init(v, s); launch_chain_fwd(v, s); launch_chain_gram(v, s); }
 void launch_chain_solve_b(const DevView& v, hipStream_t s) { chain_levels(v, s, false); }
 
 }  // namespace vc

@@ -29,7 +29,7 @@ SYMBOLS = [
     "vc_get_biases", "vc_get_scale_factor", "vc_get_gravity", "vc_time_offset", "vc_mean_squared_error", "vc_get_camera_proj_rmse",
     "vc_get_num_iterations", "vc_num_imu_measurements", "vc_get_imu_measurements", "vc_get_integration_poses", "vc_print_results", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
     "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
-    "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_pnp_planar_ransac", "vc_set_pnp_ransac", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_allreduce_calls", "vc_get_imu_weights",
+    "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_pnp_planar_ransac", "vc_set_pnp_ransac", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_allreduce_calls", "vc_last_error", "vc_get_imu_weights",
     "vc_solution_covariance_dim", "vc_get_solution_covariance", "vc_get_solution_covariance_names",
 ]
 
@@ -75,6 +75,7 @@ def load():
         L.vc_get_stream.restype = C.c_void_p
         L.vc_num_observations.restype = C.c_longlong
         L.vc_allreduce_calls.restype = C.c_longlong
+        L.vc_last_error.restype = C.c_char_p
         for name in ("vc_destroy",):
             getattr(L, name).restype = None
         _lib = L
@@ -278,7 +279,9 @@ class ViCalibrator:
         box = [bytes(buf.raw)]
         if world > 1:
             dist.broadcast_object_list(box, src=0, group=group)
-        _check(self.L.vc_set_shard_rccl(self.h, int(rank), int(world), C.create_string_buffer(box[0], 128)), "set_shard_rccl")
+        rc = self.L.vc_set_shard_rccl(self.h, int(rank), int(world), C.create_string_buffer(box[0], 128))
+        if rc != 0:          # say which RCCL call failed and why (vc_last_error) before the caller falls back to another transport
+            raise VicalibError("set_shard_rccl: status %d: %s" % (rc, (self.L.vc_last_error() or b"").decode(errors="replace")))
 
     def allreduce_calls(self): return int(self.L.vc_allreduce_calls(self.h))
 
