@@ -6,7 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vicalib_amd import synth
 from vicalib_amd.lib import ViCalibrator
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
-p = synth.generate_native(synth.BASELINE_CONFIGS[name])
+base = synth.BASELINE_CONFIGS[name]
+if len(sys.argv) > 2:       # frame count override: the per-rank size of a multi-GPU configuration
+    base = synth.Config(models=base.models, grid=base.grid, n_frames=int(sys.argv[2]), imu=base.imu, extrinsics_prior=base.extrinsics_prior)
+p = synth.generate_native(base)
 cal = ViCalibrator(0).load_problem(p)
 if p.imu_t is not None:
     cal.SetStageLimit(3); cal.Solve()

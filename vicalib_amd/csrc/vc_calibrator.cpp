@@ -216,7 +216,7 @@ struct vc_calibrator {
   DBuf<double> d_pose[2], d_cam[2], d_G[2], d_tile_cost[2], d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_sdiag,
       d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total, d_part_total2;
   DBuf<Ctrl> d_ctrl;
-  DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_segH[2], d_segg[2], d_seg_cost[2],
+  DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_seg[2], d_seg_cost[2],
       d_cW, d_cdelta, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init, d_rX[2], d_grp_part, d_wg_trial, d_wg_imu_trial,
       d_imu_delta, d_imu_delta_ab, d_imu_delta_blk;
   size_t wsqrt_frames = 0;       // number of frames the device weight_sqrt_ array was initialised for
@@ -517,7 +517,7 @@ struct vc_calibrator {
         HIP_OK(d_wsqrt[0].upload(w, stream)); HIP_OK(d_wsqrt[1].upload(w, stream)); wsqrt_frames = (size_t)N; wcur = 0;
         HIP_OK(hipStreamSynchronize(stream));
       }
-      for (int b = 0; b < 2; ++b) { HIP_OK(d_segH[b].alloc(ns * 33 * 33)); HIP_OK(d_segg[b].alloc(ns * 33)); HIP_OK(d_seg_cost[b].alloc(ns)); }
+      for (int b = 0; b < 2; ++b) { HIP_OK(d_seg[b].alloc(ns * kSegStride)); HIP_OK(d_seg_cost[b].alloc(ns)); }
       HIP_OK(d_imu_delta.alloc((size_t)std::max<size_t>(imu_t.size(), 2) * kDeltaStride)); HIP_OK(d_imu_delta_ab.alloc(ns * 2 * kDeltaStride));
       HIP_OK(d_imu_delta_blk.alloc(ns * kBlockDeltaStride));
       const size_t nf = (size_t)std::max(N, 1);
@@ -534,7 +534,7 @@ struct vc_calibrator {
     dv.vel[0] = d_vel[0].p; dv.vel[1] = d_vel[1].p; dv.imus[0] = d_imus[0].p; dv.imus[1] = d_imus[1].p;
     dv.wsqrtb[0] = d_wsqrt[0].p; dv.wsqrtb[1] = d_wsqrt[1].p;
     dv.imu_delta = d_imu_delta.p; dv.imu_delta_ab = d_imu_delta_ab.p; dv.imu_delta_blk = d_imu_delta_blk.p;
-    for (int b = 0; b < 2; ++b) { dv.segHb[b] = d_segH[b].p; dv.seggb[b] = d_segg[b].p; dv.seg_costb[b] = d_seg_cost[b].p; }
+    for (int b = 0; b < 2; ++b) { dv.segb[b] = d_seg[b].p; dv.seg_costb[b] = d_seg_cost[b].p; }
     dv.cW = d_cW.p; dv.cdelta = d_cdelta.p; dv.cg = d_cg.p;
     dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p;
     for (int b = 0; b < 2; ++b) dv.rX[b] = d_rX[b].p;
@@ -1641,8 +1641,18 @@ int vc_get_imu_blocks(vc_calibrator* h, double* H, double* g, double* cost) {
   if (!h->dv.imu_on) return VC_ERR_BAD_ARG;
   const size_t ns = (size_t)std::max(h->dv.n_frames - 1, 0);
   const int b = h->cur;
-  if (H && hipMemcpy(H, h->dv.segHb[b], ns * 33 * 33 * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
-  if (g && hipMemcpy(g, h->dv.seggb[b], ns * 33 * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
+  if ((H || g) && ns) {                          // the device keeps the blocks compact (vc_device.h: kSeg*): unfold them
+    std::vector<double> rec(ns * kSegStride);
+    if (hipMemcpy(rec.data(), h->dv.segb[b], rec.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
+    for (size_t s = 0; s < ns; ++s)
+      for (int e = 0; e < kSegLen; ++e) {
+        int a = 0, c = 0;
+        seg_entry(e, &a, &c);
+        const double val = rec[s * kSegStride + e];
+        if (c == 33) { if (g) g[s * 33 + a] = val; }
+        else if (H) { H[s * 1089 + a * 33 + c] = val; H[s * 1089 + c * 33 + a] = val; }
+      }
+  }
   if (cost && hipMemcpy(cost, h->dv.seg_costb[b], ns * 8, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
   return VC_OK;
 }

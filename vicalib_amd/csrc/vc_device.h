@@ -27,6 +27,28 @@ constexpr int kTraceCols = 10;     // iteration cost cost_change gmax gnorm step
 // termination codes in Ctrl::done (0 = keep running)
 enum { kRunning = 0, kDoneConvergence = 1, kDoneNoConvergence = 2, kDoneUserSuccess = 3, kDoneFailure = 4 };
 
+// Normal-equation record of one IMU block (k_imu_jac -> k_chain_init).  The block's 33 local columns are [frame j ("cur": pose 6,
+// velocity 3) | frame j - 1 ("prev": 9) | IMU parameters 15].  Of the symmetric 33 x 33 matrix and the gradient only what the chain
+// assembly reads is stored, once, grouped by reader -- frame j takes [kSegAcc, kSegApp), frame j - 1 takes [kSegApp, kSegHii), the
+// shared IMU block is [kSegHii, kSegLen): 771 doubles instead of 33 x 33 + 33 = 1122, and each reader touches a third of them
+// (the full blocks cost 35 of k_chain_init's 45 MB per pass at BASELINE cfg3).
+//   kSegAcc cur x cur 9 x 9 | kSegWc cur x imu 9 x 15 | kSegGc gradient cur 9 | kSegApp prev x prev 9 x 9 | kSegBpc prev (rows) x cur
+//   (cols) 9 x 9 | kSegWp prev x imu 9 x 15 | kSegGp gradient prev 9 | kSegHii imu x imu 15 x 15 | kSegGi gradient imu 15
+constexpr int kSegAcc = 0, kSegWc = 81, kSegGc = 216, kSegApp = 225, kSegBpc = 306, kSegWp = 387, kSegGp = 522, kSegHii = 531,
+              kSegGi = 756, kSegLen = 771, kSegStride = 776;
+// entry e of the record = (row a, column b) of the 33 x 33 block, b = 33: the gradient's entry a
+constexpr void seg_entry(int e, int* a, int* b) {
+  if (e < kSegWc) { *a = e / 9; *b = e % 9; }
+  else if (e < kSegGc) { const int k = e - kSegWc; *a = k / 15; *b = 18 + k % 15; }
+  else if (e < kSegApp) { *a = e - kSegGc; *b = 33; }
+  else if (e < kSegBpc) { const int k = e - kSegApp; *a = 9 + k / 9; *b = 9 + k % 9; }
+  else if (e < kSegWp) { const int k = e - kSegBpc; *a = 9 + k / 9; *b = k % 9; }
+  else if (e < kSegGp) { const int k = e - kSegWp; *a = 9 + k / 15; *b = 18 + k % 15; }
+  else if (e < kSegHii) { *a = 9 + (e - kSegGp); *b = 33; }
+  else if (e < kSegGi) { const int k = e - kSegHii; *a = 18 + k / 15; *b = 18 + k % 15; }
+  else { *a = 18 + (e - kSegGi); *b = 33; }
+}
+
 struct Ctrl {
   double radius, decrease_factor, cost, gmax, gnorm, last_gnorm;
   double ftol, gtol, ptol, mult, imu_mult;
@@ -123,8 +145,7 @@ struct DevView {
   double* wsqrtb[2];               // (n_frames-1) x 81  weight_sqrt_ of every IMU cost, double-buffered: the update of pass p
                                    // (k_imu_weights on a second stream) writes the buffer the Jacobian sweep of pass p is not reading
   // linearisation of the IMU blocks, double-buffered like the state (buffer b belongs to state buffer b)
-  double* segHb[2];                // (n_frames-1) x 33 x 33  weighted J^T J, columns [frame j (9) | frame j-1 (9) | imu (15)]
-  double* seggb[2];                // (n_frames-1) x 33       weighted J^T r
+  double* segb[2];                 // (n_frames-1) x kSegStride: weighted J^T J and J^T r of the block, compact (below)
   double* seg_costb[2];            // (n_frames-1)  imu_mult * rho at the linearisation point
   // delta form of the sample intervals (vc_imu.hpp, kDeltaStride doubles each): the stored intervals i -> i + 1 and the two partial
   // intervals at the ends of every block; written by k_imu_delta, composed along the blocks by k_imu_jac

@@ -90,7 +90,13 @@ __global__ __launch_bounds__(256) void k_imu_block(DevView v, int trial) {
   for (int k = 0; k < 11; ++k) rec[dd * 11 + k] = dd ? der[k] : val[k];
 }
 
-constexpr int kImuJacLds = 33 * 9 + 7;
+constexpr int kImuJacLds = 34 * 9 + 6;            // [34][9]: the block's 33 local columns and, as a 34th, the residual itself
+// (row a, column b) of every entry of the compact block record (vc_device.h: kSeg*), b = 33: gradient -- one table look-up per entry
+struct SegTab {
+  unsigned short v[kSegStride];
+  constexpr SegTab() : v() { for (int e = 0; e < kSegLen; ++e) { int a = 0, b = 0; seg_entry(e, &a, &b); v[e] = (unsigned short)(a | (b << 8)); } }
+};
+__constant__ SegTab d_seg_tab = SegTab();
 // The sweep proper.  Two IMU blocks per wavefront, lane = local column of the block: frame j's pose (6), frame j-1's pose (6) and
 // velocity (3), gravity (2), biases (6), scale factors (6), time offset -- 30 lanes put the block's delta on the start state and
 // run the residual's tail under one dual direction each (vc_imu.hpp: imu_block_final_direction); the three columns of frame j's
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   const bool exists = s_raw < n_blocks;
   const int s = exists ? s_raw : n_blocks - 1;                 // a half past the end shadows the last block and stores nothing
   const int cur = trial ? 1 - ct->cur : ct->cur, j = s + 1;
-  double* Jl = sh + (wave * 2 + half) * kImuJacLds;            // [33][9] local columns: cur9 | prev9 | imu15
+  double* Jl = sh + (wave * 2 + half) * kImuJacLds;            // [34][9] local columns: cur9 | prev9 | imu15 | residual
   const double* T2 = v.poses[cur] + (size_t)j * kPoseStride;
   const double* T1 = v.poses[cur] + (size_t)(j - 1) * kPoseStride;
   const double* v2 = v.vel[cur] + (size_t)j * 4;
@@ -131,6 +137,10 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
       Jl[(6 + l) * 9 + k] = (valid && !zeroed) ? -wq[(6 + l) * 9 + k] : 0.0;
     }
   }
+  if (l == 31) {                                               // the residual rides as a 34th column: J^T r = its products with the others
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Jl[33 * 9 + k] = r[k];
+  }
   wave_lds_sync();
   double ss = 0.0;
 #pragma unroll
@@ -145,19 +155,14 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
     if (threadIdx.x == 0) v.wg_imu_trial[blockIdx.x] = ((s_cost[0] + s_cost[1]) + (s_cost[2] + s_cost[3])) + ((s_cost[4] + s_cost[5]) + (s_cost[6] + s_cost[7]));
   }
   if (!exists) return;
-  double* H = v.segHb[cur] + (size_t)s * (33 * 33);
-  for (int e = l; e < 33 * 33; e += 32) {
-    const int a = e / 33, bb = e % 33;
+  // J^T J and J^T r of the block in the compact record: entry e = w * <column a, column b> with the residual as column 33
+  double* rec = v.segb[cur] + (size_t)s * kSegStride;
+  for (int e = l; e < kSegLen; e += 32) {
+    const int ab = d_seg_tab.v[e], a = ab & 255, bb = ab >> 8;
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc += Jl[a * 9 + k] * Jl[bb * 9 + k];
-    H[e] = w * acc;
-  }
-  for (int col = l; col < 33; col += 32) {
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) acc += Jl[col * 9 + k] * r[k];
-    v.seggb[cur][(size_t)s * 33 + col] = w * acc;
+    rec[e] = w * acc;
   }
   if (l == 0) v.seg_costb[cur][s] = ct->imu_mult * rho;
 }
@@ -490,28 +495,62 @@ __global__ __launch_bounds__(64) void k_imu_weights(DevView v, int wr) {
 }
 
 // ------------------------------------------------------------------------------------------ chain assembly
-// One wavefront per frame, one workgroup per chunk (groups of 4 frames).
-constexpr int kInitPad = 64;
-__global__ __launch_bounds__(256) void k_chain_init(DevView v) {
+// One wavefront per frame, one workgroup per chunk (groups of 4 frames).  The frame's image is written ONCE, column by column
+// (lane = image column: border [W | g], then the blocks [C | A | B]): every column gathers what belongs in it -- the camera's
+// columns from the frame's tile of that camera, the IMU-parameter columns and the 9 x 9 blocks from the two IMU blocks the frame
+// takes part in (compact records, vc_device.h: kSeg*), the right-hand side, the separator couplings of a sharded chain -- instead
+// of zero-filling the image and scattering into it (round 2: 22 of 45 MB per launch at BASELINE cfg3 were the zero-fill and the
+// unread parts of the 33 x 33 blocks).  The padding columns between D + 1 and ldw and behind the blocks are never read.
+constexpr int kInitPad = 160;            // per wavefront behind the Gram records: Hs 42 | A 81 | g 9 | lambda 9 | tile cameras 8 | pad
+__global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two workgroups per CU: the kernel waits on memory)
   extern __shared__ __attribute__((aligned(16))) double sh[];
+  __shared__ CamDesc s_cd[kMaxCams];
+  __shared__ double s_R[kMaxCams * 9];   // the cameras' rotations R_ck, once per workgroup
+  __shared__ int s_ci[256];              // what every image column is: owning camera (255: none) | column inside its block << 8 | "comes from the IMU records" << 16
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int C = v.n_cams, D = v.D, N = v.n_frames, ldw = v.ldw, ldx = v.ldx;
-  double* Gw = sh + wave * (C * kGStride + kInitPad);
-  double* Hs = Gw + C * kGStride;
+  const int C = v.n_cams, D = v.D, N = v.n_frames, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
   const int cur = ct->cur;
   const int init_scale = ct->init_scale, reuse = ct->reuse_diag;
   const double radius = ct->radius;
-  const double* cams = v.cams[cur];
+  if (tid < kMaxCams) s_cd[tid] = v.cd[tid];
+  if (tid < C) { double Rm[9]; quat_to_R(v.cams[cur] + (size_t)tid * kCamStride, Rm); for (int k = 0; k < 9; ++k) s_R[tid * 9 + k] = Rm[k]; }
+  double* Gw = sh + wave * (C * kGStride + kInitPad);
+  double* Hs = Gw + C * kGStride;
+  double* As = Hs + 42;                  // the frame's own 9 x 9 block (undamped)
+  double* gs = As + 81;                  // its right-hand side
+  double* ls = gs + 9;                   // its damping
+  int* tcam = reinterpret_cast<int*>(ls + 9);      // cameras of the frame's tiles [8], then the frame's tile of every camera [8]
+  int* tinv = tcam + kMaxCams;
   const int chunk = blockIdx.x;
   const int f0 = chunk * v.chunk_frames, f1 = min(f0 + v.chunk_frames, N);
   double gsum[kMaxCams][5];     // [4]: the Gram record's side vector (lanes < 16)
   double isum[4] = {0.0, 0.0, 0.0, 0.0};      // IMU shared block: Hii[a][b] at a*16+b (a,b<15), g_i[a] at a*16+15
+  double csum = 0.0;            // cost at the linearisation point: the frames' tiles (lanes 0..7) and IMU blocks (lane 8), summed per chunk here
+                                // instead of over all tiles and blocks by the one workgroup of k_reduced (32 of its 214 us at 50 000 tiles)
 #pragma unroll
   for (int c = 0; c < kMaxCams; ++c)
 #pragma unroll
     for (int q = 0; q < 5; ++q) gsum[c][q] = 0.0;
+  // what each image column is, once for all frames of the chunk: owning camera and column inside its block; the columns that come
+  // from the IMU records -- the (at most 15) IMU-parameter columns and the 9 columns of B -- belong to lanes 0..23 whatever their
+  // position in the image, so that their values can be requested before anything else happens
+  if (tid < ncol) {
+    const int col = tid, e = col - nW;
+    int cam = 255, loc = 0, skip = (e >= 18 && e < 27) ? 1 : 0;
+    if (col < D) {
+      const int cc = v.col_cam[col];
+      cam = cc >= 0 ? cc : 255; loc = v.col_local[col];
+#pragma unroll
+      for (int a = 0; a < 15; ++a) skip |= (v.imu_param_col[a] == col) ? 1 : 0;
+    }
+    s_ci[col] = cam | (loc << 8) | (skip << 16);
+  }
+  int sp_col = -1;                                 // lanes 0..14: the column of IMU parameter `lane` (or none)
+#pragma unroll
+  for (int a = 0; a < 15; ++a) sp_col = (lane == a) ? v.imu_param_col[a] : sp_col;
+  __syncthreads();
 
   for (int fg = f0; fg < f1; fg += 4) {
     const int f = fg + wave;
@@ -524,127 +563,99 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
     double* Wt = pin_self ? v.sep_strip + (size_t)(pin_f ? 0 : 1) * 9 * ldw : Wf;
     const int ldt = pin_self ? ldw : ldx;         // row stride of Wt
     const int sep_self = pin_f ? v.sep_col0 : v.sep_col1;
-    for (int i = lane; i < 9 * ldx; i += 64) Wf[i] = 0.0;
-    if (pin_self) for (int i = lane; i < 9 * ldw; i += 64) Wt[i] = 0.0;
-    if (lane < 42) Hs[lane] = 0.0;
-    wave_lds_sync();
-    if (nt > 0) {
-      for (int m = 0; m < nt * 5; ++m) {
-        const int t = m / 5, q = m % 5;
-        const int o = (q < 4) ? q * 64 + lane : kGGrad + (lane & 15);
-        const double val = (q < 4 || lane < 16) ? v.Gb[cur][(size_t)(t0 + t) * kGStride + o] : 0.0;
-        if (q < 4 || lane < 16) Gw[t * kGStride + o] = val;
-        const int c = v.tile_cam[t0 + t];
+    // IMU blocks: block f-1 has this frame as "cur", block f as "prev"
+    const double* rc = (f >= 1) ? v.segb[cur] + (size_t)(f - 1) * kSegStride : nullptr;
+    const double* rp = (f + 1 < N) ? v.segb[cur] + (size_t)f * kSegStride : nullptr;
+    // ---- everything the frame needs from memory is requested here, in one go: the tiles' Gram records (to LDS and into the
+    // chunk's per-camera sums), the parts of the two IMU records, the per-column couplings, the damping state
+    const int my_tc = (lane < nt) ? v.tile_cam[t0 + lane] : -1;
+    if (lane < nt) csum += v.tile_costb[cur][t0 + lane];
+    if (lane == 8 && rc) csum += v.seg_costb[cur][f - 1];          // every block counted once, by its "cur" frame
+    double pre[9];                                 // lanes 0..14: couplings of IMU parameter `lane`; lanes 15..23: column lane - 15 of B
+    {
+      const bool isB = lane >= 15 && lane < 24 && rp && !pin_self && !pin_next;
+      const int a = lane < 15 ? lane : 0, jb = lane >= 15 && lane < 24 ? lane - 15 : 0;
 #pragma unroll
-        for (int k = 0; k < kMaxCams; ++k)
-#pragma unroll
-          for (int qq = 0; qq < 5; ++qq) gsum[k][qq] += (k == c && qq == q) ? val : 0.0;
-      }
-      wave_lds_sync();
-      if (lane < 42) {
-        double hval = 0.0;
-        for (int t = 0; t < nt; ++t) {
-          const int c = v.tile_cam[t0 + t];
-          double Rm[9];
-          quat_to_R(cams + (size_t)c * kCamStride, Rm);
-          const double* g = Gw + t * kGStride;
-          if (lane < 36) {
-            const int i = lane / 6, j = lane % 6, a = i / 3, ii = i % 3, b = j / 3, jj = j % 3;
-            double s = 0.0;
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-              for (int q = 0; q < 3; ++q) s += Rm[3 * p + ii] * g[(3 * a + p) * 16 + 3 * b + q] * Rm[3 * q + jj];
-            hval += (a == b) ? s : -s;
-          } else {
-            const int i = lane - 36, a = i / 3, ii = i % 3;
-            const int nk = model_nk(v.cd[c].model);
-            double s = 0.0;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) s += Rm[3 * p + ii] * gram_grad(g, 3 * a + p, nk);
-            hval += (a == 0) ? -s : s;
-          }
-        }
-        Hs[lane] = hval;
-      }
-      // W columns of the cameras (unsolved): lane -> (tile, column)
-      for (int idx = lane; idx < nt * 16; idx += 64) {
-        const int t = idx >> 4, j = idx & 15;
-        const int c = v.tile_cam[t0 + t];
-        const int flags = v.cd[c].flags, nk = model_nk(v.cd[c].model);
-        const int nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
-        const int nc = nrot + ntr + ((flags & kCamKFree) ? nk : 0);
-        if (j < nc) {
-          double Rm[9];
-          quat_to_R(cams + (size_t)c * kCamStride, Rm);
-          const double* g = Gw + t * kGStride;
-          double u[6];
-          if (j < nrot) {
-#pragma unroll
-            for (int r = 0; r < 6; ++r) u[r] = -(g[r * 16 + 3] * Rm[j] + g[r * 16 + 4] * Rm[3 + j] + g[r * 16 + 5] * Rm[6 + j]);
-          } else {
-            const int jj = (j < nrot + ntr) ? j - nrot : 6 + (j - nrot - ntr);
-#pragma unroll
-            for (int r = 0; r < 6; ++r) u[r] = g[r * 16 + jj];
-          }
-          const int col = v.cd[c].col0 + j;
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            Wt[i * ldt + col] = -(Rm[i] * u[0] + Rm[3 + i] * u[1] + Rm[6 + i] * u[2]);
-            Wt[(3 + i) * ldt + col] = Rm[i] * u[3] + Rm[3 + i] * u[4] + Rm[6 + i] * u[5];
-          }
-        }
+      for (int i = 0; i < 9; ++i) {
+        double x = 0.0;
+        if (sp_col >= 0 && rc) x += rc[kSegWc + i * 15 + a];
+        if (sp_col >= 0 && rp) x += rp[kSegWp + i * 15 + a];
+        if (isB) x = rp[kSegBpc + i * 9 + jb];
+        pre[i] = x;
       }
     }
-    wave_lds_sync();
-    // IMU blocks: block f-1 has this frame as "cur" (rows/cols 0..8), block f as "prev" (9..17)
-    const double* Hc = (f >= 1) ? v.segHb[cur] + (size_t)(f - 1) * (33 * 33) : nullptr;
-    const double* Hp = (f + 1 < N) ? v.segHb[cur] + (size_t)f * (33 * 33) : nullptr;
-    const double* gc = (f >= 1) ? v.seggb[cur] + (size_t)(f - 1) * 33 : nullptr;
-    const double* gp = (f + 1 < N) ? v.seggb[cur] + (size_t)f * 33 : nullptr;
-    double aval[2] = {0.0, 0.0};
+    double a_imu[2] = {0.0, 0.0}, g_imu = 0.0, sc2_in = 0.0, dg_in = 0.0;
+#pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int e = lane + 64 * q;
-      if (e < 81) {
-        const int i = e / 9, j = e % 9;
-        double a = (i < 6 && j < 6) ? Hs[i * 6 + j] : 0.0;
-        if (Hc) a += Hc[i * 33 + j];
-        if (Hp) a += Hp[(9 + i) * 33 + 9 + j];
-        aval[q] = a;
-        // rows: this frame (prev of block f), cols: frame f+1 (cur); a pinned end cuts the chain and couples through
-        // the separator's columns of the border instead
-        Wf[i * ldx + ldw + 18 + j] = (Hp && !pin_self && !pin_next) ? Hp[(9 + i) * 33 + j] : 0.0;
-        if (pin_prev && Hc) Wf[i * ldx + v.sep_col0 + j] = Hc[i * 33 + 9 + j];
-        if (pin_next && Hp) Wf[i * ldx + v.sep_col1 + j] = Hp[(9 + i) * 33 + j];
-      }
+      if (e < 81) { if (rc) a_imu[q] += rc[kSegAcc + e]; if (rp) a_imu[q] += rp[kSegApp + e]; }
     }
-    double gval = 0.0;
     if (lane < 9) {
-      gval = (lane < 6) ? Hs[36 + lane] : 0.0;
-      if (gc) gval += gc[lane];
-      if (gp) gval += gp[9 + lane];
-    }
-    // border columns of the IMU shared parameters
-    for (int idx = lane; idx < 9 * 15; idx += 64) {
-      const int i = idx / 15, a = idx % 15;
-      const int col = v.imu_param_col[a];
-      if (col >= 0) {
-        double w = 0.0;
-        if (Hc) w += Hc[i * 33 + 18 + a];
-        if (Hp) w += Hp[(9 + i) * 33 + 18 + a];
-        Wt[i * ldt + col] = w;
-      }
+      if (rc) g_imu += rc[kSegGc + lane];
+      if (rp) g_imu += rp[kSegGp + lane];
+      if (!init_scale) sc2_in = v.cscale2[(size_t)f * 9 + lane];
+      if (reuse) dg_in = v.cdiag[(size_t)f * 9 + lane];
     }
     // IMU shared block of block f-1 (every block counted once, by its "cur" frame)
-    if (Hc) {
+    if (rc) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int e = lane + 64 * q, a = e >> 4, b = e & 15;
-        if (a < 15) isum[q] += (b < 15) ? Hc[(18 + a) * 33 + 18 + b] : gc[18 + a];
+        if (a < 15) isum[q] += (b < 15) ? rc[kSegHii + a * 15 + b] : rc[kSegGi + a];
       }
     }
-    // damping of the 9 frame parameters (Jacobi scaling fixed per Solve, diagonal re-used after rejections)
-    double lam = 0.0, hd = 0.0;
+    if (lane < kMaxCams) { tcam[lane] = my_tc; tinv[lane] = -1; }
+    wave_lds_sync();
+    if (lane < nt) tinv[my_tc] = lane;             // the frame's tile of every camera
+    for (int m = 0; m < nt * 5; ++m) {
+      const int t = m / 5, q = m % 5;
+      const int o = (q < 4) ? q * 64 + lane : kGGrad + (lane & 15);
+      const double val = (q < 4 || lane < 16) ? v.Gb[cur][(size_t)(t0 + t) * kGStride + o] : 0.0;
+      if (q < 4 || lane < 16) Gw[t * kGStride + o] = val;
+      const int c = __shfl(my_tc, t, 64);
+#pragma unroll
+      for (int k = 0; k < kMaxCams; ++k)
+#pragma unroll
+        for (int qq = 0; qq < 5; ++qq) gsum[k][qq] += (k == c && qq == q) ? val : 0.0;
+    }
+    wave_lds_sync();
+    // ---- visual part of the frame's own block: H_pp (6 x 6) and g_p (6) from the tiles (lanes 0..41)
+    if (lane < 42) {
+      double hval = 0.0;
+      for (int t = 0; t < nt; ++t) {
+        const int c = tcam[t];
+        const double* Rm = s_R + c * 9;
+        const double* g = Gw + t * kGStride;
+        if (lane < 36) {
+          const int i = lane / 6, j = lane % 6, a = i / 3, ii = i % 3, b = j / 3, jj = j % 3;
+          double s = 0.0;
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) s += Rm[3 * p + ii] * g[(3 * a + p) * 16 + 3 * b + q] * Rm[3 * q + jj];
+          hval += (a == b) ? s : -s;
+        } else {
+          const int i = lane - 36, a = i / 3, ii = i % 3;
+          const int nk = model_nk(s_cd[c].model);
+          double s = 0.0;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) s += Rm[3 * p + ii] * gram_grad(g, 3 * a + p, nk);
+          hval += (a == 0) ? -s : s;
+        }
+      }
+      Hs[lane] = hval;
+    }
+    wave_lds_sync();
+    // ---- own block A (lane e = 9 i + j, two slots), right-hand side, damping
+    double aval[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = lane + 64 * q, i = e / 9, j = e % 9;
+      aval[q] = a_imu[q] + ((e < 81 && i < 6 && j < 6) ? Hs[i * 6 + j] : 0.0);
+      if (e < 81) As[e] = aval[q];
+    }
+    const double gval = g_imu + ((lane < 6) ? Hs[36 + lane] : 0.0);
+    double hd = 0.0;
     // diagonal entry i lives in lane (i*10) % 64, slot (i*10) / 64
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -653,26 +664,92 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
       if (lane == i) hd = d;
     }
     if (lane < 9) {
-      double sc2, dg;
-      if (init_scale) { sc2 = jacobi_scale2(hd); v.cscale2[(size_t)f * 9 + lane] = sc2; } else sc2 = v.cscale2[(size_t)f * 9 + lane];
-      if (!reuse) { dg = lm_clamped_diag(hd, sc2); v.cdiag[(size_t)f * 9 + lane] = dg; } else dg = v.cdiag[(size_t)f * 9 + lane];
-      lam = pin_self ? 0.0 : dg / (radius * sc2);
+      // damping of the 9 frame parameters (Jacobi scaling fixed per Solve, diagonal re-used after rejections)
+      double sc2 = sc2_in, dg = dg_in;
+      if (init_scale) { sc2 = jacobi_scale2(hd); v.cscale2[(size_t)f * 9 + lane] = sc2; }
+      if (!reuse) { dg = lm_clamped_diag(hd, sc2); v.cdiag[(size_t)f * 9 + lane] = dg; }
+      const double lam = pin_self ? 0.0 : dg / (radius * sc2);
       v.clam[(size_t)f * 9 + lane] = lam;
       v.cg[(size_t)f * 9 + lane] = pin_self ? 0.0 : gval;
-      Wt[lane * ldt + D] = gval;                // right-hand side rides as column D
+      gs[lane] = gval; ls[lane] = lam;
     }
+    wave_lds_sync();
+    // ---- the image: every column written once.  First the columns that come from the IMU records (lanes 0..23) ...
+    if (sp_col >= 0) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int e = lane + 64 * q;
-      if (e < 81) {
-        const int i = e / 9, j = e % 9;
-        double a = aval[q];
-        const double li = __shfl(lam, i, 64);
-        if (i == j) a += li;
-        if (pin_self) { Wt[i * ldt + sep_self + j] = aval[q]; a = (i == j) ? 1.0 : 0.0; }
-        Wf[i * ldx + ldw + 9 + j] = a;
+      for (int i = 0; i < 9; ++i) Wt[i * ldt + sp_col] = pre[i];
+      if (pin_self) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Wf[i * ldx + sp_col] = 0.0;
       }
     }
+    if (lane >= 15 && lane < 24) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Wf[i * ldx + ldw + 18 + (lane - 15)] = pre[i];
+    }
+    // ... then all the others, one column per lane and round
+    for (int col = lane; col < ncol; col += 64) {
+      const int ci = s_ci[col];
+      if (ci >> 16) continue;
+      double val[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) val[i] = 0.0;
+      const int e = col - nW, jb = (e >= 0) ? e % 9 : 0;
+      const int cc = ci & 255, j = (ci >> 8) & 255;
+      const int t = (cc < kMaxCams) ? tinv[cc] : -1;
+      if (col < D && t >= 0) {                     // a camera's column: from the frame's tile of that camera
+        const int flags = s_cd[cc].flags, nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
+        const double* Rm = s_R + cc * 9;
+        const double* g = Gw + t * kGStride;
+        double u[6];
+        if (j < nrot) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) u[r] = -(g[r * 16 + 3] * Rm[j] + g[r * 16 + 4] * Rm[3 + j] + g[r * 16 + 5] * Rm[6 + j]);
+        } else {
+          const int jj = (j < nrot + ntr) ? j - nrot : 6 + (j - nrot - ntr);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) u[r] = g[r * 16 + jj];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          val[i] = -(Rm[i] * u[0] + Rm[3 + i] * u[1] + Rm[6 + i] * u[2]);
+          val[3 + i] = Rm[i] * u[3] + Rm[3 + i] * u[4] + Rm[6 + i] * u[5];
+        }
+      }
+      // a separator's columns (sharded chain): the coupling of this frame with the pinned neighbour, from the shared IMU block
+      if (col < D && pin_prev && rc && col >= v.sep_col0 && col < v.sep_col0 + 9) {       // rows: this frame (cur), cols: the pinned frame 0 (prev)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) val[i] = rc[kSegBpc + (col - v.sep_col0) * 9 + i];
+      }
+      if (col < D && pin_next && rp && col >= v.sep_col1 && col < v.sep_col1 + 9) {       // rows: this frame (prev), cols: the pinned last frame (cur)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) val[i] = rp[kSegBpc + i * 9 + (col - v.sep_col1)];
+      }
+      if (col < D && pin_self && col >= sep_self && col < sep_self + 9) {                 // a pinned frame's own block sits in its separator columns
+#pragma unroll
+        for (int i = 0; i < 9; ++i) val[i] += As[i * 9 + (col - sep_self)];
+      }
+      if (col == D) {                              // the right-hand side rides as column D
+#pragma unroll
+        for (int i = 0; i < 9; ++i) val[i] = gs[i];
+      }
+      if (e >= 9 && e < 18) {                      // A (damped; a pinned frame: the identity)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) val[i] = pin_self ? ((i == jb) ? 1.0 : 0.0) : As[i * 9 + jb] + ((i == jb) ? ls[i] : 0.0);
+      }
+      if (col < nW) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Wt[i * ldt + col] = val[i];
+        if (pin_self) {                            // (wave-uniform) the chain's image of a pinned frame has an empty border
+#pragma unroll
+          for (int i = 0; i < 9; ++i) Wf[i * ldx + col] = 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Wf[i * ldx + ldw + e] = val[i];
+      }
+    }
+    wave_lds_sync();
   }
   // chunk sums of the camera Gram blocks and of the IMU shared block (4 wavefronts combined in fixed order)
   __syncthreads();
@@ -690,6 +767,15 @@ __global__ __launch_bounds__(256) void k_chain_init(DevView v) {
   double* part = v.part + (size_t)chunk * v.part_stride;
   for (int e = tid; e < slot; e += 256)
     part[D * D + D + e] = (sh[e] + sh[slot + e]) + (sh[2 * slot + e] + sh[3 * slot + e]);
+  // the chunk's cost: nine lanes per wavefront hold terms; fixed order (lane, then wavefront)
+  __syncthreads();
+  if (lane < 9) sh[wave * 9 + lane] = csum;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 4; ++w) { double tw = 0.0; for (int k = 0; k < 9; ++k) tw += sh[w * 9 + k]; t += tw; }
+    part[v.part_stride - 1] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------ chain elimination

@@ -622,16 +622,7 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double
   }
   VC_STAMP(1);
   for (int i = tid; i < D; i += 256) { hd[i] = 0.0; gs[i] = 0.0; }
-  if (v.imu_on) {        // chain path: tile and IMU-block costs summed here (its partial records carry no cost slot)
-    double s = 0.0;
-#pragma unroll 4
-    for (int t = tid; t < v.n_tiles; t += 256) s += v.tile_costb[cur][t];
-    for (int t = tid; t < v.n_frames - 1; t += 256) s += v.seg_costb[cur][t];
-    L.red[tid] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) L.red[tid] += L.red[tid + o]; __syncthreads(); }
-    if (tid == 0) { sc[0] = 0.5 * L.red[0]; sc[1] = 0.0; }
-  } else if (tid == 0) {
+  if (tid == 0) {        // (the chain path's partial records carry the chunk cost in the same slot: k_chain_init)
     double t = 0.0;
     for (int k = 0; k < nslab; ++k) t += ptot[(size_t)k * stride + stride - 1];
     sc[0] = 0.5 * t; sc[1] = 0.0;
