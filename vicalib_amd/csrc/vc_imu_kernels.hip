@@ -800,7 +800,7 @@ constexpr int kChainM = 8;          // group size: 7 eliminations per wavefront 
 constexpr int kXsLd = 20;           // row stride of the [X_s | X_n] LDS image
 // phase stamps of the first group of level 0 (profiling builds only, -DVC_CHAIN_STAMPS): 100 MHz s_memrealtime ticks in dbg[0..31]
 #ifdef VC_CHAIN_STAMPS
-#define CSTAMP(i) do { if (blockIdx.x == 0 && lvl == 0 && threadIdx.x == 0 && (i) < 32) v.dbg[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define CSTAMP(i) do { if (group == 0 && lvl == 0 && threadIdx.x == 0 && (i) < 32) v.dbg[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define CSTAMP(i) do { } while (0)
 #endif
@@ -809,12 +809,10 @@ constexpr int kXsLd = 20;           // row stride of the [X_s | X_n] LDS image
 // solved [X_s | X_n] columns and the next frame's A are exchanged through the shared LDS images behind workgroup barriers.  For
 // wide borders (D > 36) this replaces columns per lane, which cost 25 us per elimination at three columns (256 VGPR + AGPR
 // copies) against a few us here; the columns-per-lane instances stay for A/B runs (launcher below).
+// One group of one level: `group` its index, `wave` the wavefront's index inside the group (0 .. NW - 1), the LDS images
+// XS (9 x kXsLd), An (81), Ls_all (NW x 81) the group's own.  NW > 1: all wavefronts of the workgroup belong to the group.
 template <int CPL, int NW>          // columns per lane x wavefronts: D + 1 + 27 <= 64 CPL NW
-__global__ __launch_bounds__(64 * NW) void k_chain_fwd(DevView v, int s, int m, int top, int lvl) {
-  __shared__ __attribute__((aligned(16))) double XS[9 * kXsLd];
-  __shared__ double An[81];
-  __shared__ double Ls_all[NW * 81];
-  const int wave = threadIdx.x >> 6;
+__device__ __forceinline__ void chain_fwd_group(const DevView& v, int s, int m, int top, int lvl, int group, int wave, double* XS, double* An, double* Ls_all) {
   double* Ls = Ls_all + wave * 81;
   auto group_sync = [&]() { if (NW > 1) __syncthreads(); else wave_lds_sync(); };
   CSTAMP(0);
@@ -824,7 +822,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(DevView v, int s, int m, 
   const int lane = threadIdx.x & 63;
   const int N = v.n_frames, D = v.D, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
   const long gs = (long)m * s;
-  const int a = top ? -1 : (int)(blockIdx.x * gs);
+  const int a = top ? -1 : (int)(group * gs);
   const int first = top ? 0 : a + s;
   const bool pend = lvl > 0;                                   // right contributions of level lvl - 1 are waiting
   const double* rp = v.rX[(lvl + 1) & 1];
@@ -945,7 +943,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(DevView v, int s, int m, 
         for (int k = j + 1; k < 9; ++k) row[k] -= lij * readlane_f64(lij, k);
       }
       if (bad) {               // wave-uniform (the pivots are): the frame gets an identity block, the pass is flagged
-        if (threadIdx.x == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
+        if (lane == 0 && wave == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
 #pragma unroll
         for (int k = 0; k < 9; ++k) { row[k] = (k == lane) ? 1.0 : 0.0; dinv[k] = 1.0; }
       }
@@ -1057,12 +1055,269 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(DevView v, int s, int m, 
   }
 }
 
+template <int CPL, int NW>
+__global__ __launch_bounds__(64 * NW) void k_chain_fwd(DevView v, int s, int m, int top, int lvl) {
+  __shared__ __attribute__((aligned(16))) double XS[9 * kXsLd];
+  __shared__ double An[81];
+  __shared__ double Ls_all[NW * 81];
+  chain_fwd_group<CPL, NW>(v, s, m, top, lvl, (int)blockIdx.x, (int)(threadIdx.x >> 6), XS, An, Ls_all);
+}
+
+// ---- two-sided elimination of a group (narrow borders: one column per lane) ------------------------------------------------
+// A full group [a | e_1 .. e_{m-1} | r] is eliminated from both ends at once: wavefront 0 sweeps e_1, e_2, .. left to right
+// against the left separator a (exactly the one-sided scheme), wavefront 1 sweeps e_{m-1}, e_{m-2}, .. right to left against the
+// right separator r -- the same recurrence on the mirrored chain: its "coupling to the next frame" is the transposed B block of the
+// frame to its left, its first frame's coupling to the separator is that frame's own B block, its separator updates go to r's side
+// image -- and the middle frame, which receives the updates of both sweeps, is eliminated last by wavefront 0 with a on one side and
+// r on the other.  (m - 2) / 2 + 1 dependent eliminations per level instead of m - 1: 4 instead of 7 at m = 8.  Needs m >= 4.
+// Images of the right sweep's frames hold [Y | z | X_s (coupling to r) | L | X_n (coupling to the frame on the LEFT)]; the
+// back-substitution (k_chain_back, two = 1) mirrors the order.  The short group at the chain's end works the same way without r.
+#ifdef VC_F2_STAMPS
+#define F2STAMP(i) do { if (blockIdx.x == 0 && lvl == 1 && (threadIdx.x & 63) == 0 && (i) < 16) v.dbg[(i) + 16 * (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define F2STAMP(i) do { } while (0)
+#endif
+__global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int lvl) {
+  __shared__ __attribute__((aligned(16))) double XS2[2][9 * kXsLd];
+  __shared__ double An2[2][81], Ls2[2][81];
+  __shared__ double MID[9 * 64];      // right sweep -> wavefront 0: its update of the middle frame (W, A columns) and the middle's coupling to r
+  __shared__ double SEPR[9 * 64];     // the right sweep's accumulated update of r
+  // (the wavefront's index as a scalar: everything that depends on it -- sweep direction, frame count, addresses -- stays uniform)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, group = blockIdx.x;
+  const int N = v.n_frames, D = v.D, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
+  const long long f2_t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  const long gs = (long)m * s;
+  const int a = (int)((long)group * gs), first = a + s;
+  const int done = v.ctrl->done;
+  const bool pend = lvl > 0;
+  const double* rp = v.rX[(lvl + 1) & 1];
+  double* rw = v.rX[lvl & 1];
+  const size_t isz = (size_t)9 * ldx;
+  const int c = lane, e0 = c - nW;
+  const int role = c < nW ? 0 : (e0 < 9 ? 1 : e0 < 18 ? 2 : e0 < 27 ? 3 : 4);     // 0 border (W | g), 1 C, 2 A, 3 B, 4 none
+  const int pc = c < nW ? c : (c < ncol ? ldw + e0 : 0);
+  const int sub = e0 < 9 ? e0 : e0 < 18 ? e0 - 9 : e0 - 18;
+  if (first >= N) {            // a separator without interior frames: only its pending right contribution is folded in
+    if (!done && wave == 0 && a < N) {
+      double* img = v.cW + (size_t)a * isz + pc;
+      if ((role == 0 || role == 2) && pend && a > 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) img[k * ldx] += rp[(size_t)(a / s) * isz + k * ldx + pc];
+      } else if (role == 3) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) img[k * ldx] = 0.0;
+      }
+    }
+    return;
+  }
+  const int q = min(m - 1, (N - 1 - first) / s + 1);          // interior frames e_1 .. e_q; the last group of a level may be short
+  const int r = first + q * s;                                // right separator, if the chain goes on
+  const bool has_r = q == m - 1 && r < N;
+  const int nl = (q - 1) / 2, mid = nl + 1, nr = q - 1 - nl;                     // interior indices 1 .. nl | mid | mid + 1 .. q
+  const int dir = wave == 0 ? 1 : -1, cnt = wave == 0 ? nl : nr, i0 = wave == 0 ? 1 : q;
+  double* XS = XS2[wave]; double* An = An2[wave]; double* Ls = Ls2[wave];
+  // the image columns of frame e as this sweep needs them: own values + the pending right contribution of the level below for the
+  // border and A; the coupling to the sweep's separator (first frame only: later frames get it as fill-in); the coupling to the
+  // next frame of the sweep
+  // (branch-free: every lane reads nine values from ONE address pattern -- base + k stride -- chosen by its role, idle lanes read
+  // column 0 of the image and scale it by zero; the pending contribution likewise)
+  auto load_cols = [&](int e, bool first_of_sweep, bool with_image, double* x) {
+    const double* img = v.cW + (size_t)e * isz;
+    const double* rpe = rp + (size_t)(e / s) * isz;
+    const double* p = img; long st = ldx; double sc = 0.0, psc = 0.0;
+    if (role == 0 || role == 2) { p = img + pc; sc = 1.0; psc = pend ? 1.0 : 0.0; }
+    else if (role == 1 && first_of_sweep) {
+      if (dir > 0) { p = v.cW + (size_t)a * isz + (size_t)sub * ldx + ldw + 18; st = 1; } else p = img + ldw + 18 + sub;
+      sc = 1.0;
+    } else if (role == 3) {
+      if (dir > 0) p = img + pc; else { p = v.cW + (size_t)(e - s) * isz + (size_t)sub * ldx + ldw + 18; st = 1; }
+      sc = 1.0;
+    }
+    if (!with_image) { sc = 0.0; psc = 0.0; p = img; st = ldx; }
+    const double* p2 = rpe + ((role == 0 || role == 2) ? pc : 0);
+    double y0[9], y1[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { y0[k] = p[k * st]; y1[k] = pend ? p2[k * ldx] : 0.0; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) x[k] = (sc != 0.0 ? y0[k] : 0.0) + (psc != 0.0 ? y1[k] : 0.0);
+  };
+  double xin[9], o[9], dacc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { dacc[k] = 0.0; o[k] = 0.0; }
+  // what the left separator will absorb into at the end (its own columns + the right contribution it received one level down):
+  // requested now -- nobody else writes them during this level -- so that the kernel ends with stores, not with a load round trip
+  double sep0[9];
+  {
+    const bool pa = pend && a > 0;
+    const int pcd = role == 1 ? ldw + 9 + sub : pc;
+    const double* img = v.cW + (size_t)a * isz + pcd;
+    const double* rpa = rp + (size_t)(a / s) * isz + pcd;
+    const bool mine = wave == 0 && (role == 0 || role == 1);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sep0[k] = mine ? img[k * ldx] + (pa ? rpa[k * ldx] : 0.0) : 0.0;
+  }
+  // (a side without frames of its own: wavefront 0 starts with the middle frame, wavefront 1 has nothing to load)
+  load_cols(a + (cnt > 0 ? i0 : mid) * s, true, cnt > 0 || wave == 0, xin);
+  if (done) return;
+#ifdef VC_F2_STAMPS
+  if (blockIdx.x == 0 && lvl == 1 && (threadIdx.x & 63) == 0) v.dbg[16 * (threadIdx.x >> 6)] = f2_t0;
+#endif
+  F2STAMP(1);
+  if (role == 2) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) An[k * 9 + sub] = xin[k];
+  }
+  // one elimination: A (in An) = L L^T, all columns solved, image stored, [X_s | X_n] to XS, out = [X_s | X_n]^T (column)
+  auto eliminate = [&](int e, double* x, double* out) {
+    wave_lds_sync_local();
+    double dinv[9];
+    {
+      const int rr = lane < 9 ? lane : 8;
+      double row[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) row[k] = An[rr * 9 + k];
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        double d = readlane_f64(row[j], j);
+        const bool ok = d > 0.0;
+        bad |= !ok;
+        d = ok ? d : 1.0;
+        const double ip = fast_rsqrt(d);
+        const double lij = (lane == j) ? d * ip : row[j] * ip;
+        row[j] = lij;
+        dinv[j] = ip;
+#pragma unroll
+        for (int k = j + 1; k < 9; ++k) row[k] -= lij * readlane_f64(lij, k);
+      }
+      if (bad) {               // wave-uniform (the pivots are): the frame gets an identity block, the pass is flagged
+        if (lane == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { row[k] = (k == lane) ? 1.0 : 0.0; dinv[k] = 1.0; }
+      }
+      if (lane < 9) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ls[lane * 9 + k] = (k <= lane) ? row[k] : 0.0;
+      }
+    }
+    wave_lds_sync_local();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      x[k] *= dinv[k];
+#pragma unroll
+      for (int rr = k + 1; rr < 9; ++rr) x[rr] -= Ls[rr * 9 + k] * x[k];
+    }
+    if (role == 2) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) x[k] = Ls[k * 9 + sub];
+    }
+    if (role < 4) {
+      double* img = v.cW + (size_t)e * isz + pc;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) img[k * ldx] = x[k];
+    }
+    if (role == 1 || role == 3) {
+      const int xc = sub + (role == 3 ? 9 : 0);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) XS[k * kXsLd + xc] = x[k];
+    }
+    wave_lds_sync_local();
+    if (role == 2) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) x[k] = XS[k * kXsLd + 9 + sub];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 18; ++rr) out[rr] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double xk = x[k];
+#pragma unroll
+      for (int rr = 0; rr < 18; ++rr) out[rr] += XS[k * kXsLd + rr] * xk;
+    }
+  };
+  // The sweep's frames, then -- wavefront 0 only, behind the barrier that hands it the right sweep's results -- the middle frame:
+  // a on its left (C), r on its right (B: the right sweep's fill-in, or -- no right sweep -- its own B block, already loaded).
+  // One loop, one copy of the elimination: wavefront 1 leaves at the barrier.
+  for (int j = 0; ; ++j) {
+    const bool at_mid = j == cnt;
+    F2STAMP(2 + 2 * j);
+    if (at_mid) {
+      if (wave == 1) {
+        if (cnt == 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) MID[k * 64 + lane] = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) SEPR[k * 64 + lane] = dacc[k];
+      }
+      F2STAMP(12);
+      __syncthreads();
+      F2STAMP(13);
+      if (wave == 1) return;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        if (role == 0 || role == 2) xin[k] += MID[k * 64 + lane];
+        else if (role == 3 && nr > 0) xin[k] = MID[k * 64 + nW + sub];      // (no right sweep: the middle's own B block stays)
+      }
+      if (role == 2) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) An[k * 9 + sub] = xin[k];
+      }
+    }
+    const int e = a + (at_mid ? mid : i0 + dir * j) * s;
+    if (!at_mid)                        // the columns of the frame after this one: requested now, used after the elimination
+      load_cols(a + (j + 1 < cnt ? i0 + dir * (j + 1) : mid) * s, false, j + 1 < cnt || wave == 0, o);
+    double x[9], out[18];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) x[k] = xin[k];
+    eliminate(e, x, out);
+    F2STAMP(3 + 2 * j);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dacc[k] += out[k];
+    if (at_mid) {
+      // the right separator's side image: the middle's update and the right sweep's (whose C lanes carry the update of A's columns)
+      if (has_r && role < 4) {
+        double* ri = rw + (size_t)(r / gs) * isz + pc;
+        const bool keep = role == 0 || role == 2;
+        const int src = role == 2 ? nW + sub : lane;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) ri[k * ldx] = keep ? -out[9 + k] - SEPR[k * 64 + src] : 0.0;
+      }
+      if (role == 3) {                 // the separator's coupling to the right separator at the next level (none where the chain ends)
+        double* img = v.cW + (size_t)a * isz + pc;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) img[k * ldx] = has_r ? -out[k] : 0.0;
+      }
+      break;
+    }
+    if (wave == 1 && j + 1 == cnt) {    // the next frame is the middle, which wavefront 0 eliminates: hand the update over
+#pragma unroll
+      for (int k = 0; k < 9; ++k) MID[k * 64 + lane] = -out[9 + k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) xin[k] = o[k] - (role == 3 ? 0.0 : out[9 + k]);
+      if (role == 2) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) An[k * 9 + sub] = xin[k];
+      }
+    }
+  }
+  // ---- the left separator absorbs its group (and the right contribution it received one level down)
+  if (role == 0 || role == 1) {                      // the C lanes carry the update of A's columns
+    const int pcd = role == 1 ? ldw + 9 + sub : pc;
+    double* img = v.cW + (size_t)a * isz + pcd;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) img[k * ldx] = sep0[k] - dacc[k];
+  }
+  F2STAMP(14);
+}
+
 // Back-substitution of one level: delta_e = -L^-T (z + Y delta_s + X_s delta_a + X_n delta_next), right to left inside
 // the group.  Everything that does not depend on the chain (z + Y delta_s + X_s delta_a, the rows of X_n, the columns of L)
 // is formed by lane (frame i, row k) beforehand; the dependent part is one 9 x 9 product and a triangular solve per frame,
 // exchanged through v_readlane.  At level 0 the wavefront also moves its frames (T <- T exp(delta), v <- v + dv) and
 // publishes their step terms.
-__global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int top, int lvl) {
+__global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int top, int lvl, int two) {
   __shared__ double ds[192 + 8];
   __shared__ double dl[kChainM * 9];
   const int done = v.ctrl->done;        // looked at once the level's inputs have been requested (see k_chain_fwd)
@@ -1081,6 +1336,10 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
   const int fi = lane / 9, k = lane % 9;
   const bool mine = fi < q;
   const int e = first + (mine ? fi : 0) * s;
+  // a group eliminated from both ends (k_chain_fwd2: full groups of a level launched two-sided): frames right of the middle hang
+  // on the right separator and on the frame to their left
+  const bool two_sided = two && !top && q >= 1;
+  const int fmid = (q - 1) / 2;                                  // lane group of the middle frame (interior index fmid + 1)
   double t = 0.0, dinv = 1.0, Qrow[9], Lcol[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) { Qrow[c] = 0.0; Lcol[c] = 0.0; }
@@ -1094,13 +1353,58 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
     double acc = Wr[D];
     for (int j = 0; j < D; ++j) acc += Wr[j] * ds[j];
     if (a >= 0) {
+      const bool right = two_sided && fi > fmid;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) acc += Wr[ldw + c] * da[c];
+      for (int c = 0; c < 9; ++c) acc += Wr[ldw + c] * (right ? dn[c] : da[c]);       // (dn: still the right separator's step here)
     }
     t = acc;
   }
   if (done) return;
   double my = 0.0;
+  if (two_sided) {
+    // the middle first (a on its left, r on its right), then outwards on both sides at once: two independent chains of 9 x 9
+    // products and triangular solves, interleaved instruction by instruction
+    {
+      double y = t;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) y += Qrow[c] * dn[c];
+#pragma unroll
+      for (int j = 8; j >= 0; --j) {
+        const double xj = readlane_f64(y * dinv, fmid * 9 + j);
+        dn[j] = -xj;
+        y -= Lcol[j] * xj;
+      }
+      if (fi == fmid) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) my = (j == k) ? dn[j] : my;
+      }
+    }
+    double dl_[9], dr_[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { dl_[j] = dn[j]; dr_[j] = dn[j]; }
+    const int nleft = fmid, nright = q - 1 - fmid;
+    for (int st = 1; st <= max(nleft, nright); ++st) {
+      const bool hl = st <= nleft, hr = st <= nright;              // wave-uniform
+      const int il = hl ? fmid - st : 0, ir = hr ? fmid + st : 0;
+      double yl = t, yr = t;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) { yl += Qrow[c] * dl_[c]; yr += Qrow[c] * dr_[c]; }
+#pragma unroll
+      for (int j = 8; j >= 0; --j) {
+        const double xl = readlane_f64(yl * dinv, il * 9 + j), xr = readlane_f64(yr * dinv, ir * 9 + j);
+        if (hl) { dl_[j] = -xl; yl -= Lcol[j] * xl; }
+        if (hr) { dr_[j] = -xr; yr -= Lcol[j] * xr; }
+      }
+      if (hl && fi == il) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) my = (j == k) ? dl_[j] : my;
+      }
+      if (hr && fi == ir) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) my = (j == k) ? dr_[j] : my;
+      }
+    }
+  } else
   for (int i = q - 1; i >= 0; --i) {
     double y = t;
 #pragma unroll
@@ -1271,9 +1575,16 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
   // wide borders: wavefronts side by side (measured: 1.68 -> 1.51 ms per pass at cfg5's per-rank size, 8.74 -> 8.39 ms at its full
   // size, where the chip is full either way); VICALIB_AMD_CHAIN_WAVES=0 selects columns per lane for A/B runs and the parity tests
   static const bool columns_per_lane = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_WAVES"); return e && std::atoi(e) == 0; }();
+  // narrow borders: above the bottom level the groups are eliminated from both ends (k_chain_fwd2: 4 dependent eliminations per
+  // level instead of 7; measured 26.3 -> 21.7 us per level at cfg3).  Not at the bottom level: its 250 groups would need 500
+  // wavefronts of ~370 registers next to the weight update's 500 on the other stream, and queue behind them (42 vs 32 us).
+  // VICALIB_AMD_CHAIN_TWO=0: one-sided throughout
+  static const bool two_env = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO"); return !(e && std::atoi(e) == 0); }();
+  const bool two_sided = two_env && cpl <= 1;
   auto fwd = [&](int groups, int stride, int m, int top, int lvl) {
     const bool side_by_side = cpl > 1 && !columns_per_lane;
-    if (cpl <= 1) hipLaunchKernelGGL((k_chain_fwd<1, 1>), dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
+    if (cpl <= 1 && two_sided && !top && m >= 4 && lvl >= 1) hipLaunchKernelGGL(k_chain_fwd2, dim3(groups), dim3(128), 0, s, v, stride, m, lvl);
+    else if (cpl <= 1) hipLaunchKernelGGL((k_chain_fwd<1, 1>), dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
     else if (side_by_side) {
       if (cpl <= 2) hipLaunchKernelGGL((k_chain_fwd<1, 2>), dim3(groups), dim3(128), 0, s, v, stride, m, top, lvl);
       else if (cpl <= 3) hipLaunchKernelGGL((k_chain_fwd<1, 3>), dim3(groups), dim3(192), 0, s, v, stride, m, top, lvl);
@@ -1287,9 +1598,10 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
     for (int l = 0; l < nl; ++l) fwd((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1), strides[l], ms[l], 0, l);
     fwd(1, top_stride, m_top, 1, nl);
   } else {
-    hipLaunchKernelGGL(k_chain_back, dim3(1), dim3(64), 0, s, v, top_stride, m_top, 1, nl);
+    hipLaunchKernelGGL(k_chain_back, dim3(1), dim3(64), 0, s, v, top_stride, m_top, 1, nl, 0);
     for (int l = nl - 1; l >= 0; --l)
-      hipLaunchKernelGGL(k_chain_back, dim3((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1)), dim3(64), 0, s, v, strides[l], ms[l], 0, l);
+      hipLaunchKernelGGL(k_chain_back, dim3((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1)), dim3(64), 0, s, v, strides[l], ms[l], 0, l,
+                         (two_sided && ms[l] >= 4 && l >= 1) ? 1 : 0);
   }
 }
 void launch_chain_init(const DevView& v, hipStream_t s) {

@@ -12,6 +12,14 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// The same exchange between the lanes of ONE wavefront inside a workgroup of several: wavefront-scope fences.  (With workgroup
+// scope every such point waits for the wavefront's outstanding GLOBAL loads and stores as well -- the prefetch of the next frame, the
+// stores of the solved image -- once the workgroup has more than one wavefront.)  LDS operations of a wavefront execute in order.
+__device__ __forceinline__ void wave_lds_sync_local() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ double readlane_f64(double x, int lane /* wave-uniform */) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
