@@ -204,6 +204,23 @@ int vc_get_debug_stamps(vc_calibrator* h, long long out[32]);   /* shader-clock 
 long long vc_num_observations(vc_calibrator* h);
 int vc_num_tiles(vc_calibrator* h);
 
+/* ---- image front-end, first slice -----------------------------------------------------------------------
+ * Replaces, per image stream, the pair  calibu::ImageProcessing image_processing_[i](width, height)  +  calibu::ConicFinder
+ * conic_finder_[i]  that VicalibTask owns (vicalib-task.h, constructed at vicalib-task.cc:115) and the two calls
+ *     image_processing_[ii].Process(img->data(), img->Width(), img->Height(), img->Width());     vicalib-task.cc:264-267
+ *     conic_finder_[ii].Find(image_processing_[ii]);                                             vicalib-task.cc:268
+ * of AddImageMeasurements; the result is what the reference reads as conics[i].center (:296).  Parameters and defaults are the
+ * ones VicalibTask sets (:116-122).  The image is an 8-bit greyscale HOST buffer (what HAL hands over); centres come back in
+ * pixel coordinates (x, y), ordered by the smallest pixel index of their dot.  Grid matching (FindTarget, :274) is not part of
+ * this slice.  No CPU fallback: vc_detector_create fails with VC_ERR_NO_DEVICE without a HIP device. */
+typedef struct vc_detector vc_detector;
+int vc_detector_create(int device, int width, int height, vc_detector** out);
+void vc_detector_destroy(vc_detector* d);
+int vc_detector_set_params(vc_detector* d, int black_on_white, double at_threshold, double at_window_ratio, double conic_min_area,
+                           double conic_min_density, double conic_min_aspect);
+/* centres: 2 x max_conics doubles; *n_found is the number of dots found (may exceed max_conics: the first max_conics are written) */
+int vc_detector_find(vc_detector* d, const unsigned char* image, int pitch, double* centres, int max_conics, int* n_found);
+
 #ifdef __cplusplus
 }
 #endif

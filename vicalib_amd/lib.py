@@ -31,6 +31,7 @@ SYMBOLS = [
     "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
     "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_pnp_planar_ransac", "vc_set_pnp_ransac", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_allreduce_calls", "vc_last_error", "vc_get_imu_weights",
     "vc_solution_covariance_dim", "vc_get_solution_covariance", "vc_get_solution_covariance_names",
+    "vc_detector_create", "vc_detector_destroy", "vc_detector_set_params", "vc_detector_find",
 ]
 
 
@@ -76,7 +77,7 @@ def load():
         L.vc_num_observations.restype = C.c_longlong
         L.vc_allreduce_calls.restype = C.c_longlong
         L.vc_last_error.restype = C.c_char_p
-        for name in ("vc_destroy",):
+        for name in ("vc_destroy", "vc_detector_destroy"):
             getattr(L, name).restype = None
         _lib = L
     return _lib
@@ -354,3 +355,34 @@ class ViCalibrator:
 
     def num_observations(self): return int(self.L.vc_num_observations(self.h))
     def num_tiles(self): return int(self.L.vc_num_tiles(self.h))
+
+
+class ConicDetector:
+    """The image front-end's first slice (include/vicalib_amd.h: vc_detector_*): what VicalibTask's image_processing_[i] /
+    conic_finder_[i] pair does per image (vicalib-task.cc:264-270) -- adaptive threshold, dot components, one conic per dot --
+    on the GPU.  find(image) -> centres [n, 2] (x, y)."""
+
+    def __init__(self, width, height, device=0):
+        self.L = load()
+        self.h = C.c_void_p()
+        _check(self.L.vc_detector_create(int(device), int(width), int(height), C.byref(self.h)), "detector_create")
+        self.w, self.hh = int(width), int(height)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vc_detector_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_params(self, black_on_white=True, at_threshold=0.9, at_window_ratio=30.0, conic_min_area=4.0, conic_min_density=0.6, conic_min_aspect=0.2):
+        _check(self.L.vc_detector_set_params(self.h, int(black_on_white), C.c_double(at_threshold), C.c_double(at_window_ratio), C.c_double(conic_min_area),
+                                             C.c_double(conic_min_density), C.c_double(conic_min_aspect)), "detector_set_params")
+
+    def find(self, image, max_conics=4096):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        assert image.shape == (self.hh, self.w)
+        out = np.zeros((max_conics, 2)); n = C.c_int(0)
+        _check(self.L.vc_detector_find(self.h, image.ctypes.data_as(C.c_void_p), int(image.strides[0]), _d(out), int(max_conics), C.byref(n)), "detector_find")
+        return out[:min(n.value, max_conics)]
