@@ -241,6 +241,43 @@ def test_lean_dlog_dse3_matches_the_transliterated_form():
             np.testing.assert_allclose(b, a, rtol=tol, atol=tol * max(1.0, np.abs(a).max()))
 
 
+def test_dlog_dse3_closed_forms_against_numerical_differentiation():
+    """Breaks the twin: the device's and the oracle's dLog_dSE3 are two copies of one transliteration of the reference's
+    machine-generated closed forms (vicalibrator-utils.h:107-154, :308-434: s1 ... s20), so agreeing with each other proves
+    little.  Here the 6 x 7 matrix is compared with central differences of the SE3 logarithm itself (the oracle's se3_log, pinned
+    by 50-digit known answers) with respect to the seven ambient coordinates [t, q] -- the quaternion's four components moved
+    independently, which is what the closed forms differentiate (the logarithm does not depend on the quaternion's norm).  A
+    mistranscribed term in any s_k shows at order one; agreement is at the differences' own accuracy (1e-8)."""
+    rng = np.random.default_rng(11)
+    H = hh()
+    L = ol.lib()
+
+    def se3_log(q, t):
+        out = np.zeros(6)
+        L.vco_se3_log(d(np.concatenate([q, t])), d(out))
+        return out
+
+    for ang in [1e-3, 0.05, 0.4, 1.3, 2.6]:
+        for sign in (1.0, -1.0):
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            q = np.concatenate([np.sin(ang / 2) * ax, [np.cos(ang / 2)]]) * sign
+            t = rng.normal(size=3) * 0.3
+            full = np.zeros(42); lean = np.zeros(42)
+            H.hh_dlog_dse3(d(np.concatenate([q, t])), d(full), d(lean))
+            J = np.zeros((6, 7))
+            for k in range(7):
+                h = 1e-6
+                qp, tp, qm, tm = q.copy(), t.copy(), q.copy(), t.copy()
+                if k < 3:
+                    tp[k] += h; tm[k] -= h
+                else:
+                    qp[k - 3] += h; qm[k - 3] -= h
+                J[:, k] = (se3_log(qp, tp) - se3_log(qm, tm)) / (2 * h)
+            scale = max(1.0, np.abs(J).max())
+            np.testing.assert_allclose(full.reshape(6, 7), J, rtol=0, atol=2e-8 * scale / min(ang, 1.0) ** 2 if ang < 0.01 else 2e-8 * scale)
+            np.testing.assert_allclose(lean.reshape(6, 7), J, rtol=0, atol=2e-8 * scale / min(ang, 1.0) ** 2 if ang < 0.01 else 2e-8 * scale)
+
+
 def test_imu_block_forms_match_oracle_on_irregular_sample_times():
     """Jittered, gappy IMU time stamps (the reference's index guess is then off by many samples and its walk does the work) and
     random time offsets, some of them exact multiples of the nominal period: the integrated and the delta form of the device
