@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
 // (lane = row, pivots and pivot columns by 16-lane shuffles) and the stored factor W = L^-T:  W W^T = (J Sigma J^T)^-1 exactly
 // as for the reference's symmetric square root (vicalibrator.h:783-796), and cost, gradient and Gauss-Newton Hessian of the
 // block depend on W only through W W^T -- same optimisation, no 9x9 eigen-decomposition.
-constexpr int kWLds = 128;                       // per block: the factor's rows for the inverse (81) | frame poses j-1, j (16) | v_{j-1} (4) | IMU parameters (15)
-constexpr int kWPose = 88, kWVel = 104, kWImu = 108;
+constexpr int kWLds = 184;                       // per block: the factor's rows for the inverse (81) | frame poses j-1, j (16) | v_{j-1} (4) | IMU parameters (15) | Sigma (55)
+constexpr int kWPose = 88, kWVel = 104, kWImu = 108, kWSig = 128;
 
 // DPP row operations on doubles (two 32-bit moves).  row_shr:n -- lane i of a row reads lane i - n; row_shl:n -- lane i + n;
 // lanes without a source keep `old`.
@@ -324,9 +324,8 @@ __global__ __launch_bounds__(64) void k_imu_weights(DevView v, int wr) {
   for (int o = 32; o >= 16; o >>= 1) n_max = max(n_max, __shfl_xor(n_max, o, 64));
   DeltaAcc<double> carry;                        // the block's delta up to the current round
   delta_identity(&carry);
-  double Sp[kWMapQ];                             // Sigma (packed lower triangle), the same in all lanes of the group
-#pragma unroll
-  for (int e = 0; e < kWMapQ; ++e) Sp[e] = 0.0;
+  // Sigma (packed lower triangle) rests in LDS between the rounds and until the projection: 55 doubles that would otherwise sit
+  // in registers (or, as they did, in scratch memory) across the maps of every round
   const double g0[3] = {0.0, 0.0, 0.0};
   WSTAMP(1);
 #pragma unroll 1
@@ -394,7 +393,9 @@ __global__ __launch_bounds__(64) void k_imu_weights(DevView v, int wr) {
       w_noise_term(P, G, sg2, sa2, term);
     }
     if (base > 0) {                              // a later round: the first lane takes Sigma_in through the whole round
-      double Sin[kWMapQ];
+      double Sp[kWMapQ], Sin[kWMapQ];
+#pragma unroll
+      for (int e = 0; e < kWMapQ; ++e) Sp[e] = L[kWSig + e];
       w_conj(F, Sp, Sin);
 #pragma unroll
       for (int e = 0; e < kWMapQ; ++e) term[e] += (c == 0) ? Sin[e] : 0.0;
@@ -402,14 +403,21 @@ __global__ __launch_bounds__(64) void k_imu_weights(DevView v, int wr) {
     WSTAMP(7);
 #pragma unroll
     for (int e0 = 0; e0 < kWMapQ; e0 += 11) row_allsum_n<11>(term + e0);
+    wave_lds_sync();                             // (a later round has read the previous Sigma above)
+    if (c == 0) {
 #pragma unroll
-    for (int e = 0; e < kWMapQ; ++e) Sp[e] = term[e];
+      for (int e = 0; e < kWMapQ; ++e) L[kWSig + e] = term[e];
+    }
+    wave_lds_sync();
   }
   WSTAMP(8);
   // the predicted state from the block's delta (vc_imu.hpp), then J = dLog_dSE3(T_pred T2^-1) dt1t2_dt1(T_pred, T2^-1) with
   // the velocity identity appended (9 x 10); lane i (< 9) forms row i of P = J Sigma J^T
   double a[9];
   {
+    double Sp[kWMapQ];
+#pragma unroll
+    for (int e = 0; e < kWMapQ; ++e) Sp[e] = (n_max > 0) ? L[kWSig + e] : 0.0;
     double T1[7], T2[7], v1[3], gw[3], q_end[4], p_end[3], rp[3];
 #pragma unroll
     for (int i = 0; i < 7; ++i) { T1[i] = L[kWPose + i]; T2[i] = L[kWPose + 8 + i]; }
