@@ -615,16 +615,27 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
     if (lane < kMaxCams) { tcam[lane] = my_tc; tinv[lane] = -1; }
     wave_lds_sync();
     if (lane < nt) tinv[my_tc] = lane;             // the frame's tile of every camera
-    for (int m = 0; m < nt * 5; ++m) {
-      const int t = m / 5, q = m % 5;
-      const int o = (q < 4) ? q * 64 + lane : kGGrad + (lane & 15);
-      const double val = (q < 4 || lane < 16) ? v.Gb[cur][(size_t)(t0 + t) * kGStride + o] : 0.0;
-      if (q < 4 || lane < 16) Gw[t * kGStride + o] = val;
-      const int c = __shfl(my_tc, t, 64);
+    for (int t = 0; t < nt; ++t) {
+      // (the tile's camera as a scalar: the per-camera sums take one add per loaded value behind a scalar branch, not a select
+      // over all cameras x slots -- 1600 selects per frame at 8 cameras)
+      const int c = __builtin_amdgcn_readfirstlane(__shfl(my_tc, t, 64));
+      double val[5];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int o = (q < 4) ? q * 64 + lane : kGGrad + (lane & 15);
+        val[q] = (q < 4 || lane < 16) ? v.Gb[cur][(size_t)(t0 + t) * kGStride + o] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int o = (q < 4) ? q * 64 + lane : kGGrad + (lane & 15);
+        if (q < 4 || lane < 16) Gw[t * kGStride + o] = val[q];
+      }
 #pragma unroll
       for (int k = 0; k < kMaxCams; ++k)
+        if (c == k) {
 #pragma unroll
-        for (int qq = 0; qq < 5; ++qq) gsum[k][qq] += (k == c && qq == q) ? val : 0.0;
+          for (int q = 0; q < 5; ++q) gsum[k][q] += val[q];
+        }
     }
     wave_lds_sync();
     // ---- visual part of the frame's own block: H_pp (6 x 6) and g_p (6) from the tiles (lanes 0..41)
