@@ -423,7 +423,11 @@ struct vc_calibrator {
     cur = 0;
     for (int b = 0; b < 2; ++b) { HIP_OK(d_pose[b].upload(poses, stream)); HIP_OK(d_cam[b].upload(camrec, stream)); }
     // one wavefront per frame, 4 frames per group: up to 2048 chunks (= partial sums) before chunks grow
-    const int chunk_frames = std::max(4, (((N + 2047) / 2048) + 3) / 4 * 4);
+    int chunk_frames = std::max(4, (((N + 2047) / 2048) + 3) / 4 * 4);
+    // wide borders: a chunk's partial record is D^2 doubles -- written once and read once per pass; keep all of them under ~64 MB
+    // (8 cameras, 6250 frames per rank: 197 MB at 4 frames per chunk, k_part_sum 47 -> 19 us at 16)
+    while (chunk_frames < 16 && (double)((N + chunk_frames - 1) / chunk_frames) * ((double)D * D + D + (C + 1) * kGStride) * 8.0 > 64e6) chunk_frames *= 2;
+    { const char* e = std::getenv("VICALIB_AMD_CHUNK_FRAMES"); if (e && std::atoi(e) >= 4) chunk_frames = std::atoi(e) / 4 * 4; }      // (A/B hook)
     const int n_chunks = std::max(1, (N + chunk_frames - 1) / chunk_frames);
     const int part_stride = D * D + D + C * kGStride + (imu_on() ? kGStride : 0) + 2;     // ... + [x2 of observation-less frames, chunk cost] (vision path)
     for (int b = 0; b < 2; ++b) {

@@ -805,8 +805,16 @@ __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 // trailing matrix is updated on the 16 x 16 thread grid -- a handful of barriers per panel instead of three per column
 // (D = 67: 30 instead of ~330 barriers).  Same packed storage; extra LDS after x: Lp (16 x 16 padded diagonal factor),
 // dinvp (16), red (16 x 16), dinv (D).
+#ifdef VC_REDUCED_STAMPS
+#define VC_PH(i) do { if (threadIdx.x == 0) { const long long now_ = (long long)__builtin_readcyclecounter(); ph_[i] += now_ - t_; t_ = now_; } } while (0)
+#else
+#define VC_PH(i) do { } while (0)
+#endif
 __device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M, double* x) {
   const int tid = threadIdx.x, lane = tid & 63, D = v.D;
+#ifdef VC_REDUCED_STAMPS
+  long long ph_[6] = {0, 0, 0, 0, 0, 0}, t_ = (long long)__builtin_readcyclecounter();      // load | diagonal | rows | trailing | back-subst sums | back-subst solve
+#endif
   double* Lp = x + (D + 1);
   double* dinvp = Lp + 256;
   double* red = dinvp + 16;
@@ -829,6 +837,7 @@ __device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M,
     M[tri(i) + i] += lam;
   }
   __syncthreads();
+  VC_PH(0);
   for (int p0 = 0; p0 < D; p0 += 16) {
     const int nb = min(16, D - p0);
     // (1) diagonal block -> L11 (wavefront 0; lane = row, identity padding beyond nb)
@@ -862,6 +871,7 @@ __device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M,
       if (bad && lane == 0) v.flags[5 + 2 * v.par] = 1;
     }
     __syncthreads();
+    VC_PH(1);
     // (2) rows below the panel (and the right-hand-side row D): X_i = A[i, panel] L11^-T, one row per thread
     const int r0 = p0 + nb;
     for (int i = r0 + tid; i <= D; i += 256) {
@@ -880,6 +890,7 @@ __device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M,
       for (int k = 0; k < 16; ++k) if (k < nb) M[ri + k] = a[k];
     }
     __syncthreads();
+    VC_PH(2);
     // (3) trailing update A[i][k] -= X_i . X_k for r0 <= k <= i (k < D), i <= D
     {
       const int ti = tid >> 4, tj = tid & 15;
@@ -898,6 +909,7 @@ __device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M,
       }
     }
     __syncthreads();
+    VC_PH(3);
   }
   // ---- delta_s = -L^-T y (y = row D), panels from the bottom ----------------------------------------------------------
   for (int i = tid; i < D; i += 256) x[i] = -M[tri(D) + i];
@@ -912,6 +924,7 @@ __device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M,
       red[part * 16 + jcol] = acc;
     }
     __syncthreads();
+    VC_PH(4);
     if (tid < 64) {
       double t = 0.0;
       if (lane < nb) {
@@ -932,7 +945,11 @@ __device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M,
       if (lane < nb) x[p0 + lane] = z;
     }
     __syncthreads();
+    VC_PH(5);
   }
+#ifdef VC_REDUCED_STAMPS
+  if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) v.dbg[8 + i] = ph_[i];
+#endif
 }
 
 __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dyn, double* red /* 6 x 256 */, const double* s_cam,
