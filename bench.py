@@ -250,6 +250,18 @@ def main():
             if base_name == "k_imu_weights":
                 e["executed_flops_estimate"] = n_imu_blocks * (n_meas * 8500.0 + 3000.0)
         kernels[name] = e
+    def pmc_traffic(group):
+        """HBM bytes of one launch group from the committed PMC passes (profiles/pmc_traffic_latest.json): a single kernel's
+        per-launch figure, or -- the chain elimination's levels -- everything its kernels moved per LM pass."""
+        t = PMC_TRAFFIC.get(wl, {})
+        base = group.replace("(trial)", "")
+        if base == "k_chain_fwd":
+            parts = [t.get("k_chain_fwd@pass"), t.get("k_chain_fwd2@pass")]
+            return sum(x for x in parts if x) if any(parts) else t.get(base)
+        if base == "k_chain_back":
+            return t.get("k_chain_back@pass", t.get(base))
+        return t.get(base)
+
     # the dominant kernel = the launch group with the largest share of the step among ALL groups that carry a model
     # (a group of several launches -- the levels of k_chain_fwd -- counts as one: per pass its flops / its time)
     modelled = [k for k in kernels if k.replace("(trial)", "") in algo]
@@ -261,7 +273,7 @@ def main():
         hbm = bound == "hbm"
         roofline = {"kernel": dom, "bound": bound, "achieved": e["hbm_gbs"] if hbm else e["tflops"], "peak": 8000.0 if hbm else 78.6,
                     "unit": "GB/s" if hbm else "TFLOP/s", "frac": e["hbm_frac"] if hbm else e["fp64_frac"],
-                    "traffic": PMC_TRAFFIC.get(wl, {}).get(dom.replace("(trial)", "")) if world == 1 and not args.frames else None, "avg_ms": e["avg_ms"],
+                    "traffic": pmc_traffic(dom) if world == 1 and not args.frames else None, "avg_ms": e["avg_ms"],
                     "algorithmic_flops": fl, "algorithmic_bytes": by, "hbm_gbs": e["hbm_gbs"], "hbm_frac": e["hbm_frac"],
                     "launches_in_group": "one launch per level of the partitioned elimination" if "chain_fwd" in dom or "chain_back" in dom else 1,
                     "timing": "HIP events around every launch group of this kernel inside the timed LM loop (decisions live)"}

@@ -1,0 +1,16 @@
+set -u
+R=$PWD; O=$R/gpurun_out/final; mkdir -p $O
+tools/profile_round.sh r03 cfg3 > $O/prof_cfg3.log 2>&1
+tools/profile_round.sh r03 cfg4 > $O/prof_cfg4.log 2>&1
+bash tools/timeline_round.sh cfg3 k_final > $O/pass_timeline_cfg3.txt 2>&1
+VICALIB_AMD_LIB=$R/tools/probe/libvicalib_amd_wstamps.so python tools/weights_stamps.py > $O/weights_stamps.txt 2>&1
+VICALIB_AMD_LIB=$R/tools/probe/libvicalib_amd_f2stamps.so python tools/f2_stamps.py > $O/fwd2_stamps.txt 2>&1
+(VICALIB_AMD_LIB=$R/tools/probe/libvicalib_amd_rstamps.so python tools/reduced_stamps.py cfg3; VICALIB_AMD_LIB=$R/tools/probe/libvicalib_amd_rstamps.so python tools/reduced_stamps.py cfg4 2500; VICALIB_AMD_LIB=$R/tools/probe/libvicalib_amd_rstamps.so python tools/reduced_stamps.py cfg5 6250) > $O/reduced_stamps.txt 2>&1
+tools/perrank_round.sh final > $O/perrank.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU -d $O/pmc -o p -- python $R/bench.py --workload cfg3 --steps 20 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc.err
+python $R/tools/rocpd_pmc.py $(ls $O/pmc/*results.db | head -1) > $O/sq_insts_cfg3.txt 2>&1; rm -rf $O/pmc
+cd $R
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+tail -3 $O/prof_cfg3.log; cat $O/perrank.txt | grep "frames:"; python -c "
+import json; d=json.load(open('$O/bench_default.json')); print(d['ms_per_step'], d['timing'], d['roofline']['kernel'], d['roofline']['frac'])"

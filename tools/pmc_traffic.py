@@ -41,6 +41,22 @@ def main(fetch_db, write_db, workload=None, out_json=None):
         rows.append((2048.0 * favg + 1024.0 * wavg, short(name), len(f), len(fa), favg, wavg))
     for b, n, nl, na, fa, wa in sorted(rows, reverse=True):
         print("%-20s %9d %9d %14.1f %14.1f %16.0f" % (n, nl, na, fa, wa, b))
+    # kernels launched several times per LM pass (the levels of the chain elimination): bytes per PASS = everything the kernel
+    # moved, over the number of passes (= active launches of the deciding kernel)
+    passes = 0
+    for name in F:
+        if short(name) in ("k_final", "k_trial"):
+            f = F[name]
+            passes = max(passes, len([x for x in f if x > 0.05 * max(f)]))
+    per_pass = {}
+    if passes:
+        print("# per LM pass (%d passes): all launches of a kernel summed" % passes)
+        for name in F:
+            tot = 2048.0 * sum(F[name]) + 1024.0 * sum(W.get(name, [0.0]))
+            per_pass[short(name) + "@pass"] = tot / passes
+        for n in ("k_chain_fwd", "k_chain_fwd2", "k_chain_back"):
+            if n + "@pass" in per_pass:
+                print("%-20s %16.0f bytes per pass" % (n, per_pass[n + "@pass"]))
     if workload and out_json:
         import json
         import os
@@ -48,6 +64,7 @@ def main(fetch_db, write_db, workload=None, out_json=None):
         if os.path.exists(out_json):
             d = json.load(open(out_json))
         d[workload] = {n: b for b, n, nl, na, fa, wa in rows}
+        d[workload].update(per_pass)
         json.dump(d, open(out_json, "w"), indent=1, sort_keys=True)
 
 
