@@ -102,6 +102,8 @@ def main():
     prob = synth.generate_native(cfg)
     vi = bool(base.imu)
 
+    rccl_errors = []      # native RCCL path failed on this rank: the texts go into the JSON line's comm object
+
     def attach(c):
         if world == 1 and not force_shard:
             return "none"
@@ -111,6 +113,7 @@ def main():
                 return "rccl"
             except Exception as e:      # noqa: BLE001
                 # the exception text carries vc_last_error(): which RCCL call failed and RCCL's own error string
+                rccl_errors.append(str(e))
                 print("bench[rank %d]: native RCCL path unavailable (%s); using the torch.distributed callback" % (rank, e), file=sys.stderr)
         from vicalib_amd.parallel import FrameShardComm
         c.set_shard(rank, world, FrameShardComm(device="cuda:%d" % local_rank, stream_ptr=c.stream()))
@@ -296,7 +299,8 @@ def main():
         ar = {k: kernels[k] for k in kernels if k.startswith("allreduce")}
         comm = {"transport": comm_kind, "communicator_size": world, "allreduce_calls": allreduce_calls, "per_rank_ms_per_step": per_rank_ms,
                 "allreduce_ms_per_step": {k: v["ms_per_step"] for k, v in ar.items()},
-                "payload_doubles": {"allreduce(S)": D * D + 3 * D + 2, "allreduce(step scalars)": world * 8}}
+                "payload_doubles": {"allreduce(S)": D * D + 3 * D + 2, "allreduce(step scalars)": world * 8},
+                "rccl_error": rccl_errors[0] if rccl_errors else None}
 
     out = None
     if rank == 0:

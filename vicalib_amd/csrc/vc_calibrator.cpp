@@ -149,8 +149,9 @@ struct vc_calibrator {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;        // the IMU weight update of a pass runs here, under the pass's Jacobian sweeps and chain solve
-  hipEvent_t ev_state = nullptr, ev_weights = nullptr, ev_imujac = nullptr, ev_reduced = nullptr;
+  hipEvent_t ev_state = nullptr, ev_weights = nullptr, ev_imujac = nullptr, ev_reduced = nullptr, ev_back = nullptr;
   int wcur = 0;                         // weight buffer holding the current weight_sqrt_
+  bool jac_on_stream2 = true;           // the trial point's k_imu_jac beside the vision sweep (VICALIB_AMD_JAC_STREAM2=0: after it, main stream)
   bool serial_weights = false;          // false: IMU Jacobians + weight update on the second stream (VICALIB_AMD_OVERLAP_WEIGHTS=0: in line); was: VICALIB_AMD_OVERLAP_WEIGHTS=1 moves it to a second
                                         // stream under the Jacobian sweeps / chain solve (measured: the two latency-bound kernels then
                                         // share the CUs and the pass gets 4 % slower on cfg3)
@@ -214,7 +215,7 @@ struct vc_calibrator {
   DBuf<double> d_wgpart;
   int kpass = 0;                  // passes enqueued since init_ctrl (merged mode: selects the control record and flag parity)
   DBuf<double> d_pose[2], d_cam[2], d_G[2], d_tile_cost[2], d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_sdiag,
-      d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total, d_part_total2;
+      d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total;
   DBuf<Ctrl> d_ctrl;
   DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_seg[2], d_seg_cost[2],
       d_cW, d_cdelta, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init, d_rX[2], d_grp_part, d_wg_trial, d_wg_imu_trial,
@@ -243,6 +244,7 @@ struct vc_calibrator {
     if (ev_weights) (void)hipEventDestroy(ev_weights);
     if (ev_imujac) (void)hipEventDestroy(ev_imujac);
     if (ev_reduced) (void)hipEventDestroy(ev_reduced);
+    if (ev_back) (void)hipEventDestroy(ev_back);
     if (stream) (void)hipStreamDestroy(stream);
     if (pin) (void)hipHostFree(pin);
   }
@@ -437,7 +439,7 @@ struct vc_calibrator {
     HIP_OK(d_Y.alloc((size_t)std::max(T, 1) * kYStride)); HIP_OK(d_fr.alloc((size_t)std::max(N, 1) * kFrStride));
     HIP_OK(d_fdiag.alloc((size_t)std::max(N, 1) * 6)); HIP_OK(d_fscale2.alloc((size_t)std::max(N, 1) * 6));
     HIP_OK(d_part.alloc((size_t)n_chunks * ((size_t)Dmax * Dmax + Dmax + C * kGStride + kGStride + 2)));
-    HIP_OK(d_part.alloc((size_t)n_chunks * part_stride)); HIP_OK(d_part_total.alloc((size_t)part_stride * ((n_chunks + 63) / 64))); HIP_OK(d_Sbuf.alloc((size_t)D * D + 3 * D + 2));
+    HIP_OK(d_part.alloc((size_t)n_chunks * part_stride)); HIP_OK(d_part_total.alloc((size_t)part_stride)); HIP_OK(d_Sbuf.alloc((size_t)D * D + 3 * D + 2));
     HIP_OK(d_sdiag.alloc(D)); HIP_OK(d_sscale2.alloc(D)); HIP_OK(d_slam.alloc(D)); HIP_OK(d_delta_s.alloc(D));
     HIP_OK(d_fpart.alloc((size_t)std::max(N, 1) * kNumScal));
     trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); HIP_OK(d_ctrl.alloc(2));
@@ -466,13 +468,6 @@ struct vc_calibrator {
     dv.fused = 1;
  dv.tile_trial = d_tile_trial.p; dv.Y = d_Y.p; dv.fr = d_fr.p;
     dv.fdiag = d_fdiag.p; dv.fscale2 = d_fscale2.p; dv.part = d_part.p; dv.part_total = d_part_total.p; dv.Sbuf = d_Sbuf.p;
-    {
-      // k_reduced is one workgroup: above ~0.5 MB of slab totals a second reduction level on many CUs is cheaper than its own loop
-      const int nslab = (n_chunks + 63) / 64;
-      dv.two_level_sum = (nslab > 1 && (size_t)nslab * part_stride * sizeof(double) > (512u << 10)) ? 1 : 0;
-      dv.n_slab = dv.two_level_sum ? 1 : nslab;
-      HIP_OK(d_part_total2.alloc((size_t)part_stride)); dv.part_total2 = d_part_total2.p;
-    }
     dv.sdiag = d_sdiag.p; dv.sscale2 = d_sscale2.p; dv.slam = d_slam.p; dv.delta_s = d_delta_s.p;
     dv.fpart = d_fpart.p; dv.scal = d_scal.p; dv.flags = d_flags.p;
     dv.pre_backsub = (T > 2048) ? 1 : 0;
@@ -707,11 +702,22 @@ struct vc_calibrator {
       // (second stream: weight update, then the deltas -- ev_weights covers both); the decision follows without another
       // cross-stream hop (each costs 6-13 us on the device's timeline)
       if (upd) wcur = 1 - wcur;
-      if (!serial_weights) HIP_OK(hipEventRecord(ev_weights, stream2));
-      KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
-      if (!serial_weights) HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0));
-      else KT("k_imu_delta+k_imu_block(trial)", launch_imu_delta(dv, stream, 1));
-      KT("k_imu_jac(trial)", launch_imu_jac(dv, wcur, stream, 1));
+      if (!serial_weights && jac_on_stream2) {
+        // the IMU blocks' final stage (needs the trial poses) beside the vision sweep: the second stream is already past its
+        // deltas when the back-substitution ends
+        HIP_OK(hipEventRecord(ev_back, stream));
+        HIP_OK(hipStreamWaitEvent(stream2, ev_back, 0));
+        KT2("k_imu_jac(trial)", launch_imu_jac(dv, wcur, stream2, 1));
+        HIP_OK(hipEventRecord(ev_weights, stream2));
+        KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
+        HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0));
+      } else {
+        if (!serial_weights) HIP_OK(hipEventRecord(ev_weights, stream2));
+        KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
+        if (!serial_weights) HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0));
+        else KT("k_imu_delta+k_imu_block(trial)", launch_imu_delta(dv, stream, 1));
+        KT("k_imu_jac(trial)", launch_imu_jac(dv, wcur, stream, 1));
+      }
       if (sharded()) {
         KT("k_final(reduce)", launch_final(dv, 1, stream));
         KT("allreduce(step scalars)", rc = do_allreduce(dv.gath, world * kNumScal, 0)); if (rc) return rc;
@@ -1073,6 +1079,7 @@ int vc_create(vc_calibrator** out, int device) {
   { const char* e = std::getenv("VICALIB_AMD_GRAPHS"); if (e && e[0] == '1') h->use_graphs = true; }
   { const char* e = std::getenv("VICALIB_AMD_NO_MERGED_DECISION"); if (e && e[0] == '1') h->merged_enabled = false; }
   { const char* e = std::getenv("VICALIB_AMD_OVERLAP_WEIGHTS"); if (e && e[0] == '0') h->serial_weights = true; }
+  { const char* e = std::getenv("VICALIB_AMD_JAC_STREAM2"); if (e && e[0] == '0') h->jac_on_stream2 = false; }
   // the hand-over events between the calibrator's two streams order work on ONE device: no system-scope fence at the record
   // (VICALIB_AMD_EVENT_SYSTEM_FENCE=1 restores the default, for A/B measurements)
   unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
@@ -1095,7 +1102,7 @@ int vc_create(vc_calibrator** out, int device) {
       hipEventCreateWithFlags(&h->ev_state, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_weights, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_imujac, evf) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_reduced, evf) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }
+      hipEventCreateWithFlags(&h->ev_reduced, evf) != hipSuccess || hipEventCreateWithFlags(&h->ev_back, evf) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }
   *out = h;
   return VC_OK;
 }
@@ -1628,6 +1635,8 @@ int vc_time_stages(vc_calibrator* h, int reps, double* out) {
     (void)hipEventRecord(ev[0], s); for (int i = 0; i < reps; ++i) launch_reproj_jac(h->dv, s);
     (void)hipEventRecord(ev[1], s); for (int i = 0; i < reps; ++i) launch_frame_schur(h->dv, s);
     (void)hipEventRecord(ev[2], s);
+    // (k_reduced adds the camera blocks to the S k_part_sum left in Sbuf: repeated without it, S only grows more positive definite --
+    // the timing is unaffected and the held state ignores the step)
     (void)hipEventRecord(ev[3], s); for (int i = 0; i < reps; ++i) launch_reduced(h->dv, 0, s);
     (void)hipEventRecord(ev[4], s); for (int i = 0; i < reps; ++i) launch_trial(h->dv, s);
     (void)hipEventRecord(ev[5], s); for (int i = 0; i < reps; ++i) launch_final(h->dv, 0, s);

@@ -105,9 +105,7 @@ struct DevView {
   double* fdiag;                   // n_frames x 6   clamped scaled diagonal (kept while reuse_diagonal)
   double* fscale2;                 // n_frames x 6   Jacobi scale^2 (fixed per solve)
   double* part;                    // n_chunks x part_stride
-  double* part_total;              // n_slabs x part_stride: fixed-order sums of slabs of 64 chunk partials
-  double* part_total2;             // part_stride: their sum (only when two_level_sum)
-  int two_level_sum, n_slab;       // large records / many slabs: a second k_part_sum level; n_slab = records k_reduced adds
+  double* part_total;              // part_stride: k_part_sum's fixed-order sum; only the entries behind S and g_red are used (those go straight to Sbuf)
   double* Sbuf;                    // D*D (S, no damping) + D (g_red) + D (H_ss diag) + D (g_s) + 2 (cost, spare)
   double* sdiag;                   // D
   double* sscale2;                 // D

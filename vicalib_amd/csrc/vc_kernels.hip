@@ -557,34 +557,39 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
   if (tid == 0) { part[v.part_stride - 1] = (sh[0] + sh[1]) + (sh[2] + sh[3]); part[v.part_stride - 2] = (sh[4] + sh[5]) + (sh[6] + sh[7]); }
 }
 
-// Fixed-order sum of the chunk partials, spread over many CUs (one CU can only pull ~20-50 GB/s):
-// workgroup (x, y) owns 32 entries and the slab of kSlab partials y; thread (entry = tid & 31, slice = tid >> 5)
-// sums the slab's partials k = slice (mod 8), the 8 slices are then added in order:
-//   part_total[y][e] = sum_{k in slab y} part[k][e];   the slabs are added by the consumer (k_reduced).
-constexpr int kSlab = 64;
-// second = 1: the same over the slab totals of a first launch (large problems: the consumer then adds one record instead of up to
-// 32 slabs of D^2 + ... entries -- 7 MB through one workgroup at cfg5's 8-way shard size)
-__global__ __launch_bounds__(256) void k_part_sum(DevView v, int second) {
-  __shared__ double sl[256];
+// Fixed-order sum of the chunk partials, spread over many CUs (one CU can only pull ~20-50 GB/s): workgroup x owns 16 entries
+// (one 128-byte line per chunk); thread (entry = tid & 15, slice = tid >> 4) sums the partials k = slice (mod 32) -- all of a
+// thread's loads are independent, two or three rounds of 16 --, the 32 slices are then added in order.  The result goes where its
+// consumer wants it: -sum into Sbuf's S (both triangles: the producers only fill tile pairs I <= J, whose mirror image is written
+// here -- entries of the lower block triangle are neither summed nor read) and g_red, the per-camera Gram sums / IMU parameter
+// block / chunk scalars into part_total.  k_reduced (one workgroup) used to add slab totals, negate and mirror itself: 0.5 MB
+// through one CU plus a D^2 loop of dependent round trips, 24 + 8 us at D = 67.  (A two-level version whose last workgroup per
+// column added the slab totals behind a device-scope fence was 14x slower: every release fence writes the L2 back.)
+constexpr int kSumEntries = 16, kSumSlices = 32;
+__global__ __launch_bounds__(kSumEntries * kSumSlices) void k_part_sum(DevView v) {
+  __shared__ double sl[kSumEntries * kSumSlices];
   if (v.ctrl->done) return;
-  const int tid = threadIdx.x, e = blockIdx.x * 32 + (tid & 31), ks = tid >> 5;
-  const int stride = v.part_stride;
-  const double* src = second ? v.part_total : v.part;
-  double* dst = second ? v.part_total2 : v.part_total;
-  const int n_src = second ? (v.n_chunks + kSlab - 1) / kSlab : v.n_chunks;
-  const int k0 = blockIdx.y * kSlab, k1 = min(k0 + kSlab, n_src);
+  const int tid = threadIdx.x, e = blockIdx.x * kSumEntries + (tid & (kSumEntries - 1)), ks = tid / kSumEntries;
+  const int stride = v.part_stride, D = v.D, DD = D * D, n = v.n_chunks;
+  int i = 0, j = 0;
+  bool live = e < stride;
+  if (e < DD) { i = e / D; j = e - i * D; live = (i >> 4) <= (j >> 4); }
   double s = 0.0;
-  if (e < stride) {
-#pragma unroll 8
-    for (int k = k0 + ks; k < k1; k += 8) s += src[(size_t)k * stride + e];
+  if (live) {
+    const double* src = v.part + e;
+#pragma unroll 16
+    for (int k = ks; k < n; k += kSumSlices) s += src[(size_t)k * stride];
   }
   sl[tid] = s;
   __syncthreads();
-  if (tid < 32 && e < stride) {
+  if (tid < kSumEntries && live) {
     double t = sl[tid];
 #pragma unroll
-    for (int q = 1; q < 8; ++q) t += sl[q * 32 + tid];
-    dst[(size_t)blockIdx.y * stride + e] = t;
+    for (int q = 1; q < kSumSlices; ++q) t += sl[q * kSumEntries + tid];
+    double* S = v.Sbuf;
+    if (e < DD) { S[e] = -t; if ((i >> 4) < (j >> 4)) S[j * D + i] = -t; }
+    else if (e < DD + D) S[e] = -t;        // g_red follows S
+    else v.part_total[e] = t;
   }
 }
 
@@ -598,7 +603,7 @@ struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[kMaxCams * 25
 #else
 #define VC_STAMP(i) do { } while (0)
 #endif
-__device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */) {
+__device__ __forceinline__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */) {
   VC_STAMP(0);
   const int tid = threadIdx.x, D = v.D, C = v.n_cams;
   double* S = v.Sbuf;
@@ -607,78 +612,86 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double
   double* gs = hd + D;
   double* sc = gs + D;
   const int stride = v.part_stride;
-  const int nslab = v.n_slab;
-  const double* ptot = v.n_slab == 1 && v.two_level_sum ? v.part_total2 : v.part_total;
-  // camera rotations: fetched now, under the partial sums' latency, instead of one dependent global load per camera later
+  // S = -sum of the partials (both triangles) and g_red are in place (k_part_sum's last workgroups); the rest of the summed
+  // record -- per-camera Gram sums, IMU parameter block, chunk scalars -- comes from part_total
+  const double* ptot = v.part_total;
+  // camera rotations: fetched now, under the loads' latency, instead of one dependent global load per camera later
   if (tid < C * 4) L.camq[tid] = v.cams[cur][(size_t)(tid >> 2) * kCamStride + (tid & 3)];
-  for (int e = tid; e < stride; e += 256) {
-    double t = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < nslab; ++k) t += ptot[(size_t)k * stride + e];
-    if (e < D * D) S[e] = -t;
-    else if (e < D * D + D) gred[e - D * D] = -t;
-    else if (e < stride - 2) L.gsum[e - D * D - D] = t;      // (the last two slots: x2 of observation-less frames, chunk cost)
-    else if (e == stride - 2) *x2_noobs = t;                 // same summation order as the tail's own loop
+  for (int e = D * D + D + tid; e < stride - 1; e += 256) {
+    const double t = ptot[e];
+    if (e < stride - 2) L.gsum[e - D * D - D] = t;
+    else *x2_noobs = t;                 // x2 of observation-less frames
   }
   VC_STAMP(1);
   for (int i = tid; i < D; i += 256) { hd[i] = 0.0; gs[i] = 0.0; }
-  if (tid == 0) {        // (the chain path's partial records carry the chunk cost in the same slot: k_chain_init)
-    double t = 0.0;
-    for (int k = 0; k < nslab; ++k) t += ptot[(size_t)k * stride + stride - 1];
-    sc[0] = 0.5 * t; sc[1] = 0.0;
-  }
+  if (tid == 0) { sc[0] = 0.5 * ptot[stride - 1]; sc[1] = 0.0; }      // chunk costs (the chain path's k_chain_init fills the same slot)
   __syncthreads();
   VC_STAMP(2);
-  // camera blocks H_cc = P^T G P, g_c = P^T G[:, r]   (P: u-columns -> shared columns of the camera).  The inner products
-  // run over all 16 columns (the padding of G and P is zero): fully unrolled, all LDS loads of a thread issue together.
-  // Every phase runs over all cameras before the barrier (own P / T1 per camera): two barriers, not three per camera.
-  for (int c = 0; c < C; ++c) {
-    const int flags = cd[c].flags, nk = model_nk(cd[c].model);
-    const int nu = 6 + nk, nc = cam_ncols(flags, nk);
-    const int nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
-    const int i = tid >> 4, a = tid & 15;     // P[i][a]
-    double R[9];
-    quat_to_R(L.camq + 4 * c, R);
-    double pv = 0.0;
-    if (i < nu && a < nc) {
-      if (a < nrot) { if (i >= 3 && i < 6) pv = -R[3 * (i - 3) + a]; }
-      else if (a < nrot + ntr) { if (i == a - nrot) pv = 1.0; }
-      else { if (i == 6 + (a - nrot - ntr)) pv = 1.0; }
-    }
-    L.P[c * 256 + tid] = pv;
-  }
+  // camera blocks H_cc = P^T G P, g_c = P^T G[:, r]   (P: u-columns -> shared columns of the camera).  A column of P is either a
+  // unit vector (translation and intrinsics columns) or -R's column a in rows 3..5 (rotation columns): at most three non-zeros, so
+  // thread (b, a) forms its entry directly from at most nine entries of G -- no intermediate product, no barrier between the
+  // cameras, every LDS read of the phase independent of the others (round 2's P / G P / P^T (G P) passes: 5.5k cycles per camera).
+  if (tid < C) { double R[9]; quat_to_R(L.camq + 4 * tid, R);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) L.P[tid * 256 + k] = R[k]; }
   __syncthreads();
-  for (int c = 0; c < C; ++c) {
-    const int nk = model_nk(cd[c].model), nu = 6 + nk;
-    const double* G = L.gsum + c * kGStride;
-    const double* P = L.P + c * 256;
-    const int i = tid >> 4, a = tid & 15;     // T1[i][a] = sum_k G[i][k] P[k][a] (rows i >= nu: zero)
-    double s = 0.0;
+  {
+    // the cameras' blocks are disjoint: every camera's old entries are requested before the first one is written back (one
+    // memory round trip for the phase instead of one per camera)
+    const int b = tid >> 4, a = tid & 15;
+    double so[kMaxCams], go[kMaxCams];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s += G[i * 16 + k] * P[k * 16 + a];
-    L.T1[c * 256 + tid] = (i < nu) ? s : 0.0;
-    if (tid < 16) {                           // g_c[a] = sum_k P[k][a] (J^T r)[k]
-      double gca = 0.0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) gca += (k < nu) ? P[k * 16 + tid] * gram_grad(G, k, nk) : 0.0;
-      L.gc[c * 16 + tid] = gca;
+    for (int c = 0; c < kMaxCams; ++c) {
+      so[c] = 0.0; go[c] = 0.0;
+      if (c < C) {
+        const int nc = cam_ncols(cd[c].flags, model_nk(cd[c].model)), c0 = cd[c].col0;
+        if (a < nc && b < nc && a >= b) so[c] = S[(c0 + b) * D + c0 + a];
+        if (b == 15 && a < nc) go[c] = gred[c0 + a];
+      }
     }
-  }
-  __syncthreads();
-  for (int c = 0; c < C; ++c) {
-    const int flags = cd[c].flags, nk = model_nk(cd[c].model);
-    const int nc = cam_ncols(flags, nk), c0 = cd[c].col0;
-    const double* P = L.P + c * 256;
-    const double* T1 = L.T1 + c * 256;
-    const int b = tid >> 4, a = tid & 15;     // Hcc[b][a] = sum_i P[i][b] T1[i][a]  (rows i >= nu of P and T1 are zero)
-    if (a < nc && b < nc && a >= b) {
-      double s = 0.0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s += P[i * 16 + b] * T1[i * 16 + a];
-      S[(c0 + b) * D + c0 + a] += s;
-      if (a == b) hd[c0 + a] = s;
-    }
-    if (b == 15 && a < nc) { gred[c0 + a] += L.gc[c * 16 + a]; gs[c0 + a] = L.gc[c * 16 + a]; }
+    for (int c = 0; c < kMaxCams; ++c)
+      if (c < C) {
+        const int flags = cd[c].flags, nk = model_nk(cd[c].model);
+        const int nc = cam_ncols(flags, nk), c0 = cd[c].col0;
+        const int nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
+        const double* G = L.gsum + c * kGStride;
+        const double* R = L.P + c * 256;
+        // column q of P: rows r0 + {0, 1, 2} with coefficients cf[] (unit columns: one row, the other two coefficients zero and
+        // their rows kept in range)
+        int ra, rb; double ca[3], cb[3];
+        {
+          const bool rot = a < nrot;
+          const int col = a < nc ? a : 0;
+          ra = rot ? 3 : (col < nrot + ntr ? col - nrot : 6 + (col - nrot - ntr));
+          ca[0] = rot ? -R[col] : 1.0; ca[1] = rot ? -R[3 + col] : 0.0; ca[2] = rot ? -R[6 + col] : 0.0;
+        }
+        {
+          const bool rot = b < nrot;
+          const int col = b < nc ? b : 0;
+          rb = rot ? 3 : (col < nrot + ntr ? col - nrot : 6 + (col - nrot - ntr));
+          cb[0] = rot ? -R[col] : 1.0; cb[1] = rot ? -R[3 + col] : 0.0; cb[2] = rot ? -R[6 + col] : 0.0;
+        }
+        const int sa = (a < nrot) ? 1 : 0, sb = (b < nrot) ? 1 : 0;      // row step: 1 for rotation columns, 0 for unit columns
+        if (a < nc && b < nc && a >= b) {
+          double s = 0.0;
+#pragma unroll
+          for (int x = 0; x < 3; ++x) {
+            double t = 0.0;
+#pragma unroll
+            for (int y = 0; y < 3; ++y) t += ca[y] * G[(rb + sb * x) * 16 + ra + sa * y];
+            s += cb[x] * t;
+          }
+          S[(c0 + b) * D + c0 + a] = so[c] + s;
+          if (a == b) hd[c0 + a] = s; else S[(c0 + a) * D + c0 + b] = so[c] + s;      // (S is symmetric on entry and stays so)
+        }
+        if (b == 15 && a < nc) {
+          double gca = 0.0;
+#pragma unroll
+          for (int y = 0; y < 3; ++y) gca += ca[y] * gram_grad(G, ra + sa * y, nk);
+          gred[c0 + a] = go[c] + gca; gs[c0 + a] = gca;
+        }
+      }
   }
   __syncthreads();
   VC_STAMP(3);
@@ -690,7 +703,11 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double
       if (ca >= 0) {
         if (b < 15) {
           const int cb = v.imu_param_col[b];
-          if (cb >= ca) { S[ca * D + cb] += Hi[a * 16 + b]; if (a == b) hd[ca] = Hi[a * 16 + a]; }
+          if (cb >= ca) {
+            const double sn = S[ca * D + cb] + Hi[a * 16 + b];
+            S[ca * D + cb] = sn;
+            if (a == b) hd[ca] = Hi[a * 16 + a]; else S[cb * D + ca] = sn;
+          }
         } else { gred[ca] += Hi[a * 16 + 15]; gs[ca] = Hi[a * 16 + 15]; }
       }
     }
@@ -704,17 +721,16 @@ __device__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double
         const int i = e / (D + 1), col = e % (D + 1);
         const double val = st[i * v.ldw + col];
         if (col == D) { gred[sc + i] += val; gs[sc + i] += val; }
-        else if (col < sc) S[col * D + sc + i] += val;                       // upper triangle: (col, sc + i)
-        else if (col >= sc + i) { S[(sc + i) * D + col] += val; if (col == sc + i) hd[sc + i] += val; }
+        else if (col < sc) { const double sn = S[col * D + sc + i] + val; S[col * D + sc + i] = sn; S[(sc + i) * D + col] = sn; }
+        else if (col >= sc + i) {            // each pair once, both triangles written
+          const double sn = S[(sc + i) * D + col] + val;
+          S[(sc + i) * D + col] = sn;
+          if (col == sc + i) hd[sc + i] += val; else S[col * D + sc + i] = sn;
+        }
       }
       __syncthreads();
     }
   }
-  for (int e = tid; e < D * D; e += 256) {
-    const int i = e / D, j = e % D;
-    if (j < i) S[e] = S[j * D + i];
-  }
-  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------ reduced solve
@@ -810,7 +826,7 @@ __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 #else
 #define VC_PH(i) do { } while (0)
 #endif
-__device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M, double* x) {
+__device__ __forceinline__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M, double* x) {
   const int tid = threadIdx.x, lane = tid & 63, D = v.D;
 #ifdef VC_REDUCED_STAMPS
   long long ph_[6] = {0, 0, 0, 0, 0, 0}, t_ = (long long)__builtin_readcyclecounter();      // load | diagonal | rows | trailing | back-subst sums | back-subst solve
@@ -822,9 +838,13 @@ __device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M,
   const double* S = v.Sbuf;
   const double* gred = S + D * D;
   const double* hd = gred + D;
-  for (int i = tid >> 4; i < D; i += 16) {            // 16 x 16 thread grid over (row, column)
+  for (int i = tid >> 4; i < D; i += 16) {            // 16 x 16 thread grid over (row, column); a row's loads go out together
     const int ri = tri(i);
-    for (int k = tid & 15; k <= i; k += 16) M[ri + k] = S[i * D + k];
+    double tmp[12];                                   // D <= 191: at most 12 column steps
+#pragma unroll
+    for (int u = 0; u < 12; ++u) { const int k = (tid & 15) + 16 * u; tmp[u] = (k <= i) ? S[i * D + k] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 12; ++u) { const int k = (tid & 15) + 16 * u; if (k <= i) M[ri + k] = tmp[u]; }
   }
   for (int i = tid; i < D; i += 256) M[tri(D) + i] = gred[i];
   __syncthreads();
@@ -879,33 +899,55 @@ __device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M,
       double a[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) a[k] = (k < nb) ? M[ri + k] : 0.0;
+      // right-looking: column k's result updates all later columns at once (independent FMAs) -- the dependent chain is 16
+      // multiply / FMA pairs instead of the 120 FMAs of the row-by-row dot products
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        double t = a[k];
+        const double t = a[k] * dinvp[k];
+        a[k] = t;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) if (m < k) t -= a[m] * Lp[k * 16 + m];
-        a[k] = t * dinvp[k];
+        for (int m = k + 1; m < 16; ++m) a[m] -= t * Lp[m * 16 + k];
       }
 #pragma unroll
       for (int k = 0; k < 16; ++k) if (k < nb) M[ri + k] = a[k];
     }
     __syncthreads();
     VC_PH(2);
-    // (3) trailing update A[i][k] -= X_i . X_k for r0 <= k <= i (k < D), i <= D
-    {
-      const int ti = tid >> 4, tj = tid & 15;
-      for (int i = r0 + ti; i <= D; i += 16) {
-        const int ri = tri(i);
-        double xi[16];
+    // (3) trailing update A[i][k] -= X_i . X_k for r0 <= k <= i (k < D), i <= D: on the matrix pipe, one 16 x 16 tile of the
+    // lower block triangle per wavefront and step (v_mfma_f64_16x16x4: A = -X rows of tile I, B = X rows of tile J, four k-steps
+    // over the panel's 16 columns; C straight from / to the packed triangle).  The VALU form (16 x 16 thread grid, every thread
+    // re-reading its 16 + 16 operands from LDS per entry) took 12k cycles per panel at D = 115.  Only full panels have a
+    // trailing matrix (the last, partial one is followed by the right-hand-side row alone, which has no columns left).
+    if (nb == 16 && r0 < D) {
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
+      const int nTl = (D + 1 - r0 + 15) >> 4, nP = nTl * (nTl + 1) / 2;
+      int I = 0, J = 0;
+      for (int p = 0; p < nP; ++p) {
+        if ((p & 3) == wave) {
+          const int rowA = r0 + 16 * I + lr, rowB = r0 + 16 * J + lr;
+          const double* pa = M + tri(rowA) + p0 + lq;
+          const double* pb = M + tri(rowB) + p0 + lq;
+          double a[4], b[4];
 #pragma unroll
-        for (int m = 0; m < 16; ++m) xi[m] = (m < nb) ? M[ri + p0 + m] : 0.0;
-        for (int k = r0 + tj; k <= i && k < D; k += 16) {
-          const int rk = tri(k) + p0;
-          double acc = 0.0;
+          for (int ks = 0; ks < 4; ++ks) { a[ks] = (rowA <= D) ? -pa[4 * ks] : 0.0; b[ks] = (rowB <= D) ? pb[4 * ks] : 0.0; }
+          const int col = r0 + 16 * J + lr;
+          v4d c4;
+          bool ok[4];
 #pragma unroll
-          for (int m = 0; m < 16; ++m) acc += xi[m] * ((m < nb) ? M[rk + m] : 0.0);
-          M[ri + k] -= acc;
+          for (int g = 0; g < 4; ++g) {
+            const int rC = r0 + 16 * I + lq + 4 * g;
+            ok[g] = rC <= D && col < D && col <= rC;
+            c4[g] = ok[g] ? M[tri(rC) + col] : 0.0;
+          }
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], c4, 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int rC = r0 + 16 * I + lq + 4 * g;
+            if (ok[g]) M[tri(rC) + col] = c4[g];
+          }
         }
+        if (++J > I) { ++I; J = 0; }
       }
     }
     __syncthreads();
@@ -952,7 +994,7 @@ __device__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M,
 #endif
 }
 
-__device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dyn, double* red /* 6 x 256 */, const double* s_cam,
+__device__ __forceinline__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dyn, double* red /* 6 x 256 */, const double* s_cam,
                                     double pre_sc2, double pre_dg, const double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */) {
   const int tid = threadIdx.x, D = v.D, cur = ct->cur;
   double* x;
@@ -1060,11 +1102,7 @@ __device__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dy
       // (x2_noobs: that sum, left in LDS by phase A when it ran in this launch)
       double x2 = 0.0;
       if (x2_noobs) x2 = *x2_noobs;
-      else {
-        const int stride = v.part_stride, nslab = v.n_slab;
-        const double* ptot = v.n_slab == 1 && v.two_level_sum ? v.part_total2 : v.part_total;
-        for (int k = 0; k < nslab; ++k) x2 += ptot[(size_t)k * stride + stride - 2];
-      }
+      else x2 = v.part_total[v.part_stride - 2];
       h[kScX2] += x2;
       v.ctrl->needs_decision = 1;
       v.flags[4 + 2 * (1 - v.par)] = 0; v.flags[5 + 2 * (1 - v.par)] = 0;
@@ -1543,9 +1581,7 @@ void launch_reproj_jac(const DevView& v, hipStream_t s, int trial) {
   hipLaunchKernelGGL(k_reproj_jac, dim3(tiles_grid(v)), dim3(256), lds, s, v, trial);
 }
 void launch_part_sum(const DevView& v, hipStream_t s) {
-  const int nslab = (v.n_chunks + kSlab - 1) / kSlab;
-  hipLaunchKernelGGL(k_part_sum, dim3((v.part_stride + 31) / 32, nslab), dim3(256), 0, s, v, 0);
-  if (v.two_level_sum) hipLaunchKernelGGL(k_part_sum, dim3((v.part_stride + 31) / 32, 1), dim3(256), 0, s, v, 1);
+  hipLaunchKernelGGL(k_part_sum, dim3((v.part_stride + kSumEntries - 1) / kSumEntries), dim3(kSumEntries * kSumSlices), 0, s, v);
 }
 void launch_frame_schur(const DevView& v, hipStream_t s) {
   const int D = v.D;
