@@ -1487,66 +1487,95 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
 
 // sum over all frames of [Y | z]^T [Y | z]: part[chunk] = [ D x D | D ]  (same layout as the vision path)
 constexpr int kMaxPairsPerWaveI = 9;
-__global__ __launch_bounds__(256) void k_chain_gram(DevView v) {
+// phase stamps of one workgroup of k_chain_gram (profiling builds only: -DVC_GRAM_STAMPS, tools/gram_stamps.py)
+#ifdef VC_GRAM_STAMPS
+#define GSTAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0 && (i) < 16) v.dbg[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
+// NQ: column-tile pairs per wavefront and batch (accumulators with compile-time indices: the version that picked its accumulator
+// with a runtime index spent ~150 v_cndmask per pair on it and ran the nine MFMAs of a pair as one dependent chain -- 7.8 us per
+// group of four frames at D = 115; here the NQ chains advance side by side).  Rows of the next group are requested before the
+// current group's MFMAs and land in registers meanwhile.
+// NL: entries of the 36 x ld row image per thread (36 ld / 256, rounded up).
+template <int NQ, int NL>
+__global__ __launch_bounds__(256, 2) void k_chain_gram(DevView v) {
   extern __shared__ __attribute__((aligned(16))) double R[];    // 36 x ld
+  __shared__ unsigned short s_pair[128];                         // pair p -> I | J << 8
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  GSTAMP(0);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int D = v.D, ld = v.ldw, N = v.n_frames;
   const int nT = (D + 1 + 15) / 16, nPairs = nT * (nT + 1) / 2;
   const int chunk = blockIdx.x;
   const int f0 = chunk * v.chunk_frames, f1 = min(f0 + v.chunk_frames, N);
   double* part = v.part + (size_t)chunk * v.part_stride;
-  // column-tile pairs are processed in batches of 36 (9 accumulators per wavefront); more than 8 column tiles
-  // (D + 1 > 128) re-reads the chunk's rows once per batch
-  for (int pb = 0; pb < nPairs; pb += 4 * kMaxPairsPerWaveI) {
-    const int pe = min(nPairs, pb + 4 * kMaxPairsPerWaveI);
-    int Ib = 0, Jb = 0;
-    for (int p = 0; p < pb; ++p) if (++Jb == nT) { ++Ib; Jb = Ib; }
-    v4d acc[kMaxPairsPerWaveI];
+  if (tid < nPairs) {
+    int I = 0, J = 0;
+    for (int k = 0; k < tid; ++k) if (++J == nT) { ++I; J = I; }
+    s_pair[tid] = (unsigned short)(I | (J << 8));
+  }
+  // this thread's entries of the row image: i = tid + 256 u -> (row, col) by stepping (no division per entry)
+  const int step_r = 256 / ld, step_c = 256 - step_r * ld, row0 = tid / ld, col0 = tid - row0 * ld;
+  int gs_ = 1;
+  // column-tile pairs are processed in batches of 4 NQ (NQ accumulators per wavefront); more pairs than that re-read the chunk's
+  // rows once per batch
+  for (int pb = 0; pb < nPairs; pb += 4 * NQ) {
+    v4d acc[NQ];
 #pragma unroll
-    for (int i = 0; i < kMaxPairsPerWaveI; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < NQ; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double tmp[NL];
+    auto request = [&](int fg) {
+      const int nrow = min(4, f1 - fg) * 9;
+      const double* src = v.cW + (size_t)fg * 9 * v.ldx;
+      int row = row0, col = col0;
+#pragma unroll
+      for (int u = 0; u < NL; ++u) {
+        tmp[u] = (row < nrow) ? src[(unsigned)(row * v.ldx + col)] : 0.0;      // (uniform base + 32-bit offset: one register per entry if hoisted)
+        row += step_r; col += step_c;
+        if (col >= ld) { col -= ld; ++row; }
+      }
+    };
+    request(f0);
     for (int fg = f0; fg < f1; fg += 4) {
-      const int nf = min(4, f1 - fg);
-      for (int i = tid; i < 36 * ld; i += 256) {
-        const int row = i / ld;
-        R[i] = (row < nf * 9) ? v.cW[((size_t)fg * 9 + row) * v.ldx + (i - row * ld)] : 0.0;
-      }
+#pragma unroll
+      for (int u = 0; u < NL; ++u) { const int i = tid + 256 * u; if (i < 36 * ld) R[i] = tmp[u]; }
       __syncthreads();
-      int I = Ib, J = Jb, pi = 0;
-      for (int p = pb; p < pe; ++p) {
-        if ((p & 3) == wave) {
-          const double* ra = R + (lane >> 4) * ld + I * 16 + (lane & 15);
-          const double* rb = R + (lane >> 4) * ld + J * 16 + (lane & 15);
-          v4d a4 = acc[0];
+      GSTAMP(gs_); ++gs_;
+      if (fg + 4 < f1) request(fg + 4);
+      const double* rq = R + (lane >> 4) * ld + (lane & 15);
+      int oa[NQ], ob[NQ];
 #pragma unroll
-          for (int q = 0; q < kMaxPairsPerWaveI; ++q) a4 = (q == pi) ? acc[q] : a4;
-#pragma unroll
-          for (int ks = 0; ks < 9; ++ks) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[ks * 4 * ld], rb[ks * 4 * ld], a4, 0, 0, 0);
-#pragma unroll
-          for (int q = 0; q < kMaxPairsPerWaveI; ++q) acc[q] = (q == pi) ? a4 : acc[q];
-          ++pi;
-        }
-        if (++J == nT) { ++I; J = I; }
+      for (int q = 0; q < NQ; ++q) {
+        const int p = min(pb + 4 * q + wave, nPairs - 1);      // (past the end: recomputes the last pair, never written)
+        const int ij = s_pair[p];
+        oa[q] = (ij & 255) * 16; ob[q] = (ij >> 8) * 16;
       }
+#pragma unroll
+      for (int ks = 0; ks < 9; ++ks)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rq[ks * 4 * ld + oa[q]], rq[ks * 4 * ld + ob[q]], acc[q], 0, 0, 0);
       __syncthreads();
+      GSTAMP(gs_); ++gs_;
     }
-    int I = Ib, J = Jb, pi = 0;
-    for (int p = pb; p < pe; ++p) {
-      if ((p & 3) == wave) {
-        v4d a4 = acc[0];
 #pragma unroll
-        for (int q = 0; q < kMaxPairsPerWaveI; ++q) a4 = (q == pi) ? acc[q] : a4;
+    for (int q = 0; q < NQ; ++q) {
+      const int p = pb + 4 * q + wave;
+      if (p < nPairs) {
+        const int ij = s_pair[p], I = ij & 255, J = ij >> 8;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int row = I * 16 + (lane >> 4) + 4 * g, col = J * 16 + (lane & 15);
-          if (row < D) { if (col < D) part[row * D + col] = a4[g]; else if (col == D) part[D * D + row] = a4[g]; }
+          if (row < D) { if (col < D) part[row * D + col] = acc[q][g]; else if (col == D) part[D * D + row] = acc[q][g]; }
         }
-        ++pi;
       }
-      if (++J == nT) { ++I; J = I; }
     }
   }
+#ifdef VC_GRAM_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  GSTAMP(15);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ launchers
@@ -1633,9 +1662,19 @@ void launch_chain_init(const DevView& v, hipStream_t s) {
 void launch_chain_fwd(const DevView& v, hipStream_t s) { chain_levels(v, s, true); }
 void launch_chain_gram(const DevView& v, hipStream_t s) {
   const size_t lds = (size_t)36 * v.ldw * sizeof(double);
-  static size_t granted = 0;
-  if (lds > 65536 && lds > granted) { (void)hipFuncSetAttribute((const void*)k_chain_gram, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
-  hipLaunchKernelGGL(k_chain_gram, dim3(v.n_chunks), dim3(256), lds, s, v);
+  const int nT = (v.D + 1 + 15) / 16, nPairs = nT * (nT + 1) / 2, nq = std::min(kMaxPairsPerWaveI, (nPairs + 3) / 4);
+  auto go = [&](auto kern) {
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(v.n_chunks), dim3(256), lds, s, v);
+  };
+  // (pairs per wavefront, row-image entries per thread) by the number of column tiles: ld = 48, 80, 112, 144, 176, 208
+  const int nl = (36 * v.ldw + 255) / 256;
+  if (nl <= 7) { if (nq <= 1) go(k_chain_gram<1, 7>); else go(k_chain_gram<2, 7>); }
+  else if (nl <= 12) go(k_chain_gram<4, 12>);
+  else if (nl <= 16) { if (nq <= 6) go(k_chain_gram<6, 16>); else go(k_chain_gram<9, 16>); }
+  else if (nl <= 21) go(k_chain_gram<9, 21>);
+  else if (nl <= 25) go(k_chain_gram<9, 25>);
+  else go(k_chain_gram<9, 30>);
 }
 void launch_chain_solve_a(const DevView& v, hipStream_t s) { launch_chain_init(v, s); launch_chain_fwd(v, s); launch_chain_gram(v, s); }
 void launch_chain_solve_b(const DevView& v, hipStream_t s) { chain_levels(v, s, false); }

@@ -1488,19 +1488,25 @@ __device__ void final_phase(const DevView& v, int mode, double* red) {
   if (mode != 2) {
     double s[7] = {0, 0, 0, 0, 0, 0, 0};
     if (v.imu_on) {      // pre-reduced where they are produced (k_chain_back, k_reproj_jac / k_imu_jac in trial mode)
+      // (unrolled: the loads of several rounds are in flight together -- one workgroup on the critical path, 49 rounds at 50 000 tiles)
+#pragma unroll 4
       for (int g = tid; g < v.n_chain_groups; g += 256) {
         const double* p = v.grp_part + (size_t)g * kNumScal;
         s[0] += p[kScGd]; s[1] += p[kScDld]; s[2] += p[kScStep2]; s[3] += p[kScX2]; s[4] += p[kScG2];
         s[6] = fmax(s[6], p[kScGmax]);
       }
+#pragma unroll 16
       for (int t = tid; t < (v.n_tiles + 3) / 4; t += 256) s[5] += v.wg_trial[t];
+#pragma unroll 4
       for (int t = tid; t < (v.n_frames - 1 + 7) / 8; t += 256) s[5] += v.wg_imu_trial[t];
     } else {
+#pragma unroll 4
       for (int f = tid; f < v.n_frames; f += 256) {
         const double* p = v.fpart + (size_t)f * kNumScal;
         s[0] += p[kScGd]; s[1] += p[kScDld]; s[2] += p[kScStep2]; s[3] += p[kScX2]; s[4] += p[kScG2];
         s[6] = fmax(s[6], p[kScGmax]);
       }
+#pragma unroll 16
       for (int t = tid; t < v.n_tiles; t += 256) s[5] += v.tile_trial[2 * t];
     }
     for (int k = 0; k < 7; ++k) red[k * 256 + tid] = s[k];
