@@ -1104,7 +1104,9 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
   // (the wavefront's index as a scalar: everything that depends on it -- sweep direction, frame count, addresses -- stays uniform)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, group = blockIdx.x;
   const int N = v.n_frames, D = v.D, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
+#ifdef VC_F2_STAMPS
   const long long f2_t0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   const long gs = (long)m * s;
   const int a = (int)((long)group * gs), first = a + s;
   const int done = v.ctrl->done;
@@ -1518,7 +1520,7 @@ __global__ __launch_bounds__(256, 2) void k_chain_gram(DevView v) {
   }
   // this thread's entries of the row image: i = tid + 256 u -> (row, col) by stepping (no division per entry)
   const int step_r = 256 / ld, step_c = 256 - step_r * ld, row0 = tid / ld, col0 = tid - row0 * ld;
-  int gs_ = 1;
+  [[maybe_unused]] int gs_ = 1;
   // column-tile pairs are processed in batches of 4 NQ (NQ accumulators per wavefront); more pairs than that re-read the chunk's
   // rows once per batch
   for (int pb = 0; pb < nPairs; pb += 4 * NQ) {

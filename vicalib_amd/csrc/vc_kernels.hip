@@ -329,14 +329,23 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   __shared__ Ctrl s_ctrl;
   __shared__ CamDesc s_cd[kMaxCams];     // LDS copy of the kernel-argument table (dynamically indexed below)
+  __shared__ unsigned short s_pair[4 * kMaxPairsPerWave];      // column-tile pair p -> I | J << 8
   if (threadIdx.x < kMaxCams) s_cd[threadIdx.x] = v.cd[threadIdx.x];
+  {
+    const int nT_ = (v.D + 1 + 15) / 16, nP_ = nT_ * (nT_ + 1) / 2;
+    if ((int)threadIdx.x < nP_ && threadIdx.x < 4 * kMaxPairsPerWave) {
+      int I = 0, J = 0;
+      for (int k = 0; k < (int)threadIdx.x; ++k) if (++J == nT_) { ++I; J = I; }
+      s_pair[threadIdx.x] = (unsigned short)(I | (J << 8));
+    }
+  }
   const Ctrl* ct = v.ctrl;
   if (v.merged) { merged_control(v, &s_ctrl, sh, blockIdx.x == 0); ct = &s_ctrl; }
   else __syncthreads();
   if (ct->done) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int C = v.n_cams, D = v.D;
-  const int nT = (D + 1 + 15) / 16, ld = schur_ld(D), nPairs = nT * (nT + 1) / 2;
+  const int nT = (D + 1 + 15) / 16, ld = schur_ld(D), nPairs = min(nT * (nT + 1) / 2, 4 * kMaxPairsPerWave);
   double* Gw = sh + wave * (C * kGStride + kPrepPad);
   double* Hs = Gw + C * kGStride;
   double* R = sh + 4 * (C * kGStride + kPrepPad);
@@ -500,41 +509,33 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
     }
     __syncthreads();
     {
-      int I = 0, J = 0, pi = 0;
-      for (int p = 0; p < nPairs; ++p) {
-        if ((p & 3) == wave) {
-          const double* ra = R + (lane >> 4) * ld + I * 16 + (lane & 15);
-          const double* rb = R + (lane >> 4) * ld + J * 16 + (lane & 15);
-          v4d a4 = acc[0];
+      // accumulator q of wavefront w belongs to pair 4 q + w (compile-time index: no select chains, and the MAXP chains of
+      // dependent MFMAs advance side by side); past the last pair the last one is recomputed and never written
+      const double* rq = R + (lane >> 4) * ld + (lane & 15);
+      int oa[MAXP], ob[MAXP];
 #pragma unroll
-          for (int q = 0; q < MAXP; ++q) a4 = (q == pi) ? acc[q] : a4;
-#pragma unroll
-          for (int ks = 0; ks < 6; ++ks) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[ks * 4 * ld], rb[ks * 4 * ld], a4, 0, 0, 0);
-#pragma unroll
-          for (int q = 0; q < MAXP; ++q) acc[q] = (q == pi) ? a4 : acc[q];
-          ++pi;
-        }
-        if (++J == nT) { ++I; J = I; }
+      for (int q = 0; q < MAXP; ++q) {
+        const int ij = s_pair[min(4 * q + wave, nPairs - 1)];
+        oa[q] = (ij & 255) * 16; ob[q] = (ij >> 8) * 16;
       }
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rq[ks * 4 * ld + oa[q]], rq[ks * 4 * ld + ob[q]], acc[q], 0, 0, 0);
     }
     __syncthreads();
   }
   double* part = v.part + (size_t)chunk * v.part_stride;
-  {
-    int I = 0, J = 0, pi = 0;
-    for (int p = 0; p < nPairs; ++p) {
-      if ((p & 3) == wave) {
-        v4d a4 = acc[0];
 #pragma unroll
-        for (int q = 0; q < MAXP; ++q) a4 = (q == pi) ? acc[q] : a4;
+  for (int q = 0; q < MAXP; ++q) {
+    const int p = 4 * q + wave;
+    if (p < nPairs) {
+      const int ij = s_pair[p], I = ij & 255, J = ij >> 8;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = I * 16 + (lane >> 4) + 4 * g, col = J * 16 + (lane & 15);
-          if (row < D) { if (col < D) part[row * D + col] = a4[g]; else if (col == D) part[D * D + row] = a4[g]; }
-        }
-        ++pi;
+      for (int g = 0; g < 4; ++g) {
+        const int row = I * 16 + (lane >> 4) + 4 * g, col = J * 16 + (lane & 15);
+        if (row < D) { if (col < D) part[row * D + col] = acc[q][g]; else if (col == D) part[D * D + row] = acc[q][g]; }
       }
-      if (++J == nT) { ++I; J = I; }
     }
   }
   // per-camera sum of G over the chunk: combine the 4 wavefronts through LDS (fixed order)
