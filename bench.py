@@ -241,6 +241,8 @@ def main():
             "k_reduced": ("fp64-valu", flops_red, bytes_red)}
     # launch groups that run on the second stream next to the critical path (vc_calibrator.cpp: enqueue_pass)
     overlapped = {"k_imu_weights", "k_imu_delta+k_imu_block(trial)", "k_imu_delta+k_imu_block", "k_imu_jac"} if vi else set()
+    if vi and os.environ.get("VICALIB_AMD_JAC_STREAM2", "1") != "0" and os.environ.get("VICALIB_AMD_OVERLAP_WEIGHTS", "1") != "0":
+        overlapped.add("k_imu_jac(trial)")      # beside the vision sweep of the trial point (round 3)
     kernels = {}
     for name, (cnt, avg_ms) in kt.items():
         e = {"launch_groups": cnt, "avg_ms": avg_ms, "ms_per_step": avg_ms * cnt / max(done, 1),

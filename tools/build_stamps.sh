@@ -1,0 +1,13 @@
+#!/bin/bash
+# profiling builds of the library, one per stamped kernel (loaded through VICALIB_AMD_LIB by the stamp tools):
+#   -DVC_W_STAMPS        k_imu_weights   tools/weights_stamps.py
+#   -DVC_F2_STAMPS       k_chain_fwd2    tools/f2_stamps.py
+#   -DVC_REDUCED_STAMPS  k_reduced       tools/reduced_stamps.py
+#   -DVC_GRAM_STAMPS     k_chain_gram    tools/gram_stamps.py
+cd "$(dirname "$0")/.."
+for spec in "W_STAMPS wstamps" "F2_STAMPS f2stamps" "REDUCED_STAMPS rstamps" "GRAM_STAMPS gstamps"; do
+  set -- $spec
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-function -DVC_$1 \
+    -o tools/probe/libvicalib_amd_$2.so vicalib_amd/csrc/vc_kernels.hip vicalib_amd/csrc/vc_imu_kernels.hip vicalib_amd/csrc/vc_detect.hip vicalib_amd/csrc/vc_calibrator.cpp 2>&1 | grep -i "error" &
+done
+wait
