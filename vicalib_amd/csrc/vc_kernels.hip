@@ -80,6 +80,10 @@ __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* 
     const double* pa = rowp + 4 * xa;
     const double* pb = rowp + 4 * xb;
     const double* pc = rowp + 4 * xc;
+    // four column blocks: the (b, b + 2) products of TWO steps share one instruction -- blocks 0, 1 take them from the even step
+    // (A = block b, B = block b + 2), blocks 2, 3 from the odd step (A = block b - 2, B = block b); see `pair_step`
+    const double* pa2 = rowp + (b < 2 ? 4 * b : 4 * (b - 2) + 2 * kDotStride);
+    const double* pb2 = rowp + (b < 2 ? 4 * (b + 2) : 4 * b + 2 * kDotStride);
     // software prefetch: the corner of the NEXT pass (detection + target point) is in flight while this pass computes
     double2 uv_n = make_double2(0.0, 0.0);
     double pw_n[3] = {0.0, 0.0, 0.0};
@@ -118,41 +122,88 @@ __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* 
       wave_lds_sync();
       if (base == 0) JSTAMP(2);
       const int ngroups = (min(64, cnt - base) + 1) >> 1;      // groups of 4 rows (2 corners) that hold data; the rest is zero
-      auto step = [&](int s, double a, double bb, double cc) {
+      auto step = [&](int s, double a, double bb, double cc) {      // three column blocks: 2 instructions per step
         acc[s][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, a, acc[s][0], 0, 0, 0);
-        if (kThreeCols) {
-          acc[s][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(bb, cc, acc[s][1], 0, 0, 0);     // A = (0,0,1,3), B = (1,2,2,3)
-        } else {
-          acc[s][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb, acc[s][1], 0, 0, 0);
-          acc[s][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, cc, acc[s][2], 0, 0, 0);
-        }
+        acc[s][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(bb, cc, acc[s][1], 0, 0, 0);     // A = (0,0,1,3), B = (1,2,2,3)
       };
-      if (ngroups == 32) {
-        // full pass, straight-line: operands of 4 groups at a time, the next chunk's LDS reads in flight under the
-        // current chunk's MFMAs
-        double ua[2][4], ub[2][4], uc[2][4];
+      // Four column blocks: a step needs the 10 distinct 4x4 blocks of the symmetric 16x16 product -- diagonal (4), (b, b + 1)
+      // (4, with (3,0) for (0,3)) and (0,2), (1,3).  The four blocks of an instruction are independent, so the two (b, b + 2)
+      // products of two consecutive steps fill ONE instruction: 5 instructions per two steps instead of 6 (the third
+      // instruction of a step used to compute (2,0) and (3,1) a second time).  The matrix pipe is what this kernel saturates
+      // (profiles/r03_sq_sweep_cfg4_2500.txt), so the instruction count is its time.
+      auto pair_step = [&](int s, double a0, double b0, double a1, double b1, double a2, double b2) {
+        acc[0][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, a0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, b0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, a1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        acc[s][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2, b2, acc[s][2], 0, 0, 0);
+      };
+      if (kThreeCols) {
+        if (ngroups == 32) {
+          // full pass, straight-line: operands of 4 groups at a time, the next chunk's LDS reads in flight under the
+          // current chunk's MFMAs
+          double ua[2][4], ub[2][4], uc[2][4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { ua[0][g] = pa[g * 2 * kDotStride]; ub[0][g] = pb[g * 2 * kDotStride]; uc[0][g] = pc[g * 2 * kDotStride]; }
+          for (int g = 0; g < 4; ++g) { ua[0][g] = pa[g * 2 * kDotStride]; ub[0][g] = pb[g * 2 * kDotStride]; uc[0][g] = pc[g * 2 * kDotStride]; }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          if (c < 7) {
+          for (int c = 0; c < 8; ++c) {
+            if (c < 7) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int gg = (c + 1) * 4 + g;
-              ua[(c + 1) & 1][g] = pa[gg * 2 * kDotStride]; ub[(c + 1) & 1][g] = pb[gg * 2 * kDotStride]; uc[(c + 1) & 1][g] = pc[gg * 2 * kDotStride];
+              for (int g = 0; g < 4; ++g) {
+                const int gg = (c + 1) * 4 + g;
+                ua[(c + 1) & 1][g] = pa[gg * 2 * kDotStride]; ub[(c + 1) & 1][g] = pb[gg * 2 * kDotStride]; uc[(c + 1) & 1][g] = pc[gg * 2 * kDotStride];
+              }
             }
-          }
 #pragma unroll
-          for (int g = 0; g < 4; ++g) step(g & 1, ua[c & 1][g], ub[c & 1][g], uc[c & 1][g]);
+            for (int g = 0; g < 4; ++g) step(g & 1, ua[c & 1][g], ub[c & 1][g], uc[c & 1][g]);
+          }
+        } else {
+          // ragged last pass: chunks of 8 groups (rows past the data are zero, so a chunk may run over the end)
+          for (int g0 = 0; g0 < ngroups; g0 += 8) {
+            double va[8], vb[8], vc8[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { va[g] = pa[(g0 + g) * 2 * kDotStride]; vb[g] = pb[(g0 + g) * 2 * kDotStride]; vc8[g] = pc[(g0 + g) * 2 * kDotStride]; }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) step(g & 1, va[g], vb[g], vc8[g]);
+          }
         }
       } else {
-        // ragged last pass: chunks of 8 groups (rows past the data are zero, so a chunk may run over the end)
-        for (int g0 = 0; g0 < ngroups; g0 += 8) {
-          double va[8], vb[8], vc8[8];
+        if (ngroups == 32) {
+          // full pass, straight-line: two pairs of steps at a time, the next chunk's LDS reads in flight under the MFMAs
+          double ua[2][4], ub[2][4], u2a[2][2], u2b[2][2];
 #pragma unroll
-          for (int g = 0; g < 8; ++g) { va[g] = pa[(g0 + g) * 2 * kDotStride]; vb[g] = pb[(g0 + g) * 2 * kDotStride]; vc8[g] = pc[(g0 + g) * 2 * kDotStride]; }
+          for (int g = 0; g < 4; ++g) { ua[0][g] = pa[g * 2 * kDotStride]; ub[0][g] = pb[g * 2 * kDotStride]; }
 #pragma unroll
-          for (int g = 0; g < 8; ++g) step(g & 1, va[g], vb[g], vc8[g]);
+          for (int q = 0; q < 2; ++q) { u2a[0][q] = pa2[q * 4 * kDotStride]; u2b[0][q] = pb2[q * 4 * kDotStride]; }
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            if (c < 7) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int gg = (c + 1) * 4 + g;
+                ua[(c + 1) & 1][g] = pa[gg * 2 * kDotStride]; ub[(c + 1) & 1][g] = pb[gg * 2 * kDotStride];
+              }
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                const int pp = (c + 1) * 2 + q;
+                u2a[(c + 1) & 1][q] = pa2[pp * 4 * kDotStride]; u2b[(c + 1) & 1][q] = pb2[pp * 4 * kDotStride];
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+              pair_step(q, ua[c & 1][2 * q], ub[c & 1][2 * q], ua[c & 1][2 * q + 1], ub[c & 1][2 * q + 1], u2a[c & 1][q], u2b[c & 1][q]);
+          }
+        } else {
+          // ragged last pass: chunks of 4 pairs of steps (rows past the data are zero, so a chunk may run over the end)
+          for (int g0 = 0; g0 < ngroups; g0 += 8) {
+            double va[8], vb[8], v2a[4], v2b[4];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { va[g] = pa[(g0 + g) * 2 * kDotStride]; vb[g] = pb[(g0 + g) * 2 * kDotStride]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v2a[q] = pa2[(g0 / 2 + q) * 4 * kDotStride]; v2b[q] = pb2[(g0 / 2 + q) * 4 * kDotStride]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pair_step(q & 1, va[2 * q], vb[2 * q], va[2 * q + 1], vb[2 * q + 1], v2a[q], v2b[q]);
+          }
         }
       }
       wave_lds_sync();
@@ -169,8 +220,13 @@ __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* 
     const int r1 = 4 * (kThreeCols ? xb : b) + i, c1 = 4 * (kThreeCols ? xc : ((b + 1) & 3)) + j;
     G[r1 * 16 + c1] = d1; G[c1 * 16 + r1] = d1;
     if (!kThreeCols) {
-      const int r2 = 4 * b + i, c2 = 4 * ((b + 2) & 3) + j;
-      G[r2 * 16 + c2] = d2; G[c2 * 16 + r2] = d2;
+      // blocks 2, 3 hold the odd steps' share of (0,2), (1,3): added to blocks 0, 1 (eight lanes further on in the row of 16)
+      const double d2o = dpp_row_f64<0x128, 0xF>(d2, d2);      // row_ror:8
+      if (b < 2) {
+        const double d2t = d2 + d2o;
+        const int r2 = 4 * b + i, c2 = 4 * (b + 2) + j;
+        G[r2 * 16 + c2] = d2t; G[c2 * 16 + r2] = d2t;
+      }
     }
   }
   if (kSideGrad) {

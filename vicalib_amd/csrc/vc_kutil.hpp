@@ -25,6 +25,14 @@ __device__ __forceinline__ double readlane_f64(double x, int lane /* wave-unifor
   const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
   return __hiloint2double(hi, lo);
 }
+// DPP move of a double within rows of 16 lanes (two 32-bit moves): lanes of the banks (groups of four lanes) selected by BANK
+// receive `src` through the row operation CTRL, the others keep `old`.  row_ror:n = 0x120 + n: lane i reads lane (i - n) mod 16.
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_row_f64(double old, double src) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xF, BANK, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xF, BANK, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double x) {      // result valid in lane 0
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
