@@ -5,7 +5,7 @@
 #   -DVC_REDUCED_STAMPS  k_reduced       tools/reduced_stamps.py
 #   -DVC_GRAM_STAMPS     k_chain_gram    tools/gram_stamps.py
 cd "$(dirname "$0")/.."
-for spec in "W_STAMPS wstamps" "F2_STAMPS f2stamps" "REDUCED_STAMPS rstamps" "GRAM_STAMPS gstamps"; do
+for spec in "W_STAMPS wstamps" "F2_STAMPS f2stamps" "REDUCED_STAMPS rstamps" "GRAM_STAMPS gstamps" "BACK_STAMPS bstamps" "JAC_STAMPS jstamps"; do
   set -- $spec
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-function -DVC_$1 \
     -o tools/probe/libvicalib_amd_$2.so vicalib_amd/csrc/vc_kernels.hip vicalib_amd/csrc/vc_imu_kernels.hip vicalib_amd/csrc/vc_detect.hip vicalib_amd/csrc/vc_calibrator.cpp 2>&1 | grep -i "error" &

@@ -218,7 +218,7 @@ struct vc_calibrator {
       d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total;
   DBuf<Ctrl> d_ctrl;
   DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_seg[2], d_seg_cost[2],
-      d_cW, d_cdelta, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init, d_rX[2], d_grp_part, d_wg_trial, d_wg_imu_trial,
+      d_cW, d_cdelta, d_ct0, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init, d_rX[2], d_grp_part, d_wg_trial, d_wg_imu_trial,
       d_imu_delta, d_imu_delta_ab, d_imu_delta_blk;
   size_t wsqrt_frames = 0;       // number of frames the device weight_sqrt_ array was initialised for
   size_t imu_uploaded = 0; double imu_uploaded_last = 0.0;      // sample count / last time stamp of the device copy of the IMU samples
@@ -525,7 +525,7 @@ struct vc_calibrator {
         HIP_OK(d_cW.alloc(nf * 9 * (ldw_max + 32)));
         for (int b = 0; b < 2; ++b) HIP_OK(d_rX[b].alloc((nf / std::min(chain_group_size(), chain_group_size_upper()) + 2) * 9 * (ldw_max + 32)));
       }
-      HIP_OK(d_cW.alloc(nf * 9 * dv.ldx)); HIP_OK(d_cdelta.alloc(nf * 9)); HIP_OK(d_cg.alloc(nf * 9)); HIP_OK(d_clam.alloc(nf * 9));
+      HIP_OK(d_cW.alloc(nf * 9 * dv.ldx)); HIP_OK(d_cdelta.alloc(nf * 9)); HIP_OK(d_ct0.alloc(nf * 9)); HIP_OK(d_cg.alloc(nf * 9)); HIP_OK(d_clam.alloc(nf * 9));
       HIP_OK(d_cdiag.alloc(nf * 9)); HIP_OK(d_cscale2.alloc(nf * 9));
       for (int b = 0; b < 2; ++b) HIP_OK(d_rX[b].alloc((nf / std::min(chain_group_size(), chain_group_size_upper()) + 2) * 9 * dv.ldx));
     }
@@ -534,7 +534,7 @@ struct vc_calibrator {
     dv.wsqrtb[0] = d_wsqrt[0].p; dv.wsqrtb[1] = d_wsqrt[1].p;
     dv.imu_delta = d_imu_delta.p; dv.imu_delta_ab = d_imu_delta_ab.p; dv.imu_delta_blk = d_imu_delta_blk.p;
     for (int b = 0; b < 2; ++b) { dv.segb[b] = d_seg[b].p; dv.seg_costb[b] = d_seg_cost[b].p; }
-    dv.cW = d_cW.p; dv.cdelta = d_cdelta.p; dv.cg = d_cg.p;
+    dv.cW = d_cW.p; dv.cdelta = d_cdelta.p; dv.ct0 = d_ct0.p; dv.cg = d_cg.p;
     dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p;
     for (int b = 0; b < 2; ++b) dv.rX[b] = d_rX[b].p;
     up_c = up_ms();

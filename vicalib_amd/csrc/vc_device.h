@@ -155,6 +155,7 @@ struct DevView {
                                    // from column ldw three 9 x 9 blocks: C (coupling to the group's left separator) -> X_s = L^-1 C,
                                    // A (diagonal block) -> L, B (coupling to the next active frame, rows = this frame) -> X_n = L^-1 B
   double* cdelta;                  // n_frames x 9
+  double* ct0;                     // n_frames x 9: z + Y delta_s of every frame (k_chain_back's top-level launch)
   double* cg;                      // n_frames x 9  gradient
   double* clam;                    // n_frames x 9
   double* cdiag;                   // n_frames x 9

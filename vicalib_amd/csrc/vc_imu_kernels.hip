@@ -1338,16 +1338,52 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
 // is formed by lane (frame i, row k) beforehand; the dependent part is one 9 x 9 product and a triangular solve per frame,
 // exchanged through v_readlane.  At level 0 the wavefront also moves its frames (T <- T exp(delta), v <- v + dv) and
 // publishes their step terms.
+// phase stamps of one group of k_chain_back per level (profiling builds only: -DVC_BACK_STAMPS, tools/back_stamps.py): dbg[8 lvl + i]
+#ifdef VC_BACK_STAMPS
+#define BSTAMP(i) do { if (blockIdx.x == (top ? 0 : gridDim.x / 2) && threadIdx.x == 0 && lvl < 4) v.dbg[8 * lvl + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
+constexpr int kBackT0Frames = 1;      // frames per extra workgroup of the top-level launch (t0 = z + Y delta_s)
 __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int top, int lvl, int two) {
   __shared__ double ds[192 + 8];
   __shared__ double dl[kChainM * 9];
   const int done = v.ctrl->done;        // looked at once the level's inputs have been requested (see k_chain_fwd)
   const int lane = threadIdx.x;
+#ifdef VC_BACK_STAMPS
+  const long long bs0_ = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   const int N = v.n_frames, D = v.D, ldw = v.ldw, ldx = v.ldx;
   const long gs = (long)m * s;
   const int a = top ? -1 : (int)(blockIdx.x * gs);
   const int first = top ? 0 : a + s;
   const size_t isz = (size_t)9 * ldx;
+  // The chain-independent part of every right-hand side, t0 = z + Y delta_s, for ALL frames: extra workgroups of the top level's
+  // launch (which has one group and an idle chip beside it), lane = column so that a load instruction covers one row segment --
+  // the levels below read one value per (frame, row) instead of walking D entries of a row per lane, 63 cache lines per load
+  // instruction (2.5 us per level at D = 29, 7-16 us at D = 115; tools/back_stamps.py).
+  if (top && blockIdx.x > 0) {
+    if (done) return;
+    const int f = (int)blockIdx.x - 1;      // one frame per wavefront: its nine rows' loads go out together
+    double dsl[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { const int j = lane + 64 * u; dsl[u] = j < D ? v.delta_s[j] : (j == D ? 1.0 : 0.0); }      // (column D: z itself)
+    double p[9];
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk) {
+      const double* Wr = v.cW + (size_t)f * isz + (size_t)kk * ldx;
+      double acc = 0.0;
+#pragma unroll
+      for (int w = 0; w < 3; ++w) { const int j = lane + 64 * w; if (j <= D) acc += Wr[j] * dsl[w]; }
+      p[kk] = acc;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk) {
+      const double t0 = wave_sum(p[kk]);
+      if (lane == 0) v.ct0[(size_t)f * 9 + kk] = t0;
+    }
+    return;
+  }
   for (int j = lane; j < D; j += 64) ds[j] = v.delta_s[j];
   const int q = first < N ? (top ? (N - 1) / s + 1 : min(m - 1, (N - 1 - first) / s + 1)) : 0;
   const int r = first + q * s;                                  // right separator (or past the end)
@@ -1364,15 +1400,19 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
   double t = 0.0, dinv = 1.0, Qrow[9], Lcol[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) { Qrow[c] = 0.0; Lcol[c] = 0.0; }
-  wave_lds_sync();
+  if (top) wave_lds_sync();      // (the levels below need delta_s only in the bottom level's epilogue, behind its own synchronisation)
+#ifdef VC_BACK_STAMPS
+  const long long bs1_ = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   if (mine) {
     const double* img = v.cW + (size_t)e * isz;
     const double* Wr = img + (size_t)k * ldx;
 #pragma unroll
     for (int c = 0; c < 9; ++c) { Qrow[c] = Wr[ldw + 18 + c]; Lcol[c] = (c > k) ? img[c * ldx + ldw + 9 + k] : 0.0; }
     dinv = 1.0 / Wr[ldw + 9 + k];
-    double acc = Wr[D];
-    for (int j = 0; j < D; ++j) acc += Wr[j] * ds[j];
+    double acc;
+    if (top) { acc = Wr[D]; for (int j = 0; j < D; ++j) acc += Wr[j] * ds[j]; }      // (its own frames: the extra workgroups run beside it)
+    else acc = v.ct0[(size_t)e * 9 + k];
     if (a >= 0) {
       const bool right = two_sided && fi > fmid;
 #pragma unroll
@@ -1381,6 +1421,11 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
     t = acc;
   }
   if (done) return;
+#ifdef VC_BACK_STAMPS
+  if (__builtin_amdgcn_readfirstlane(__double2loint(t)) == 0x7fffffff) return;      // (forces t before the stamp)
+  if (blockIdx.x == (top ? 0 : gridDim.x / 2) && threadIdx.x == 0 && lvl < 4) { v.dbg[8 * lvl] = bs0_; v.dbg[8 * lvl + 1] = bs1_; }      // (not in passes that exit early)
+#endif
+  BSTAMP(2);
   double my = 0.0;
   if (two_sided) {
     // the middle first (a on its left, r on its right), then outwards on both sides at once: two independent chains of 9 x 9
@@ -1441,8 +1486,12 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
       for (int j = 0; j < 9; ++j) my = (j == k) ? dn[j] : my;
     }
   }
+#ifdef VC_BACK_STAMPS
+  if (__builtin_amdgcn_readfirstlane(__double2loint(my)) == 0x7fffffff) return;
+#endif
+  BSTAMP(3);
   if (mine) v.cdelta[(size_t)e * 9 + k] = my;
-  if (lvl != 0) return;
+  if (lvl != 0) { BSTAMP(4); return; }
   // ---- level 0: trial poses / velocities of the group's frames and their step terms
   if (mine) dl[(fi + 1) * 9 + k] = my;
   if (lane < 9) dl[lane] = da[lane];
@@ -1485,6 +1534,7 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
     double* o = v.grp_part + (size_t)blockIdx.x * kNumScal;
     o[kScGd] = gd; o[kScDld] = dld; o[kScStep2] = step2; o[kScX2] = x2; o[kScG2] = g2; o[kScCost] = 0.0; o[kScGmax] = gmax; o[kScSq] = 0.0;
   }
+  BSTAMP(4);
 }
 
 // sum over all frames of [Y | z]^T [Y | z]: part[chunk] = [ D x D | D ]  (same layout as the vision path)
@@ -1648,7 +1698,7 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
     for (int l = 0; l < nl; ++l) fwd((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1), strides[l], ms[l], 0, l);
     fwd(1, top_stride, m_top, 1, nl);
   } else {
-    hipLaunchKernelGGL(k_chain_back, dim3(1), dim3(64), 0, s, v, top_stride, m_top, 1, nl, 0);
+    hipLaunchKernelGGL(k_chain_back, dim3(1 + (nl > 0 ? (N + kBackT0Frames - 1) / kBackT0Frames : 0)), dim3(64), 0, s, v, top_stride, m_top, 1, nl, 0);
     for (int l = nl - 1; l >= 0; --l)
       hipLaunchKernelGGL(k_chain_back, dim3((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1)), dim3(64), 0, s, v, strides[l], ms[l], 0, l,
                          (two_sided && ms[l] >= 4 && l >= 1) ? 1 : 0);
