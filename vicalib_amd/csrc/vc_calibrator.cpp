@@ -393,6 +393,9 @@ struct vc_calibrator {
     Dmax = std::max(Dmax, D);
     // the reduced solve lives in LDS (packed lower triangle + 12 KB of staging), the chain Gram handles 12 column tiles
     if (((size_t)(D + 1) * (D + 2) / 2 + 3 * (D + 1) + 528) * sizeof(double) + 13 * 1024 > 160 * 1024 || D + 1 > 12 * 16) return VC_ERR_UNSUPPORTED;
+    // vision-only passes: k_frame_schur keeps at most 36 column-tile pairs (8 column tiles: D <= 127; eight 16-column cameras
+    // with the first one's extrinsics fixed are 122)
+    if (!imu_on() && D + 1 > 8 * 16) return VC_ERR_UNSUPPORTED;
     for (int c = 0; c < C; ++c) cam_model[c] = cams[c].model;
     up_b = up_ms();
     // ---- upload ---------------------------------------------------------------------------------
