@@ -220,6 +220,12 @@ int vc_detector_set_params(vc_detector* d, int black_on_white, double at_thresho
                            double conic_min_density, double conic_min_aspect);
 /* centres: 2 x max_conics doubles; *n_found is the number of dots found (may exceed max_conics: the first max_conics are written) */
 int vc_detector_find(vc_detector* d, const unsigned char* image, int pitch, double* centres, int max_conics, int* n_found);
+/* The same with the rest of what calibu::Conic carries (vicalib-task.cc:270-277 hands the conics to TargetGridDot::FindTarget):
+ * conics (nullable): 9 doubles per dot, the ellipse as a symmetric 3 x 3 matrix C with x^T C x = 0 on its edge, image coordinates
+ * (pixel centres at integers), unit Frobenius norm, C[0][0] > 0 (calibu::Conic::C; Dual is its inverse, center what `centres` holds);
+ * boxes (nullable): 4 ints per dot, the dot's bounding box x0, y0, x1, y1 inclusive (calibu::Conic::bbox). */
+int vc_detector_find_conics(vc_detector* d, const unsigned char* image, int pitch, double* centres, double* conics, int* boxes, int max_conics,
+                            int* n_found);
 
 #ifdef __cplusplus
 }

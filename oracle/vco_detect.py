@@ -76,7 +76,7 @@ def label4(fg):
         lab = new
 
 
-def fit_dual_conic(gx, gy, x0, y0, x1, y1):
+def fit_dual_conic(gx, gy, x0, y0, x1, y1, full=False):
     """Centre of the ellipse whose edge runs through the box [x0, x1) x [y0, y1).  Coordinates relative to the box centre."""
     cx, cy = 0.5 * (x0 + x1 - 1), 0.5 * (y0 + y1 - 1)
     M = np.zeros((5, 5)); rhs = np.zeros(5)
@@ -90,18 +90,30 @@ def fit_dual_conic(gx, gy, x0, y0, x1, y1):
             K = np.array([a * a, a * b, b * b, a * c, b * c])
             M += w2 * np.outer(K, K); rhs += w2 * K * (-(c * c))
     th = np.linalg.solve(M, rhs)
-    return cx + 0.5 * th[3], cy + 0.5 * th[4]
+    if not full:
+        return cx + 0.5 * th[3], cy + 0.5 * th[4]
+    # the dual conic in image coordinates (translation by the box centre), its inverse = the ellipse x^T C x = 0, unit Frobenius
+    # norm and C[0, 0] > 0 (calibu::Conic::C)
+    A, B, Cq, D, E = th
+    Q = np.array([[A, 0.5 * B, 0.5 * D], [0.5 * B, Cq, 0.5 * E], [0.5 * D, 0.5 * E, 1.0]])
+    T = np.array([[1.0, 0.0, cx], [0.0, 1.0, cy], [0.0, 0.0, 1.0]])
+    Cm = np.linalg.inv(T @ Q @ T.T)
+    Cm = Cm / np.linalg.norm(Cm)
+    if Cm[0, 0] < 0:
+        Cm = -Cm
+    return (cx + 0.5 * th[3], cy + 0.5 * th[4]), Cm
 
 
-def find_conics(img, at_threshold=0.9, at_window_ratio=30.0, min_area=4.0, min_density=0.6, min_aspect=0.2, black_on_white=True):
-    """Centres (x, y) of the detected dots, ordered by the label (= the smallest pixel index) of their component."""
+def find_conics(img, at_threshold=0.9, at_window_ratio=30.0, min_area=4.0, min_density=0.6, min_aspect=0.2, black_on_white=True, full=False):
+    """Centres (x, y) of the detected dots, ordered by the label (= the smallest pixel index) of their component.
+    full: -> (centres [n, 2], conics [n, 3, 3], boxes [n, 4] = x0, y0, x1, y1 inclusive)."""
     if not black_on_white:
         img = 255 - img                       # white dots on black: the same detector on the inverted image
     h, w = img.shape
     fg = adaptive_threshold(img, at_threshold, at_window_ratio)
     lab = label4(fg)
     gx, gy = gradient(img)
-    out = []
+    out, conics, boxes = [], [], []
     for L in np.unique(lab[lab >= 0]):
         ys, xs = np.nonzero(lab == L)
         x0, x1, y0, y1 = xs.min(), xs.max() + 1, ys.min(), ys.max() + 1
@@ -110,5 +122,11 @@ def find_conics(img, at_threshold=0.9, at_window_ratio=30.0, min_area=4.0, min_d
             continue
         if x0 - GROW < 1 or y0 - GROW < 1 or x1 + GROW > w - 1 or y1 + GROW > h - 1:
             continue
-        out.append(fit_dual_conic(gx, gy, x0 - GROW, y0 - GROW, x1 + GROW, y1 + GROW))
+        if full:
+            c, Cm = fit_dual_conic(gx, gy, x0 - GROW, y0 - GROW, x1 + GROW, y1 + GROW, full=True)
+            out.append(c); conics.append(Cm); boxes.append((x0, y0, x1 - 1, y1 - 1))
+        else:
+            out.append(fit_dual_conic(gx, gy, x0 - GROW, y0 - GROW, x1 + GROW, y1 + GROW))
+    if full:
+        return np.array(out).reshape(-1, 2), np.array(conics).reshape(-1, 3, 3), np.array(boxes, dtype=np.int64).reshape(-1, 4)
     return np.array(out).reshape(-1, 2)

@@ -6,8 +6,9 @@ import numpy as np
 
 
 def render(width=640, height=480, nx=9, ny=6, spacing=0.03, r_large=0.0094, r_small=0.0063, fu=420.0, fv=420.0, seed=0,
-           tilt=(0.25, -0.2, 0.1), dist=0.42, ss=8, white=230, black=25):
-    """Returns (image u8 [h, w], centres [n, 2] in pixel coordinates (x, y), pixel centres at integers)."""
+           tilt=(0.25, -0.2, 0.1), dist=0.42, ss=8, white=230, black=25, with_conics=False):
+    """Returns (image u8 [h, w], centres [n, 2] in pixel coordinates (x, y), pixel centres at integers); with_conics: also the
+    image ellipses as 3 x 3 matrices (unit Frobenius norm, first entry positive)."""
     rng = np.random.default_rng(seed)
     from scipy.spatial.transform import Rotation as R
     Rcw = R.from_euler("xyz", tilt).as_matrix()
@@ -17,7 +18,7 @@ def render(width=640, height=480, nx=9, ny=6, spacing=0.03, r_large=0.0094, r_sm
     H = K @ np.column_stack([Rcw[:, 0], Rcw[:, 1], t])          # plane (X, Y, 1) -> pixels
     Hi = np.linalg.inv(H)
     img = np.full((height, width), float(white))
-    centres = []
+    centres, conics = [], []
     big = rng.random((ny, nx)) < 0.4
     for j in range(ny):
         for i in range(nx):
@@ -26,6 +27,8 @@ def render(width=640, height=480, nx=9, ny=6, spacing=0.03, r_large=0.0094, r_sm
             Ci = Hi.T @ Cc @ Hi                                                                   # its image
             c = -np.linalg.solve(Ci[:2, :2], Ci[:2, 2])
             centres.append(c)
+            Cn = Ci / np.linalg.norm(Ci)
+            conics.append(Cn if Cn[0, 0] > 0 else -Cn)
             # coverage by supersampling inside a box around the ellipse
             p = H @ np.array([X, Y, 1.0]); p = p[:2] / p[2]
             rad_px = 1.6 * r * max(fu, fv) / dist + 2
@@ -41,4 +44,7 @@ def render(width=640, height=480, nx=9, ny=6, spacing=0.03, r_large=0.0094, r_sm
                     cov += (q * np.sign(Cc[0, 0] * 1.0) < 0) if Ci[0, 0] > 0 else (q > 0)
             cov /= ss * ss
             img[y0:y1, x0:x1] = np.minimum(img[y0:y1, x0:x1], white - (white - black) * cov)
-    return np.clip(np.rint(img), 0, 255).astype(np.uint8), np.array(centres)
+    out = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    if with_conics:
+        return out, np.array(centres), np.array(conics)
+    return out, np.array(centres)

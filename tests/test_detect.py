@@ -35,6 +35,28 @@ def test_restatement_finds_the_rendered_ellipse_centres(seed, tilt):
     assert e.max() < 0.02
 
 
+def _axes(Cm):
+    """Centre, semi-axes (descending) of the ellipse x^T C x = 0."""
+    c = -np.linalg.solve(Cm[:2, :2], Cm[:2, 2])
+    k = -(Cm[2, 2] + Cm[:2, 2] @ c)                       # (x - c)^T A (x - c) = k
+    ev = np.linalg.eigvalsh(Cm[:2, :2] / k)
+    return c, np.sort(1.0 / np.sqrt(ev))[::-1]
+
+
+def test_restatement_recovers_the_ellipses_themselves():
+    """calibu::Conic carries the ellipse as a matrix (TargetGridDot::FindTarget uses it): the restatement's conic, in image
+    coordinates, has the rendered ellipse's centre (by construction of the fit) and its semi-axes within 2.5 % on blurred edges."""
+    img, truth, conics = dot_images.render(seed=3, tilt=(-0.35, 0.3, -0.4), with_conics=True)
+    cen, Cs, boxes = vco_detect.find_conics(_blurred(img, 0.9), full=True)
+    d = np.linalg.norm(cen[:, None, :] - truth[None, :, :], axis=2)
+    for i, j in enumerate(d.argmin(axis=1)):
+        c, ax = _axes(Cs[i]); ct, axt = _axes(conics[j])
+        np.testing.assert_allclose(c, cen[i], atol=1e-9)
+        np.testing.assert_allclose(ax, axt, rtol=0.025)
+        assert abs(np.linalg.norm(Cs[i]) - 1.0) < 1e-12 and Cs[i][0, 0] > 0
+        assert boxes[i][0] <= truth[j][0] <= boxes[i][2] and boxes[i][1] <= truth[j][1] <= boxes[i][3]
+
+
 def test_restatement_rejects_what_is_not_a_dot():
     img, truth = dot_images.render()
     img[200:203, 10:300] = 20            # a thin dark line: fails the aspect test
@@ -80,3 +102,23 @@ def test_gpu_detector_handles_extra_blobs_and_empty_images():
     np.testing.assert_allclose(det.find(img), vco_detect.find_conics(img), rtol=0, atol=1e-7)
     assert len(det.find(np.full_like(img, 200))) == 0                      # nothing to find
     assert len(det.find(np.zeros_like(img))) == 0                           # all dark: the local mean is dark too
+
+
+@pytest.mark.gpu
+def test_gpu_detector_returns_the_conics_and_boxes():
+    """vc_detector_find_conics: the ellipse matrices and bounding boxes of calibu::Conic, equal to the restatement's (the 3 x 3
+    inverse and the normalisation in a different order of operations: 1e-9 on unit-norm matrices)."""
+    from vicalib_amd.lib import ConicDetector
+    img, truth, conics = dot_images.render(seed=5, tilt=(0.1, 0.45, 1.2), with_conics=True)
+    img = _blurred(img, 0.6)
+    cen, Cs, boxes = vco_detect.find_conics(img, full=True)
+    det = ConicDetector(img.shape[1], img.shape[0])
+    g_cen, g_C, g_box = det.find_conics(img)
+    np.testing.assert_allclose(g_cen, cen, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(g_C, Cs, rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(g_box, boxes)
+    np.testing.assert_allclose(det.find(img), g_cen, rtol=0, atol=0)
+    d = np.linalg.norm(g_cen[:, None, :] - truth[None, :, :], axis=2)
+    for i, j in enumerate(d.argmin(axis=1)):
+        _, ax = _axes(g_C[i]); _, axt = _axes(conics[j])
+        np.testing.assert_allclose(ax, axt, rtol=0.03)

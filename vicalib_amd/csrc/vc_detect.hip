@@ -42,6 +42,8 @@ struct DetView {
   double min_area, min_density, min_aspect;
   int black_on_white;
   double* centres;
+  double* conics;                  // 9 per candidate (primal conic, image coordinates) or nullptr
+  int* boxes;                      // 4 per candidate (x0, y0, x1, y1 inclusive: the component's bounding box) or nullptr
 };
 
 // integral image, rows: one wavefront per row, ten consecutive pixels per lane round, exclusive scan of the lane sums
@@ -192,6 +194,21 @@ __global__ __launch_bounds__(64) void k_det_fit(DetView v, int n) {
     if (ok) for (int i = 4; i >= 0; --i) { double s = M[i][5]; for (int j = i + 1; j < 5; ++j) s -= M[i][j] * th[j]; th[i] = s / M[i][i]; }
     v.centres[2 * ci] = ok ? cx + 0.5 * th[3] : -1.0;
     v.centres[2 * ci + 1] = ok ? cy + 0.5 * th[4] : -1.0;
+    if (v.boxes) { v.boxes[4 * ci] = v.x0[r]; v.boxes[4 * ci + 1] = v.y0[r]; v.boxes[4 * ci + 2] = v.x1[r] - 1; v.boxes[4 * ci + 3] = v.y1[r] - 1; }
+    if (v.conics) {
+      // the fitted dual conic [[A, B/2, D/2], [B/2, C, E/2], [D/2, E/2, 1]] lives in box-centred coordinates: moved to image
+      // coordinates (T Q T^T, T = translation by the box centre), inverted (adjugate: the scale of a conic is free) and scaled
+      // to unit Frobenius norm with a positive first entry -- what calibu::Conic keeps as `C` (`Dual` is its inverse)
+      const double A = th[0], B = th[1], Cc = th[2], Dd = th[3], E = th[4];
+      const double q00 = A + cx * Dd + cx * cx, q01 = 0.5 * B + 0.5 * (cx * E + cy * Dd) + cx * cy, q11 = Cc + cy * E + cy * cy;
+      const double q02 = 0.5 * Dd + cx, q12 = 0.5 * E + cy, q22 = 1.0;
+      double c00 = q11 * q22 - q12 * q12, c01 = q02 * q12 - q01 * q22, c02 = q01 * q12 - q02 * q11;
+      double c11 = q00 * q22 - q02 * q02, c12 = q01 * q02 - q00 * q12, c22 = q00 * q11 - q01 * q01;
+      const double nrm = sqrt(c00 * c00 + c11 * c11 + c22 * c22 + 2.0 * (c01 * c01 + c02 * c02 + c12 * c12));
+      const double sc = (ok && nrm > 0.0) ? (c00 < 0.0 ? -1.0 : 1.0) / nrm : 0.0;
+      double* o = v.conics + 9 * (size_t)ci;
+      o[0] = sc * c00; o[1] = sc * c01; o[2] = sc * c02; o[3] = sc * c01; o[4] = sc * c11; o[5] = sc * c12; o[6] = sc * c02; o[7] = sc * c12; o[8] = sc * c22;
+    }
   }
 }
 
@@ -204,6 +221,8 @@ struct vc_detector {
   unsigned* d_S = nullptr;
   int* d_lab = nullptr; int* d_stats = nullptr; int* d_cand = nullptr; int* d_ncand = nullptr;
   double* d_centres = nullptr;
+  double* d_conics = nullptr;
+  int* d_boxes = nullptr;
   int max_cand = 4096;
   // calibu::ImageProcessing / ConicFinder parameters as VicalibTask sets them (vicalib-task.cc:116-122)
   int black_on_white = 1;
@@ -223,7 +242,8 @@ int vc_detector_create(int device, int width, int height, vc_detector** out) {
   bool ok = hipStreamCreate(&d->stream) == hipSuccess && hipMalloc((void**)&d->d_img, np) == hipSuccess &&
             hipMalloc((void**)&d->d_S, (size_t)(width + 1) * (height + 1) * 4) == hipSuccess && hipMalloc((void**)&d->d_lab, np * 4) == hipSuccess &&
             hipMalloc((void**)&d->d_stats, np * 4 * 5) == hipSuccess && hipMalloc((void**)&d->d_cand, (size_t)d->max_cand * 4) == hipSuccess &&
-            hipMalloc((void**)&d->d_ncand, 4) == hipSuccess && hipMalloc((void**)&d->d_centres, (size_t)d->max_cand * 16) == hipSuccess;
+            hipMalloc((void**)&d->d_ncand, 4) == hipSuccess && hipMalloc((void**)&d->d_centres, (size_t)d->max_cand * 16) == hipSuccess &&
+            hipMalloc((void**)&d->d_conics, (size_t)d->max_cand * 72) == hipSuccess && hipMalloc((void**)&d->d_boxes, (size_t)d->max_cand * 16) == hipSuccess;
   if (!ok) { vc_detector_destroy(d); return VC_ERR_NO_DEVICE; }
   *out = d;
   return VC_OK;
@@ -233,7 +253,7 @@ void vc_detector_destroy(vc_detector* d) {
   (void)hipSetDevice(d->device);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   (void)hipFree(d->d_img); (void)hipFree(d->d_S); (void)hipFree(d->d_lab); (void)hipFree(d->d_stats); (void)hipFree(d->d_cand);
-  (void)hipFree(d->d_ncand); (void)hipFree(d->d_centres);
+  (void)hipFree(d->d_ncand); (void)hipFree(d->d_centres); (void)hipFree(d->d_conics); (void)hipFree(d->d_boxes);
   delete d;
 }
 int vc_detector_set_params(vc_detector* d, int black_on_white, double at_threshold, double at_window_ratio, double conic_min_area,
@@ -243,7 +263,8 @@ int vc_detector_set_params(vc_detector* d, int black_on_white, double at_thresho
   d->conic_min_area = conic_min_area; d->conic_min_density = conic_min_density; d->conic_min_aspect = conic_min_aspect;
   return VC_OK;
 }
-int vc_detector_find(vc_detector* d, const unsigned char* image, int pitch, double* centres, int max_conics, int* n_found) {
+int vc_detector_find_conics(vc_detector* d, const unsigned char* image, int pitch, double* centres, double* conics, int* boxes, int max_conics,
+                            int* n_found) {
   if (!d || !image || pitch < d->w || !n_found || max_conics < 0 || (max_conics > 0 && !centres)) return VC_ERR_BAD_ARG;
   if (hipSetDevice(d->device) != hipSuccess) return VC_ERR_NO_DEVICE;
   const int w = d->w, h = d->h, np = w * h;
@@ -255,7 +276,7 @@ int vc_detector_find(vc_detector* d, const unsigned char* image, int pitch, doub
   v.cand = d->d_cand; v.n_cand = d->d_ncand; v.max_cand = d->max_cand;
   v.thr = d->at_threshold; v.rad = (int)((double)w / d->at_window_ratio);
   v.min_area = d->conic_min_area; v.min_density = d->conic_min_density; v.min_aspect = d->conic_min_aspect;
-  v.black_on_white = d->black_on_white; v.centres = d->d_centres;
+  v.black_on_white = d->black_on_white; v.centres = d->d_centres; v.conics = conics ? d->d_conics : nullptr; v.boxes = boxes ? d->d_boxes : nullptr;
   const int gb = (np + 255) / 256;
   hipLaunchKernelGGL(k_det_rows, dim3(h), dim3(64), 0, d->stream, v);
   hipLaunchKernelGGL(k_det_cols, dim3((w + 1 + 63) / 64), dim3(64), 0, d->stream, v);
@@ -276,8 +297,14 @@ int vc_detector_find(vc_detector* d, const unsigned char* image, int pitch, doub
   hipLaunchKernelGGL(k_det_fit, dim3(n), dim3(64), 0, d->stream, v, n);
   std::vector<double> out((size_t)n * 2);
   if (hipMemcpyAsync(out.data(), d->d_centres, out.size() * 8, hipMemcpyDeviceToHost, d->stream) != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess) return VC_ERR_NO_DEVICE;
-  std::memcpy(centres, out.data(), (size_t)std::min(n, max_conics) * 16);
+  const int nout = std::min(n, max_conics);
+  std::memcpy(centres, out.data(), (size_t)nout * 16);
+  if (conics && nout > 0 && hipMemcpy(conics, d->d_conics, (size_t)nout * 72, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
+  if (boxes && nout > 0 && hipMemcpy(boxes, d->d_boxes, (size_t)nout * 16, hipMemcpyDeviceToHost) != hipSuccess) return VC_ERR_NO_DEVICE;
   return VC_OK;
+}
+int vc_detector_find(vc_detector* d, const unsigned char* image, int pitch, double* centres, int max_conics, int* n_found) {
+  return vc_detector_find_conics(d, image, pitch, centres, nullptr, nullptr, max_conics, n_found);
 }
 
 }  // extern "C"

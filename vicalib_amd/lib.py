@@ -31,7 +31,7 @@ SYMBOLS = [
     "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
     "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_pnp_planar_ransac", "vc_set_pnp_ransac", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_allreduce_calls", "vc_last_error", "vc_get_imu_weights",
     "vc_solution_covariance_dim", "vc_get_solution_covariance", "vc_get_solution_covariance_names",
-    "vc_detector_create", "vc_detector_destroy", "vc_detector_set_params", "vc_detector_find",
+    "vc_detector_create", "vc_detector_destroy", "vc_detector_set_params", "vc_detector_find", "vc_detector_find_conics",
 ]
 
 
@@ -386,3 +386,13 @@ class ConicDetector:
         out = np.zeros((max_conics, 2)); n = C.c_int(0)
         _check(self.L.vc_detector_find(self.h, image.ctypes.data_as(C.c_void_p), int(image.strides[0]), _d(out), int(max_conics), C.byref(n)), "detector_find")
         return out[:min(n.value, max_conics)]
+
+    def find_conics(self, image, max_conics=4096):
+        """-> (centres [n, 2], conics [n, 3, 3] (x^T C x = 0 on the edge, unit Frobenius norm), boxes [n, 4] (x0, y0, x1, y1 inclusive))"""
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        assert image.shape == (self.hh, self.w)
+        out = np.zeros((max_conics, 2)); con = np.zeros((max_conics, 9)); box = np.zeros((max_conics, 4), dtype=np.int32); n = C.c_int(0)
+        _check(self.L.vc_detector_find_conics(self.h, image.ctypes.data_as(C.c_void_p), int(image.strides[0]), _d(out), _d(con),
+                                              box.ctypes.data_as(C.c_void_p), int(max_conics), C.byref(n)), "detector_find_conics")
+        k = min(n.value, max_conics)
+        return out[:k], con[:k].reshape(-1, 3, 3), box[:k]
