@@ -108,12 +108,26 @@ def main():
         if world == 1 and not force_shard:
             return "none"
         if os.environ.get("VICALIB_AMD_SHARD_COMM", "rccl") == "rccl":
+            ok = 1
             try:
                 c.set_shard_rccl(rank, world)
-                return "rccl"
             except Exception as e:      # noqa: BLE001
                 # the exception text carries vc_last_error(): which RCCL call failed and RCCL's own error string
+                ok = 0
                 rccl_errors.append(str(e))
+            # every rank must end up on the same transport: one failed rank sends all of them to the torch.distributed callback
+            if world > 1:
+                flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                all_ok = int(flag.item())
+            else:
+                all_ok = ok
+            if all_ok:
+                return "rccl"
+            if ok:
+                rccl_errors.append("native RCCL communicator dropped: another rank failed to create its own")
+            else:
+                e = rccl_errors[-1]
                 print("bench[rank %d]: native RCCL path unavailable (%s); using the torch.distributed callback" % (rank, e), file=sys.stderr)
         from vicalib_amd.parallel import FrameShardComm
         c.set_shard(rank, world, FrameShardComm(device="cuda:%d" % local_rank, stream_ptr=c.stream()))

@@ -1476,6 +1476,9 @@ int vc_get_trace(vc_calibrator* h, double* rows, int max_rows) {
 int vc_set_shard(vc_calibrator* h, int rank, int world_size, vc_allreduce_fn fn, void* ctx) {
   NOT_RUNNING(h);
   if (world_size < 1 || rank < 0 || rank >= world_size || (world_size > 1 && !fn)) return VC_ERR_BAD_ARG;
+  // a callback replaces the library's own communicator (a caller that falls back after vc_set_shard_rccl succeeded on this rank but
+  // failed on another one must end up on the same transport everywhere)
+  if (h->rccl_comm) { (void)g_rccl.CommDestroy(h->rccl_comm); h->rccl_comm = nullptr; }
   h->rank = rank; h->world = world_size; h->allreduce = fn; h->allreduce_ctx = ctx; h->device_dirty = true;
   { const char* e = std::getenv("VICALIB_AMD_FORCE_SHARD_PATH"); h->force_shard_path = e && e[0] == '1'; }
   return VC_OK;
@@ -1491,7 +1494,11 @@ int vc_rccl_unique_id(void* out128) {
 int vc_set_shard_rccl(vc_calibrator* h, int rank, int world_size, const void* unique_id128) {
   NOT_RUNNING(h);
   if (world_size < 1 || rank < 0 || rank >= world_size || !unique_id128) return VC_ERR_BAD_ARG;
-  if (!g_rccl.load()) { g_last_error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy not all found"); return VC_ERR_UNSUPPORTED; }
+  if (!g_rccl.load()) {
+    const char* de = dlerror();      // (one call: dlerror() clears the message it returns)
+    g_last_error = std::string("librccl could not be loaded: ") + (de ? de : "ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy not all found");
+    return VC_ERR_UNSUPPORTED;
+  }
   if (hipSetDevice(h->device) != hipSuccess) { g_last_error = "hipSetDevice(" + std::to_string(h->device) + ") failed"; return VC_ERR_NO_DEVICE; }
   RcclUniqueId id;
   std::memcpy(&id, unique_id128, sizeof(id));
