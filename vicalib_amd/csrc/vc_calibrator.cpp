@@ -151,6 +151,10 @@ struct vc_calibrator {
   hipStream_t stream2 = nullptr;        // the IMU weight update of a pass runs here, under the pass's Jacobian sweeps and chain solve
   hipEvent_t ev_state = nullptr, ev_weights = nullptr, ev_imujac = nullptr, ev_reduced = nullptr, ev_back = nullptr;
   int wcur = 0;                         // weight buffer holding the current weight_sqrt_
+  bool flag_sync = false;               // hand-overs to the second stream through device flags instead of event records (set at creation)
+  long long pass_seq = 0;               // passes enqueued (the value the flags carry)
+  bool prev_pass_signals = false;       // the previous pass of this solve was enqueued with signalling kernels
+  DBuf<long long> d_sync;
   bool jac_on_stream2 = true;           // the trial point's k_imu_jac beside the vision sweep (VICALIB_AMD_JAC_STREAM2=0: after it, main stream)
   bool serial_weights = false;          // false: IMU Jacobians + weight update on the second stream (VICALIB_AMD_OVERLAP_WEIGHTS=0: in line); was: VICALIB_AMD_OVERLAP_WEIGHTS=1 moves it to a second
                                         // stream under the Jacobian sweeps / chain solve (measured: the two latency-bound kernels then
@@ -659,12 +663,19 @@ struct vc_calibrator {
       // chain, both trial sweeps, decision -- stays on the main stream: kernels of one stream follow each other without a gap,
       // an event hand-over costs 5-13 us.
       const bool upd = dv.weights_on != 0;
+      const bool fs = flag_sync && !serial_weights && !sharded();
+      ++pass_seq;
+      dv.sync_flags = d_sync.p; dv.sync_seq = fs ? pass_seq : 0; dv.final_wait = 0;
+      const bool fs_trial = fs && jac_on_stream2 && dv.n_tiles > 0;      // (no tiles: no trial sweep to publish the back-substitution's end)
       // The Jacobian sweeps at the head of the pass only run when the control record asks for a linearisation: the first pass
       // of a solve.  Afterwards the trial point is evaluated by the same sweeps in trial mode (below), which leave the next
       // linearisation behind if the step is accepted; after a rejected step the old one is still in place.
       if (!serial_weights) {
-        HIP_OK(hipEventRecord(ev_state, stream));
-        HIP_OK(hipStreamWaitEvent(stream2, ev_state, 0));
+        if (fs && !first_pass && prev_pass_signals) launch_wait_flag(dv, 0, pass_seq - 1, stream2);      // the previous pass's k_final
+        else {
+          HIP_OK(hipEventRecord(ev_state, stream));
+          HIP_OK(hipStreamWaitEvent(stream2, ev_state, 0));
+        }
         if (first_pass) {
           KT2("k_imu_delta+k_imu_block", launch_imu_delta(dv, stream2, 0)); KT2("k_imu_jac", launch_imu_jac(dv, wcur, stream2, 0));
           HIP_OK(hipEventRecord(ev_imujac, stream2));       // ahead of the weight update: the chain does not read the weights
@@ -696,8 +707,11 @@ struct vc_calibrator {
       // the trial IMU parameters exist: the interval deltas of the trial point run on the second stream next to the chain's
       // back-substitution (they depend on no pose)
       if (!serial_weights) {
-        HIP_OK(hipEventRecord(ev_reduced, stream));
-        HIP_OK(hipStreamWaitEvent(stream2, ev_reduced, 0));
+        if (fs) launch_wait_flag(dv, 1, pass_seq, stream2);      // this pass's k_reduced
+        else {
+          HIP_OK(hipEventRecord(ev_reduced, stream));
+          HIP_OK(hipStreamWaitEvent(stream2, ev_reduced, 0));
+        }
         KT2("k_imu_delta+k_imu_block(trial)", launch_imu_delta(dv, stream2, 1));
       }
       KT("k_chain_back", launch_chain_solve_b(dv, stream));
@@ -708,12 +722,20 @@ struct vc_calibrator {
       if (!serial_weights && jac_on_stream2) {
         // the IMU blocks' final stage (needs the trial poses) beside the vision sweep: the second stream is already past its
         // deltas when the back-substitution ends
-        HIP_OK(hipEventRecord(ev_back, stream));
-        HIP_OK(hipStreamWaitEvent(stream2, ev_back, 0));
+        // (a one-wavefront kernel waits for the flag the first workgroup of k_reproj_jac(trial) sets.  Letting k_imu_jac's own
+        // workgroups wait at their entry saved that kernel's 5 us on the second stream's queue and cost 25 us: 250 workgroups
+        // each invalidating the L2 under the running vision sweep -- measured)
+        if (fs_trial) launch_wait_flag(dv, 2, pass_seq, stream2);
+        else {
+          HIP_OK(hipEventRecord(ev_back, stream));
+          HIP_OK(hipStreamWaitEvent(stream2, ev_back, 0));
+        }
         KT2("k_imu_jac(trial)", launch_imu_jac(dv, wcur, stream2, 1));
-        HIP_OK(hipEventRecord(ev_weights, stream2));
+        if (fs_trial) launch_signal_flag(dv, 3, stream2);
+        else HIP_OK(hipEventRecord(ev_weights, stream2));
         KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
-        HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0));
+        if (fs_trial) dv.final_wait = pass_seq;                        // k_final waits for the second stream itself
+        else HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0));
       } else {
         if (!serial_weights) HIP_OK(hipEventRecord(ev_weights, stream2));
         KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
@@ -728,8 +750,10 @@ struct vc_calibrator {
       } else {
         KT("k_final", launch_final(dv, 0, stream));
       }
+      prev_pass_signals = fs;
       return VC_OK;
     }
+    dv.sync_seq = 0; dv.final_wait = 0;
     // merged decision (single process): control records alternate, pass k judges pass k-1 at the head of k_frame_schur
     const bool merged = merged_enabled && !use_graphs;      // (a captured graph has fixed kernel arguments)
     dv.shard_src = sharded() ? 1 : 0;
@@ -1097,7 +1121,7 @@ int vc_create(vc_calibrator** out, int device) {
   const char* prio_env = std::getenv("VICALIB_AMD_STREAM2_PRIORITY");      // "default": plain hipStreamCreate (A/B measurements)
   const bool plain2 = prio_env && std::strcmp(prio_env, "default") == 0;
   auto make_stream2 = [&]() -> hipError_t {
-    if (!plain2 && hipStreamCreateWithPriority(&h->stream2, hipStreamDefault, prio_least) == hipSuccess) return hipSuccess;
+    if (!plain2 && prio_least != prio_greatest && hipStreamCreateWithPriority(&h->stream2, hipStreamDefault, prio_least) == hipSuccess) { h->flag_sync = true; return hipSuccess; }
     (void)hipGetLastError();
     return hipStreamCreate(&h->stream2);          // (a runtime without stream priorities: plain stream, same results)
   };
@@ -1106,6 +1130,10 @@ int vc_create(vc_calibrator** out, int device) {
       hipEventCreateWithFlags(&h->ev_weights, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_imujac, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_reduced, evf) != hipSuccess || hipEventCreateWithFlags(&h->ev_back, evf) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }
+  // flag hand-overs need the two streams on different hardware queues (a waiting kernel at the head of a shared queue would hold
+  // its own producer back): only with the second stream in its own priority class; VICALIB_AMD_FLAG_SYNC=0 keeps the events
+  { const char* e = std::getenv("VICALIB_AMD_FLAG_SYNC"); if (e && e[0] == '0') h->flag_sync = false; }
+  if (h->flag_sync && (h->d_sync.alloc(4) != hipSuccess || hipMemset(h->d_sync.p, 0, 4 * sizeof(long long)) != hipSuccess)) h->flag_sync = false;
   *out = h;
   return VC_OK;
 }

@@ -122,6 +122,11 @@ struct DevView {
   unsigned long long* host_progress;   // page-locked host word, (decisions taken << 32) | Ctrl::done, stored by the deciding thread after
                                    // every decision: the host feeds passes against it without synchronising the stream (null: off)
   int* flags;                      // [0]: frame Cholesky failures, [1]: reduced Cholesky failure (per pass)
+  // cross-stream hand-overs without event records on the main stream (visual-inertial pass, single process): single-workgroup
+  // kernels publish the pass number when they are done, a one-wavefront kernel on the second stream waits for it
+  long long* sync_flags;           // [0]: k_final, [1]: k_reduced, [2]: back-substitution done (k_reproj_jac(trial) has started), [3]: second stream's trial-point kernels done
+  long long sync_seq;              // this pass's number (0: no signalling)
+  long long final_wait;            // k_final waits for sync_flags[3] >= final_wait before it reads the second stream's sums (0: ordered by an event)
   Ctrl* ctrl;
   long long* dbg;                  // 32 cycle-counter stamps (profiling aid)
   double* trace;                   // trace_cap x kTraceCols
@@ -190,6 +195,8 @@ void launch_frame_schur(const DevView& v, hipStream_t s);      // frame eliminat
 void launch_reduced(const DevView& v, int mode, hipStream_t s);
 void launch_trial(const DevView& v, hipStream_t s);            // back-substitution + manifold update + trial residual sweep
 void launch_final(const DevView& v, int mode, hipStream_t s);
+void launch_wait_flag(const DevView& v, int idx, long long seq, hipStream_t s);      // returns when sync_flags[idx] >= seq
+void launch_signal_flag(const DevView& v, int idx, hipStream_t s);                    // sync_flags[idx] <- sync_seq once everything before it in the stream is done
 void launch_final_merged(const DevView& v, hipStream_t s);   // merged mode, batch end: judges the last pass (ctrl = next record, ctrl_prev = last pass's)  // mode 0: reduce + decide, 1: reduce only, 2: decide only
 void launch_reproj_res(const DevView& v, int state, double mult, hipStream_t s);   // residual sweep; state 0/1 buffer, 2 accepted, 3 trial (mult from Ctrl)
 void launch_reset_state(const DevView& v, const double* pose0, const double* cam0, const double* vel0, const double* imu0, hipStream_t s);

@@ -261,6 +261,9 @@ __global__ __launch_bounds__(256) void k_reproj_jac(DevView v, int trial) {
   if (blockIdx.x == 0 && threadIdx.x == 0) v.dbg[7] = (long long)__builtin_readcyclecounter();
 #endif
   __shared__ double s_cost[4];
+  // the trial sweep follows the back-substitution on the main stream: that this kernel has started says the trial poses are complete
+  // and written back -- published for the second stream's k_imu_jac (no event record between the two kernels of the critical path)
+  if (trial && blockIdx.x == 0 && threadIdx.x == 0) signal_flag(v, 2);
   if (ct->done || (!trial && !ct->need_lin)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
@@ -1176,7 +1179,7 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   __shared__ double s_x2;
   __shared__ CamDesc s_cd[kMaxCams];     // the kernel-argument table costs a scalar memory round trip per (dynamically indexed) access
   const Ctrl* ct = v.ctrl;
-  if (ct->done) return;
+  if (ct->done) { if (threadIdx.x == 0 && mode == 0) signal_flag(v, 1); return; }
   if (threadIdx.x < kMaxCams) s_cd[threadIdx.x] = v.cd[threadIdx.x];
   double pre_sc2 = 1.0, pre_dg = 1.0;      // damping inputs of the small solve: requested now, consumed after phase A
   if (mode != 1) {
@@ -1185,6 +1188,7 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   }
   if (mode != 2) { schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2, s_cd); __syncthreads(); }
   if (mode != 1) reduced_solve_phase(v, ct, dyn, red, s_cam, pre_sc2, pre_dg, mode == 0 ? &s_x2 : nullptr, s_cd);
+  if (mode == 0) { __syncthreads(); if (threadIdx.x == 0) signal_flag(v, 1); }      // the trial IMU parameters exist (stream B's deltas wait for this)
 }
 
 // ------------------------------------------------------------------------------------------ trial point
@@ -1596,10 +1600,27 @@ __device__ void final_phase(const DevView& v, int mode, double* red) {
   }
   if (mode != 1 && tid == 0) lm_decide(v);
 }
+// The waiting side as a kernel of its own: one wavefront on the second stream; the kernels behind it in that stream start when it
+// returns (vc_kutil.hpp: spin_until_flag).
+__global__ __launch_bounds__(64) void k_wait_flag(DevView v, int idx, long long seq) {
+  if (threadIdx.x == 0) spin_until_flag(v, idx, seq);
+}
+// the producing side for kernels of many workgroups: a one-thread kernel behind them in their stream (the kernel boundary has
+// written their results back; one fence per workgroup would cost more than this launch)
+__global__ __launch_bounds__(64) void k_signal_flag(DevView v, int idx) {
+  if (threadIdx.x == 0) signal_flag(v, idx);
+}
 __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
   __shared__ double red[256 * 7];
-  if (v.ctrl->done) return;
+  // the second stream's share of the trial cost (k_imu_jac's workgroup sums): wait for its flag here, inside the kernel, instead of
+  // behind a cross-stream event (12 us between the second stream's last kernel and this one on the timeline); every wavefront
+  // then drops what it may have cached of the other stream's results.  Also when the solve is over: the main stream must not
+  // run ahead of the second one.
+  if (v.final_wait > 0) workgroup_wait_flag(v, 3, v.final_wait);
+  if (v.ctrl->done) { if (threadIdx.x == 0) signal_flag(v, 0); return; }
   final_phase(v, mode, red);
+  __syncthreads();
+  if (threadIdx.x == 0) signal_flag(v, 0);
 }
 
 // both state buffers <- the uploaded initial state (benchmark restarts), one launch
@@ -1683,6 +1704,8 @@ void launch_final_merged(const DevView& v, hipStream_t s) { hipLaunchKernelGGL(k
 void launch_final(const DevView& v, int mode, hipStream_t s) {
   hipLaunchKernelGGL(k_final, dim3(1), dim3(256), 0, s, v, mode);
 }
+void launch_wait_flag(const DevView& v, int idx, long long seq, hipStream_t s) { hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, s, v, idx, seq); }
+void launch_signal_flag(const DevView& v, int idx, hipStream_t s) { hipLaunchKernelGGL(k_signal_flag, dim3(1), dim3(64), 0, s, v, idx); }
 void launch_reproj_res(const DevView& v, int state, double mult, hipStream_t s) {
   if (v.n_tiles == 0) return;
   hipLaunchKernelGGL(k_reproj_res, dim3(tiles_grid(v)), dim3(256), 0, s, v, state, mult);

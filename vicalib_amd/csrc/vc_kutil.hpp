@@ -1,6 +1,7 @@
 // vc_kutil.hpp -- small device helpers shared by the kernel translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "vc_device.h"
 
 namespace vc {
 
@@ -68,5 +69,35 @@ __device__ __forceinline__ double wave_allsum(double x) {   // result in every l
   return x;
 }
 
+
+// ---- cross-stream hand-overs through device flags (DevView::sync_flags) --------------------------------------------------
+// Publishing "this kernel of pass sync_seq is done" to the other stream (one thread of a single-workgroup kernel, behind a
+// workgroup barrier: everybody's stores have reached the L2, the device-scope fence writes them back before the flag moves).
+// An event record on the main stream would cost it 5 us per hand-over (the record's barrier packet sits between two kernels
+// of the critical path); the flag costs the producer one fence at its very end.
+__device__ __forceinline__ void signal_flag(const DevView& v, int idx) {
+  if (v.sync_seq > 0) {
+    __threadfence();
+    __hip_atomic_store(v.sync_flags + idx, v.sync_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// The waiting side.  Bounded: a flag that never comes (the two streams sharing one hardware queue would do it: the producer
+// queued behind the waiting kernel) ends as a failed step after ~0.2 s, not as a hang.
+__device__ __forceinline__ void spin_until_flag(const DevView& v, int idx, long long seq) {      // one thread
+  long long n = 0;
+  while (__hip_atomic_load(v.sync_flags + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+    __builtin_amdgcn_s_sleep(16);
+    if (++n > 400000) { v.flags[4 + 2 * v.par] = 1; v.flags[5 + 2 * v.par] = 1; break; }
+  }
+}
+// ... and for a whole workgroup at its entry: thread 0 waits, then every wavefront drops what it may hold of the other stream's
+// results (device-scope acquire).  For single-workgroup kernels: a grid of workgroups doing this invalidates the L2 under whatever
+// runs beside it (k_imu_jac with 250 workgroups: itself and the vision sweep 2.3x slower)
+__device__ __forceinline__ void workgroup_wait_flag(const DevView& v, int idx, long long seq) {
+  if (threadIdx.x == 0) spin_until_flag(v, idx, seq);
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (acquire only: nothing of this workgroup's needs writing back here)
+}
 
 }  // namespace vc
