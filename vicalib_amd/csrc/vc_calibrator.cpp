@@ -665,8 +665,10 @@ struct vc_calibrator {
       const bool upd = dv.weights_on != 0;
       const bool fs = flag_sync && !serial_weights && !sharded();
       ++pass_seq;
-      dv.sync_flags = d_sync.p; dv.sync_seq = fs ? pass_seq : 0; dv.final_wait = 0;
+      dv.sync_flags = d_sync.p; dv.sync_seq = fs ? pass_seq : 0; dv.final_wait = 0; dv.block_wait = 0;
       const bool fs_trial = fs && jac_on_stream2 && dv.n_tiles > 0;      // (no tiles: no trial sweep to publish the back-substitution's end)
+      dv.final_wait = fs_trial ? pass_seq : 0;      // (k_imu_jac(trial) and k_final both look at it)
+      dv.block_wait = fs_trial ? pass_seq : 0;      // (k_imu_block(trial))
       // The Jacobian sweeps at the head of the pass only run when the control record asks for a linearisation: the first pass
       // of a solve.  Afterwards the trial point is evaluated by the same sweeps in trial mode (below), which leave the next
       // linearisation behind if the step is accepted; after a rejected step the old one is still in place.
@@ -722,11 +724,11 @@ struct vc_calibrator {
       if (!serial_weights && jac_on_stream2) {
         // the IMU blocks' final stage (needs the trial poses) beside the vision sweep: the second stream is already past its
         // deltas when the back-substitution ends
-        // (a one-wavefront kernel waits for the flag the first workgroup of k_reproj_jac(trial) sets.  Letting k_imu_jac's own
-        // workgroups wait at their entry saved that kernel's 5 us on the second stream's queue and cost 25 us: 250 workgroups
-        // each invalidating the L2 under the running vision sweep -- measured)
-        if (fs_trial) launch_wait_flag(dv, 2, pass_seq, stream2);
-        else {
+        // (flag hand-overs: k_imu_block(trial), the kernel before it on the second stream, has waited for the flag the first
+        // workgroup of k_reproj_jac(trial) sets -- one thread, before the kernel ended.  Letting k_imu_jac's own workgroups wait
+        // at their entry was tried: 250 workgroups each invalidating the L2 under the running vision sweep, both kernels 2.3x
+        // slower; a waiting kernel of its own costs 5 us on this stream's queue)
+        if (!fs_trial) {
           HIP_OK(hipEventRecord(ev_back, stream));
           HIP_OK(hipStreamWaitEvent(stream2, ev_back, 0));
         }
@@ -734,8 +736,7 @@ struct vc_calibrator {
         if (fs_trial) launch_signal_flag(dv, 3, stream2);
         else HIP_OK(hipEventRecord(ev_weights, stream2));
         KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
-        if (fs_trial) dv.final_wait = pass_seq;                        // k_final waits for the second stream itself
-        else HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0));
+        if (!fs_trial) HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0));      // (flag hand-overs: k_final waits for the second stream itself)
       } else {
         if (!serial_weights) HIP_OK(hipEventRecord(ev_weights, stream2));
         KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
@@ -753,7 +754,7 @@ struct vc_calibrator {
       prev_pass_signals = fs;
       return VC_OK;
     }
-    dv.sync_seq = 0; dv.final_wait = 0;
+    dv.sync_seq = 0; dv.final_wait = 0; dv.block_wait = 0;
     // merged decision (single process): control records alternate, pass k judges pass k-1 at the head of k_frame_schur
     const bool merged = merged_enabled && !use_graphs;      // (a captured graph has fixed kernel arguments)
     dv.shard_src = sharded() ? 1 : 0;
@@ -1133,7 +1134,7 @@ int vc_create(vc_calibrator** out, int device) {
   // flag hand-overs need the two streams on different hardware queues (a waiting kernel at the head of a shared queue would hold
   // its own producer back): only with the second stream in its own priority class; VICALIB_AMD_FLAG_SYNC=0 keeps the events
   { const char* e = std::getenv("VICALIB_AMD_FLAG_SYNC"); if (e && e[0] == '0') h->flag_sync = false; }
-  if (h->flag_sync && (h->d_sync.alloc(4) != hipSuccess || hipMemset(h->d_sync.p, 0, 4 * sizeof(long long)) != hipSuccess)) h->flag_sync = false;
+  if (h->flag_sync && (h->d_sync.alloc(8) != hipSuccess || hipMemset(h->d_sync.p, 0, 8 * sizeof(long long)) != hipSuccess)) h->flag_sync = false;
   *out = h;
   return VC_OK;
 }

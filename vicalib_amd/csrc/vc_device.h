@@ -124,8 +124,9 @@ struct DevView {
   int* flags;                      // [0]: frame Cholesky failures, [1]: reduced Cholesky failure (per pass)
   // cross-stream hand-overs without event records on the main stream (visual-inertial pass, single process): single-workgroup
   // kernels publish the pass number when they are done, a one-wavefront kernel on the second stream waits for it
-  long long* sync_flags;           // [0]: k_final, [1]: k_reduced, [2]: back-substitution done (k_reproj_jac(trial) has started), [3]: second stream's trial-point kernels done
+  long long* sync_flags;           // [0]: k_final, [1]: k_reduced, [2]: back-substitution done (k_reproj_jac(trial) has started), [3]: second stream's trial-point kernels done, [4]: workgroups of k_imu_jac(trial) that have delivered their cost share (a count, back to 0 per pass)
   long long sync_seq;              // this pass's number (0: no signalling)
+  long long block_wait;            // k_imu_block(trial): one thread waits for sync_flags[2] >= block_wait before the kernel ends (0: no)
   long long final_wait;            // k_final waits for sync_flags[3] >= final_wait before it reads the second stream's sums (0: ordered by an event)
   Ctrl* ctrl;
   long long* dbg;                  // 32 cycle-counter stamps (profiling aid)

@@ -73,9 +73,7 @@ __global__ __launch_bounds__(256) void k_imu_delta(DevView v, int trial) {
 // The blocks' deltas: 16 lanes per block (values + 13 dual directions), the block's interval records appended in order.  Poses
 // play no part here either: in a solve this runs behind k_imu_delta, still next to the back-substitution, and leaves one record
 // per block for the sweep.  An empty sample range is flagged by T = -1 in the record.
-__global__ __launch_bounds__(256) void k_imu_block(DevView v, int trial) {
-  const Ctrl* ct = v.ctrl;
-  if (ct->done || (!trial && !ct->need_lin)) return;
+__device__ __forceinline__ void imu_block_body(const DevView& v, const Ctrl* ct, int trial) {
   const int dd = threadIdx.x & 15;
   const int s = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (s >= v.n_frames - 1 || dd >= kDeltaCols) return;
@@ -88,6 +86,15 @@ __global__ __launch_bounds__(256) void k_imu_block(DevView v, int trial) {
   if (!valid) { if (dd == 0) rec[10] = -1.0; return; }
 #pragma unroll
   for (int k = 0; k < 11; ++k) rec[dd * 11 + k] = dd ? der[k] : val[k];
+}
+__global__ __launch_bounds__(256) void k_imu_block(DevView v, int trial) {
+  const Ctrl* ct = v.ctrl;
+  if (ct->done || (!trial && !ct->need_lin)) return;
+  imu_block_body(v, ct, trial);
+  // flag hand-overs, trial point: k_imu_jac behind this kernel needs the main stream's trial poses.  One thread of this kernel
+  // waits for their flag before the kernel ends -- the kernel boundary then orders k_imu_jac behind it like any other kernel,
+  // without a waiting kernel of its own (5 us on this stream's queue, which is the critical one at the end of a small pass)
+  if (trial && v.block_wait > 0 && blockIdx.x == 0 && threadIdx.x == 0) spin_until_flag(v, 2, v.block_wait);
 }
 
 constexpr int kImuJacLds = 34 * 9 + 6;            // [34][9]: the block's 33 local columns and, as a 34th, the residual itself
@@ -152,7 +159,16 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
     __shared__ double s_cost[8];
     if (l == 0) s_cost[wave * 2 + half] = exists ? ct->imu_mult * rho : 0.0;
     __syncthreads();
-    if (threadIdx.x == 0) v.wg_imu_trial[blockIdx.x] = ((s_cost[0] + s_cost[1]) + (s_cost[2] + s_cost[3])) + ((s_cost[4] + s_cost[5]) + (s_cost[6] + s_cost[7]));
+    if (threadIdx.x == 0) {
+      const double wc = ((s_cost[0] + s_cost[1]) + (s_cost[2] + s_cost[3])) + ((s_cost[4] + s_cost[5]) + (s_cost[6] + s_cost[7]));
+      if (v.final_wait > 0) {
+        // flag hand-overs: k_final (main stream) takes the trial cost as soon as every workgroup has delivered its share -- a
+        // device-coherent store and a count, no cache write-back -- and decides while this kernel still writes its records
+        __hip_atomic_store(v.wg_imu_trial + blockIdx.x, wc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);          // the store has been performed before the count moves
+        __hip_atomic_fetch_add(v.sync_flags + 4, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else v.wg_imu_trial[blockIdx.x] = wc;
+    }
   }
   if (!exists) return;
   // J^T J and J^T r of the block in the compact record: entry e = w * <column a, column b> with the residual as column 33

@@ -1558,8 +1558,13 @@ __device__ void final_phase(const DevView& v, int mode, double* red) {
       }
 #pragma unroll 16
       for (int t = tid; t < (v.n_tiles + 3) / 4; t += 256) s[5] += v.wg_trial[t];
+      if (v.final_wait > 0) {      // delivered by device-coherent stores while k_imu_jac still runs (see k_final)
 #pragma unroll 4
-      for (int t = tid; t < (v.n_frames - 1 + 7) / 8; t += 256) s[5] += v.wg_imu_trial[t];
+        for (int t = tid; t < (v.n_frames - 1 + 7) / 8; t += 256) s[5] += __hip_atomic_load(v.wg_imu_trial + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+#pragma unroll 4
+        for (int t = tid; t < (v.n_frames - 1 + 7) / 8; t += 256) s[5] += v.wg_imu_trial[t];
+      }
     } else {
 #pragma unroll 4
       for (int f = tid; f < v.n_frames; f += 256) {
@@ -1616,10 +1621,25 @@ __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
   // behind a cross-stream event (12 us between the second stream's last kernel and this one on the timeline); every wavefront
   // then drops what it may have cached of the other stream's results.  Also when the solve is over: the main stream must not
   // run ahead of the second one.
-  if (v.final_wait > 0) workgroup_wait_flag(v, 3, v.final_wait);
-  if (v.ctrl->done) { if (threadIdx.x == 0) signal_flag(v, 0); return; }
-  final_phase(v, mode, red);
+  //
+  // Two waits: (1) for the count of k_imu_jac's workgroups that have delivered their share of the trial cost -- the decision is
+  // taken while that kernel still writes its records; (2) at the very end, for the flag behind that kernel (k_signal_flag on the
+  // second stream): this kernel must not end before the second stream's results are complete and written back -- the next pass's
+  // k_chain_init reads them, and a solve that is over must leave nothing running.
+  const bool over = v.ctrl->done != 0;
+  if (v.final_wait > 0 && !over && v.n_frames > 1) {
+    if (threadIdx.x == 0) spin_until_flag(v, 4, (long long)((v.n_frames - 1 + 7) / 8));
+    __syncthreads();
+  }
+  if (!over) final_phase(v, mode, red);
   __syncthreads();
+  if (v.final_wait > 0) {
+    if (threadIdx.x == 0) {
+      spin_until_flag(v, 3, v.final_wait);
+      __hip_atomic_store(v.sync_flags + 4, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the count starts over with the next pass
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) signal_flag(v, 0);
 }
 
