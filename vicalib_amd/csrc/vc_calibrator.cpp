@@ -663,6 +663,8 @@ struct vc_calibrator {
       // chain, both trial sweeps, decision -- stays on the main stream: kernels of one stream follow each other without a gap,
       // an event hand-over costs 5-13 us.
       const bool upd = dv.weights_on != 0;
+      // (single process only: with the flags a two-rank visual-inertial solve on one GPU failed its parity test -- two processes'
+      // waiting kernels on one device; left on events until that is understood)
       const bool fs = flag_sync && !serial_weights && !sharded();
       ++pass_seq;
       dv.sync_flags = d_sync.p; dv.sync_seq = fs ? pass_seq : 0; dv.final_wait = 0; dv.block_wait = 0;

@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   __shared__ double s_x2;
   __shared__ CamDesc s_cd[kMaxCams];     // the kernel-argument table costs a scalar memory round trip per (dynamically indexed) access
   const Ctrl* ct = v.ctrl;
-  if (ct->done) { if (threadIdx.x == 0 && mode == 0) signal_flag(v, 1); return; }
+  if (ct->done) { if (threadIdx.x == 0 && mode != 1) signal_flag(v, 1); return; }
   if (threadIdx.x < kMaxCams) s_cd[threadIdx.x] = v.cd[threadIdx.x];
   double pre_sc2 = 1.0, pre_dg = 1.0;      // damping inputs of the small solve: requested now, consumed after phase A
   if (mode != 1) {
@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   }
   if (mode != 2) { schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2, s_cd); __syncthreads(); }
   if (mode != 1) reduced_solve_phase(v, ct, dyn, red, s_cam, pre_sc2, pre_dg, mode == 0 ? &s_x2 : nullptr, s_cd);
-  if (mode == 0) { __syncthreads(); if (threadIdx.x == 0) signal_flag(v, 1); }      // the trial IMU parameters exist (stream B's deltas wait for this)
+  if (mode != 1) { __syncthreads(); if (threadIdx.x == 0) signal_flag(v, 1); }      // the trial IMU parameters exist (stream B's deltas wait for this)
 }
 
 // ------------------------------------------------------------------------------------------ trial point
@@ -1626,12 +1626,15 @@ __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
   // taken while that kernel still writes its records; (2) at the very end, for the flag behind that kernel (k_signal_flag on the
   // second stream): this kernel must not end before the second stream's results are complete and written back -- the next pass's
   // k_chain_init reads them, and a solve that is over must leave nothing running.
+  // Sharded (mode 1: reduce, all-reduce, mode 2: decide): the first wait belongs to the reducing launch, the second wait and the
+  // flag to the deciding one.
   const bool over = v.ctrl->done != 0;
-  if (v.final_wait > 0 && !over && v.n_frames > 1) {
+  if (v.final_wait > 0 && !over && v.n_frames > 1 && mode != 2) {
     if (threadIdx.x == 0) spin_until_flag(v, 4, (long long)((v.n_frames - 1 + 7) / 8));
     __syncthreads();
   }
   if (!over) final_phase(v, mode, red);
+  if (mode == 1) return;
   __syncthreads();
   if (v.final_wait > 0) {
     if (threadIdx.x == 0) {
