@@ -13,10 +13,10 @@ VICALIB_AMD_LIB=$R/tools/probe/libvicalib_amd_f2stamps.so python tools/f2_stamps
 (for spec in "cfg3" "cfg4 2500"; do echo "== $spec"; VICALIB_AMD_LIB=$R/tools/probe/libvicalib_amd_jstamps.so python tools/jac_stamps.py $spec; done) > $O/jac_stamps.txt 2>&1
 tools/perrank_round.sh final > $O/perrank.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU -d $O/pmc -o p -- python $R/bench.py --workload cfg3 --steps 20 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc.err
+VICALIB_AMD_FLAG_SYNC=0 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU -d $O/pmc -o p -- python $R/bench.py --workload cfg3 --steps 20 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc.err
 python $R/tools/rocpd_pmc.py $(ls $O/pmc/*results.db | head -1) > $O/sq_insts_cfg3.txt 2>&1; rm -rf $O/pmc
 # the vision sweep's pipes at the per-rank size of cfg4 (one PMC pass, no tracing beside it)
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VALU -d $O/pmc2 -o p -- python $R/bench.py --workload cfg4 --frames 2500 --steps 20 --warmup 2 --repeats 1 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc2.err
+VICALIB_AMD_FLAG_SYNC=0 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VALU -d $O/pmc2 -o p -- python $R/bench.py --workload cfg4 --frames 2500 --steps 20 --warmup 2 --repeats 1 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc2.err
 python $R/tools/rocpd_pmc.py $(ls $O/pmc2/*results.db | head -1) > $O/sq_sweep_cfg4_2500.txt 2>&1; rm -rf $O/pmc2
 cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.err

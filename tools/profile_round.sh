@@ -10,8 +10,10 @@ ROOT=$PWD
 BENCH="python $ROOT/bench.py --workload $WL --steps 40 --warmup 5 --no-cpu-baseline --no-secondary"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $BENCH > $OUT/bench_traced.json 2> $OUT/trace.err
-rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f -- $BENCH > /dev/null 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w -- $BENCH > /dev/null 2> $OUT/write.err
+# counter passes serialise the kernels of all queues: a kernel that waits for a flag of the other stream would sit there
+# until its bound runs out -- the counter passes therefore run with the event hand-overs (the bytes a kernel moves do not depend on them)
+VICALIB_AMD_FLAG_SYNC=0 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f -- $BENCH > /dev/null 2> $OUT/fetch.err
+VICALIB_AMD_FLAG_SYNC=0 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w -- $BENCH > /dev/null 2> $OUT/write.err
 cd $ROOT
 python tools/rocpd_stats.py $(ls $OUT/trace/*results.db | head -1) > $OUT/kernel_stats.txt
 python tools/pmc_traffic.py $(ls $OUT/fetch/*results.db | head -1) $(ls $OUT/write/*results.db | head -1) $WL $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt
