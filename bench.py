@@ -301,7 +301,8 @@ def main():
     crit_sum = sum(x[1] for x in crit) or 1.0
     critical_path = {"entries": [{"kernel": k, "us_per_step": 1e3 * v, "share": v / crit_sum} for k, v in sorted(crit, key=lambda x: -x[1])],
                      "sum_us_per_step": 1e3 * crit_sum,
-                     "note": "main-stream launch groups; the gap to ms_per_step is event hand-overs between the two streams, the first pass of "
+                     "note": "main-stream launch groups, from an instrumented repeat of the loop (the timing events are barriers of their own on the "
+                             "main stream: with the device-flag hand-overs the sum can exceed ms_per_step); not in the sum: the first pass of "
                              "every solve (both sweeps at the accepted state) and the host's feeding of the passes"}
     nm = "k_reproj_jac(trial)" if "k_reproj_jac(trial)" in kernels else ("k_trial" if "k_trial" in kernels else None)
     roofline_sweep = None
