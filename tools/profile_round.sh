@@ -9,7 +9,9 @@ mkdir -p $OUT
 ROOT=$PWD
 BENCH="python $ROOT/bench.py --workload $WL --steps 40 --warmup 5 --no-cpu-baseline --no-secondary"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $BENCH > $OUT/bench_traced.json 2> $OUT/trace.err
+# (kernel statistics also with the event hand-overs: per-kernel durations do not depend on the hand-over mode, except that with the
+#  flags k_final / k_imu_block contain their waits; the pass timeline -- tools/timeline_round.sh -- is taken with the flags)
+VICALIB_AMD_FLAG_SYNC=0 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $BENCH > $OUT/bench_traced.json 2> $OUT/trace.err
 # counter passes serialise the kernels of all queues: a kernel that waits for a flag of the other stream would sit there
 # until its bound runs out -- the counter passes therefore run with the event hand-overs (the bytes a kernel moves do not depend on them)
 VICALIB_AMD_FLAG_SYNC=0 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f -- $BENCH > /dev/null 2> $OUT/fetch.err
