@@ -1668,6 +1668,7 @@ int vc_time_stages(vc_calibrator* h, int reps, double* out) {
   const int rc_pass = h->enqueue_pass();
   h->merged_enabled = was_merged;
   if (rc_pass) return VC_ERR_NO_DEVICE;
+  h->dv.sync_seq = 0; h->dv.final_wait = 0; h->dv.block_wait = 0;      // the stand-alone launches below neither signal nor wait for the other stream
   EventSet<7> evs;
   if (!evs.create()) return VC_ERR_NO_DEVICE;
   hipEvent_t* ev = evs.e;
