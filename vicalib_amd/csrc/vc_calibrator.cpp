@@ -665,7 +665,7 @@ struct vc_calibrator {
       const bool upd = dv.weights_on != 0;
       // (single process only: with the flags a two-rank visual-inertial solve on one GPU failed its parity test -- two processes'
       // waiting kernels on one device; left on events until that is understood)
-      const bool fs = flag_sync && !serial_weights && !sharded();
+      const bool fs = flag_sync && !serial_weights && !sharded() && !use_graphs;      // (a captured pass has fixed arguments and needs the events to fork the capture)
       ++pass_seq;
       dv.sync_flags = d_sync.p; dv.sync_seq = fs ? pass_seq : 0; dv.final_wait = 0; dv.block_wait = 0;
       const bool fs_trial = fs && jac_on_stream2 && dv.n_tiles > 0;      // (no tiles: no trial sweep to publish the back-substitution's end)
