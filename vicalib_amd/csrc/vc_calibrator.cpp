@@ -868,6 +868,14 @@ struct vc_calibrator {
           // the queue is full: nothing to do until the device decides a pass (~0.3 ms); past ~50 us without news, yield the core
           const auto idle = std::chrono::steady_clock::now() - t_seen;
           if (idle > std::chrono::microseconds(50)) std::this_thread::yield();
+          if (flag_sync && idle > std::chrono::milliseconds(150)) {
+            // no pass of any BASELINE size takes a tenth of this: a device-flag hand-over between the two streams has probably run
+            // into its bound (a tool that serialises the kernels of all queues, or both streams on one hardware queue).  The
+            // step it belonged to is rejected on the device; every pass enqueued from here on uses the event hand-overs.
+            flag_sync = false;
+            std::fprintf(stderr, "vicalib_amd: no LM decision for 150 ms -- a device-flag hand-over between the two streams seems to have run "
+                                 "into its bound; continuing with event hand-overs (VICALIB_AMD_FLAG_SYNC=0 selects them from the start)\n");
+          }
           if (idle > std::chrono::seconds(5)) {          // a stuck device (or a progress word the host cannot see): say so, then
             std::fprintf(stderr, "vicalib_amd: no progress from the device for 5 s (%d passes queued, %d decided) -- falling back to a "
                                  "synchronising read\n", n_enq, decided);                     // fall through to the synchronising read
