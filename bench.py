@@ -220,15 +220,14 @@ def main():
     bytes_res = 18.0 * n_obs_local + n_tiles * (64 + 8)
     imu_samples = len(prob.imu_t) if vi else 0
     # IMU sweep in delta form, counted as the kernels run it (dual number = value + one partial, ~2.5 flop per operation):
-    #   k_imu_delta: one RK4 step from the identity state per sample interval and lane (14 lanes: values + 13 directions), ~4 x 400 flop;
-    #                in 56 B of samples, out a 140-double record
-    #   k_imu_block: per block 14 lanes append its n_meas interval records (~265 flop each); in the records, out a 154-double record
+    #   k_imu_block: per block and column (14: values + 13 directions) one RK4 step from the identity state per sample interval (~4 x 400
+    #                flop) and the ordered product of the interval deltas (~265 flop per append, log-depth scan); in 56 B per sample + the
+    #                IMU parameters, out one 154-double record per block (round 3 wrote and re-read a 140-double record per interval)
     #   k_imu_jac:   per block 30 lanes put the delta on the start state and run the residual's tail (~900 flop each), then the 33 x 33
     #                weighted J^T J (9 x 33 x 33 x 2 flop); in the record, two states, the 9 x 9 weight; out 33 x 33 + 33 + 1 doubles
     n_meas = imu_samples / max(n_imu_blocks, 1) + 2
-    n_int = max(imu_samples - 1, 0) + 2 * n_imu_blocks
-    flops_delta = n_int * 14 * 1600.0 + n_imu_blocks * 14 * n_meas * 265.0
-    bytes_delta = n_int * (56 + 1120.0) + n_imu_blocks * (n_meas * 1120.0 + 154 * 8)
+    flops_delta = n_imu_blocks * 14 * (n_meas - 1) * (1600.0 + 265.0)
+    bytes_delta = imu_samples * 56.0 + n_imu_blocks * (2 * 56 + 15 * 8 + 154 * 8)
     flops_imu = n_imu_blocks * (30 * 900.0 + 9 * 33 * 33 * 2.0)
     bytes_imu = n_imu_blocks * (154 * 8 + 2 * 12 * 8 + 81 * 8 + (33 * 33 + 34) * 8.0)
     # weight update: per RK4 step 16 sensitivity columns through 4 stages (~9 kflop) + Sigma <- F Sigma F^T + G R G^T (~5.2 kflop)
@@ -249,12 +248,12 @@ def main():
     flops_red = D ** 3 / 3.0 + 4.0 * D * D; bytes_red = 2.0 * (D * D + 3 * D) * 8
     algo = {"k_reproj_jac": ("mfma", flops_jac, bytes_jac), "k_trial": ("mfma", flops_jac, bytes_jac + n_tiles * 8 * 96 + n_frames_local * 8 * 48),
             "k_imu_jac": ("fp64-valu", flops_imu, bytes_imu), "k_imu_weights": ("fp64-valu", flops_w, bytes_w),
-            "k_imu_delta+k_imu_block": ("fp64-valu", flops_delta, bytes_delta),
+            "k_imu_block": ("fp64-valu", flops_delta, bytes_delta),
             "k_chain_init": ("hbm", flops_init, bytes_init), "k_chain_fwd": ("fp64-valu", flops_fwd, bytes_fwd),
             "k_chain_back": ("fp64-valu", flops_back, bytes_back), "k_chain_gram": ("mfma", flops_gram, bytes_gram),
             "k_reduced": ("fp64-valu", flops_red, bytes_red)}
     # launch groups that run on the second stream next to the critical path (vc_calibrator.cpp: enqueue_pass)
-    overlapped = {"k_imu_weights", "k_imu_delta+k_imu_block(trial)", "k_imu_delta+k_imu_block", "k_imu_jac"} if vi else set()
+    overlapped = {"k_imu_weights", "k_imu_block(trial)", "k_imu_block", "k_imu_jac"} if vi else set()
     if vi and os.environ.get("VICALIB_AMD_JAC_STREAM2", "1") != "0" and os.environ.get("VICALIB_AMD_OVERLAP_WEIGHTS", "1") != "0":
         overlapped.add("k_imu_jac(trial)")      # beside the vision sweep of the trial point (round 3)
     kernels = {}

@@ -86,38 +86,15 @@ void hh_imu_block(int n, const double* t, const double* w, const double* a, doub
     for (int c = 0; c < 21; ++c) o[12 + c] = Jg[14 + c][row];
   }
 }
-// The same block in the delta form the device runs (vc_imu.hpp: imu_delta_direction for every stored sample interval and the
-// block's two partial intervals, imu_block_delta_direction over the block, then imu_block_final_direction per local column).  Same output layout as hh_imu_block.
+// The same block in the delta form the device runs (vc_imu.hpp: imu_block_delta_record = the block's interval deltas from the
+// identity state -- one dual direction per gyro parameter / the time offset, accelerometer partials analytically --, composed in
+// k_imu_block's bracketing, then imu_block_final_direction per local column).  Same output layout as hh_imu_block.
 void hh_imu_block_deltas(int n, const double* t, const double* w, const double* a, double t_start, double t_end, const double* w_sqrt,
                          int rotation_only, const double* T2, const double* T1, const double* v2, const double* v1, const double* gdir,
                          const double* b, const double* sf, double toff, double* r, double* J) {
   ImuView buf = {t, w, a, n, imu_average_dt(t, n)};
-  std::vector<double> ds((size_t)(n - 1) * kDeltaStride, 0.0), dab(2 * kDeltaStride, 0.0);
-  const ImuRange rg = imu_range(buf, t_start, t_end, toff);
-  for (int i = 0; i + 1 < n; ++i)
-    for (int dd = 0; dd < 13; ++dd) {
-      double val[10], der[10];
-      imu_delta_direction(buf, 0, i, rg, t_start, t_end, b, sf, toff, dd, val, der);
-      for (int k = 0; k < 10; ++k) { if (dd == 0) ds[(size_t)i * kDeltaStride + k] = val[k]; else ds[(size_t)i * kDeltaStride + dd * 10 + k] = der[k]; }
-    }
-  if (rg.valid)
-    for (int kind = 1; kind <= 2; ++kind) {
-      if (kind == 2 && (rg.k1 - rg.k0 + 1) + 2 < 3) continue;
-      for (int dd = 0; dd < 14; ++dd) {
-        double val[10], der[10];
-        imu_delta_direction(buf, kind, 0, rg, t_start, t_end, b, sf, toff, dd, val, der);
-        double* rec = dab.data() + (size_t)(kind - 1) * kDeltaStride;
-        for (int k = 0; k < 10; ++k) { if (dd == 0) rec[k] = val[k]; else rec[dd * 10 + k] = der[k]; }
-      }
-    }
   std::vector<double> blk(kBlockDeltaStride, 0.0);
-  int valid = 0;
-  for (int dd = 0; dd < 14; ++dd) {
-    double val[11], der[11];
-    valid = imu_block_delta_direction(buf, t_start, t_end, toff, ds.data(), dab.data(), dd, val, der);
-    if (!valid) break;
-    for (int k = 0; k < 11; ++k) { if (dd == 0) blk[k] = val[k]; else blk[dd * 11 + k] = der[k]; }
-  }
+  const int valid = imu_block_delta_record(buf, t_start, t_end, toff, b, sf, blk.data());
   for (int oc = 0; oc < 33; ++oc) {
     const int col = oc < 6 ? oc : oc < 12 ? oc + 3 : oc < 15 ? oc - 6 : oc;
     double dr[9];

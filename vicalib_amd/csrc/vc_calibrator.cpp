@@ -223,7 +223,7 @@ struct vc_calibrator {
   DBuf<Ctrl> d_ctrl;
   DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_seg[2], d_seg_cost[2],
       d_cW, d_cdelta, d_ct0, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init, d_rX[2], d_grp_part, d_wg_trial, d_wg_imu_trial,
-      d_imu_delta, d_imu_delta_ab, d_imu_delta_blk;
+      d_imu_delta_blk;
   size_t wsqrt_frames = 0;       // number of frames the device weight_sqrt_ array was initialised for
   size_t imu_uploaded = 0; double imu_uploaded_last = 0.0;      // sample count / last time stamp of the device copy of the IMU samples
   int trace_cap = 0;
@@ -524,7 +524,6 @@ struct vc_calibrator {
         HIP_OK(hipStreamSynchronize(stream));
       }
       for (int b = 0; b < 2; ++b) { HIP_OK(d_seg[b].alloc(ns * kSegStride)); HIP_OK(d_seg_cost[b].alloc(ns)); }
-      HIP_OK(d_imu_delta.alloc((size_t)std::max<size_t>(imu_t.size(), 2) * kDeltaStride)); HIP_OK(d_imu_delta_ab.alloc(ns * 2 * kDeltaStride));
       HIP_OK(d_imu_delta_blk.alloc(ns * kBlockDeltaStride));
       const size_t nf = (size_t)std::max(N, 1);
       {
@@ -539,7 +538,7 @@ struct vc_calibrator {
     dv.imu_t = d_imu_t.p; dv.imu_w = d_imu_w.p; dv.imu_a = d_imu_a.p; dv.frame_time = d_frame_time.p;
     dv.vel[0] = d_vel[0].p; dv.vel[1] = d_vel[1].p; dv.imus[0] = d_imus[0].p; dv.imus[1] = d_imus[1].p;
     dv.wsqrtb[0] = d_wsqrt[0].p; dv.wsqrtb[1] = d_wsqrt[1].p;
-    dv.imu_delta = d_imu_delta.p; dv.imu_delta_ab = d_imu_delta_ab.p; dv.imu_delta_blk = d_imu_delta_blk.p;
+    dv.imu_delta_blk = d_imu_delta_blk.p;
     for (int b = 0; b < 2; ++b) { dv.segb[b] = d_seg[b].p; dv.seg_costb[b] = d_seg_cost[b].p; }
     dv.cW = d_cW.p; dv.cdelta = d_cdelta.p; dv.ct0 = d_ct0.p; dv.cg = d_cg.p;
     dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p;
@@ -681,7 +680,7 @@ struct vc_calibrator {
           HIP_OK(hipStreamWaitEvent(stream2, ev_state, 0));
         }
         if (first_pass) {
-          KT2("k_imu_delta+k_imu_block", launch_imu_delta(dv, stream2, 0)); KT2("k_imu_jac", launch_imu_jac(dv, wcur, stream2, 0));
+          KT2("k_imu_block", launch_imu_delta(dv, stream2, 0)); KT2("k_imu_jac", launch_imu_jac(dv, wcur, stream2, 0));
           HIP_OK(hipEventRecord(ev_imujac, stream2));       // ahead of the weight update: the chain does not read the weights
         }
         if (upd) KT2("k_imu_weights", launch_imu_weights(dv, wcur, stream2));
@@ -693,7 +692,7 @@ struct vc_calibrator {
         if (upd) KT("k_imu_weights", launch_imu_weights(dv, wcur, stream));
         if (first_pass) {
           KT("k_reproj_jac", launch_reproj_jac(dv, stream, 0));
-          KT("k_imu_delta+k_imu_block", launch_imu_delta(dv, stream, 0)); KT("k_imu_jac", launch_imu_jac(dv, wcur, stream, 0));
+          KT("k_imu_block", launch_imu_delta(dv, stream, 0)); KT("k_imu_jac", launch_imu_jac(dv, wcur, stream, 0));
         }
       }
       KT("k_chain_init", launch_chain_init(dv, stream));
@@ -716,7 +715,7 @@ struct vc_calibrator {
           HIP_OK(hipEventRecord(ev_reduced, stream));
           HIP_OK(hipStreamWaitEvent(stream2, ev_reduced, 0));
         }
-        KT2("k_imu_delta+k_imu_block(trial)", launch_imu_delta(dv, stream2, 1));
+        KT2("k_imu_block(trial)", launch_imu_delta(dv, stream2, 1));
       }
       KT("k_chain_back", launch_chain_solve_b(dv, stream));
       // trial point: both sweeps in trial mode on the main stream, the IMU blocks with the weights this pass has just updated
@@ -743,7 +742,7 @@ struct vc_calibrator {
         if (!serial_weights) HIP_OK(hipEventRecord(ev_weights, stream2));
         KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
         if (!serial_weights) HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0));
-        else KT("k_imu_delta+k_imu_block(trial)", launch_imu_delta(dv, stream, 1));
+        else KT("k_imu_block(trial)", launch_imu_delta(dv, stream, 1));
         KT("k_imu_jac(trial)", launch_imu_jac(dv, wcur, stream, 1));
       }
       if (sharded()) {

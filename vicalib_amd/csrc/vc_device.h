@@ -151,11 +151,9 @@ struct DevView {
   // linearisation of the IMU blocks, double-buffered like the state (buffer b belongs to state buffer b)
   double* segb[2];                 // (n_frames-1) x kSegStride: weighted J^T J and J^T r of the block, compact (below)
   double* seg_costb[2];            // (n_frames-1)  imu_mult * rho at the linearisation point
-  // delta form of the sample intervals (vc_imu.hpp, kDeltaStride doubles each): the stored intervals i -> i + 1 and the two partial
-  // intervals at the ends of every block; written by k_imu_delta, composed along the blocks by k_imu_jac
-  double* imu_delta;               // (n_imu - 1) x kDeltaStride
-  double* imu_delta_ab;            // (n_frames - 1) x 2 x kDeltaStride
-  double* imu_delta_blk;           // (n_frames - 1) x kBlockDeltaStride: the intervals of a block appended (k_imu_block); T = -1: empty range
+  // delta form of the IMU blocks (vc_imu.hpp): the block's sample intervals, each an RK4 step from the identity state, appended in
+  // order -- values + 13 partials (biases, scale factors, time offset).  The interval deltas themselves never reach memory
+  double* imu_delta_blk;           // (n_frames - 1) x kBlockDeltaStride, written by k_imu_block, read by k_imu_jac; T = -1: empty range
   // ---- block-tridiagonal frame chain (9 x 9 blocks: pose 6 + velocity 3), cyclic reduction ----------------
   double* cW;                      // n_frames x 9 x ldx, one image per frame: columns 0..D-1 W -> Y = L^-1 W, column D: g -> z, then
                                    // from column ldw three 9 x 9 blocks: C (coupling to the group's left separator) -> X_s = L^-1 C,
@@ -208,7 +206,7 @@ void launch_outlier_mask(const DevView& v, int state, const double* thresh /*dev
 // inertial path (vc_imu_kernels.hip)
 int chain_group_size_upper();    // ... above the bottom level (VICALIB_AMD_CHAIN_M_UPPER)
 int chain_group_size();          // frames per group of the partitioned chain elimination (test hook: VICALIB_AMD_CHAIN_M)
-void launch_imu_delta(const DevView& v, hipStream_t s, int trial = 0);         // interval and block deltas under the IMU parameters of the accepted (0) / trial (1) state (two launches)
+void launch_imu_delta(const DevView& v, hipStream_t s, int trial = 0);         // block deltas under the IMU parameters of the accepted (0) / trial (1) state (k_imu_block)
 void launch_imu_jac(const DevView& v, int wr, hipStream_t s, int trial = 0);   // wr: weight buffer to read; trial as for launch_reproj_jac; needs launch_imu_delta
 void launch_imu_weights(const DevView& v, int wr, hipStream_t s);          // reads wsqrtb[wr], writes wsqrtb[1 - wr];                   // weight_sqrt_ from the accepted state
 void launch_chain_solve_a(const DevView& v, hipStream_t s);                 // the three below in a row: assemble + partitioned elimination + Gram partials

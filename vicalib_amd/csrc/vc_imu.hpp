@@ -255,46 +255,57 @@ template <class T> VC_HD void imu_range_get_flat(const ImuView& b, const ImuRang
 
 // ---- RK4 (ceres-cost-functions.h:39-177) --------------------------------------------------------------
 template <class T> struct PoseV { T q[4], p[3], v[3]; };
-template <class T> VC_HD void imu_integrate_pose(const PoseV<T>& s, const T* k, T dt, PoseV<T>* y) {
+template <class T, class M> VC_HD void imu_integrate_pose(const PoseV<T>& s, const T* k, M dt, PoseV<T>* y) {
   const T wdt[3] = {k[3] * dt, k[4] * dt, k[5] * dt};
   T rq[4];
   tso3_exp(wdt, rq);
   for (int i = 0; i < 3; ++i) { y->p[i] = s.p[i] + k[i] * dt; y->v[i] = s.v[i] + k[6 + i] * dt; }
   tq_mul(rq, s.q, y->q);
 }
-template <class T> VC_HD void imu_pose_derivative(const PoseV<T>& s, const T* g_w, const Meas<T>& z0, const Meas<T>& z1,
-                                                 const T* b, const T* sf, T dt, T* k) {
-  const T alpha = (z1.time - (z0.time + dt)) / (z1.time - z0.time);
-  const T oma = 1.0 - alpha;
+// The gyro / accelerometer model u = measurement * scale factor + bias (ceres-cost-functions.h:93-100) behind a small accessor.
+// The measurements' scalar type M may be plainer than the state's T: along a bias / scale-factor direction the samples, their
+// times and the interpolation weights carry no derivative at all (M = double under T = D1), only the time-offset direction moves them.
+template <class T> struct ImuParamsPtr {
+  const T* b; const T* sf;
+  template <class X> VC_HD auto apply(int i, X x) const -> decltype(x * sf[i] + b[i]) { return x * sf[i] + b[i]; }
+};
+template <class T, class M, class P> VC_HD void imu_pose_derivative(const PoseV<T>& s, const T* g_w, const Meas<M>& z0, const Meas<M>& z1,
+                                                                   const P& par, M dt, T* k) {
+  const M alpha = (z1.time - (z0.time + dt)) / (z1.time - z0.time);
+  const M oma = 1.0 - alpha;
   T u[3], o[3];
   for (int i = 0; i < 3; ++i) k[i] = s.v[i];
-  for (int i = 0; i < 3; ++i) u[i] = (z0.w[i] * alpha + z1.w[i] * oma) * sf[i] + b[i];
+  for (int i = 0; i < 3; ++i) u[i] = par.apply(i, z0.w[i] * alpha + z1.w[i] * oma);
   tq_matvec(s.q, u, o);
   for (int i = 0; i < 3; ++i) k[3 + i] = o[i];
-  for (int i = 0; i < 3; ++i) u[i] = (z0.a[i] * alpha + z1.a[i] * oma) * sf[3 + i] + b[3 + i];
+  for (int i = 0; i < 3; ++i) u[i] = par.apply(3 + i, z0.a[i] * alpha + z1.a[i] * oma);
   tq_rotate(s.q, u, o);
   for (int i = 0; i < 3; ++i) k[6 + i] = o[i] - g_w[i];
 }
-template <class T> VC_HD void imu_rk4_step(PoseV<T>* s, const Meas<T>& z0, const Meas<T>& z1, const T* b, const T* sf, const T* g_w) {
+template <class T, class M, class P> VC_HD void imu_rk4_step_p(PoseV<T>* s, const Meas<M>& z0, const Meas<M>& z1, const P& par, const T* g_w) {
   if (val(z1.time) == val(z0.time)) return;       // :150-152
-  const T dt = z1.time - z0.time;
+  const M dt = z1.time - z0.time;
   // k1 + 2 k2 + 2 k3 + k4 as a running sum in that order (bit-identical to summing at the end): one stage vector and the sum
   // are live instead of all four -- 27 fewer values per lane, 54 under dual numbers, which is what kept k_imu_jac in scratch
   T k[9], ks[9];
   PoseV<T> y;
-  imu_pose_derivative(*s, g_w, z0, z1, b, sf, cst<T>(0.0), k);
+  imu_pose_derivative(*s, g_w, z0, z1, par, cst<M>(0.0), k);
   for (int i = 0; i < 9; ++i) ks[i] = k[i];
   imu_integrate_pose(*s, k, dt * 0.5, &y);
-  imu_pose_derivative(y, g_w, z0, z1, b, sf, dt / 2.0, k);
+  imu_pose_derivative(y, g_w, z0, z1, par, dt / 2.0, k);
   for (int i = 0; i < 9; ++i) ks[i] = ks[i] + 2.0 * k[i];
   imu_integrate_pose(*s, k, dt * 0.5, &y);
-  imu_pose_derivative(y, g_w, z0, z1, b, sf, dt / 2.0, k);
+  imu_pose_derivative(y, g_w, z0, z1, par, dt / 2.0, k);
   for (int i = 0; i < 9; ++i) ks[i] = ks[i] + 2.0 * k[i];
   imu_integrate_pose(*s, k, dt, &y);
-  imu_pose_derivative(y, g_w, z0, z1, b, sf, dt, k);
+  imu_pose_derivative(y, g_w, z0, z1, par, dt, k);
   for (int i = 0; i < 9; ++i) k[i] = ks[i] + k[i];
   imu_integrate_pose(*s, k, dt / 6.0, &y);
   *s = y;
+}
+template <class T> VC_HD void imu_rk4_step(PoseV<T>* s, const Meas<T>& z0, const Meas<T>& z1, const T* b, const T* sf, const T* g_w) {
+  const ImuParamsPtr<T> par = {b, sf};
+  imu_rk4_step_p(s, z0, z1, par, g_w);
 }
 // types.h:94-104
 template <class T> VC_HD void imu_gravity(const T* dir, T* out) {
@@ -393,34 +404,11 @@ VC_HD void imu_block_direction(const ImuView& buf, double t_start, double t_end,
 // the left-multiplied exponential of the world-frame rate is exp(R(q) u h) q = q exp(u h), Runge-Kutta schemes are
 // affine-equivariant, and the contributions of v and g are polynomials of degree <= 2 in time, which RK4 integrates exactly.
 // The deltas depend on the samples, biases and scale factors and -- the two partial intervals at the ends of a block -- on the
-// time offset, not on any pose: they are formed for all intervals in parallel (k_imu_delta), and a block then costs one
-// composition per interval (k_imu_jac) instead of a dependent RK4 step under dual numbers.  Equal to imu_residual up to
+// time offset, not on any pose: they are formed for all intervals in parallel and composed by a scan (k_imu_block, in
+// registers), and a block then costs one application of its delta to the start state (k_imu_jac) instead of a dependent RK4
+// chain under dual numbers.  Equal to imu_residual up to
 // rounding (tests/test_device_math_cpu.py compares the two and the oracle).
 constexpr int kDeltaCols = 14;                    // value | d/db (6) | d/dsf (6) | d/dtoff
-constexpr int kDeltaStride = kDeltaCols * 10;     // one interval: [column][dq 4, dp 3, dv 3]
-
-// Interval kinds: 0 = stored samples i -> i + 1; 1 = first interval of a block (range elements 0 -> 1); 2 = its last interval
-// (elements n_meas - 2 -> n_meas - 1; only when n_meas >= 3).  dd: 0 = values only, 1..6 bias, 7..12 scale factor, 13 time offset.
-VC_HD void imu_delta_direction(const ImuView& buf, int kind, int i, const ImuRange& rg, double t_start, double t_end, const double* b,
-                               const double* sf, double toff, int dd, double* value /* 10 */, double* deriv /* 10 */) {
-  D1 bD[6], sD[6];
-  for (int k = 0; k < 6; ++k) { bD[k] = mk(b[k], dd == 1 + k ? 1.0 : 0.0); sD[k] = mk(sf[k], dd == 7 + k ? 1.0 : 0.0); }
-  const D1 offD = mk(toff, dd == 13 ? 1.0 : 0.0);
-  Meas<D1> z0, z1;
-  if (kind == 0) { imu_shift(buf, i, offD, &z0); imu_shift(buf, i + 1, offD, &z1); }
-  else {
-    const int m = (kind == 1) ? 1 : (rg.k1 - rg.k0 + 1) + 1;
-    imu_range_get(buf, rg, offD, t_start, t_end, m - 1, &z0);
-    imu_range_get(buf, rg, offD, t_start, t_end, m, &z1);
-  }
-  PoseV<D1> d;
-  for (int k = 0; k < 3; ++k) { d.q[k] = mk(0.0); d.p[k] = mk(0.0); d.v[k] = mk(0.0); }
-  d.q[3] = mk(1.0);
-  const D1 g0[3] = {mk(0.0), mk(0.0), mk(0.0)};
-  imu_rk4_step(&d, z0, z1, bD, sD, g0);
-  for (int k = 0; k < 4; ++k) { value[k] = d.q[k].a; deriv[k] = d.q[k].v; }
-  for (int k = 0; k < 3; ++k) { value[4 + k] = d.p[k].a; deriv[4 + k] = d.p[k].v; value[7 + k] = d.v[k].a; deriv[7 + k] = d.v[k].v; }
-}
 
 // Deltas accumulate without reference to a pose: appending the interval (dq, dp, dv; dt) to the block's running delta (Q, P, V; T),
 //     P <- P + V dt + R(Q) dp,   V <- V + R(Q) dv,   Q <- Q dq,   T <- T + dt,
@@ -438,75 +426,178 @@ template <class T> VC_HD void imu_delta_append(DeltaAcc<T>* A, const PoseV<T>& d
   for (int i = 0; i < 4; ++i) A->q[i] = q[i];
   A->t = A->t + dt;
 }
+// a <- a followed by x (appending is associative: the block's delta is the ordered product of its intervals' deltas, in any bracketing)
+template <class T> VC_HD void imu_delta_then(DeltaAcc<T>* a, const DeltaAcc<T>& x) {
+  PoseV<T> d;
+  for (int k = 0; k < 4; ++k) d.q[k] = x.q[k];
+  for (int k = 0; k < 3; ++k) { d.p[k] = x.p[k]; d.v[k] = x.v[k]; }
+  imu_delta_append(a, d, x.t);
+}
+template <class T> VC_HD void imu_delta_identity(DeltaAcc<T>* a) {
+  for (int k = 0; k < 3; ++k) { a->q[k] = cst<T>(0.0); a->p[k] = cst<T>(0.0); a->v[k] = cst<T>(0.0); }
+  a->q[3] = cst<T>(1.0); a->t = cst<T>(0.0);
+}
 constexpr int kBlockDeltaStride = kDeltaCols * 11;     // one block: [column][Q 4, P 3, V 3, T]
 
-struct DeltaRec { double v[10], d[10]; };
-// (unconditional loads, the partial selected afterwards: a conditional load is a branch around every element on the device)
-VC_HD void imu_delta_load(const double* rec, int dcol, DeltaRec* o) {
-  for (int k = 0; k < 10; ++k) { o->v[k] = rec[k]; const double d = rec[dcol * 10 + k]; o->d[k] = (dcol > 0) ? d : 0.0; }
-}
-// Part `part` of `n_parts` of the block's delta along direction dd (as imu_delta_direction): the block's intervals cut into
-// n_parts contiguous runs, the run's intervals appended in order from the identity (appending is associative; the kernel runs
-// one part -- splitting a block over lane groups bought nothing, the kernel waits on dependent loads, not on the appends).
-// The records are requested three intervals ahead of their use (registers A, B, C in rotation).  Returns 0 for an empty range.
-VC_HD int imu_block_delta_part(const ImuView& buf, double t_start, double t_end, double toff, const double* delta_samples,
-                               const double* delta_ab, int dd, int part, int n_parts, DeltaAcc<D1>* acc_out) {
-  const ImuRange rg = imu_range(buf, t_start, t_end, toff);
-  if (!rg.valid) return 0;
-  const D1 offD = mk(toff, dd == 13 ? 1.0 : 0.0);
-  const int dcol_s = (dd < 13) ? dd : 0;               // stored intervals do not move with the offset
-  const int n_meas = (rg.k1 - rg.k0 + 1) + 2, n_steps = n_meas - 1;
-  // interval m (1 .. n_meas - 1) runs from range element m - 1 to m: the first is the block's record 0, the last (when there are
-  // interior samples) its record 1, those in between the stored intervals k0 + m - 2
-  const int m_lo = 1 + (part * n_steps) / n_parts, m_hi = 1 + ((part + 1) * n_steps) / n_parts;      // [m_lo, m_hi)
-  auto request = [&](int m, DeltaRec* o) {
-    // one address, one column, no branch: a request past the run re-reads the block's last interval (never used)
-    const int mc = m < n_meas - 1 ? m : n_meas - 1;
-    const bool ends = (mc == 1) || (mc == n_meas - 1);
-    const double* rec = (mc == 1) ? delta_ab : (mc == n_meas - 1) ? delta_ab + kDeltaStride
-                                                                   : delta_samples + (size_t)(rg.k0 + mc - 2) * kDeltaStride;
-    imu_delta_load(rec, ends ? dd : dcol_s, o);
-  };
-  DeltaRec A, B, C;
-  for (int k = 0; k < 10; ++k) { A.v[k] = A.d[k] = B.v[k] = B.d[k] = C.v[k] = C.d[k] = 0.0; }
-  request(m_lo, &A); request(m_lo + 1, &B); request(m_lo + 2, &C);
-  DeltaAcc<D1> acc;
-  for (int k = 0; k < 3; ++k) { acc.q[k] = mk(0.0); acc.p[k] = mk(0.0); acc.v[k] = mk(0.0); }
-  acc.q[3] = mk(1.0); acc.t = mk(0.0);
-  Meas<D1> zt;
-  D1 t_prev;
-  if (m_lo == 1) { imu_range_get(buf, rg, offD, t_start, t_end, 0, &zt); t_prev = zt.time; }
-  else t_prev = buf.t[rg.k0 + m_lo - 2] + offD;                 // element m_lo - 1 is an interior sample
-  auto step = [&](int m, DeltaRec* X) {
-    if (m >= m_hi) return;
-    D1 t_now;
-    if (m == n_meas - 1) { imu_range_get(buf, rg, offD, t_start, t_end, m, &zt); t_now = zt.time; }
-    else t_now = buf.t[rg.k0 + m - 1] + offD;
-    const D1 dt = t_now - t_prev;
-    if (dt.a != 0.0) {           // (a zero-length interval is skipped, imu_rk4_step)
-      PoseV<D1> d;
-      for (int k = 0; k < 4; ++k) d.q[k] = mk(X->v[k], X->d[k]);
-      for (int k = 0; k < 3; ++k) { d.p[k] = mk(X->v[4 + k], X->d[4 + k]); d.v[k] = mk(X->v[7 + k], X->d[7 + k]); }
-      imu_delta_append(&acc, d, dt);
+// ---- the block's delta record as k_imu_block forms it ------------------------------------------------------------------------
+// One interval: m = 1 .. n_int runs from range element m - 1 to element m (the first and the last are the partial intervals at the
+// frame times, those in between stored sample pairs).  Its RK4 step from the identity state without gravity, written out
+// (the stage states of imu_rk4_step_p from s = identity: the products with the identity quaternion are exact):
+//     w1 = ug(t0)                                 q1 = exp(w1 h/2)
+//     w2 = R(q1) ug(tm),  a2 = q1 * ua(tm)        q2 = exp(w2 h/2)
+//     w3 = R(q2) ug(tm),  a3 = q2 * ua(tm)        q3 = exp(w3 h)
+//     w4 = R(q3) ug(t1),  a4 = q3 * ua(t1)
+//     dq = exp((w1 + 2 w2 + 2 w3 + w4) h/6),  dv = (ua(t0) + 2 a2 + 2 a3 + a4) h/6,  dp = (2 ua(t0) h/2 + 2 a2 h/2 + a3 h) h/6
+// with ug = gyro sample * scale factor + bias, ua likewise (ceres-cost-functions.h:93-100), the samples interpolated at t0, the
+// midpoint and t1 (weights 1, 1/2, 0: the interpolation weight of :89 does not depend on anything that is optimised).
+// One dual direction rides along (D1): gyro bias / scale factor `gsel` (0..2 / 3..5), or -- gsel >= 6 with off.v = 1 -- the time
+// offset, which moves the interpolated end samples and the interval's length.  The ACCELEROMETER parameters need no dual
+// number: dq does not depend on them and dv, dp are linear in ua, so the partials along accelerometer bias / scale factor
+// gsel are sums of the stage rotations' columns (ap, av: values only, ~100 flop instead of a second dual pass).
+struct IntervalDeltaGA { DeltaAcc<D1> d; double ap[3], av[3]; };
+VC_HD void imu_interval_delta_ga(const ImuView& buf, const ImuRange& rg, D1 off, double t_start, double t_end, int m, int n_int,
+                                 const double* b, const double* sf, int gsel, IntervalDeltaGA* X) {
+  imu_delta_identity(&X->d);
+  for (int i = 0; i < 3; ++i) { X->ap[i] = 0.0; X->av[i] = 0.0; }
+  const int kk = gsel < 3 ? gsel : (gsel < 6 ? gsel - 3 : 0);
+  const bool seeded = gsel < 6, scale = gsel >= 3;
+  // the model inputs at t0 (they become the running sums' first terms) and t1, formed as soon as the samples are there: the
+  // samples themselves -- 28 doubles under the dual direction -- are not kept.  The midpoint's inputs are the mean of the two (the
+  // model is affine in the sample; the mean of the seeds is the midpoint sample's seed).
+  D1 ws[3], vs[3], ug1[3], ua1[3], h;
+  double c0, c1;                                   // component kk of the accelerometer samples at t0, t1 (scale factor) or 1 (bias)
+  {
+    Meas<D1> z0, z1;
+    for (int k = 0; k < 3; ++k) { z0.w[k] = z0.a[k] = z1.w[k] = z1.a[k] = mk(0.0); }
+    z0.time = z1.time = mk(0.0);
+    if (m <= n_int) { imu_range_get_flat(buf, rg, off, t_start, t_end, m - 1, &z0); imu_range_get_flat(buf, rg, off, t_start, t_end, m, &z1); }
+    if (z1.time.a == z0.time.a) return;            // a zero-length interval is skipped (:150-152), and so is m > n_int
+    h = z1.time - z0.time;
+    for (int i = 0; i < 3; ++i) {
+      const double s0 = (seeded && i == kk) ? (scale ? z0.w[i].a : 1.0) : 0.0, s1 = (seeded && i == kk) ? (scale ? z1.w[i].a : 1.0) : 0.0;
+      ws[i] = mk(z0.w[i].a * sf[i] + b[i], z0.w[i].v * sf[i] + s0);
+      ug1[i] = mk(z1.w[i].a * sf[i] + b[i], z1.w[i].v * sf[i] + s1);
+      vs[i] = mk(z0.a[i].a * sf[3 + i] + b[3 + i], z0.a[i].v * sf[3 + i]);
+      ua1[i] = mk(z1.a[i].a * sf[3 + i] + b[3 + i], z1.a[i].v * sf[3 + i]);
     }
-    t_prev = t_now;
-    request(m + 3, X);
-  };
-  for (int m = m_lo; m < m_hi; m += 3) { step(m, &A); step(m + 1, &B); step(m + 2, &C); }
-  *acc_out = acc;
-  return 1;
+    // (selected, not indexed: a run-time index would put the arrays into scratch memory on the device)
+    c0 = scale ? (kk == 0 ? z0.a[0].a : kk == 1 ? z0.a[1].a : z0.a[2].a) : 1.0;
+    c1 = scale ? (kk == 0 ? z1.a[0].a : kk == 1 ? z1.a[1].a : z1.a[2].a) : 1.0;
+  }
+  const D1 hh = h * 0.5, h6 = h / 6.0;
+  const double cm = 0.5 * c0 + 0.5 * c1;
+  const double e[3] = {kk == 0 ? 1.0 : 0.0, kk == 1 ? 1.0 : 0.0, kk == 2 ? 1.0 : 0.0};
+  // running sums k1 + 2 k2 + 2 k3 + k4 in that order (ws, vs start as k1); sv, sp: the same sums for
+  // d ua / d (accelerometer parameter kk) = c(t) e_kk -- the stage rotations' columns, values only
+  D1 ugm[3], uam[3], ps[3], wk[3], ak[3], t[3], q[4];
+  double sv[3], sp[3], r[3], qa[4];
+  for (int i = 0; i < 3; ++i) {                    // stage 1: w1 = ug(t0), a1 = ua(t0)
+    ugm[i] = ws[i] * 0.5 + ug1[i] * 0.5;
+    uam[i] = vs[i] * 0.5 + ua1[i] * 0.5;
+    ps[i] = 2.0 * (vs[i] * hh);
+    sv[i] = c0 * e[i]; sp[i] = 2.0 * (c0 * e[i] * hh.a);
+    t[i] = ws[i] * hh;
+  }
+  tso3_exp(t, q);
+  tq_matvec(q, ugm, wk);                           // stage 2
+  tq_rotate(q, uam, ak);
+  for (int i = 0; i < 4; ++i) qa[i] = q[i].a;
+  tq_rotate(qa, e, r);
+  for (int i = 0; i < 3; ++i) {
+    ws[i] = ws[i] + 2.0 * wk[i]; vs[i] = vs[i] + 2.0 * ak[i]; ps[i] = ps[i] + 2.0 * (ak[i] * hh);
+    sv[i] = sv[i] + 2.0 * (cm * r[i]); sp[i] = sp[i] + 2.0 * (cm * r[i] * hh.a);
+    t[i] = wk[i] * hh;
+  }
+  tso3_exp(t, q);
+  tq_matvec(q, ugm, wk);                           // stage 3
+  tq_rotate(q, uam, ak);
+  for (int i = 0; i < 4; ++i) qa[i] = q[i].a;
+  tq_rotate(qa, e, r);
+  for (int i = 0; i < 3; ++i) {
+    ws[i] = ws[i] + 2.0 * wk[i]; vs[i] = vs[i] + 2.0 * ak[i]; ps[i] = ps[i] + ak[i] * h;
+    sv[i] = sv[i] + 2.0 * (cm * r[i]); sp[i] = sp[i] + cm * r[i] * h.a;
+    t[i] = wk[i] * h;
+  }
+  tso3_exp(t, q);
+  tq_matvec(q, ug1, wk);                           // stage 4
+  tq_rotate(q, ua1, ak);
+  for (int i = 0; i < 4; ++i) qa[i] = q[i].a;
+  tq_rotate(qa, e, r);
+  for (int i = 0; i < 3; ++i) {
+    ws[i] = ws[i] + wk[i]; vs[i] = vs[i] + ak[i];
+    sv[i] = sv[i] + c1 * r[i];
+    t[i] = ws[i] * h6;
+    X->d.v[i] = vs[i] * h6;
+    X->d.p[i] = ps[i] * h6;
+    X->av[i] = sv[i] * h6.a;
+    X->ap[i] = sp[i] * h6.a;
+  }
+  tso3_exp(t, X->d.q);
+  X->d.t = h;
 }
-VC_HD void imu_delta_unpack(const DeltaAcc<D1>& acc, double* value /* 11 */, double* deriv /* 11 */) {
-  for (int k = 0; k < 4; ++k) { value[k] = acc.q[k].a; deriv[k] = acc.q[k].v; }
-  for (int k = 0; k < 3; ++k) { value[4 + k] = acc.p[k].a; deriv[4 + k] = acc.p[k].v; value[7 + k] = acc.v[k].a; deriv[7 + k] = acc.v[k].v; }
-  value[10] = acc.t.a; deriv[10] = acc.t.v;
+// a <- a followed by x, with the accelerometer partials (Q carries none: dP' = dP + dV dt + R(Q) dp, dV' = dV + R(Q) dv)
+VC_HD void imu_delta_ga_then(IntervalDeltaGA* A, const IntervalDeltaGA& X) {
+  const double qa[4] = {A->d.q[0].a, A->d.q[1].a, A->d.q[2].a, A->d.q[3].a};
+  double rp[3], rv[3];
+  tq_rotate(qa, X.ap, rp);
+  tq_rotate(qa, X.av, rv);
+  for (int i = 0; i < 3; ++i) {
+    A->ap[i] = (A->ap[i] + A->av[i] * X.d.t.a) + rp[i];
+    A->av[i] = A->av[i] + rv[i];
+  }
+  imu_delta_then(&A->d, X.d);
 }
-// The whole block along direction dd: values and partials of (Q, P, V, T).
-VC_HD int imu_block_delta_direction(const ImuView& buf, double t_start, double t_end, double toff, const double* delta_samples,
-                                    const double* delta_ab, int dd, double* value /* 11 */, double* deriv /* 11 */) {
-  DeltaAcc<D1> a;
-  if (!imu_block_delta_part(buf, t_start, t_end, toff, delta_samples, delta_ab, dd, 0, 1, &a)) return 0;
-  imu_delta_unpack(a, value, deriv);
+// Record columns (k_imu_jac's dcol): 0 values | 1..3 gyro bias | 4..6 accelerometer bias | 7..9 gyro scale | 10..12 accelerometer
+// scale | 13 time offset.  Group g of the kernel (8 lanes) carries dual direction g (0..5: gyro parameter g, 6: time offset) and the
+// accelerometer parameter g beside it.
+VC_HD int imu_group_dual_col(int g) { return g < 3 ? 1 + g : (g < 6 ? 4 + g : 13); }
+VC_HD int imu_group_accel_col(int g) { return g < 3 ? 4 + g : 7 + g; }
+// what lane 7 of group g stores once the block's delta has been composed
+VC_HD void imu_block_record_store(const IntervalDeltaGA& X, int g, double* rec) {
+  if (g > 6) return;
+  double* cd = rec + imu_group_dual_col(g) * 11;
+  for (int k = 0; k < 4; ++k) cd[k] = X.d.q[k].v;
+  for (int k = 0; k < 3; ++k) { cd[4 + k] = X.d.p[k].v; cd[7 + k] = X.d.v[k].v; }
+  cd[10] = X.d.t.v;
+  if (g < 6) {
+    double* ca = rec + imu_group_accel_col(g) * 11;
+    for (int k = 0; k < 4; ++k) ca[k] = 0.0;
+    for (int k = 0; k < 3; ++k) { ca[4 + k] = X.ap[k]; ca[7 + k] = X.av[k]; }
+    ca[10] = 0.0;
+  }
+  if (g == 0) {
+    for (int k = 0; k < 4; ++k) rec[k] = X.d.q[k].a;
+    for (int k = 0; k < 3; ++k) { rec[4 + k] = X.d.p[k].a; rec[7 + k] = X.d.v[k].a; }
+    rec[10] = X.d.t.a;
+  }
+}
+// Host form of k_imu_block, for tests/host_harness: the same bracketing -- rounds of 16 intervals, lane l of a group takes
+// intervals 2 l + 1, 2 l + 2 of the round and appends them, a Hillis-Steele inclusive scan over the group's 8 lanes, the rounds'
+// totals appended in order.  Returns 0 for an empty sample range (the kernel flags it by T = -1 in the record).
+inline int imu_block_delta_record(const ImuView& buf, double t_start, double t_end, double toff, const double* b, const double* sf,
+                                  double* rec /* kBlockDeltaStride */) {
+  const ImuRange rg = imu_range(buf, t_start, t_end, toff);
+  if (!rg.valid) { rec[10] = -1.0; return 0; }
+  const int n_int = (rg.k1 - rg.k0 + 1) + 1;
+  for (int g = 0; g < 7; ++g) {
+    const D1 offD = mk(toff, g == 6 ? 1.0 : 0.0);
+    IntervalDeltaGA carry;
+    for (int base = 0; base < n_int; base += 16) {
+      IntervalDeltaGA X[8], Y[8];
+      for (int l = 0; l < 8; ++l) {
+        IntervalDeltaGA second;
+        imu_interval_delta_ga(buf, rg, offD, t_start, t_end, base + 2 * l + 1, n_int, b, sf, g, &X[l]);
+        imu_interval_delta_ga(buf, rg, offD, t_start, t_end, base + 2 * l + 2, n_int, b, sf, g, &second);
+        imu_delta_ga_then(&X[l], second);
+      }
+      for (int n = 1; n < 8; n <<= 1) {
+        for (int l = 0; l < 8; ++l) { Y[l] = X[l]; if (l >= n) { Y[l] = X[l - n]; imu_delta_ga_then(&Y[l], X[l]); } }
+        for (int l = 0; l < 8; ++l) X[l] = Y[l];
+      }
+      if (base == 0) carry = X[7]; else imu_delta_ga_then(&carry, X[7]);
+    }
+    imu_block_record_store(carry, g, rec);
+  }
   return 1;
 }
 

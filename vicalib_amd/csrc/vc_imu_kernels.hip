@@ -4,9 +4,9 @@
 // coupled, so the per-frame elimination of the vision-only path becomes the factorisation of a
 // block-tridiagonal chain (9 x 9 blocks: pose 6 + velocity 3) bordered by the shared parameters.
 //
-//  k_imu_delta     one RK4 step from the identity state per sample interval, 14 lanes each (values + 13 dual directions of the
-//                  biases / scale factors / time offset): the part of the preintegration that does not depend on any pose
-//  k_imu_block     the intervals of every block appended into the block's delta, 14 lanes per block
+//  k_imu_block     the part of the preintegration that does not depend on any pose, one wavefront per block: eight lanes per dual
+//                  direction (gyro biases / scale factors, time offset; accelerometer parameters analytically beside them), lane =
+//                  two sample intervals (RK4 steps from the identity state), inclusive DPP scan over the eight lanes
 //  k_imu_jac       half a wavefront per IMU block; lane = local column of the block, carried as a dual number through the
 //                  application of the block's delta to the start state and the residual's tail -- the lane-parallel form of
 //                  ceres::Jet<double,35> (vc_imu.hpp, "delta form"); then Cauchy(100) weight and the 33 x 33 weighted
@@ -33,70 +33,6 @@ namespace vc {
 __device__ __forceinline__ ImuView imu_view(const DevView& v) { ImuView b = {v.imu_t, v.imu_w, v.imu_a, v.n_imu, v.imu_avg_dt}; return b; }
 
 // ------------------------------------------------------------------------------------------ IMU Jacobian
-// Interval deltas (vc_imu.hpp, "delta form"): 16 lanes per interval, lane dd carries the values (dd = 0) or one derivative
-// direction (biases, scale factors, time offset) through one RK4 step from the identity state.  Intervals: the stored sample
-// intervals that fall inside the frames' time span, then two partial intervals per block.  Depends on the shared IMU parameters
-// only -- in a solve it runs behind the reduced solve, next to the chain's back-substitution.
-__global__ __launch_bounds__(256) void k_imu_delta(DevView v, int trial) {
-  const Ctrl* ct = v.ctrl;
-  if (ct->done || (!trial && !ct->need_lin)) return;
-  const int dd = threadIdx.x & 15;
-  const int g = blockIdx.x * 16 + (threadIdx.x >> 4);
-  const int n_s = v.n_imu - 1, n_blocks = v.n_frames - 1;
-  if (g >= n_s + 2 * n_blocks || dd >= kDeltaCols) return;
-  const int cur = trial ? 1 - ct->cur : ct->cur;
-  const double* im = v.imus[cur];
-  const double toff = im[14];
-  const ImuView buf = imu_view(v);
-  ImuRange rg; rg.valid = 0; rg.k0 = 0; rg.k1 = -1; rg.i0 = rg.i1 = 0; rg.first_end = rg.last_end = 0;
-  int kind = 0, i = g;
-  double t_start = 0.0, t_end = 0.0;
-  double* rec;
-  if (g < n_s) {
-    // a stored interval outside the span of the frames belongs to no block
-    if (dd == 13 || v.imu_t[g + 1] + toff < v.frame_time[0] || v.imu_t[g] + toff > v.frame_time[v.n_frames - 1]) return;
-    rec = v.imu_delta + (size_t)g * kDeltaStride;
-  } else {
-    const int e = g - n_s, s = e >> 1;
-    kind = 1 + (e & 1); i = 0;
-    t_start = v.frame_time[s]; t_end = v.frame_time[s + 1];
-    rg = imu_range(buf, t_start, t_end, toff);
-    if (!rg.valid || (kind == 2 && rg.k1 - rg.k0 + 1 < 1)) return;
-    rec = v.imu_delta_ab + (size_t)e * kDeltaStride;
-  }
-  double val[10], der[10];
-  imu_delta_direction(buf, kind, i, rg, t_start, t_end, im + 2, im + 8, toff, dd, val, der);
-#pragma unroll
-  for (int k = 0; k < 10; ++k) rec[dd * 10 + k] = dd ? der[k] : val[k];
-}
-
-// The blocks' deltas: 16 lanes per block (values + 13 dual directions), the block's interval records appended in order.  Poses
-// play no part here either: in a solve this runs behind k_imu_delta, still next to the back-substitution, and leaves one record
-// per block for the sweep.  An empty sample range is flagged by T = -1 in the record.
-__device__ __forceinline__ void imu_block_body(const DevView& v, const Ctrl* ct, int trial) {
-  const int dd = threadIdx.x & 15;
-  const int s = blockIdx.x * 16 + (threadIdx.x >> 4);
-  if (s >= v.n_frames - 1 || dd >= kDeltaCols) return;
-  const int cur = trial ? 1 - ct->cur : ct->cur;
-  const double toff = v.imus[cur][14];
-  double val[11], der[11];
-  const int valid = imu_block_delta_direction(imu_view(v), v.frame_time[s], v.frame_time[s + 1], toff, v.imu_delta,
-                                              v.imu_delta_ab + (size_t)s * 2 * kDeltaStride, dd, val, der);
-  double* rec = v.imu_delta_blk + (size_t)s * kBlockDeltaStride;
-  if (!valid) { if (dd == 0) rec[10] = -1.0; return; }
-#pragma unroll
-  for (int k = 0; k < 11; ++k) rec[dd * 11 + k] = dd ? der[k] : val[k];
-}
-__global__ __launch_bounds__(256) void k_imu_block(DevView v, int trial) {
-  const Ctrl* ct = v.ctrl;
-  if (ct->done || (!trial && !ct->need_lin)) return;
-  imu_block_body(v, ct, trial);
-  // flag hand-overs, trial point: k_imu_jac behind this kernel needs the main stream's trial poses.  One thread of this kernel
-  // waits for their flag before the kernel ends -- the kernel boundary then orders k_imu_jac behind it like any other kernel,
-  // without a waiting kernel of its own (5 us on this stream's queue, which is the critical one at the end of a small pass)
-  if (trial && v.block_wait > 0 && blockIdx.x == 0 && threadIdx.x == 0) spin_until_flag(v, 2, v.block_wait);
-}
-
 constexpr int kImuJacLds = 34 * 9 + 6;            // [34][9]: the block's 33 local columns and, as a 34th, the residual itself
 // (row a, column b) of every entry of the compact block record (vc_device.h: kSeg*), b = 33: gradient -- one table look-up per entry
 struct SegTab {
@@ -285,6 +221,128 @@ __device__ __forceinline__ ImuRange imu_range_lanes(const ImuView& b, double t0,
   r.k1 = odd ? le : le_o;
   if (r.k1 < r.i0) r.k1 = r.i0;
   return r;
+}
+
+// ------------------------------------------------------------------------------------------ IMU block deltas
+// The pose-independent half of the IMU sweep (vc_imu.hpp, "delta form") in one launch, nothing but the block records written: the
+// interval deltas never leave the registers (round 3 wrote a 1120-byte record per sample interval with k_imu_delta and read it
+// straight back with k_imu_block: 53 of the sweep's 73 MB per pass at BASELINE cfg3, behind a chain of ~12 dependent appends per
+// block).  ONE WAVEFRONT PER IMU BLOCK, eight groups of eight lanes:
+//   group g = 0..5   dual direction = gyro bias / scale factor g, and beside it -- no dual number needed, the velocity and position
+//                    deltas are linear in the accelerometer inputs -- the partials along accelerometer bias / scale factor g;
+//   group 6          dual direction = time offset (moves the interpolated end samples and the end intervals' lengths);
+//   group 7          spare (shadows group 6, stores nothing);  the values ride in every group, group 0 stores them.
+// Lane l of a group takes sample intervals 2 l + 1 and 2 l + 2 of the block (vc_imu.hpp: imu_interval_delta_ga, the RK4 step from
+// the identity state written out) and appends the second to the first; an inclusive scan over the group's eight lanes (composition is
+// associative; DPP row shifts, three levels, no LDS) leaves the block's delta in lane 7.  Blocks with more than 16 intervals run in
+// rounds, lane 7 appending the rounds' totals (kept in LDS between rounds).  Round 4's first cut had one lane per (interval,
+// record column) -- 14 x 16 lanes, 3.5 wavefronts per block, every lane repeating the values under its own direction and the scan
+// costing as much as the steps: 57 us at cfg3 against 53 for the two kernels it replaced; this form runs a quarter of the wavefronts.
+// Depends on the shared IMU parameters only: in a solve it runs behind the reduced solve, next to the chain's back-substitution.
+// An empty sample range is flagged by T = -1 in the record.
+template <int N> __device__ __forceinline__ void delta_ga_scan_level(IntervalDeltaGA* X, int l) {
+  IntervalDeltaGA A;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { A.d.q[k].a = row_shr<N>(X->d.q[k].a, X->d.q[k].a); A.d.q[k].v = row_shr<N>(X->d.q[k].v, X->d.q[k].v); }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    A.d.p[k].a = row_shr<N>(X->d.p[k].a, X->d.p[k].a); A.d.p[k].v = row_shr<N>(X->d.p[k].v, X->d.p[k].v);
+    A.d.v[k].a = row_shr<N>(X->d.v[k].a, X->d.v[k].a); A.d.v[k].v = row_shr<N>(X->d.v[k].v, X->d.v[k].v);
+    A.ap[k] = row_shr<N>(X->ap[k], X->ap[k]); A.av[k] = row_shr<N>(X->av[k], X->av[k]);
+  }
+  A.d.t.a = row_shr<N>(X->d.t.a, X->d.t.a); A.d.t.v = row_shr<N>(X->d.t.v, X->d.t.v);
+  imu_delta_ga_then(&A, *X);
+  if (l >= N) *X = A;                            // (the first N lanes of a group have no partner: what the shift brought them belongs to the group below)
+}
+constexpr int kGaDoubles = 28;                   // an IntervalDeltaGA as doubles: D1 delta 22 | ap 3 | av 3
+__global__ __launch_bounds__(256, 2) void k_imu_block(DevView v, int trial) {
+  __shared__ double s_carry[32 * kGaDoubles];
+  __shared__ double s_park[256 * kGaDoubles];
+  const Ctrl* ct = v.ctrl;
+  if (ct->done || (!trial && !ct->need_lin)) return;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: everything per block stays out of the vector registers)
+  const int g = lane >> 3, l = lane & 7;
+  const int n_blocks = v.n_frames - 1;
+  const int s_raw = blockIdx.x * 4 + wave;                             // block s couples frames s -> s + 1
+  const int s = s_raw < n_blocks ? s_raw : n_blocks - 1;               // (a wavefront past the end shadows the last block and stores nothing)
+  const int cur = trial ? 1 - ct->cur : ct->cur;
+  const double* im = v.imus[cur];
+  const double toff = im[14];
+  const ImuView buf = imu_view(v);
+  const double t_start = v.frame_time[s], t_end = v.frame_time[s + 1];
+  ImuRange rg = imu_range_lanes(buf, t_start, t_end, toff, lane);
+  rg.valid = __builtin_amdgcn_readfirstlane(rg.valid); rg.i0 = __builtin_amdgcn_readfirstlane(rg.i0); rg.i1 = __builtin_amdgcn_readfirstlane(rg.i1);
+  rg.k0 = __builtin_amdgcn_readfirstlane(rg.k0); rg.k1 = __builtin_amdgcn_readfirstlane(rg.k1);
+  rg.first_end = __builtin_amdgcn_readfirstlane(rg.first_end); rg.last_end = __builtin_amdgcn_readfirstlane(rg.last_end);
+  double* rec = v.imu_delta_blk + (size_t)s * kBlockDeltaStride;
+  if (rg.valid) {                                                      // (wave-uniform)
+    const int n_int = (rg.k1 - rg.k0 + 1) + 1;                         // intervals between the n_int + 1 range elements
+    const int gsel = g < 7 ? g : 6;
+    double* cr = s_carry + (threadIdx.x >> 3) * kGaDoubles;
+    IntervalDeltaGA X;
+#pragma unroll 1
+    for (int base = 0; base < n_int; base += 16) {
+      {
+        // the first interval's delta waits in LDS while the second is formed (28 doubles that would otherwise sit -- or spill --
+        // under the second RK4 step); a loop that is not unrolled: one copy of the step, nothing of the second interval scheduled
+        // into the first
+        double* pk = s_park + threadIdx.x;
+        IntervalDeltaGA Y;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+          // (the group index made opaque per iteration: otherwise everything the step derives from it -- seed masks, unit vector,
+          //  selects -- is hoisted out of the loops and sits in ~90 registers across both steps and the scan)
+          int gs = gsel;
+          asm volatile("" : "+v"(gs));
+          imu_interval_delta_ga(buf, rg, mk(toff, gs == 6 ? 1.0 : 0.0), t_start, t_end, base + 2 * l + 1 + half, n_int, im + 2, im + 8, gs, &Y);
+          if (half == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { pk[k * 256] = Y.d.q[k].a; pk[(11 + k) * 256] = Y.d.q[k].v; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              pk[(4 + k) * 256] = Y.d.p[k].a; pk[(15 + k) * 256] = Y.d.p[k].v; pk[(7 + k) * 256] = Y.d.v[k].a; pk[(18 + k) * 256] = Y.d.v[k].v;
+              pk[(22 + k) * 256] = Y.ap[k]; pk[(25 + k) * 256] = Y.av[k];
+            }
+            pk[10 * 256] = Y.d.t.a; pk[21 * 256] = Y.d.t.v;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X.d.q[k] = mk(pk[k * 256], pk[(11 + k) * 256]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          X.d.p[k] = mk(pk[(4 + k) * 256], pk[(15 + k) * 256]); X.d.v[k] = mk(pk[(7 + k) * 256], pk[(18 + k) * 256]);
+          X.ap[k] = pk[(22 + k) * 256]; X.av[k] = pk[(25 + k) * 256];
+        }
+        X.d.t = mk(pk[10 * 256], pk[21 * 256]);
+        imu_delta_ga_then(&X, Y);
+      }
+      delta_ga_scan_level<1>(&X, l); delta_ga_scan_level<2>(&X, l); delta_ga_scan_level<4>(&X, l);
+      if (l == 7) {                                                    // the round's total; the rounds before it rest in LDS
+        if (base > 0) {
+          IntervalDeltaGA A;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) A.d.q[k] = mk(cr[k], cr[11 + k]);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { A.d.p[k] = mk(cr[4 + k], cr[15 + k]); A.d.v[k] = mk(cr[7 + k], cr[18 + k]); A.ap[k] = cr[22 + k]; A.av[k] = cr[25 + k]; }
+          A.d.t = mk(cr[10], cr[21]);
+          imu_delta_ga_then(&A, X);
+          X = A;
+        }
+        if (base + 16 < n_int) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { cr[k] = X.d.q[k].a; cr[11 + k] = X.d.q[k].v; }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { cr[4 + k] = X.d.p[k].a; cr[15 + k] = X.d.p[k].v; cr[7 + k] = X.d.v[k].a; cr[18 + k] = X.d.v[k].v; cr[22 + k] = X.ap[k]; cr[25 + k] = X.av[k]; }
+          cr[10] = X.d.t.a; cr[21] = X.d.t.v;
+        }
+      }
+    }
+    if (l == 7 && s_raw < n_blocks) imu_block_record_store(X, g, rec);
+  } else if (lane == 0 && s_raw < n_blocks) rec[10] = -1.0;
+  // flag hand-overs, trial point: k_imu_jac behind this kernel needs the main stream's trial poses.  One thread of this kernel
+  // waits for their flag before the kernel ends -- the kernel boundary then orders k_imu_jac behind it like any other kernel,
+  // without a waiting kernel of its own (5 us on this stream's queue, which is the critical one at the end of a small pass)
+  if (trial && v.block_wait > 0 && blockIdx.x == 0 && threadIdx.x == 0) spin_until_flag(v, 2, v.block_wait);
 }
 
 // phase stamps of the first wavefront (profiling builds only, -DVC_W_STAMPS): 100 MHz s_memrealtime ticks in dbg[0..15]
@@ -1648,10 +1706,8 @@ __global__ __launch_bounds__(256, 2) void k_chain_gram(DevView v) {
 
 // ------------------------------------------------------------------------------------------ launchers
 void launch_imu_delta(const DevView& v, hipStream_t s, int trial) {
-  const int n = (v.n_imu - 1) + 2 * (v.n_frames - 1);
-  if (n <= 0 || v.n_frames < 2) return;
-  hipLaunchKernelGGL(k_imu_delta, dim3((n + 15) / 16), dim3(256), 0, s, v, trial);
-  hipLaunchKernelGGL(k_imu_block, dim3((v.n_frames - 1 + 15) / 16), dim3(256), 0, s, v, trial);
+  if (v.n_frames < 2) return;
+  hipLaunchKernelGGL(k_imu_block, dim3((v.n_frames - 1 + 3) / 4), dim3(256), 0, s, v, trial);      // one wavefront per IMU block
 }
 void launch_imu_jac(const DevView& v, int wr, hipStream_t s, int trial) {
   if (v.n_frames < 2) return;
