@@ -190,6 +190,10 @@ int vc_time_kernels(vc_calibrator* h, int reps, double* jac_ms, double* res_ms);
  * on the calibrator's stream (the real loop, decisions live -- not held back-to-back launches); vc_get_kernel_timing
  * returns, per group that ran, its name (';'-joined into names), the summed duration and the launch count. */
 int vc_set_kernel_timing(vc_calibrator* h, int on);
+/* Cross-stream hand-overs of the visual-inertial pass go through device flags.  A wait that runs into its bound is
+ * never a silent change of results: the device withholds that pass's decision, the library reports it on stderr, resumes the
+ * solve with event hand-overs (same iterates) and keeps them for this calibrator.  Returns how often that has happened. */
+int vc_sync_timeouts(const vc_calibrator* h);
 int vc_get_kernel_timing(vc_calibrator* h, char* names, int names_len, double* total_ms, long long* count, int max_entries);
 /* Average ms per launch of each stage of one LM pass (Jacobian sweep, frame elimination, Schur partials,
  * reduced solve, trial sweep, decision), `reps` back-to-back launches each */

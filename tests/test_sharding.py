@@ -14,13 +14,18 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run(mode, timeout, nproc=2):
+def _run(mode, timeout, nproc=2, flags=False):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(HERE, "dist_worker.py"), mode]
     # several processes share ONE GPU here (not how the library is deployed: one process per GPU).  The single-process reference
     # solves inside the workers would otherwise use the device-flag hand-overs between their two streams: a waiting
     # kernel burns its process's time slice while the device runs another process -- correct, but the tests take twice as long
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", VICALIB_AMD_FLAG_SYNC="0")
+    # (flags=True keeps them: a wait that starves there is reported and resumed with events, never a different result -- one test does)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if not flags:
+        env["VICALIB_AMD_FLAG_SYNC"] = "0"
+    else:
+        env.pop("VICALIB_AMD_FLAG_SYNC", None)
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     fail = out.stdout.find("WORKER-FAILURE")
     assert out.returncode == 0, (out.stdout[fail:fail + 7000] if fail >= 0 else out.stdout[-3000:] + out.stderr[-3000:])
@@ -50,6 +55,13 @@ def test_two_rank_sharded_solve_gloo_on_one_gpu():
 def test_two_rank_sharded_visual_inertial_solve_on_one_gpu():
     """IMU chain across the shard boundary: the second rank's first frame is a separator in the reduced system."""
     _run("gpu_imu", 900)
+
+
+@pytest.mark.gpu
+def test_two_processes_on_one_gpu_with_flag_handovers():
+    """The same two-rank solve with the device-flag hand-overs left on in the workers' single-process reference solves: two
+    processes' waiting kernels time-sliced on one device (advice r3).  Parity must hold whether or not a wait starves."""
+    _run("gpu_imu", 900, flags=True)
 
 
 @pytest.mark.gpu

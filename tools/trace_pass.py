@@ -19,4 +19,4 @@ else:
     cal.SetCalibrateImu(False)
 cal.prepare()
 cal.run_iterations(5)
-cal.run_iterations(20)
+cal.run_iterations(30)

@@ -149,9 +149,13 @@ struct vc_calibrator {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;        // the IMU weight update of a pass runs here, under the pass's Jacobian sweeps and chain solve
-  hipEvent_t ev_state = nullptr, ev_weights = nullptr, ev_imujac = nullptr, ev_reduced = nullptr, ev_back = nullptr;
+  hipEvent_t ev_state = nullptr, ev_weights = nullptr, ev_imujac = nullptr, ev_reduced = nullptr, ev_back = nullptr, ev_pre = nullptr;
+  bool pre_weights_pending = false;     // solve_once has recorded ev_pre ahead of the weight update that precedes a solve
   int wcur = 0;                         // weight buffer holding the current weight_sqrt_
   bool flag_sync = false;               // hand-overs to the second stream through device flags instead of event records (set at creation)
+  long long sync_bound = 400000;        // polls before a flag wait gives up (~0.2 s); VICALIB_AMD_SYNC_BOUND (test hook: a tiny bound forces the time-out path)
+  int wr_ring[16] = {0};                // weight buffer read by pass (pass_seq & 15)
+  int sync_timeouts = 0;                // flag hand-overs that ran into their bound (each one reported on stderr, the solve resumed with events)
   long long pass_seq = 0;               // passes enqueued (the value the flags carry)
   bool prev_pass_signals = false;       // the previous pass of this solve was enqueued with signalling kernels
   DBuf<long long> d_sync;
@@ -227,7 +231,7 @@ struct vc_calibrator {
   size_t wsqrt_frames = 0;       // number of frames the device weight_sqrt_ array was initialised for
   size_t imu_uploaded = 0; double imu_uploaded_last = 0.0;      // sample count / last time stamp of the device copy of the IMU samples
   int trace_cap = 0;
-  struct Pinned { Ctrl up; Ctrl down; double trace[64 * kTraceCols]; unsigned long long progress; };
+  struct Pinned { Ctrl up; Ctrl down; Ctrl dev; double trace[64 * kTraceCols]; unsigned long long progress; };      // dev / trace / progress: written by the device
   Pinned* pin = nullptr;        // page-locked staging (async copies without a bounce buffer)
   long nres_global_cached = -1; int nres_mult_cached[2] = {-1, -1};      // sharded: the all-reduced residual count and the multiplicities it was formed with
   long solve_epoch = 0, nres_epoch_cached = -1;     // ... and the public solve call it was formed in (bumped by every rank at the same entry points)
@@ -245,6 +249,7 @@ struct vc_calibrator {
     kt_free();
     if (stream2) (void)hipStreamDestroy(stream2);
     if (ev_state) (void)hipEventDestroy(ev_state);
+    if (ev_pre) (void)hipEventDestroy(ev_pre);
     if (ev_weights) (void)hipEventDestroy(ev_weights);
     if (ev_imujac) (void)hipEventDestroy(ev_imujac);
     if (ev_reduced) (void)hipEventDestroy(ev_reduced);
@@ -650,7 +655,8 @@ struct vc_calibrator {
     return VC_OK;
   }
   // first_pass: the pass right after init_ctrl (the only one that needs k_reproj_jac when k_trial carries the sweep)
-  int enqueue_pass(bool first_pass = true) {
+  // events_only: a stand-alone pass outside a solve (parity hooks, timing): nobody would resume it after a flag time-out
+  int enqueue_pass(bool first_pass = true, bool events_only = false) {
     const int D = dv.D;
     dv.merged = 0; dv.par = 0; dv.ctrl = d_ctrl.p; dv.ctrl_prev = d_ctrl.p + 1;
     if (dv.imu_on) {
@@ -664,9 +670,10 @@ struct vc_calibrator {
       const bool upd = dv.weights_on != 0;
       // (single process only: with the flags a two-rank visual-inertial solve on one GPU failed its parity test -- two processes'
       // waiting kernels on one device; left on events until that is understood)
-      const bool fs = flag_sync && !serial_weights && !sharded() && !use_graphs;      // (a captured pass has fixed arguments and needs the events to fork the capture)
+      const bool fs = flag_sync && !serial_weights && !sharded() && !use_graphs && !events_only;      // (a captured pass has fixed arguments and needs the events to fork the capture)
       ++pass_seq;
-      dv.sync_flags = d_sync.p; dv.sync_seq = fs ? pass_seq : 0; dv.final_wait = 0; dv.block_wait = 0;
+      wr_ring[pass_seq & 15] = wcur;              // (what a resume after a flag time-out restores: the weight buffer this pass reads)
+      dv.sync_flags = d_sync.p; dv.sync_seq = fs ? pass_seq : 0; dv.final_wait = 0; dv.block_wait = 0; dv.sync_bound = sync_bound;
       const bool fs_trial = fs && jac_on_stream2 && dv.n_tiles > 0;      // (no tiles: no trial sweep to publish the back-substitution's end)
       dv.final_wait = fs_trial ? pass_seq : 0;      // (k_imu_jac(trial) and k_final both look at it)
       dv.block_wait = fs_trial ? pass_seq : 0;      // (k_imu_block(trial))
@@ -674,13 +681,23 @@ struct vc_calibrator {
       // of a solve.  Afterwards the trial point is evaluated by the same sweeps in trial mode (below), which leave the next
       // linearisation behind if the step is accepted; after a rejected step the old one is still in place.
       if (!serial_weights) {
+        bool block_done = false;
+        if (first_pass && pre_weights_pending) {
+          // the weight update that precedes a solve (solve_once) is still running on the main stream: the block deltas need the IMU
+          // parameters only, not the weights -- they start from the event recorded ahead of it (35 us less per solve at cfg3)
+          HIP_OK(hipStreamWaitEvent(stream2, ev_pre, 0));
+          KT2("k_imu_block", launch_imu_delta(dv, stream2, 0));
+          block_done = true;
+        }
+        pre_weights_pending = false;
         if (fs && !first_pass && prev_pass_signals) launch_wait_flag(dv, 0, pass_seq - 1, stream2);      // the previous pass's k_final
         else {
           HIP_OK(hipEventRecord(ev_state, stream));
           HIP_OK(hipStreamWaitEvent(stream2, ev_state, 0));
         }
         if (first_pass) {
-          KT2("k_imu_block", launch_imu_delta(dv, stream2, 0)); KT2("k_imu_jac", launch_imu_jac(dv, wcur, stream2, 0));
+          if (!block_done) KT2("k_imu_block", launch_imu_delta(dv, stream2, 0));
+          KT2("k_imu_jac", launch_imu_jac(dv, wcur, stream2, 0));
           HIP_OK(hipEventRecord(ev_imujac, stream2));       // ahead of the weight update: the chain does not read the weights
         }
         if (upd) KT2("k_imu_weights", launch_imu_weights(dv, wcur, stream2));
@@ -794,8 +811,7 @@ struct vc_calibrator {
   bool merged_enabled = true;
   // a fresh control record goes to buffer 0; buffer 1 (the "previous pass" of the first pass in merged mode) is blanked
   int upload_ctrl(const Ctrl* c) {
-    HIP_OK(hipMemcpyAsync(d_ctrl.p, c, sizeof(Ctrl), hipMemcpyHostToDevice, stream));
-    HIP_OK(hipMemsetAsync(d_ctrl.p + 1, 0, sizeof(Ctrl), stream));
+    launch_set_ctrl(d_ctrl.p, *c, stream);
     kpass = 0;
     return VC_OK;
   }
@@ -808,6 +824,32 @@ struct vc_calibrator {
     c->first = 1; c->trace_cap = trace_cap; c->stage = stage;
   }
 
+  // A device-flag hand-over ran into its bound (vc_kutil.hpp: spin_until_flag): the device has withheld the decision of pass
+  // `abort_seq` and of everything queued behind it, the accepted state and the control record are those of the last valid decision.
+  // Say so, switch this calibrator to event hand-overs for good, and put the solve back on its feet: both streams idle, flags
+  // cleared, the weight buffer that pass was reading current again, `done` cleared and a fresh linearisation at the accepted state
+  // requested (what the trial sweeps of the last judged pass left behind may be incomplete).  The passes that follow repeat the
+  // withheld ones with events: the same iterates as a run that never used the flags.
+  int resume_after_sync_timeout(const Ctrl& c) {
+    HIP_OK(hipStreamSynchronize(stream));
+    if (stream2) HIP_OK(hipStreamSynchronize(stream2));
+    ++sync_timeouts;
+    flag_sync = false;
+    std::fprintf(stderr, "vicalib_amd: a device-flag hand-over between the two streams ran into its bound in LM pass %d (the streams share a hardware "
+                         "queue, a tool serialises the queues, or several processes share the device); no step was taken on its data -- resuming the "
+                         "solve with event hand-overs, which this calibrator keeps from now on (VICALIB_AMD_FLAG_SYNC=0 selects them from the start)\n",
+                 c.passes + 1);
+    wcur = wr_ring[c.abort_seq & 15];
+    if (d_sync.p) HIP_OK(hipMemsetAsync(d_sync.p, 0, 8 * sizeof(long long), stream));
+    HIP_OK(hipMemsetAsync(dv.flags + 4, 0, 4 * sizeof(int), stream));      // numeric-failure marks of the void passes
+    Ctrl r = c;
+    r.done = 0; r.abort_seq = 0; r.need_lin = 1;
+    HIP_OK(hipMemcpyAsync(d_ctrl.p, &r, sizeof(Ctrl), hipMemcpyHostToDevice, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    pin->down.done = 0;
+    prev_pass_signals = false;
+    return VC_OK;
+  }
   // The trust-region loop (ceres::Solve :956 with LEVENBERG_MARQUARDT).  The loop itself runs
   // on the device (lm_decide in vc_kernels.hip); the host enqueues passes in batches and polls Ctrl::done.
   int solve_once(Termination* term, double* final_cost, long* nres) {
@@ -832,11 +874,16 @@ struct vc_calibrator {
     if (!pin) HIP_OK(hipHostMalloc((void**)&pin, sizeof(Pinned), hipHostMallocCoherent | hipHostMallocMapped));
     init_ctrl(&pin->up);
     { int rcu = upload_ctrl(&pin->up); if (rcu) return rcu; }
-    if (dv.imu_on && dv.weights_on) { launch_imu_weights(dv, wcur, stream); wcur = 1 - wcur; }     // UpdateImuWeights() before ceres::Solve (vicalibrator.h:955)
+    if (dv.imu_on && dv.weights_on) {     // UpdateImuWeights() before ceres::Solve (vicalibrator.h:955)
+      if (!serial_weights && stream2) { HIP_OK(hipEventRecord(ev_pre, stream)); pre_weights_pending = true; }
+      launch_imu_weights(dv, wcur, stream); wcur = 1 - wcur;
+    }
     const size_t trace_bytes = (size_t)std::min(trace_cap, 64) * kTraceCols * 8;
     int guard = 0, n_enq = 0;
+    bool first_enq = true;              // the next pass enqueued linearises at the accepted state (start of the solve, resume after a flag time-out)
     double enqueue_ms = 0.0, wait_ms = 0.0;
     const auto tso0 = std::chrono::steady_clock::now();
+    for (;;) {                          // (one round, unless a device-flag hand-over runs into its bound: then a second one, with events)
     const bool feed = !sharded() && !use_graphs && feed_passes && dv.imu_on;
     if (feed) {
       // Single process, visual-inertial passes (18 launches at cfg3, ~270 us): the deciding thread publishes (decisions << 32 | done) to a page-locked word after every decision and
@@ -848,33 +895,31 @@ struct vc_calibrator {
       // the launch-ahead schedules unaffected) and the device has been idle; a longer queue rides such gaps out.
       int& kAhead = feed_ahead;
       volatile unsigned long long* prog = &pin->progress;
-      *prog = 0ull;
-      dv.host_progress = &pin->progress;
+      *prog = (unsigned long long)(unsigned)n_enq << 32;      // (0 at the start of a solve; the decisions taken so far when a solve is resumed)
+      dv.host_progress = &pin->progress; dv.host_ctrl = &pin->dev; dv.host_trace = pin->trace;
+      bool done_seen = false;
       auto t_seen = std::chrono::steady_clock::now();
       unsigned long long last = 0ull;
       while (should_run) {
         const unsigned long long f = *prog;
-        if ((unsigned)(f & 0xffffffffull) != 0u) break;                       // Ctrl::done
+        if ((unsigned)(f & 0xffffffffull & ~(unsigned long long)kProgressLikelyLast) != 0u) { done_seen = true; break; }     // Ctrl::done
         if (f != last) { last = f; t_seen = std::chrono::steady_clock::now(); }
         const int decided = (int)(f >> 32);
         if (n_enq >= max_iters + 8) break;
-        if (n_enq > 0 && decided >= n_enq && kAhead < 4) ++kAhead;
-        if (n_enq - decided <= kAhead) {
-          int rc = enqueue_pass(n_enq == 0); if (rc) { dv.host_progress = nullptr; return rc; }
+        if (!first_enq && decided >= n_enq && kAhead < 4 && !(f & kProgressLikelyLast)) ++kAhead;
+        // the device expects the pass after the last decision to end the solve (lm_decide_local: likely_last): nothing is queued
+        // past it -- a pass queued past the end costs ~90 us of empty launches at cfg3 before the stream is free again, a wrong guess
+        // one host round trip
+        const int ahead = (f & kProgressLikelyLast) ? 0 : kAhead;
+        if (n_enq - decided <= ahead) {
+          int rc = enqueue_pass(first_enq); if (rc) { dv.host_progress = nullptr; return rc; }
+          first_enq = false;
           ++n_enq; t_seen = std::chrono::steady_clock::now();
         } else {
           __builtin_ia32_pause();
           // the queue is full: nothing to do until the device decides a pass (~0.3 ms); past ~50 us without news, yield the core
           const auto idle = std::chrono::steady_clock::now() - t_seen;
           if (idle > std::chrono::microseconds(50)) std::this_thread::yield();
-          if (flag_sync && idle > std::chrono::milliseconds(150)) {
-            // no pass of any BASELINE size takes a tenth of this: a device-flag hand-over between the two streams has probably run
-            // into its bound (a tool that serialises the kernels of all queues, or both streams on one hardware queue).  The
-            // step it belonged to is rejected on the device; every pass enqueued from here on uses the event hand-overs.
-            flag_sync = false;
-            std::fprintf(stderr, "vicalib_amd: no LM decision for 150 ms -- a device-flag hand-over between the two streams seems to have run "
-                                 "into its bound; continuing with event hand-overs (VICALIB_AMD_FLAG_SYNC=0 selects them from the start)\n");
-          }
           if (idle > std::chrono::seconds(5)) {          // a stuck device (or a progress word the host cannot see): say so, then
             std::fprintf(stderr, "vicalib_amd: no progress from the device for 5 s (%d passes queued, %d decided) -- falling back to a "
                                  "synchronising read\n", n_enq, decided);                     // fall through to the synchronising read
@@ -882,12 +927,20 @@ struct vc_calibrator {
           }
         }
       }
-      dv.host_progress = nullptr;
+      dv.host_progress = nullptr; dv.host_ctrl = nullptr; dv.host_trace = nullptr;
       finish_batch();
-      HIP_OK(hipMemcpyAsync(&pin->down, ctrl_result(), sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
-      HIP_OK(hipMemcpyAsync(pin->trace, d_trace.p, trace_bytes, hipMemcpyDeviceToHost, stream));
-      HIP_OK(hipStreamSynchronize(stream));
-      if (ktime_on) kt_collect();
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (done_seen && !ktime_on && pin->dev.trace_len <= 64 && pin->dev.done != kDoneSyncTimeout) {
+        // the deciding thread has left the record and the trace rows in page-locked memory before it said `done`: nothing to
+        // copy and nothing to wait for -- the passes queued past the end (they return at their first instruction) drain while the
+        // host goes on; whatever the caller enqueues next is ordered behind them by the streams
+        pin->down = pin->dev;
+      } else {
+        HIP_OK(hipMemcpyAsync(&pin->down, ctrl_result(), sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(pin->trace, d_trace.p, trace_bytes, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        if (ktime_on) kt_collect();
+      }
     }
     // Sharded (every rank must run the same schedule: the passes contain collectives), graph replay and the vision-only path
     // (four launches of ~13 us per pass, a handful of passes per solve: measured 60 vs 63 us per iteration at cfg2 -- the
@@ -900,7 +953,7 @@ struct vc_calibrator {
     while (!feed || (!pin->down.done && should_run && n_enq < max_iters + 8)) {
       const auto tq0 = std::chrono::steady_clock::now();
       for (int b = 0; b < batch; ++b) {
-        const bool first = (n_enq++ == 0);
+        const bool first = first_enq; first_enq = false; ++n_enq;
         int rc = (first || sharded() || !use_graphs) ? enqueue_pass(first) : launch_pass_graph();
         if (rc) return rc;
       }
@@ -923,6 +976,10 @@ struct vc_calibrator {
       }
       if (!should_run || ++guard > max_iters + 8) break;
       batch = dv.imu_on ? 8 : 2;        // (vision-only passes are 50 us: a synchronisation every two of them was the better trade there)
+    }
+    if (pin->down.done != kDoneSyncTimeout) break;
+    { int rc = resume_after_sync_timeout(pin->down); if (rc) return rc; }
+    n_enq = pin->down.passes; first_enq = true; guard = 0;
     }
     const Ctrl c = pin->down;
     if (std::getenv("VICALIB_AMD_TIMING") && enqueue_ms > 0.0)
@@ -961,7 +1018,7 @@ struct vc_calibrator {
     init_ctrl(&c);
     c.hold = 1; c.radius = radius; c.first = 0;
     { int rcu = upload_ctrl(&c); if (rcu) return rcu; }
-    int rc = enqueue_pass(); if (rc) return rc;
+    int rc = enqueue_pass(true, true); if (rc) return rc;
     finish_batch();
     HIP_OK(hipMemcpyAsync(&c, ctrl_result(), sizeof(Ctrl), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
@@ -1136,13 +1193,15 @@ int vc_create(vc_calibrator** out, int device) {
     return hipStreamCreate(&h->stream2);          // (a runtime without stream priorities: plain stream, same results)
   };
   if (hipStreamCreate(&h->stream) != hipSuccess || make_stream2() != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_state, evf) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_state, evf) != hipSuccess || hipEventCreateWithFlags(&h->ev_pre, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_weights, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_imujac, evf) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_reduced, evf) != hipSuccess || hipEventCreateWithFlags(&h->ev_back, evf) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }
   // flag hand-overs need the two streams on different hardware queues (a waiting kernel at the head of a shared queue would hold
   // its own producer back): only with the second stream in its own priority class; VICALIB_AMD_FLAG_SYNC=0 keeps the events
-  { const char* e = std::getenv("VICALIB_AMD_FLAG_SYNC"); if (e && e[0] == '0') h->flag_sync = false; }
+  // (=1 forces the flags on whatever the second stream's priority class: the test that puts both streams on one hardware queue)
+  { const char* e = std::getenv("VICALIB_AMD_FLAG_SYNC"); if (e && e[0] == '0') h->flag_sync = false; if (e && e[0] == '1') h->flag_sync = true; }
+  { const char* e = std::getenv("VICALIB_AMD_SYNC_BOUND"); if (e && std::atoll(e) > 0) h->sync_bound = std::atoll(e); }      // (test hook: a tiny bound forces the time-out path)
   if (h->flag_sync && (h->d_sync.alloc(8) != hipSuccess || hipMemset(h->d_sync.p, 0, 8 * sizeof(long long)) != hipSuccess)) h->flag_sync = false;
   *out = h;
   return VC_OK;
@@ -1338,6 +1397,7 @@ int vc_start(vc_calibrator* h) {
   return VC_OK;
 }
 int vc_set_stage_limit(vc_calibrator* h, int n) { NOT_RUNNING(h); h->stage_limit = n; return VC_OK; }
+int vc_sync_timeouts(const vc_calibrator* h) { return h ? h->sync_timeouts : 0; }
 int vc_set_kernel_timing(vc_calibrator* h, int on) {
   NOT_RUNNING(h);
   h->ktime_on = on != 0;
@@ -1672,7 +1732,7 @@ int vc_time_stages(vc_calibrator* h, int reps, double* out) {
   // stage timing uses the stand-alone kernels of the unmerged pipeline (k_final as its own launch)
   const bool was_merged = h->merged_enabled;
   h->merged_enabled = false;
-  const int rc_pass = h->enqueue_pass();
+  const int rc_pass = h->enqueue_pass(true, true);
   h->merged_enabled = was_merged;
   if (rc_pass) return VC_ERR_NO_DEVICE;
   h->dv.sync_seq = 0; h->dv.final_wait = 0; h->dv.block_wait = 0;      // the stand-alone launches below neither signal nor wait for the other stream

@@ -25,7 +25,9 @@ enum { kScGd = 0, kScDld = 1, kScStep2 = 2, kScX2 = 3, kScG2 = 4, kScCost = 5, k
 constexpr int kTraceCols = 10;     // iteration cost cost_change gmax gnorm step_norm rho radius accepted stage
 
 // termination codes in Ctrl::done (0 = keep running)
-enum { kRunning = 0, kDoneConvergence = 1, kDoneNoConvergence = 2, kDoneUserSuccess = 3, kDoneFailure = 4 };
+constexpr unsigned kProgressLikelyLast = 1u << 30;      // progress word, low half: Ctrl::done | this hint
+enum { kRunning = 0, kDoneConvergence = 1, kDoneNoConvergence = 2, kDoneUserSuccess = 3, kDoneFailure = 4,
+       kDoneSyncTimeout = 5 };   // a device-flag hand-over between the two streams ran into its bound: the pass is void, the host re-runs it with events
 
 // Normal-equation record of one IMU block (k_imu_jac -> k_chain_init).  The block's 33 local columns are [frame j ("cur": pose 6,
 // velocity 3) | frame j - 1 ("prev": 9) | IMU parameters 15].  Of the symmetric 33 x 33 matrix and the gradient only what the chain
@@ -62,7 +64,10 @@ struct Ctrl {
   int stage, hold, num_callbacks, jac_sweeps;
   int res_sweeps, passes;
   int needs_decision;   // merged mode: the pass that used this record has produced a trial point nobody has judged yet
-  int pad1;
+  int abort_seq;        // kDoneSyncTimeout: low 31 bits of the pass number (DevView::sync_seq) whose decision was withheld
+  int likely_last;      // the step just accepted cut the cost by less than 1e3 x the function tolerance and by a tenth of the step before: the
+  int pad1;             // next decision will very probably end the solve (published to the feeding host, which then queues nothing past it)
+  double last_rel;      // relative cost change of the last accepted step
 };
 
 // per-camera descriptor, carried in the kernel arguments (scalar loads, no dependent global look-ups)
@@ -119,15 +124,18 @@ struct DevView {
   double* wg_imu_trial;            // (n_frames - 1 + 7) / 8: trial cost of the 8 blocks of a k_imu_jac workgroup
   int n_chain_groups;
   double* scal;                    // kNumScal (frame sums) + kNumScal (shared-parameter terms)
+  struct Ctrl* host_ctrl;          // page-locked host copies the deciding thread fills when host_progress is set: the control record once the solve is
+  double* host_trace;              // over, every trace row (the first 64) as it is pushed -- the host needs neither a copy nor a synchronisation to read a solve's result
   unsigned long long* host_progress;   // page-locked host word, (decisions taken << 32) | Ctrl::done, stored by the deciding thread after
                                    // every decision: the host feeds passes against it without synchronising the stream (null: off)
   int* flags;                      // [0]: frame Cholesky failures, [1]: reduced Cholesky failure (per pass)
   // cross-stream hand-overs without event records on the main stream (visual-inertial pass, single process): single-workgroup
   // kernels publish the pass number when they are done, a one-wavefront kernel on the second stream waits for it
-  long long* sync_flags;           // [0]: k_final, [1]: k_reduced, [2]: back-substitution done (k_reproj_jac(trial) has started), [3]: second stream's trial-point kernels done, [4]: workgroups of k_imu_jac(trial) that have delivered their cost share (a count, back to 0 per pass)
+  long long* sync_flags;           // [0]: k_final, [1]: k_reduced, [2]: back-substitution done (k_reproj_jac(trial) has started), [3]: second stream's trial-point kernels done, [4]: workgroups of k_imu_jac(trial) that have delivered their cost share (a running count, never reset inside a solve), [5]: that count at the end of the last judged pass (k_final's own book-keeping), [6]: STICKY -- number of the first pass in which a wait ran into its bound (0: none)
   long long sync_seq;              // this pass's number (0: no signalling)
   long long block_wait;            // k_imu_block(trial): one thread waits for sync_flags[2] >= block_wait before the kernel ends (0: no)
   long long final_wait;            // k_final waits for sync_flags[3] >= final_wait before it reads the second stream's sums (0: ordered by an event)
+  long long sync_bound;            // polls of a flag wait before it gives up and marks its pass (spin_until_flag; ~0.5 us each)
   Ctrl* ctrl;
   long long* dbg;                  // 32 cycle-counter stamps (profiling aid)
   double* trace;                   // trace_cap x kTraceCols
@@ -194,6 +202,7 @@ void launch_frame_schur(const DevView& v, hipStream_t s);      // frame eliminat
 void launch_reduced(const DevView& v, int mode, hipStream_t s);
 void launch_trial(const DevView& v, hipStream_t s);            // back-substitution + manifold update + trial residual sweep
 void launch_final(const DevView& v, int mode, hipStream_t s);
+void launch_set_ctrl(Ctrl* d, const Ctrl& c, hipStream_t s);      // d[0] <- c, d[1] <- 0
 void launch_wait_flag(const DevView& v, int idx, long long seq, hipStream_t s);      // returns when sync_flags[idx] >= seq
 void launch_signal_flag(const DevView& v, int idx, hipStream_t s);                    // sync_flags[idx] <- sync_seq once everything before it in the stream is done
 void launch_final_merged(const DevView& v, hipStream_t s);   // merged mode, batch end: judges the last pass (ctrl = next record, ctrl_prev = last pass's)  // mode 0: reduce + decide, 1: reduce only, 2: decide only

@@ -1385,6 +1385,10 @@ __device__ void trace_push(const DevView& v, Ctrl* c, const double* rec, bool wr
   if (writer && c->trace_len < c->trace_cap) {
     double* o = v.trace + (size_t)c->trace_len * kTraceCols;
     for (int i = 0; i < kTraceCols; ++i) o[i] = rec[i];
+    if (v.host_progress && v.host_trace && c->trace_len < 64) {        // the host's copy (published by the progress word's store)
+      double* ho = v.host_trace + (size_t)c->trace_len * kTraceCols;
+      for (int i = 0; i < kTraceCols; ++i) ho[i] = rec[i];
+    }
   }
   c->trace_len += 1;
   c->last_gnorm = rec[4];
@@ -1400,6 +1404,7 @@ __device__ void lm_decide_local(const DevView& v, Ctrl* c, const double* s, bool
   const double R_gnorm = sqrt(s[kScG2] + t[kScG2]), R_gmax = fmax(s[kScGmax], t[kScGmax]);
   const double R_new_cost = s[kScCost];
   c->passes += 1;
+  c->likely_last = 0;
   c->res_sweeps += v.fused ? 0 : 1;
   c->jac_sweeps += (c->need_lin ? 1 : 0) + (v.fused ? 1 : 0);
   if (c->hold) { c->cost = R_cost; c->gmax = R_gmax; c->gnorm = R_gnorm; return; }
@@ -1440,6 +1445,12 @@ __device__ void lm_decide_local(const DevView& v, Ctrl* c, const double* s, bool
   if (fabs(rec[2]) < c->ftol * c->cost) { trace_push(v, c, rec, writer); c->done = kDoneConvergence; return; }
   rec[6] = rec[2] / model_change;
   if (rec[6] > 1e-3) {
+    {
+      // convergence predictor for the feeding host (vc_calibrator.cpp: solve_once): quadratic-looking approach to the function tolerance
+      const double rel = fabs(rec[2]) / c->cost;
+      c->likely_last = (rel < 1e3 * c->ftol && rel < 0.1 * c->last_rel) ? 1 : 0;
+      c->last_rel = rel;
+    }
     c->cur = 1 - c->cur;
     const double q = 2.0 * rec[6] - 1.0;
     c->radius = fmin(1e16, c->radius / fmax(1.0 / 3.0, 1.0 - q * q * q));
@@ -1458,11 +1469,28 @@ __device__ void lm_decide_local(const DevView& v, Ctrl* c, const double* s, bool
 
 // the host's view of the loop: one system-scope store per decision (vc_calibrator.cpp: solve_once feeds passes against it)
 __device__ __forceinline__ void publish_progress(const DevView& v, const Ctrl& c) {
-  if (v.host_progress)
-    __hip_atomic_store(v.host_progress, ((unsigned long long)(unsigned)c.passes << 32) | (unsigned)c.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (v.host_progress) {
+    // a finished solve: the record itself goes to the host's page-locked copy, then -- after a system-scope fence -- the progress word
+    // says `done`; the host reads the result from there while the passes queued past the end drain (no copy, no synchronisation)
+    if (c.done && v.host_ctrl) *v.host_ctrl = c;
+    __threadfence_system();
+    __hip_atomic_store(v.host_progress, ((unsigned long long)(unsigned)c.passes << 32) | (unsigned)c.done | (c.likely_last ? kProgressLikelyLast : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 __device__ void lm_decide(const DevView& v) {
   Ctrl local = *v.ctrl;          // one burst of loads, one burst of stores
+  // device-flag hand-overs: a wait of this pass (or of one before it, noticed after that pass's decision) ran into its bound --
+  // what this pass computed cannot be trusted.  No judgement: the record stays as the last valid decision left it, the solve ends
+  // with kDoneSyncTimeout and the host resumes it with event hand-overs (vc_kutil.hpp: spin_until_flag)
+  if (v.sync_seq > 0) {
+    const long long m = sync_marked(v);
+    if (m != 0 && m <= v.sync_seq) {
+      local.done = kDoneSyncTimeout; local.abort_seq = (int)(v.sync_seq & 0x7fffffff);      // (this pass is the first one without a decision)
+      *v.ctrl = local;
+      publish_progress(v, local);
+      return;
+    }
+  }
   const bool fail = (v.flags[4 + 2 * v.par] != 0) || (v.flags[5 + 2 * v.par] != 0);
   v.flags[4 + 2 * v.par] = 0; v.flags[5 + 2 * v.par] = 0;
   lm_decide_local(v, &local, v.scal, fail, true);
@@ -1629,8 +1657,16 @@ __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
   // Sharded (mode 1: reduce, all-reduce, mode 2: decide): the first wait belongs to the reducing launch, the second wait and the
   // flag to the deciding one.
   const bool over = v.ctrl->done != 0;
-  if (v.final_wait > 0 && !over && v.n_frames > 1 && mode != 2) {
-    if (threadIdx.x == 0) spin_until_flag(v, 4, (long long)((v.n_frames - 1 + 7) / 8));
+  __shared__ long long s_count_base;
+  const long long nwg_imu = (long long)((v.n_frames - 1 + 7) / 8);
+  const bool counted = v.final_wait > 0 && !over && v.n_frames > 1 && mode != 2;
+  if (counted) {
+    // the count is a running one (never reset inside a solve: a reset could race with workgroups still adding); this kernel keeps
+    // the count at the end of the last judged pass in sync_flags[5]
+    if (threadIdx.x == 0) {
+      s_count_base = __hip_atomic_load(v.sync_flags + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      spin_until_flag(v, 4, s_count_base + nwg_imu);
+    }
     __syncthreads();
   }
   if (!over) final_phase(v, mode, red);
@@ -1639,13 +1675,19 @@ __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
   if (v.final_wait > 0) {
     if (threadIdx.x == 0) {
       spin_until_flag(v, 3, v.final_wait);
-      __hip_atomic_store(v.sync_flags + 4, 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the count starts over with the next pass
+      if (counted) __hip_atomic_store(v.sync_flags + 5, s_count_base + nwg_imu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
   }
+  // (a pass that has been marked void still signals: the next pass's waiters return at once anyway, and the host takes over)
   if (threadIdx.x == 0) signal_flag(v, 0);
 }
 
+// a fresh control record for a solve: record 0 <- the host's (a kernel argument), record 1 blank -- one launch instead of a copy and a fill
+__global__ __launch_bounds__(64) void k_set_ctrl(Ctrl* d, Ctrl c) {
+  if (threadIdx.x == 0) { d[0] = c; Ctrl z = Ctrl(); d[1] = z; }
+}
+void launch_set_ctrl(Ctrl* d, const Ctrl& c, hipStream_t s) { hipLaunchKernelGGL(k_set_ctrl, dim3(1), dim3(64), 0, s, d, c); }
 // both state buffers <- the uploaded initial state (benchmark restarts), one launch
 __global__ __launch_bounds__(256) void k_reset_state(DevView v, const double* pose0, const double* cam0, const double* vel0, const double* imu0) {
   const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)gridDim.x * 256;

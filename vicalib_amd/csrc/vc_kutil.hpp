@@ -83,12 +83,29 @@ __device__ __forceinline__ void signal_flag(const DevView& v, int idx) {
 }
 
 // The waiting side.  Bounded: a flag that never comes (the two streams sharing one hardware queue would do it: the producer
-// queued behind the waiting kernel) ends as a failed step after ~0.2 s, not as a hang.
+// queued behind the waiting kernel; a tool that serialises the kernels of all queues; several processes time-sliced on one
+// device) must not hang the device -- and must not change a result either.  A wait that runs into its bound (~0.2 s) marks the
+// pass it belongs to in a STICKY word, sync_flags[6] (the smallest pass number wins), and lets its kernel continue on whatever
+// data there is: everything that can be wrong from here on lives in the trial-side buffers of that pass and the passes behind
+// it, and the deciding thread of a marked pass (lm_decide) does not judge -- it ends the solve with kDoneSyncTimeout, the accepted
+// state and the control record exactly as the last valid decision left them.  The host reports the time-out, switches to
+// event hand-overs and resumes from there (vc_calibrator.cpp: solve_once): same iterates as a run without flags.  Once a pass is
+// marked every later wait returns at once (no cascade of 0.2 s bounds through the passes already queued).
+__device__ __forceinline__ long long sync_marked(const DevView& v) {
+  return __hip_atomic_load(v.sync_flags + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void spin_until_flag(const DevView& v, int idx, long long seq) {      // one thread
   long long n = 0;
   while (__hip_atomic_load(v.sync_flags + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
     __builtin_amdgcn_s_sleep(16);
-    if (++n > 400000) { v.flags[4 + 2 * v.par] = 1; v.flags[5 + 2 * v.par] = 1; break; }
+    const long long m = sync_marked(v);
+    if (m != 0 && m <= v.sync_seq) return;             // this pass is void already
+    if (++n > v.sync_bound) {
+      long long expect = 0;
+      if (!__hip_atomic_compare_exchange_strong(v.sync_flags + 6, &expect, v.sync_seq, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        __hip_atomic_fetch_min(v.sync_flags + 6, v.sync_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
   }
 }
 // ... and for a whole workgroup at its entry: thread 0 waits, then every wavefront drops what it may hold of the other stream's

@@ -25,7 +25,7 @@ SYMBOLS = [
     "vc_create", "vc_destroy", "vc_clear", "vc_add_camera", "vc_fix_camera_intrinsics", "vc_add_frame", "vc_set_frame_pose",
     "vc_add_observations", "vc_add_observation_tiles", "vc_add_imu", "vc_set_sigmas", "vc_set_biases", "vc_set_scale_factor", "vc_set_time_offset",
     "vc_set_function_tolerance", "vc_set_optimization_flags", "vc_set_max_iters", "vc_set_tolerances", "vc_set_gravity", "vc_set_frame_velocities", "vc_set_calibrate_imu", "vc_set_remove_outliers",
-    "vc_solve", "vc_start", "vc_resume", "vc_set_stage_limit", "vc_set_kernel_timing", "vc_get_kernel_timing", "vc_is_running", "vc_stop", "vc_num_frames", "vc_num_cameras", "vc_get_camera", "vc_get_frame",
+    "vc_solve", "vc_start", "vc_resume", "vc_set_stage_limit", "vc_sync_timeouts", "vc_set_kernel_timing", "vc_get_kernel_timing", "vc_is_running", "vc_stop", "vc_num_frames", "vc_num_cameras", "vc_get_camera", "vc_get_frame",
     "vc_get_biases", "vc_get_scale_factor", "vc_get_gravity", "vc_time_offset", "vc_mean_squared_error", "vc_get_camera_proj_rmse",
     "vc_get_num_iterations", "vc_num_imu_measurements", "vc_get_imu_measurements", "vc_get_integration_poses", "vc_print_results", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
     "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
@@ -318,6 +318,10 @@ class ViCalibrator:
         return dict(zip(["jac", "frame_schur", "-", "reduced", "trial", "final"], (out * 1e3).tolist()))
 
     def set_kernel_timing(self, on=True): _check(self.L.vc_set_kernel_timing(self.h, int(on)), "set_kernel_timing")
+
+    def sync_timeouts(self):
+        """Device-flag hand-overs that ran into their bound so far (each one reported on stderr, the solve resumed with events)."""
+        return int(self.L.vc_sync_timeouts(self.h))
 
     def kernel_timing(self):
         """{launch group: (launches, average ms)} of the solves run since set_kernel_timing(True)."""
