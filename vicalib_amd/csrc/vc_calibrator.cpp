@@ -153,6 +153,7 @@ struct vc_calibrator {
   bool pre_weights_pending = false;     // solve_once has recorded ev_pre ahead of the weight update that precedes a solve
   int wcur = 0;                         // weight buffer holding the current weight_sqrt_
   bool flag_sync = false;               // hand-overs to the second stream through device flags instead of event records (set at creation)
+  bool weights_behind_l0 = !(std::getenv("VICALIB_AMD_WEIGHTS_BEHIND_L0") && std::getenv("VICALIB_AMD_WEIGHTS_BEHIND_L0")[0] == '0');
   long long sync_bound = 400000;        // polls before a flag wait gives up (~0.2 s); VICALIB_AMD_SYNC_BOUND (test hook: a tiny bound forces the time-out path)
   int wr_ring[16] = {0};                // weight buffer read by pass (pass_seq & 15)
   int sync_timeouts = 0;                // flag hand-overs that ran into their bound (each one reported on stderr, the solve resumed with events)
@@ -700,6 +701,9 @@ struct vc_calibrator {
           KT2("k_imu_jac", launch_imu_jac(dv, wcur, stream2, 0));
           HIP_OK(hipEventRecord(ev_imujac, stream2));       // ahead of the weight update: the chain does not read the weights
         }
+        // flag hand-overs: the weight update (500 wavefronts that take a SIMD's whole register file each) starts behind the bottom level of
+        // the chain elimination, whose two-sided form needs the chip to itself; it is not needed before k_imu_jac(trial)
+        if (upd && fs && !first_pass && weights_behind_l0 && chain_forward_launches(dv) >= 2) launch_wait_flag(dv, 7, pass_seq, stream2);
         if (upd) KT2("k_imu_weights", launch_imu_weights(dv, wcur, stream2));
         if (first_pass) {
           KT("k_reproj_jac", launch_reproj_jac(dv, stream, 0));

@@ -131,7 +131,7 @@ struct DevView {
   int* flags;                      // [0]: frame Cholesky failures, [1]: reduced Cholesky failure (per pass)
   // cross-stream hand-overs without event records on the main stream (visual-inertial pass, single process): single-workgroup
   // kernels publish the pass number when they are done, a one-wavefront kernel on the second stream waits for it
-  long long* sync_flags;           // [0]: k_final, [1]: k_reduced, [2]: back-substitution done (k_reproj_jac(trial) has started), [3]: second stream's trial-point kernels done, [4]: workgroups of k_imu_jac(trial) that have delivered their cost share (a running count, never reset inside a solve), [5]: that count at the end of the last judged pass (k_final's own book-keeping), [6]: STICKY -- number of the first pass in which a wait ran into its bound (0: none)
+  long long* sync_flags;           // [0]: k_final, [1]: k_reduced, [2]: back-substitution done (k_reproj_jac(trial) has started), [3]: second stream's trial-point kernels done, [4]: workgroups of k_imu_jac(trial) that have delivered their cost share (a running count, never reset inside a solve), [5]: that count at the end of the last judged pass (k_final's own book-keeping), [6]: STICKY -- number of the first pass in which a wait ran into its bound (0: none), [7]: bottom level of the chain elimination complete
   long long sync_seq;              // this pass's number (0: no signalling)
   long long block_wait;            // k_imu_block(trial): one thread waits for sync_flags[2] >= block_wait before the kernel ends (0: no)
   long long final_wait;            // k_final waits for sync_flags[3] >= final_wait before it reads the second stream's sums (0: ordered by an event)
@@ -202,6 +202,7 @@ void launch_frame_schur(const DevView& v, hipStream_t s);      // frame eliminat
 void launch_reduced(const DevView& v, int mode, hipStream_t s);
 void launch_trial(const DevView& v, hipStream_t s);            // back-substitution + manifold update + trial residual sweep
 void launch_final(const DevView& v, int mode, hipStream_t s);
+int chain_forward_launches(const DevView& v);      // launches of the chain's forward elimination (levels + top)
 void launch_set_ctrl(Ctrl* d, const Ctrl& c, hipStream_t s);      // d[0] <- c, d[1] <- 0
 void launch_wait_flag(const DevView& v, int idx, long long seq, hipStream_t s);      // returns when sync_flags[idx] >= seq
 void launch_signal_flag(const DevView& v, int idx, hipStream_t s);                    // sync_flags[idx] <- sync_seq once everything before it in the stream is done

@@ -912,6 +912,7 @@ __device__ __forceinline__ void chain_fwd_group(const DevView& v, int s, int m, 
   // the control record is requested here and looked at after the first frame's image has been requested as well: a finished
   // solve costs a few wasted loads, a running one saves the record's round trip at the head of every level
   const int done = v.ctrl->done;
+  if (lvl == 1 && blockIdx.x == 0 && threadIdx.x == 0) signal_flag(v, 7);      // the bottom level is complete: this launch runs (the weight update waits for it)
   const int lane = threadIdx.x & 63;
   const int N = v.n_frames, D = v.D, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
   const long gs = (long)m * s;
@@ -1184,6 +1185,7 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
   const long gs = (long)m * s;
   const int a = (int)((long)group * gs), first = a + s;
   const int done = v.ctrl->done;
+  if (lvl == 1 && blockIdx.x == 0 && threadIdx.x == 0) signal_flag(v, 7);      // the bottom level is complete: this launch runs (the weight update waits for it)
   const bool pend = lvl > 0;
   const double* rp = v.rX[(lvl + 1) & 1];
   double* rw = v.rX[lvl & 1];
@@ -1753,9 +1755,13 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
   // VICALIB_AMD_CHAIN_TWO=0: one-sided throughout
   static const bool two_env = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO"); return !(e && std::atoi(e) == 0); }();
   const bool two_sided = two_env && cpl <= 1;
+  // ... and at the bottom level too once the weight update on the other stream starts behind it (vc_calibrator.cpp: enqueue_pass;
+  // VICALIB_AMD_CHAIN_TWO_BOTTOM=0: one-sided bottom level)
+  static const bool two_bottom = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO_BOTTOM"); return !(e && std::atoi(e) == 0); }();
+  const int two_from = two_bottom ? 0 : 1;
   auto fwd = [&](int groups, int stride, int m, int top, int lvl) {
     const bool side_by_side = cpl > 1 && !columns_per_lane;
-    if (cpl <= 1 && two_sided && !top && m >= 4 && lvl >= 1) hipLaunchKernelGGL(k_chain_fwd2, dim3(groups), dim3(128), 0, s, v, stride, m, lvl);
+    if (cpl <= 1 && two_sided && !top && m >= 4 && lvl >= two_from) hipLaunchKernelGGL(k_chain_fwd2, dim3(groups), dim3(128), 0, s, v, stride, m, lvl);
     else if (cpl <= 1) hipLaunchKernelGGL((k_chain_fwd<1, 1>), dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
     else if (side_by_side) {
       if (cpl <= 2) hipLaunchKernelGGL((k_chain_fwd<1, 2>), dim3(groups), dim3(128), 0, s, v, stride, m, top, lvl);
@@ -1773,8 +1779,20 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
     hipLaunchKernelGGL(k_chain_back, dim3(1 + (nl > 0 ? (N + kBackT0Frames - 1) / kBackT0Frames : 0)), dim3(64), 0, s, v, top_stride, m_top, 1, nl, 0);
     for (int l = nl - 1; l >= 0; --l)
       hipLaunchKernelGGL(k_chain_back, dim3((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1)), dim3(64), 0, s, v, strides[l], ms[l], 0, l,
-                         (two_sided && ms[l] >= 4 && l >= 1) ? 1 : 0);
+                         (two_sided && ms[l] >= 4 && l >= two_from) ? 1 : 0);
   }
+}
+// launches of the forward elimination (levels + the top level)
+int chain_forward_launches(const DevView& v) {
+  const int N = v.n_frames;
+  if (N < 1) return 0;
+  int nl = 0; long st = 1;
+  while (true) {
+    const int m = nl == 0 ? chain_group_size() : chain_group_size_upper();
+    if (!((N - 1) / st + 1 > m - 1)) break;
+    ++nl; st *= m;
+  }
+  return nl + 1;
 }
 void launch_chain_init(const DevView& v, hipStream_t s) {
   const size_t slot = (size_t)v.n_cams * kGStride + kGStride;
