@@ -95,10 +95,12 @@ void hh_imu_block_deltas(int n, const double* t, const double* w, const double* 
   ImuView buf = {t, w, a, n, imu_average_dt(t, n)};
   std::vector<double> blk(kBlockDeltaStride, 0.0);
   const int valid = imu_block_delta_record(buf, t_start, t_end, toff, b, sf, blk.data());
+  double grav9[9];
+  imu_gravity_record(gdir, grav9);
   for (int oc = 0; oc < 33; ++oc) {
     const int col = oc < 6 ? oc : oc < 12 ? oc + 3 : oc < 15 ? oc - 6 : oc;
     double dr[9];
-    imu_block_final_direction(valid, blk.data(), w_sqrt, rotation_only, T2, T1, v2, v1, gdir, col, r, dr);
+    imu_block_final_direction(valid, blk.data(), w_sqrt, rotation_only, T2, T1, v2, v1, grav9, col, r, dr);
     for (int row = 0; row < 9; ++row) J[row * 33 + oc] = dr[row];
   }
 }

@@ -228,7 +228,7 @@ struct vc_calibrator {
   DBuf<Ctrl> d_ctrl;
   DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_seg[2], d_seg_cost[2],
       d_cW, d_cdelta, d_ct0, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init, d_rX[2], d_grp_part, d_wg_trial, d_wg_imu_trial,
-      d_imu_delta_blk;
+      d_imu_delta_blk, d_imu_grav;
   size_t wsqrt_frames = 0;       // number of frames the device weight_sqrt_ array was initialised for
   size_t imu_uploaded = 0; double imu_uploaded_last = 0.0;      // sample count / last time stamp of the device copy of the IMU samples
   int trace_cap = 0;
@@ -530,7 +530,7 @@ struct vc_calibrator {
         HIP_OK(hipStreamSynchronize(stream));
       }
       for (int b = 0; b < 2; ++b) { HIP_OK(d_seg[b].alloc(ns * kSegStride)); HIP_OK(d_seg_cost[b].alloc(ns)); }
-      HIP_OK(d_imu_delta_blk.alloc(ns * kBlockDeltaStride));
+      HIP_OK(d_imu_delta_blk.alloc(ns * kBlockDeltaStride)); HIP_OK(d_imu_grav.alloc(32));
       const size_t nf = (size_t)std::max(N, 1);
       {
         const int ldw_max = (((Dmax + 1 + 15) / 16) * 16 % 32 == 0) ? ((Dmax + 1 + 15) / 16) * 16 + 16 : ((Dmax + 1 + 15) / 16) * 16;
@@ -544,7 +544,7 @@ struct vc_calibrator {
     dv.imu_t = d_imu_t.p; dv.imu_w = d_imu_w.p; dv.imu_a = d_imu_a.p; dv.frame_time = d_frame_time.p;
     dv.vel[0] = d_vel[0].p; dv.vel[1] = d_vel[1].p; dv.imus[0] = d_imus[0].p; dv.imus[1] = d_imus[1].p;
     dv.wsqrtb[0] = d_wsqrt[0].p; dv.wsqrtb[1] = d_wsqrt[1].p;
-    dv.imu_delta_blk = d_imu_delta_blk.p;
+    dv.imu_delta_blk = d_imu_delta_blk.p; dv.imu_grav = d_imu_grav.p;
     for (int b = 0; b < 2; ++b) { dv.segb[b] = d_seg[b].p; dv.seg_costb[b] = d_seg_cost[b].p; }
     dv.cW = d_cW.p; dv.cdelta = d_cdelta.p; dv.ct0 = d_ct0.p; dv.cg = d_cg.p;
     dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p;

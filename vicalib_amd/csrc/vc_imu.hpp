@@ -22,7 +22,9 @@ VC_HD D1 operator+(D1 x, D1 y) { return mk(x.a + y.a, x.v + y.v); }
 VC_HD D1 operator-(D1 x, D1 y) { return mk(x.a - y.a, x.v - y.v); }
 VC_HD D1 operator-(D1 x) { return mk(-x.a, -x.v); }
 VC_HD D1 operator*(D1 x, D1 y) { return mk(x.a * y.a, x.a * y.v + x.v * y.a); }
-VC_HD D1 operator/(D1 x, D1 y) { const double inv = 1.0 / y.a, q = x.a * inv; return mk(q, (x.v - q * y.v) * inv); }
+// (denominators: reciprocal by v_rcp_f64 + Newton on the device -- fast_rcp, vc_math.hpp; a literal divisor keeps the plain quotient,
+//  which the compiler folds)
+VC_HD D1 operator/(D1 x, D1 y) { const double inv = fast_rcp(y.a), q = x.a * inv; return mk(q, (x.v - q * y.v) * inv); }
 VC_HD D1 operator+(D1 x, double s) { return mk(x.a + s, x.v); }
 VC_HD D1 operator+(double s, D1 x) { return mk(x.a + s, x.v); }
 VC_HD D1 operator-(D1 x, double s) { return mk(x.a - s, x.v); }
@@ -30,14 +32,14 @@ VC_HD D1 operator-(double s, D1 x) { return mk(s - x.a, -x.v); }
 VC_HD D1 operator*(D1 x, double s) { return mk(x.a * s, x.v * s); }
 VC_HD D1 operator*(double s, D1 x) { return mk(x.a * s, x.v * s); }
 VC_HD D1 operator/(D1 x, double s) { const double inv = 1.0 / s; return mk(x.a * inv, x.v * inv); }
-VC_HD D1 operator/(double s, D1 y) { const double inv = 1.0 / y.a; return mk(s * inv, -s * inv * inv * y.v); }
+VC_HD D1 operator/(double s, D1 y) { const double inv = fast_rcp(y.a); return mk(s * inv, -s * inv * inv * y.v); }
 VC_HD bool operator<(D1 x, double y) { return x.a < y; }
 VC_HD bool operator>(D1 x, double y) { return x.a > y; }
-VC_HD D1 sqrt(D1 x) { const double s = ::sqrt(x.a); return mk(s, x.v / (2.0 * s)); }
+VC_HD D1 sqrt(D1 x) { double s, is; fast_sqrt_rsqrt(x.a, &s, &is); return mk(s, 0.5 * x.v * is); }
 VC_HD D1 sin(D1 x) { return mk(::sin(x.a), ::cos(x.a) * x.v); }
 VC_HD D1 cos(D1 x) { return mk(::cos(x.a), -::sin(x.a) * x.v); }
 VC_HD D1 tan(D1 x) { const double t = ::tan(x.a); return mk(t, (1.0 + t * t) * x.v); }
-VC_HD D1 atan(D1 x) { return mk(::atan(x.a), x.v / (1.0 + x.a * x.a)); }
+VC_HD D1 atan(D1 x) { return mk(vc_atan(x.a), x.v * fast_rcp(1.0 + x.a * x.a)); }      // (branch-free arctangent, < 2 ulp: vc_math.hpp)
 VC_HD D1 fabs(D1 x) { return x.a < 0.0 ? -x : x; }
 VC_HD double val(double x) { return x; }
 VC_HD double val(D1 x) { return x.a; }
@@ -108,8 +110,11 @@ template <class T> VC_HD void tse3_log(const T* X, T* d) {
   const T th = c * n;
   const T w0 = c * X[0], w1 = c * X[1], w2 = c * X[2];
   d[3] = w0; d[4] = w1; d[5] = w2;
+  // k = (1 - th / (2 tan(th/2))) / th^2.  On the regular branch th/2 = atan(n / qw), so tan(th/2) = n / qw: no tangent to evaluate
+  // (the reference's tan() of that very angle returns the same number up to rounding); the |qw| < eps branch keeps the call
   T k;
   if (fabs(th) < kSophusEps) k = cst<T>(1.0 / 12.0);
+  else if (!(n < kSophusEps) && !(fabs(qw) < kSophusEps)) k = (1.0 - (th * qw) / (2.0 * n)) / (th * th);
   else k = (1.0 - th / (2.0 * tan(th / 2.0))) / (th * th);
   // V^-1 t = t - 1/2 w x t + k w x (w x t)
   const T* t = X + 4;
@@ -316,6 +321,16 @@ template <class T> VC_HD void imu_gravity(const T* dir, T* out) {
   out[2] = (cp * cq) * (-g);
 }
 
+// the gravity vector and its partials along the two direction angles, [g_w 3 | d/d dir0 3 | d/d dir1 3]: formed once per state (one thread
+// of k_imu_block) instead of four sin / cos calls in every lane of every IMU block of k_imu_jac
+VC_HD void imu_gravity_record(const double* gdir, double* rec9) {
+  for (int c = 0; c < 2; ++c) {
+    const D1 d[2] = {mk(gdir[0], c == 0 ? 1.0 : 0.0), mk(gdir[1], c == 1 ? 1.0 : 0.0)};
+    D1 g[3];
+    imu_gravity(d, g);
+    for (int i = 0; i < 3; ++i) { rec9[i] = g[i].a; rec9[3 + 3 * c + i] = g[i].v; }
+  }
+}
 // Tail of the residual: the predicted state against frame j -- [log(T_pred T_j^-1); v_pred - v_j] times weight_sqrt, then the
 // rotation-only switch (ceres-cost-functions.h:468-482).
 template <class T>
@@ -605,8 +620,8 @@ inline int imu_block_delta_record(const ImuView& buf, double t_start, double t_e
 // biases 6 | scale factors 6 | time offset.  One lane's share: residual values r[9] and their partials along local column `col`
 // (col < 0: values only), from the block's delta record.  `valid`: the block's sample range is not empty.
 VC_HD void imu_block_final_direction(int valid, const double* block_rec, const double* w_sqrt, int rotation_only, const double* T2,
-                                     const double* T1, const double* v2, const double* v1, const double* gdir, int col, double* r,
-                                     double* dr) {
+                                     const double* T1, const double* v2, const double* v1, const double* grav9 /* imu_gravity_record */, int col,
+                                     double* r, double* dr) {
   if (!valid) { for (int i = 0; i < 9; ++i) { r[i] = 0.0; dr[i] = 0.0; } return; }
   const int dcol = (col >= 20) ? col - 19 : 0;                 // biases 1..6, scale factors 7..12, time offset 13
   D1 Q[4], P[3], V[3];
@@ -616,7 +631,7 @@ VC_HD void imu_block_final_direction(int valid, const double* block_rec, const d
   for (int k = 0; k < 3; ++k) { P[k] = mk(block_rec[4 + k], bd[4 + k]); V[k] = mk(block_rec[7 + k], bd[7 + k]); }
   const D1 Tt = mk(block_rec[10], bd[10]);
   // seeds: poses move along T exp(delta) (local_jac_se3), everything else is a plain coordinate
-  D1 T2D[7], v2D[3], gD[2], gw[3], q0[4], p0[3], v0[3];
+  D1 T2D[7], v2D[3], gw[3], q0[4], p0[3], v0[3];
   {
     double J[42];
     local_jac_se3(T2, J);
@@ -633,8 +648,7 @@ VC_HD void imu_block_final_direction(int valid, const double* block_rec, const d
     }
   }
   for (int k = 0; k < 3; ++k) { v2D[k] = mk(v2[k], col == 6 + k ? 1.0 : 0.0); v0[k] = mk(v1[k], col == 15 + k ? 1.0 : 0.0); }
-  gD[0] = mk(gdir[0], col == 18 ? 1.0 : 0.0); gD[1] = mk(gdir[1], col == 19 ? 1.0 : 0.0);
-  imu_gravity(gD, gw);
+  for (int k = 0; k < 3; ++k) gw[k] = mk(grav9[k], col == 18 ? grav9[3 + k] : (col == 19 ? grav9[6 + k] : 0.0));
   PoseV<D1> x;
   D1 rp[3], rv[3];
   tq_rotate(q0, P, rp);

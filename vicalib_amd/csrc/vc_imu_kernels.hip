@@ -40,14 +40,22 @@ struct SegTab {
   constexpr SegTab() : v() { for (int e = 0; e < kSegLen; ++e) { int a = 0, b = 0; seg_entry(e, &a, &b); v[e] = (unsigned short)(a | (b << 8)); } }
 };
 __constant__ SegTab d_seg_tab = SegTab();
+constexpr int kSegIters = (kSegLen + 31) / 32;      // entries of the record per lane (32 lanes per block)
 // The sweep proper.  Two IMU blocks per wavefront, lane = local column of the block: frame j's pose (6), frame j-1's pose (6) and
 // velocity (3), gravity (2), biases (6), scale factors (6), time offset -- 30 lanes put the block's delta on the start state and
 // run the residual's tail under one dual direction each (vc_imu.hpp: imu_block_final_direction); the three columns of frame j's
 // velocity are -W^T rows 6..8, written directly.  Then Cauchy(100) weight and the 33 x 33 weighted J^T J / J^T r of the block.
 // trial = 0: at the accepted state, when the control record asks for a linearisation; trial = 1: at the trial state into buffer
 // 1 - cur (cost = the block's trial cost; the blocks are the next linearisation if the step is accepted) -- see k_reproj_jac.
+// phase stamps of the first wavefront (profiling builds only, -DVC_IJ_STAMPS): 100 MHz s_memrealtime ticks in dbg[0..7]
+#ifdef VC_IJ_STAMPS
+#define IJSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) v.dbg[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define IJSTAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   __shared__ double sh[8 * kImuJacLds];
+  IJSTAMP(0);
   const Ctrl* ct = v.ctrl;
   if (ct->done || (!trial && !ct->need_lin)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -62,13 +70,17 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   const double* T1 = v.poses[cur] + (size_t)(j - 1) * kPoseStride;
   const double* v2 = v.vel[cur] + (size_t)j * 4;
   const double* v1 = v.vel[cur] + (size_t)(j - 1) * 4;
-  const double* im = v.imus[cur];
   const double* wq = v.wsqrtb[wr] + (size_t)s * 81;
   const double* brec = v.imu_delta_blk + (size_t)s * kBlockDeltaStride;
   double r[9], dr[9];
   const int col = (l < 6) ? l : (l < 30 ? l + 3 : -1);         // lanes 30, 31 carry the values only
   const bool valid = brec[10] >= 0.0;
-  imu_block_final_direction(valid, brec, wq, v.rotation_only, T2, T1, v2, v1, im, col, r, dr);
+  int seg_ab[kSegIters];
+#pragma unroll
+  for (int it = 0; it < kSegIters; ++it) { const int e = l + 32 * it; seg_ab[it] = d_seg_tab.v[e < kSegLen ? e : 0]; }
+  IJSTAMP(1);
+  imu_block_final_direction(valid, brec, wq, v.rotation_only, T2, T1, v2, v1, v.imu_grav + cur * 16, col, r, dr);
+  IJSTAMP(2);
   if (col >= 0) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) Jl[col * 9 + k] = dr[k];
@@ -106,17 +118,23 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
       } else v.wg_imu_trial[blockIdx.x] = wc;
     }
   }
+  IJSTAMP(3);
   if (!exists) return;
   // J^T J and J^T r of the block in the compact record: entry e = w * <column a, column b> with the residual as column 33
+  // (statically unrolled, the (row, column) pairs of the lane's 25 entries requested at the kernel's entry: as a loop every entry
+  //  waited for its own table look-up -- 25 dependent global round trips, 10 of the kernel's 24 us at cfg3)
   double* rec = v.segb[cur] + (size_t)s * kSegStride;
-  for (int e = l; e < kSegLen; e += 32) {
-    const int ab = d_seg_tab.v[e], a = ab & 255, bb = ab >> 8;
+#pragma unroll
+  for (int it = 0; it < kSegIters; ++it) {
+    const int e = l + 32 * it;
+    const int ab = seg_ab[it], a = ab & 255, bb = ab >> 8;
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc += Jl[a * 9 + k] * Jl[bb * 9 + k];
-    rec[e] = w * acc;
+    if (e < kSegLen) rec[e] = w * acc;
   }
   if (l == 0) v.seg_costb[cur][s] = ct->imu_mult * rho;
+  IJSTAMP(4);
 }
 
 // UpdateImuWeights from the accepted state (vicalibrator.h:723-799), interval-parallel (vc_imu_weights.hpp, second half).
@@ -339,6 +357,8 @@ __global__ __launch_bounds__(256, 2) void k_imu_block(DevView v, int trial) {
     }
     if (l == 7 && s_raw < n_blocks) imu_block_record_store(X, g, rec);
   } else if (lane == 0 && s_raw < n_blocks) rec[10] = -1.0;
+  // the gravity record of this state for k_imu_jac (one lane of the spare group)
+  if (blockIdx.x == 0 && threadIdx.x == 63) imu_gravity_record(im, v.imu_grav + cur * 16);
   // flag hand-overs, trial point: k_imu_jac behind this kernel needs the main stream's trial poses.  One thread of this kernel
   // waits for their flag before the kernel ends -- the kernel boundary then orders k_imu_jac behind it like any other kernel,
   // without a waiting kernel of its own (5 us on this stream's queue, which is the critical one at the end of a small pass)

@@ -75,6 +75,30 @@ VC_HD double fast_rsqrt(double d) {
   return 1.0 / sqrt(d);
 #endif
 }
+// 1/d to full double precision: hardware estimate (v_rcp_f64) + two Newton steps on the device -- 5 instructions instead of the
+// ~11 of an IEEE divide (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup), no special-case handling: operands here are
+// finite, normal and non-zero (depths, norms, polynomial denominators), or the result is discarded by a select.
+VC_HD double fast_rcp(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(d);
+  y = y * (2.0 - d * y);
+  y = y * (2.0 - d * y);
+  return y;
+#else
+  return 1.0 / d;
+#endif
+}
+// sqrt(d) and 1/sqrt(d) from one v_rsq_f64 chain (d > 0; d = 0 gives 0 and +inf)
+VC_HD void fast_sqrt_rsqrt(double d, double* s, double* is) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double r = fast_rsqrt(d);
+  *is = r;
+  *s = d > 0.0 ? d * r : 0.0;
+#else
+  const double q = sqrt(d);
+  *s = q; *is = 1.0 / q;
+#endif
+}
 // exp of a rotation vector as a unit quaternion [sin(th/2) w/th, cos(th/2)].  For th/2 <= pi/4 both factors are
 // polynomials in z = th^2/4 (the fdlibm kernel forms sin h = h + h^3 S(z), cos h = 1 - z/2 + z^2 C(z), < 1 ulp): no square
 // root, no division, no library call and no special case at th -> 0 -- LM steps practically never leave this range, and
@@ -139,9 +163,10 @@ VC_HD void se3_plus(const double* T, const double* d, double* o) {
 // ---- robust losses (ceres::SoftLOneLoss(0.5) vicalibrator.h:127, CauchyLoss(100) :133) ----
 VC_HD void loss_soft_l1(double s, double* rho, double* rho1) {
   const double b = 0.25, c = 4.0;
-  const double t = sqrt(1.0 + s * c);
+  double t, it;
+  fast_sqrt_rsqrt(1.0 + s * c, &t, &it);
   *rho = 2.0 * b * (t - 1.0);
-  *rho1 = 1.0 / t;
+  *rho1 = it;
 }
 VC_HD void loss_cauchy100(double s, double* rho, double* rho1) {
   const double b = 1.0e4, c = 1.0e-4;
@@ -156,7 +181,7 @@ VC_HD double vc_atan(double x) {
   const double ax = fabs(x);
   const bool big = ax > 2.41421356237309504880, mid = ax > 0.66;
   // one division with selected operands (two conditional divisions would be turned back into branches by the compiler)
-  const double t = (big ? -1.0 : (mid ? ax - 1.0 : ax)) / (big ? ax : (mid ? ax + 1.0 : 1.0));
+  const double t = (big ? -1.0 : (mid ? ax - 1.0 : ax)) * fast_rcp(big ? ax : (mid ? ax + 1.0 : 1.0));
   const double y0 = big ? 1.57079632679489661923 : (mid ? 0.78539816339744830962 : 0.0);
   const double more = big ? 6.123233995736765886130e-17 : (mid ? 3.061616997868382943065e-17 : 0.0);
   const double z = t * t;
@@ -164,12 +189,28 @@ VC_HD double vc_atan(double x) {
                      - 1.228866684490136173410e2) * z - 6.485021904942025371773e1;
   const double qd = ((((z + 2.485846490142306297962e1) * z + 1.650270098316988542046e2) * z + 4.328810604912902668951e2) * z
                      + 4.853903996359136964868e2) * z + 1.945506571482613964425e2;
-  const double r = y0 + (t * (z * pn / qd) + t + more);
+  const double r = y0 + (t * (z * pn * fast_rcp(qd)) + t + more);
+  return x < 0.0 ? -r : r;
+}
+// atan(y / x) for y >= 0 without forming the quotient: the argument reduction of vc_atan works on the pair (the reduced argument is a
+// ratio of sums of y and |x|), one reciprocal instead of a division followed by a second one
+VC_HD double vc_atan_ratio_pos(double y, double x) {
+  const double ax = fabs(x);
+  const bool big = y > 2.41421356237309504880 * ax, mid = y > 0.66 * ax;
+  const double t = (big ? -ax : (mid ? y - ax : y)) * fast_rcp(big ? y : (mid ? y + ax : ax));
+  const double y0 = big ? 1.57079632679489661923 : (mid ? 0.78539816339744830962 : 0.0);
+  const double more = big ? 6.123233995736765886130e-17 : (mid ? 3.061616997868382943065e-17 : 0.0);
+  const double z = t * t;
+  const double pn = (((-8.750608600031904122785e-1 * z - 1.615753718733365076637e1) * z - 7.500855792314704667340e1) * z
+                     - 1.228866684490136173410e2) * z - 6.485021904942025371773e1;
+  const double qd = ((((z + 2.485846490142306297962e1) * z + 1.650270098316988542046e2) * z + 4.328810604912902668951e2) * z
+                     + 4.853903996359136964868e2) * z + 1.945506571482613964425e2;
+  const double r = y0 + (t * (z * pn * fast_rcp(qd)) + t + more);
   return x < 0.0 ? -r : r;
 }
 // atan2(y, x) for y >= 0
 VC_HD double vc_atan2_pos(double y, double x) {
-  const double a = vc_atan(y / x);
+  const double a = vc_atan_ratio_pos(y, x);
   return x > 0.0 ? a : (x < 0.0 ? a + 3.14159265358979323846 : 1.57079632679489661923);
 }
 
@@ -184,7 +225,7 @@ VC_HD void model_precompute(int model, const double* K, ModelPre* p) {
 // A: 2x3 d pix / d p_c ; B: 2 x nk d pix / d K  (row-major). JAC=false skips A and B.
 template <bool JAC>
 VC_HD void project_radial(int model, const double* pc, const double* K, const ModelPre& pre, double* pix, double* A, double* B) {
-  const double iz = 1.0 / pc[2];
+  const double iz = fast_rcp(pc[2]);
   const double x = pc[0] * iz, y = pc[1] * iz;
   const double r2 = x * x + y * y;
   double fac = 1.0, h = 0.0;           // h = fac'(r) / r
@@ -195,10 +236,11 @@ VC_HD void project_radial(int model, const double* pc, const double* K, const Mo
     const double w = K[4];
     const double m = pre.m, dm = pre.dm;
     const bool w_big = w * w > 1e-5, r_small = r2 < 1e-5;
-    const double r = sqrt(r2);
+    double r, ir_raw;
+    fast_sqrt_rsqrt(r2, &r, &ir_raw);
     const double at = vc_atan(r * m);
-    // every division is unconditional and on a safe operand; the alternatives differ only by cheap selects
-    const double iw = 1.0 / (w_big ? w : 1.0), ir = 1.0 / (r_small ? 1.0 : r), iden = 1.0 / (1.0 + r2 * m * m);
+    // every reciprocal is unconditional and on a safe operand; the alternatives differ only by cheap selects
+    const double iw = fast_rcp(w_big ? w : 1.0), ir = r_small ? 1.0 : ir_raw, iden = fast_rcp(1.0 + r2 * m * m);
     const double fac_g = at * ir * iw, fac_s = m * iw;
     fac = w_big ? (r_small ? fac_s : fac_g) : 1.0;
     if (JAC) {
@@ -216,7 +258,7 @@ VC_HD void project_radial(int model, const double* pc, const double* K, const Mo
   } else if (model == kRational6) {
     // fac = N / Dn, N = 1 + k1 r^2 + k2 r^4 + k3 r^6, Dn = 1 + k4 r^2 + k5 r^4 + k6 r^6
     const double N = 1.0 + r2 * (K[4] + r2 * (K[5] + r2 * K[6])), Dn = 1.0 + r2 * (K[7] + r2 * (K[8] + r2 * K[9]));
-    const double iD = 1.0 / Dn;
+    const double iD = fast_rcp(Dn);
     fac = N * iD;
     if (JAC) {
       const double dN = K[4] + r2 * (2.0 * K[5] + 3.0 * K[6] * r2), dD = K[7] + r2 * (2.0 * K[8] + 3.0 * K[9] * r2);
@@ -246,13 +288,14 @@ template <bool JAC>
 VC_HD void project_kb4(const double* pc, const double* K, double* pix, double* A, double* B) {
   const double X = pc[0], Y = pc[1], Z = pc[2];
   const double rho2 = X * X + Y * Y;
-  const double rho = sqrt(rho2);
+  double rho, irho;
+  fast_sqrt_rsqrt(rho2, &rho, &irho);
   const double th = vc_atan2_pos(rho, Z);
   const double t2 = th * th;
   const double poly = 1.0 + t2 * (K[4] + t2 * (K[5] + t2 * (K[6] + t2 * K[7])));
   const double Rr = th * poly;
   const bool off_axis = rho > 0.0;            // selects, not jumps (see project_radial)
-  const double irho1 = 1.0 / (off_axis ? rho : 1.0);      // unconditional division on a safe operand
+  const double irho1 = off_axis ? irho : 1.0;
   const double c = X * irho1 + (off_axis ? 0.0 : 1.0), s = Y * irho1;   // on the axis X = Y = 0
   const double fu = K[0], fv = K[1];
   pix[0] = fu * Rr * c + K[2];
@@ -260,10 +303,10 @@ VC_HD void project_kb4(const double* pc, const double* K, double* pix, double* A
   if (JAC) {
     const double dR = 1.0 + t2 * (3.0 * K[4] + t2 * (5.0 * K[5] + t2 * (7.0 * K[6] + t2 * 9.0 * K[7])));
     const double n2 = rho2 + Z * Z;
-    const double in2 = 1.0 / n2;
+    const double in2 = fast_rcp(n2);
     const double thX = Z * c * in2, thY = Z * s * in2, thZ = -rho * in2;
     // R/rho -> 1/Z on the axis
-    const double Rq = (off_axis ? Rr : 1.0) / (off_axis ? rho : Z);
+    const double Rq = off_axis ? Rr * irho : fast_rcp(Z);
     const double cX = s * s * Rq, cY = -c * s * Rq, sX = cY, sY = c * c * Rq;   // R * dc/dX etc.
     A[0] = fu * (dR * thX * c + cX); A[1] = fu * (dR * thY * c + cY); A[2] = fu * dR * thZ * c;
     A[3] = fv * (dR * thX * s + sX); A[4] = fv * (dR * thY * s + sY); A[5] = fv * dR * thZ * s;
@@ -313,7 +356,8 @@ VC_HD double corner_rows(const TileXf& x, const double* K, const ModelPre& pre, 
   const double r0 = pix[0] - u, r1 = pix[1] - v;
   double rho, rho1;
   loss_soft_l1(r0 * r0 + r1 * r1, &rho, &rho1);
-  const double sw = sqrt(mult * rho1);
+  double sw, isw_unused;
+  fast_sqrt_rsqrt(mult * rho1, &sw, &isw_unused);
   const double q0 = pc[0] - x.tck[0], q1 = pc[1] - x.tck[1], q2 = pc[2] - x.tck[2];
   constexpr int nk = MODEL == kFov ? 5 : MODEL == kPoly2 ? 6 : MODEL == kPoly3 ? 7 : MODEL == kKb4 ? 8 : MODEL == kRational6 ? 10 : 4;
   for (int i = 7 + nk; i < kUCols; ++i) { row0[i] = 0.0; row1[i] = 0.0; }
