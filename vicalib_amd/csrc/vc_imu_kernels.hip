@@ -926,7 +926,6 @@ constexpr int kXsLd = 20;           // row stride of the [X_s | X_n] LDS image
 // XS (9 x kXsLd), An (81), Ls_all (NW x 81) the group's own.  NW > 1: all wavefronts of the workgroup belong to the group.
 template <int CPL, int NW>          // columns per lane x wavefronts: D + 1 + 27 <= 64 CPL NW
 __device__ __forceinline__ void chain_fwd_group(const DevView& v, int s, int m, int top, int lvl, int group, int wave, double* XS, double* An, double* Ls_all) {
-  double* Ls = Ls_all + wave * 81;
   auto group_sync = [&]() { if (NW > 1) __syncthreads(); else wave_lds_sync(); };
   CSTAMP(0);
   // the control record is requested here and looked at after the first frame's image has been requested as well: a finished
@@ -1035,38 +1034,41 @@ __device__ __forceinline__ void chain_fwd_group(const DevView& v, int s, int m, 
     if (i > 0) request_next(e, i);       // the next frame's columns: requested now, used after the factorisation and the solve
     group_sync();                        // the frame's A block (LDS) is complete
     CSTAMP(2 + 4 * i);
-    // ---- A = L L^T: lane = row (lanes 0..8), pivots and pivot columns through v_readlane
-    double dinv[9];
+    // ---- A = L L^T in every lane, from registers (see k_chain_fwd2: before, nine lanes factored through v_readlane and the factor
+    // went through LDS); the triangular solves take L from registers
+    double Lr[45], dinv[9];
     {
-      const int rr = lane < 9 ? lane : 8;
-      double row[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) row[k] = An[rr * 9 + k];
+      for (int ii = 0; ii < 9; ++ii)
+#pragma unroll
+        for (int j = 0; j <= ii; ++j) Lr[ii * (ii + 1) / 2 + j] = An[ii * 9 + j];
       bool bad = false;
 #pragma unroll
       for (int j = 0; j < 9; ++j) {
-        double d = readlane_f64(row[j], j);
+        double d = Lr[j * (j + 1) / 2 + j];
         const bool ok = d > 0.0;
         bad |= !ok;
         d = ok ? d : 1.0;
         const double ip = fast_rsqrt(d);
-        const double lij = (lane == j) ? d * ip : row[j] * ip;
-        row[j] = lij;
         dinv[j] = ip;
+        Lr[j * (j + 1) / 2 + j] = d * ip;
 #pragma unroll
-        for (int k = j + 1; k < 9; ++k) row[k] -= lij * readlane_f64(lij, k);
+        for (int ii = j + 1; ii < 9; ++ii) Lr[ii * (ii + 1) / 2 + j] *= ip;
+#pragma unroll
+        for (int ii = j + 1; ii < 9; ++ii)
+#pragma unroll
+          for (int k = j + 1; k <= ii; ++k) Lr[ii * (ii + 1) / 2 + k] -= Lr[ii * (ii + 1) / 2 + j] * Lr[k * (k + 1) / 2 + j];
       }
-      if (bad) {               // wave-uniform (the pivots are): the frame gets an identity block, the pass is flagged
+      if (bad) {               // uniform (every lane holds the same numbers): the frame gets an identity block, the pass is flagged
         if (lane == 0 && wave == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { row[k] = (k == lane) ? 1.0 : 0.0; dinv[k] = 1.0; }
-      }
-      if (lane < 9) {
+        for (int ii = 0; ii < 9; ++ii) {
+          dinv[ii] = 1.0;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Ls[lane * 9 + k] = (k <= lane) ? row[k] : 0.0;
+          for (int j = 0; j <= ii; ++j) Lr[ii * (ii + 1) / 2 + j] = (ii == j) ? 1.0 : 0.0;
+        }
       }
     }
-    wave_lds_sync();
     CSTAMP(3 + 4 * i);
     // ---- forward solves, lane = column; the image of e becomes [Y | z | X_s | L | X_n]
     double x[CPL][9];
@@ -1079,13 +1081,15 @@ __device__ __forceinline__ void chain_fwd_group(const DevView& v, int s, int m, 
       for (int k = 0; k < 9; ++k) {
         x[ci][k] *= dinv[k];
 #pragma unroll
-        for (int r = k + 1; r < 9; ++r) x[ci][r] -= Ls[r * 9 + k] * x[ci][k];
+        for (int r = k + 1; r < 9; ++r) x[ci][r] -= Lr[r * (r + 1) / 2 + k] * x[ci][k];
       }
+      // an A lane has solved L x = A e_sub: x = row `sub` of L; the image wants column `sub` -- the nine lanes (of whichever
+      // wavefronts) transpose through the group's LDS image behind the barrier of the [X_s | X_n] exchange
       if (role[ci] == 2) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) x[ci][k] = Ls[k * 9 + sub[ci]];
+        for (int k = 0; k < 9; ++k) Ls_all[k * 9 + sub[ci]] = (k <= sub[ci]) ? x[ci][k] : 0.0;
       }
-      if (role[ci] < 4) {
+      if (role[ci] == 0 || role[ci] == 1 || role[ci] == 3) {
         double* img = v.cW + (size_t)e * isz + pc[ci];
 #pragma unroll
         for (int k = 0; k < 9; ++k) img[k * ldx] = x[ci][k];
@@ -1102,6 +1106,9 @@ __device__ __forceinline__ void chain_fwd_group(const DevView& v, int s, int m, 
 #pragma unroll
     for (int ci = 0; ci < CPL; ++ci) {
       if (role[ci] == 2) {
+        double* img = v.cW + (size_t)e * isz + pc[ci];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) img[k * ldx] = Ls_all[sub[ci] * 9 + k];      // L[k][sub] (zero above the diagonal)
 #pragma unroll
         for (int k = 0; k < 9; ++k) x[ci][k] = XS[k * kXsLd + 9 + sub[ci]];
       }
@@ -1287,48 +1294,56 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
   // one elimination: A (in An) = L L^T, all columns solved, image stored, [X_s | X_n] to XS, out = [X_s | X_n]^T (column)
   auto eliminate = [&](int e, double* x, double* out) {
     wave_lds_sync_local();
-    double dinv[9];
+    // A = L L^T in EVERY lane, from registers (round 4; before: nine lanes, one row each, pivots and pivot columns through
+    // v_readlane -- ~240 cycles per pivot, 0.9 us per frame, and the factor went through LDS to the lanes that solve with it).  All
+    // lanes read the lower triangle (broadcast LDS reads) and run the same scalar factorisation: per pivot one v_rsq_f64 chain,
+    // then independent multiplies / FMAs; the triangular solve that follows takes L from registers.
+    double Lr[45], dinv[9];
     {
-      const int rr = lane < 9 ? lane : 8;
-      double row[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) row[k] = An[rr * 9 + k];
+      for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Lr[i * (i + 1) / 2 + j] = An[i * 9 + j];
       bool bad = false;
 #pragma unroll
       for (int j = 0; j < 9; ++j) {
-        double d = readlane_f64(row[j], j);
+        double d = Lr[j * (j + 1) / 2 + j];
         const bool ok = d > 0.0;
         bad |= !ok;
         d = ok ? d : 1.0;
         const double ip = fast_rsqrt(d);
-        const double lij = (lane == j) ? d * ip : row[j] * ip;
-        row[j] = lij;
         dinv[j] = ip;
+        Lr[j * (j + 1) / 2 + j] = d * ip;
 #pragma unroll
-        for (int k = j + 1; k < 9; ++k) row[k] -= lij * readlane_f64(lij, k);
+        for (int i = j + 1; i < 9; ++i) Lr[i * (i + 1) / 2 + j] *= ip;
+#pragma unroll
+        for (int i = j + 1; i < 9; ++i)
+#pragma unroll
+          for (int k = j + 1; k <= i; ++k) Lr[i * (i + 1) / 2 + k] -= Lr[i * (i + 1) / 2 + j] * Lr[k * (k + 1) / 2 + j];
       }
-      if (bad) {               // wave-uniform (the pivots are): the frame gets an identity block, the pass is flagged
+      if (bad) {               // wave-uniform (every lane holds the same numbers): the frame gets an identity block, the pass is flagged
         if (lane == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { row[k] = (k == lane) ? 1.0 : 0.0; dinv[k] = 1.0; }
-      }
-      if (lane < 9) {
+        for (int i = 0; i < 9; ++i) {
+          dinv[i] = 1.0;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Ls[lane * 9 + k] = (k <= lane) ? row[k] : 0.0;
+          for (int j = 0; j <= i; ++j) Lr[i * (i + 1) / 2 + j] = (i == j) ? 1.0 : 0.0;
+        }
       }
     }
-    wave_lds_sync_local();
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       x[k] *= dinv[k];
 #pragma unroll
-      for (int rr = k + 1; rr < 9; ++rr) x[rr] -= Ls[rr * 9 + k] * x[k];
+      for (int rr = k + 1; rr < 9; ++rr) x[rr] -= Lr[rr * (rr + 1) / 2 + k] * x[k];
     }
+    // an A lane has solved L x = A e_sub: x = L^T e_sub, row `sub` of L.  The image wants column `sub`: the nine lanes transpose
+    // through LDS, behind the barrier the [X_s | X_n] exchange needs anyway
     if (role == 2) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) x[k] = Ls[k * 9 + sub];
+      for (int k = 0; k < 9; ++k) Ls[k * 9 + sub] = (k <= sub) ? x[k] : 0.0;
     }
-    if (role < 4) {
+    if (role == 0 || role == 1 || role == 3) {
       double* img = v.cW + (size_t)e * isz + pc;
 #pragma unroll
       for (int k = 0; k < 9; ++k) img[k * ldx] = x[k];
@@ -1340,6 +1355,9 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
     }
     wave_lds_sync_local();
     if (role == 2) {
+      double* img = v.cW + (size_t)e * isz + pc;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) img[k * ldx] = Ls[sub * 9 + k];       // L[k][sub] (zero above the diagonal)
 #pragma unroll
       for (int k = 0; k < 9; ++k) x[k] = XS[k * kXsLd + 9 + sub];
     }
