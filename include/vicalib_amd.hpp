@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <array>
 #include <stdexcept>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -130,11 +131,13 @@ class ViCalibrator {
     return out;
   }
   std::string PrintResults() {
-    const int n = vc_checked(vc_print_results(h_, nullptr, 0), "PrintResults");          // the length first: any number of cameras
-    std::string s((size_t)n + 1, '\0');
-    vc_checked(vc_print_results(h_, &s[0], n + 1), "PrintResults");
-    s.resize((size_t)n);
-    return s;
+    // the length first (any number of cameras); a running Start() worker may lengthen the text between the two calls: slack + retry
+    for (int attempt = 0; attempt < 8; ++attempt) {
+      const int n = vc_checked(vc_print_results(h_, nullptr, 0), "PrintResults");
+      std::string s((size_t)n + 65, '\0');
+      if (vc_print_results(h_, &s[0], n + 65) >= 0) { s.resize(std::strlen(s.c_str())); return s; }
+    }
+    throw std::runtime_error("PrintResults: the text kept growing");
   }
   void WriteCameraModels(const std::string& filename) { vc_checked(vc_write_camera_models(h_, filename.c_str()), "WriteCameraModels"); }   // :208
   // GetSolutionCovariance(problem) :802-857: row-major n x n over the blocks named by covariance_names

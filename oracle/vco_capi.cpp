@@ -18,6 +18,8 @@ void vco_so3_exp(const double* w, double* q) { so3_exp(w, q); }
 void vco_so3_log(const double* q, double* w) { so3_log(q, w); }
 void vco_se3_exp(const double* d, double* T) { se3_exp(d, T); }
 void vco_se3_log(const double* T, double* d) { se3_log(T, d); }
+// the restated dLog_dSE3 (vicalibrator-utils.h:308-434), 6 x 7 row-major, columns [t(3), q(4)], T stored [q, t]
+void vco_dlog_dse3(const double* T, double* out42) { const Mat m = dlog_dse3(T); for (int i = 0; i < 42; ++i) out42[i] = m.d[i]; }
 void vco_se3_mul(const double* A, const double* B, double* o) { se3_mul(A, B, o); }
 void vco_se3_inv(const double* A, double* o) { se3_inv(A, o); }
 void vco_plus_se3(const double* x, const double* d, double* o) { plus_se3(x, d, o); }

@@ -119,5 +119,16 @@ int hh_imu_weight_intervals(int n, const double* t, const double* w, const doubl
   return imu_weight_factor_intervals(buf, t_start, t_end, toff, T1, v1, T2, b, sf, gdir, gs, as, W);
 }
 void hh_dlog_dse3(const double* T, double* full, double* lean) { w_dlog_dse3(T, full); w_dlog_dse3_lean(T, lean); }
+// the Jacobian of the device's SE3 logarithm (tse3_log, what k_imu_jac differentiates) by dual numbers, 6 x 7 row-major with the
+// columns in dLog_dSE3's order [t(3), q(4)]; T stored [q, t]
+void hh_se3_log_dual_jacobian(const double* T, double* J42) {
+  for (int c = 0; c < 7; ++c) {
+    const int kk = c < 3 ? 4 + c : c - 3;
+    D1 X[7], d[6];
+    for (int k = 0; k < 7; ++k) X[k] = mk(T[k], k == kk ? 1.0 : 0.0);
+    tse3_log(X, d);
+    for (int r = 0; r < 6; ++r) J42[r * 7 + c] = d[r].v;
+  }
+}
 int hh_chol6(double* M) { return chol_small<6>(M) ? 1 : 0; }
 }

@@ -540,6 +540,38 @@ def test_imu_weight_update_matches_oracle():
         assert np.allclose(np.tril(Wg[j], -1), 0.0)          # W = L^-T is upper triangular
 
 
+def test_imu_weight_update_on_a_stationary_rig_takes_the_small_angle_branch():
+    """The theta < eps branch of dLog_dSE3 (vicalibrator-utils.h:352-374, with the reference's `div_12 * (wx_x * wy_y)` term) on the
+    device AND in the oracle (verdict r3 weak #5: reachable by no test on either side): a rig at rest -- gyro samples zero, accelerometer
+    samples the reaction to gravity, every frame at the same pose with zero velocity -- predicts exactly the pose it is compared with,
+    so the relative rotation the projection differentiates is the identity quaternion, theta = 0.  W W^T of every block against the oracle."""
+    p = _vi_problem(12)
+    n = len(p.imu_t)
+    p.imu_gyro = np.zeros((n, 3))
+    g_w = np.array([0.0, 0.0, -9.8007])                       # imu_gravity at direction (0, 0)
+    T0 = np.array([0.0, 0.0, 0.0, 1.0, 0.3, -0.2, 0.1])
+    p.imu_accel = np.tile(g_w, (n, 1))                        # k_v = R a - g_w = 0 at the identity orientation
+    cal = ViCalibrator(0).load_problem(p, init=False)
+    orc = ol.Oracle().load(p, init=False); orc.set_options(calibrate_imu=True)
+    b0 = np.zeros(6); s0 = np.ones(6)
+    orc.set_flags(True, True, False, True); orc.set_imu_state(b0, s0, np.zeros(2), 0.0)
+    cal.SetOptimizationFlags(True, True, False, True); cal.SetBiases(b0); cal.SetScaleFactor(s0); cal.SetTimeOffset(0.0); cal.SetGravity(np.zeros(2))
+    for f in range(len(p.frame_time)):
+        orc.set_frame(f, T0, np.zeros(3))
+        cal.SetFramePose(f, T0)
+    assert lib.load().vc_set_frame_velocities(cal.h, lib._d(np.zeros((len(p.frame_time), 3))), len(p.frame_time)) == 0
+    orc.prepare(vis_mult=1, imu_mult=1)
+    cal.linearize()
+    Wg = cal.imu_weights()
+    orc.update_imu_weights(); Wo = orc.imu_weights().reshape(-1, 9, 9)
+    n_new = 0
+    for j in range(len(Wg)):
+        Cg = Wg[j] @ Wg[j].T; Co = Wo[j] @ Wo[j].T
+        np.testing.assert_allclose(Cg, Co, rtol=1e-7, atol=1e-9 * np.abs(Co).max())
+        n_new += not np.allclose(Wo[j], np.eye(9) * Wo[j][0, 0])
+    assert n_new >= len(Wg) - 2            # the update ran
+
+
 @pytest.mark.parametrize("imu_rate,toff", [(40.0, 0.004), (330.0, 0.0025), (345.0, -0.011), (1000.0, 0.0007), (700.0, 0.05)])
 def test_imu_weight_update_across_sample_rates(imu_rate, toff):
     """The interval-parallel weight update over blocks of 1 to 51 sample intervals (the kernel handles 16 intervals of a block per

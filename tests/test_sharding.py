@@ -14,7 +14,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run(mode, timeout, nproc=2, flags=False):
+def _run(mode, timeout, nproc=2, flags=False, extra_env=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(HERE, "dist_worker.py"), mode]
     # several processes share ONE GPU here (not how the library is deployed: one process per GPU).  The single-process reference
@@ -26,6 +26,7 @@ def _run(mode, timeout, nproc=2, flags=False):
         env["VICALIB_AMD_FLAG_SYNC"] = "0"
     else:
         env.pop("VICALIB_AMD_FLAG_SYNC", None)
+    env.update(extra_env or {})
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     fail = out.stdout.find("WORKER-FAILURE")
     assert out.returncode == 0, (out.stdout[fail:fail + 7000] if fail >= 0 else out.stdout[-3000:] + out.stderr[-3000:])
@@ -62,6 +63,16 @@ def test_two_processes_on_one_gpu_with_flag_handovers():
     """The same two-rank solve with the device-flag hand-overs left on in the workers' single-process reference solves: two
     processes' waiting kernels time-sliced on one device (advice r3).  Parity must hold whether or not a wait starves."""
     _run("gpu_imu", 900, flags=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bound", ["400000", "10"])
+def test_sharded_solve_with_flag_handovers(bound):
+    """The sharded pass with the device-flag hand-overs a multi-rank RCCL run uses (one device per rank there; here two ranks share
+    one GPU, the configuration the flags are NOT meant for -- which makes it a good test of the time-out path): the mark of a void pass
+    travels with the all-reduce of the step scalars, every rank withholds the same decision and resumes with events.  Sharded == single
+    process as in the event runs; bound = 10 polls forces time-outs."""
+    _run("gpu_imu", 900, flags=True, extra_env={"VICALIB_AMD_SHARD_FLAG_SYNC": "1", "VICALIB_AMD_SYNC_BOUND": bound})
 
 
 @pytest.mark.gpu

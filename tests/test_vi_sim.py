@@ -60,5 +60,8 @@ def test_vi_sim_gpu():
     o = ol.Oracle().load(p); o.set_options(calibrate_imu=True, num_threads=8); o.solve()
     tg, to = cal.trace(), o.trace()
     assert len(tg) == len(to)
-    np.testing.assert_allclose(tg[:, 1], to[:, 1], rtol=1e-6, atol=1e-12)
+    # 1e-6 relative (north_star); the data are noise-free, so the last vision iterations sit on the rounding floor -- costs of
+    # ~1e-7 against 8.6e5 at the start, i.e. below 1e-12 of the problem's scale, where the two implementations' last bits decide
+    # (the device's reciprocals are v_rcp_f64 + Newton, ~1 ulp): an absolute floor of 1e-15 of the initial cost
+    np.testing.assert_allclose(tg[:, 1], to[:, 1], rtol=1e-6, atol=1e-15 * to[0, 1])
     np.testing.assert_allclose(K, o.camera(0)[0], rtol=1e-6)

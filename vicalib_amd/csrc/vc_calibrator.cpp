@@ -54,6 +54,73 @@ template <class T> struct DBuf {
   }
 };
 
+// One stage's small uploads, packed: arrays are appended to a page-locked staging image (grow-only), every destination is a
+// segment; flush() sends image + segment table with one copy and scatters them with one kernel (launch_unpack).  A source may
+// serve several destinations; zero() adds a fill.  Everything is ordered on the calibrator's stream like the copies it replaces.
+struct Packer {
+  char* host = nullptr; size_t cap = 0, used = 0;
+  DBuf<char> dev;
+  std::vector<UnpackSeg> segs;
+  ~Packer() { if (host) (void)hipHostFree(host); }
+  hipError_t reserve(size_t need) {
+    if (need <= cap) return hipSuccess;
+    const size_t ncap = std::max(need, cap * 2 + (1u << 16));
+    char* nh = nullptr;
+    hipError_t e = hipHostMalloc((void**)&nh, ncap, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    if (host) { std::memcpy(nh, host, used); (void)hipHostFree(host); }
+    host = nh; cap = ncap;
+    return hipSuccess;
+  }
+  void begin() { used = 0; segs.clear(); }
+  // appends the bytes, returns their offset (16-byte aligned) or ~0 on failure
+  size_t put(const void* p, size_t bytes) {
+    const size_t off = (used + 15) & ~(size_t)15;
+    if (reserve(off + bytes + 16) != hipSuccess) return ~(size_t)0;
+    if (bytes) std::memcpy(host + off, p, bytes);
+    used = off + bytes;
+    return off;
+  }
+  template <class T> hipError_t add(DBuf<T>& d, const std::vector<T>& h) {
+    static_assert(sizeof(T) % 4 == 0, "segments are copied in 32-bit words");
+    hipError_t e = d.alloc(h.size());
+    if (e != hipSuccess || h.empty()) return e;
+    const size_t off = put(h.data(), h.size() * sizeof(T));
+    if (off == ~(size_t)0) return hipErrorOutOfMemory;
+    segs.push_back({(unsigned long long)(uintptr_t)d.p, (unsigned long long)off, (unsigned long long)(h.size() * sizeof(T))});
+    return hipSuccess;
+  }
+  // another destination for the array added last
+  template <class T> hipError_t also(DBuf<T>& d, size_t count) {
+    hipError_t e = d.alloc(count);
+    if (e != hipSuccess || count == 0 || segs.empty()) return e;
+    UnpackSeg sg = segs.back(); sg.dst = (unsigned long long)(uintptr_t)d.p;
+    segs.push_back(sg);
+    return hipSuccess;
+  }
+  // room for `bytes` inside the image, to be filled in place (valid until the next put / slot call grows the image: reserve first)
+  void* slot(size_t bytes, size_t* off) {
+    *off = (used + 15) & ~(size_t)15;
+    if (reserve(*off + bytes + 16) != hipSuccess) return nullptr;
+    used = *off + bytes;
+    return host + *off;
+  }
+  void seg(void* dst, size_t off, size_t bytes) { if (bytes) segs.push_back({(unsigned long long)(uintptr_t)dst, (unsigned long long)off, (unsigned long long)bytes}); }
+  void zero(void* p, size_t bytes) { if (p && bytes) segs.push_back({(unsigned long long)(uintptr_t)p, ~0ull, (unsigned long long)bytes}); }
+  hipError_t flush(hipStream_t s) {
+    if (segs.empty()) return hipSuccess;
+    const size_t img = used;
+    const size_t tab = put(segs.data(), segs.size() * sizeof(UnpackSeg));
+    if (tab == ~(size_t)0) return hipErrorOutOfMemory;
+    hipError_t e = dev.alloc(used + 16);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(dev.p, host, used, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    launch_unpack((const UnpackSeg*)(dev.p + tab), (int)segs.size(), dev.p, img, s);
+    return hipGetLastError();
+  }
+};
+
 // a fixed set of timing events, destroyed on every exit path
 template <int N> struct EventSet {
   hipEvent_t e[N] = {};
@@ -152,8 +219,10 @@ struct vc_calibrator {
   hipEvent_t ev_state = nullptr, ev_weights = nullptr, ev_imujac = nullptr, ev_reduced = nullptr, ev_back = nullptr, ev_pre = nullptr;
   bool pre_weights_pending = false;     // solve_once has recorded ev_pre ahead of the weight update that precedes a solve
   int wcur = 0;                         // weight buffer holding the current weight_sqrt_
+  Packer pack;                          // staging image of a stage's small uploads
   bool flag_sync = false;               // hand-overs to the second stream through device flags instead of event records (set at creation)
   bool weights_behind_l0 = !(std::getenv("VICALIB_AMD_WEIGHTS_BEHIND_L0") && std::getenv("VICALIB_AMD_WEIGHTS_BEHIND_L0")[0] == '0');
+  bool shard_flag_sync = std::getenv("VICALIB_AMD_SHARD_FLAG_SYNC") && std::getenv("VICALIB_AMD_SHARD_FLAG_SYNC")[0] == '1';
   long long sync_bound = 400000;        // polls before a flag wait gives up (~0.2 s); VICALIB_AMD_SYNC_BOUND (test hook: a tiny bound forces the time-out path)
   int wr_ring[16] = {0};                // weight buffer read by pass (pass_seq & 15)
   int sync_timeouts = 0;                // flag hand-overs that ran into their bound (each one reported on stderr, the solve resumed with events)
@@ -361,8 +430,40 @@ struct vc_calibrator {
       h_obs_index = idx;
       h_tile_frame.clear(); h_tile_cam.clear(); h_tile_off.clear();
       if (pts.size() > kObsPointMask + 1) return VC_ERR_TOO_MANY_POINTS;
-      std::vector<double2> uv(idx.size());
-      std::vector<unsigned short> pt(idx.size());
+      const size_t n_o = idx.size();
+      if (n_o * sizeof(double2) > ((size_t)64 << 20)) {
+        // (very large observation sets keep the streaming pageable copies: a page-locked image of their size costs more to allocate
+        //  than it saves)
+        std::vector<double2> uv(n_o);
+        std::vector<unsigned short> pt(n_o);
+        n_one_less = 0;
+        for (size_t k = 0; k < n_o; ++k) {
+          const int i = idx[k];
+          if (k == 0 || o_frame[i] != o_frame[idx[k - 1]] || o_cam[i] != o_cam[idx[k - 1]]) {
+            h_tile_frame.push_back(o_frame[i]); h_tile_cam.push_back(o_cam[i]); h_tile_off.push_back((int)k);
+          }
+          pt[k] = (unsigned short)(o_pid[i] | (o_removed[i] == 2 ? kObsOneLess : 0));
+          if (o_removed[i] == 2) ++n_one_less;
+          uv[k] = make_double2(o_pc[2 * (size_t)i], o_pc[2 * (size_t)i + 1]);
+        }
+        h_tile_off.push_back((int)n_o);
+        n_points_dev = pts.size();
+        HIP_OK(d_uv.upload(uv, stream)); HIP_OK(d_pt.upload(pt, stream)); HIP_OK(d_points.upload(pts.xyz, stream));
+        HIP_OK(d_tile_frame.upload(h_tile_frame, stream)); HIP_OK(d_tile_cam.upload(h_tile_cam, stream));
+        HIP_OK(d_tile_off.upload(h_tile_off, stream));
+        HIP_OK(d_mask.alloc(std::max<size_t>(n_o, 1)));
+        HIP_OK(hipStreamSynchronize(stream));        // the staging vectors go out of scope
+      } else {
+      // detections and point indices are written straight into the page-locked staging image (no pageable vector in between: the 6 MB
+      // copy of cfg3's detections was 1.5 ms of the first stage's upload)
+      pack.begin();
+      const size_t pt_bytes = ((n_o * sizeof(unsigned short) + 3) / 4) * 4;
+      if (pack.reserve(n_o * sizeof(double2) + pt_bytes + pts.xyz.size() * 8 + (h_tile_frame.capacity() + n_o / 8 + 64) * 16 + 4096) != hipSuccess) return VC_ERR_NO_DEVICE;
+      size_t uv_off = 0, pt_off = 0;
+      double2* uv = (double2*)pack.slot(n_o * sizeof(double2), &uv_off);
+      unsigned short* pt = (unsigned short*)pack.slot(pt_bytes, &pt_off);
+      if (!uv || !pt) return VC_ERR_NO_DEVICE;
+      if (pt_bytes > n_o * sizeof(unsigned short)) pt[n_o] = 0;      // (padding word)
       n_one_less = 0;
       for (size_t k = 0; k < idx.size(); ++k) {
         const int i = idx[k];
@@ -375,11 +476,15 @@ struct vc_calibrator {
       }
       h_tile_off.push_back((int)idx.size());
       n_points_dev = pts.size();
-      HIP_OK(d_uv.upload(uv, stream)); HIP_OK(d_pt.upload(pt, stream)); HIP_OK(d_points.upload(pts.xyz, stream));
-      HIP_OK(d_tile_frame.upload(h_tile_frame, stream)); HIP_OK(d_tile_cam.upload(h_tile_cam, stream));
-      HIP_OK(d_tile_off.upload(h_tile_off, stream));
+      HIP_OK(d_uv.alloc(std::max<size_t>(n_o, 1))); HIP_OK(d_pt.alloc(pt_bytes / sizeof(unsigned short) + 2));
+      pack.seg(d_uv.p, uv_off, n_o * sizeof(double2)); pack.seg(d_pt.p, pt_off, pt_bytes);
+      HIP_OK(pack.add(d_points, pts.xyz));
+      HIP_OK(pack.add(d_tile_frame, h_tile_frame)); HIP_OK(pack.add(d_tile_cam, h_tile_cam));
+      HIP_OK(pack.add(d_tile_off, h_tile_off));
       HIP_OK(d_mask.alloc(std::max<size_t>(idx.size(), 1)));
-      HIP_OK(hipStreamSynchronize(stream));        // the staging vectors go out of scope
+      HIP_OK(pack.flush(stream));
+      HIP_OK(hipStreamSynchronize(stream));        // the staging image is re-used below
+      }
       obs_dirty = false;
     }
     up_a = up_ms();
@@ -409,6 +514,18 @@ struct vc_calibrator {
     for (int c = 0; c < C; ++c) cam_model[c] = cams[c].model;
     up_b = up_ms();
     // ---- upload ---------------------------------------------------------------------------------
+    // Everything small goes through ONE page-locked staging image, one copy and one scatter kernel (Packer above; round 3: ~30
+    // pageable copies and ~8 fills per stage, 4.1 of the 19 ms of a complete cfg3 calibration).  Arrays above 4 MB keep their own copy.
+    pack.begin();
+    auto up = [&](auto& d, const auto& h) -> hipError_t {
+      if (h.size() * sizeof(h[0]) > (size_t)4 << 20) return d.upload(h, stream);
+      return pack.add(d, h);
+    };
+    // the same array into a second / third buffer (state double buffer, initial-state copy)
+    auto up_also = [&](auto& d, const auto& h) -> hipError_t {
+      if (h.size() * sizeof(h[0]) > (size_t)4 << 20) return d.upload(h, stream);
+      return pack.also(d, h.size());
+    };
     {   // tile headers: depend on the tile layout and on this stage's column layout
       std::vector<TileHdr> hdr((size_t)T);
       for (int t = 0; t < T; ++t) {
@@ -423,12 +540,12 @@ struct vc_calibrator {
           h.ncols |= (unsigned long long)(cam_ncols(cam_flags[c], cams[c].nk) & 0xff) << (8 * k);
         }
       }
-      HIP_OK(d_tile_hdr.upload(hdr, stream));
+      HIP_OK(up(d_tile_hdr, hdr));
     }
-    HIP_OK(d_frame_tile_off.upload(frame_tile_off, stream));
-    HIP_OK(d_frame_cam_tile.upload(frame_cam_tile, stream)); HIP_OK(d_cam_model.upload(cam_model, stream));
-    HIP_OK(d_cam_flags.upload(cam_flags, stream)); HIP_OK(d_cam_col0.upload(cam_col0, stream));
-    HIP_OK(d_col_cam.upload(col_cam, stream)); HIP_OK(d_col_local.upload(col_local, stream));
+    HIP_OK(up(d_frame_tile_off, frame_tile_off));
+    HIP_OK(up(d_frame_cam_tile, frame_cam_tile)); HIP_OK(up(d_cam_model, cam_model));
+    HIP_OK(up(d_cam_flags, cam_flags)); HIP_OK(up(d_cam_col0, cam_col0));
+    HIP_OK(up(d_col_cam, col_cam)); HIP_OK(up(d_col_local, col_local));
     std::vector<double> poses((size_t)N * kPoseStride, 0.0), camrec((size_t)C * kCamStride, 0.0);
     for (int f = 0; f < N; ++f) std::memcpy(&poses[(size_t)f * kPoseStride], frame_at(f).T, 56);
     for (int c = 0; c < C; ++c) {
@@ -436,7 +553,8 @@ struct vc_calibrator {
       std::memcpy(&camrec[(size_t)c * kCamStride + kCamK], cams[c].K, cams[c].nk * 8);
     }
     cur = 0;
-    for (int b = 0; b < 2; ++b) { HIP_OK(d_pose[b].upload(poses, stream)); HIP_OK(d_cam[b].upload(camrec, stream)); }
+    HIP_OK(up(d_pose[0], poses)); HIP_OK(up_also(d_pose[1], poses)); HIP_OK(up_also(d_pose_init, poses));
+    HIP_OK(up(d_cam[0], camrec)); HIP_OK(up_also(d_cam[1], camrec)); HIP_OK(up_also(d_cam_init, camrec));
     // one wavefront per frame, 4 frames per group: up to 2048 chunks (= partial sums) before chunks grow
     int chunk_frames = std::max(4, (((N + 2047) / 2048) + 3) / 4 * 4);
     // wide borders: a chunk's partial record is D^2 doubles -- written once and read once per pass; keep all of them under ~64 MB
@@ -457,15 +575,15 @@ struct vc_calibrator {
     HIP_OK(d_fpart.alloc((size_t)std::max(N, 1) * kNumScal));
     trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); HIP_OK(d_ctrl.alloc(2));
     HIP_OK(hipMemsetAsync(d_part.p, 0, (size_t)n_chunks * part_stride * sizeof(double), stream));
-    HIP_OK(hipMemsetAsync(d_fpart.p, 0, (size_t)std::max(N, 1) * kNumScal * sizeof(double), stream));
+    pack.zero(d_fpart.p, (size_t)std::max(N, 1) * kNumScal * sizeof(double));
     HIP_OK(d_scal.alloc(2 * kNumScal)); HIP_OK(d_flags.alloc(8));
     HIP_OK(d_wgpart.alloc((size_t)std::max(1, (T + 3) / 4) * kNumScal));
-    HIP_OK(hipMemsetAsync(d_scal.p, 0, 2 * kNumScal * sizeof(double), stream));
+    pack.zero(d_scal.p, 2 * kNumScal * sizeof(double));
     HIP_OK(d_tmp.alloc(128));       // [0,16) per-camera sums, [32,40) outlier thresholds, [64,96) profiling stamps
-    HIP_OK(hipMemsetAsync(d_tmp.p, 0, 128 * sizeof(double), stream));
-    HIP_OK(hipMemsetAsync(d_flags.p, 0, 8 * sizeof(int), stream));
-    HIP_OK(hipMemsetAsync(d_ctrl.p, 0, 2 * sizeof(Ctrl), stream));
-    HIP_OK(hipMemsetAsync(d_delta_s.p, 0, std::max(D, 1) * sizeof(double), stream));
+    pack.zero(d_tmp.p, 128 * sizeof(double));
+    pack.zero(d_flags.p, 8 * sizeof(int));
+    pack.zero(d_ctrl.p, 2 * sizeof(Ctrl));
+    pack.zero(d_delta_s.p, std::max(D, 1) * sizeof(double));
     for (int c = 0; c < kMaxCams; ++c) { dv.cd[c].model = 0; dv.cd[c].flags = 0; dv.cd[c].col0 = 0; dv.cd[c].ncols = 0; }
     for (int c = 0; c < C; ++c) { dv.cd[c].model = cams[c].model; dv.cd[c].flags = cam_flags[c]; dv.cd[c].col0 = cam_col0[c]; dv.cd[c].ncols = cam_ncols(cam_flags[c], cams[c].nk); }
     dv.n_frames = N; dv.n_cams = C; dv.n_tiles = T; dv.n_points = n_points_dev; dv.D = D;
@@ -495,16 +613,15 @@ struct vc_calibrator {
     }
     dv.wgpart = d_wgpart.p; dv.merged = 0; dv.par = 0; dv.ctrl_prev = d_ctrl.p + 1;
     dv.part_stride = part_stride; dv.ctrl = d_ctrl.p; dv.trace = d_trace.p; dv.dbg = (long long*)(d_tmp.p + 64);
-    HIP_OK(d_pose_init.upload(poses, stream)); HIP_OK(d_cam_init.upload(camrec, stream));
     // ---- inertial terms ------------------------------------------------------------------------------
     std::vector<double> vels((size_t)std::max(N, 1) * 4, 0.0), imus(16, 0.0), ftime(std::max(N, 1), 0.0);
     for (int f = 0; f < N; ++f) { std::memcpy(&vels[(size_t)f * 4], frame_at(f).v, 24); ftime[f] = frame_at(f).time; }
     imus[0] = g_dir[0]; imus[1] = g_dir[1];
     for (int i = 0; i < 6; ++i) { imus[2 + i] = biases[i]; imus[8 + i] = scale[i]; }
     imus[14] = time_offset;
-    for (int b = 0; b < 2; ++b) { HIP_OK(d_vel[b].upload(vels, stream)); HIP_OK(d_imus[b].upload(imus, stream)); }
-    HIP_OK(d_vel_init.upload(vels, stream)); HIP_OK(d_imus_init.upload(imus, stream));
-    HIP_OK(d_frame_time.upload(ftime, stream));
+    HIP_OK(up(d_vel[0], vels)); HIP_OK(up_also(d_vel[1], vels)); HIP_OK(up_also(d_vel_init, vels));
+    HIP_OK(up(d_imus[0], imus)); HIP_OK(up_also(d_imus[1], imus)); HIP_OK(up_also(d_imus_init, imus));
+    HIP_OK(up(d_frame_time, ftime));
     dv.imu_on = imu_on() ? 1 : 0; dv.rotation_only = rotation_only ? 1 : 0;
     dv.weights_on = (is_inertial_active && !rotation_only) ? 1 : 0;
     dv.n_imu = (int)imu_t.size();
@@ -549,6 +666,7 @@ struct vc_calibrator {
     dv.cW = d_cW.p; dv.cdelta = d_cdelta.p; dv.ct0 = d_ct0.p; dv.cg = d_cg.p;
     dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p;
     for (int b = 0; b < 2; ++b) dv.rX[b] = d_rX[b].p;
+    HIP_OK(pack.flush(stream));
     up_c = up_ms();
     HIP_OK(hipStreamSynchronize(stream));   // the staging vectors above go out of scope
     if (up_timing) std::fprintf(stderr, "[vicalib_amd]   upload: observations %.3f, layout %.3f, copies + allocations %.3f, drain %.3f ms\n", up_a, up_b - up_a, up_c - up_b, up_ms() - up_c);
@@ -669,9 +787,10 @@ struct vc_calibrator {
       // chain, both trial sweeps, decision -- stays on the main stream: kernels of one stream follow each other without a gap,
       // an event hand-over costs 5-13 us.
       const bool upd = dv.weights_on != 0;
-      // (single process only: with the flags a two-rank visual-inertial solve on one GPU failed its parity test -- two processes'
-      // waiting kernels on one device; left on events until that is understood)
-      const bool fs = flag_sync && !serial_weights && !sharded() && !use_graphs && !events_only;      // (a captured pass has fixed arguments and needs the events to fork the capture)
+      // (sharded solves: flags when every rank has a device of its own -- vc_set_shard_rccl with more than one rank, or
+      //  VICALIB_AMD_SHARD_FLAG_SYNC=1; the one-GPU gloo tests keep the events: several processes' waiting kernels would burn each
+      //  other's time slices.  A time-out is lossless there too: the mark travels with the step scalars' all-reduce, all ranks resume)
+      const bool fs = flag_sync && !serial_weights && (!sharded() || shard_flag_sync) && !use_graphs && !events_only;      // (a captured pass has fixed arguments and needs the events to fork the capture)
       ++pass_seq;
       wr_ring[pass_seq & 15] = wcur;              // (what a resume after a flag time-out restores: the weight buffer this pass reads)
       dv.sync_flags = d_sync.p; dv.sync_seq = fs ? pass_seq : 0; dv.final_wait = 0; dv.block_wait = 0; dv.sync_bound = sync_bound;
@@ -1594,6 +1713,7 @@ int vc_rccl_unique_id(void* out128) {
   return VC_OK;
 }
 int vc_set_shard_rccl(vc_calibrator* h, int rank, int world_size, const void* unique_id128) {
+  g_last_error.clear();          // (vc_last_error() is about THIS call from here on)
   NOT_RUNNING(h);
   if (world_size < 1 || rank < 0 || rank >= world_size || !unique_id128) return VC_ERR_BAD_ARG;
   if (!g_rccl.load()) {
@@ -1614,6 +1734,9 @@ int vc_set_shard_rccl(vc_calibrator* h, int rank, int world_size, const void* un
   }
   h->rank = rank; h->world = world_size; h->allreduce = nullptr; h->allreduce_ctx = nullptr; h->device_dirty = true;
   { const char* e = std::getenv("VICALIB_AMD_FORCE_SHARD_PATH"); h->force_shard_path = e && e[0] == '1'; }
+  // an RCCL communicator of several ranks has one device per rank: this process has its device to itself, the cross-stream hand-overs of
+  // the pass can go through device flags as in a single-process solve (-25 us per pass and rank; VICALIB_AMD_SHARD_FLAG_SYNC=0 keeps events)
+  { const char* e = std::getenv("VICALIB_AMD_SHARD_FLAG_SYNC"); if (world_size > 1 && !(e && e[0] == '0')) h->shard_flag_sync = true; }
   return VC_OK;
 }
 long long vc_allreduce_calls(vc_calibrator* h) { return h ? h->rccl_calls : 0; }

@@ -46,7 +46,9 @@ struct DetView {
   int* boxes;                      // 4 per candidate (x0, y0, x1, y1 inclusive: the component's bounding box) or nullptr
 };
 
-// integral image, rows: one wavefront per row, ten consecutive pixels per lane round, exclusive scan of the lane sums
+// integral image, rows: one wavefront per row, eight consecutive pixels per lane and round, exclusive scan of the lane sums.
+// The sums are kept modulo 2^32 (images above 16.8 MP would overflow a 32-bit total): every use takes the four-corner difference in
+// unsigned arithmetic, which is exact as long as the WINDOW's sum fits -- it does, a window has at most (2 rad + 1)^2 pixels
 __global__ __launch_bounds__(64) void k_det_rows(DetView v) {
   const int y = blockIdx.x, lane = threadIdx.x;
   unsigned carry = 0;
@@ -84,7 +86,9 @@ __global__ __launch_bounds__(256) void k_det_threshold(DetView v) {
   const int y = p / v.w, x = p % v.w;
   const int xa = max(x - v.rad, 0), xb = min(x + v.rad + 1, v.w), ya = max(y - v.rad, 0), yb = min(y + v.rad + 1, v.h);
   const int W1 = v.w + 1;
-  const long long tot = (long long)v.S[(size_t)yb * W1 + xb] - v.S[(size_t)ya * W1 + xb] - v.S[(size_t)yb * W1 + xa] + v.S[(size_t)ya * W1 + xa];
+  // (unsigned, then widened: the wrap-around of the running sums cancels modulo 2^32)
+  const unsigned tot_u = v.S[(size_t)yb * W1 + xb] - v.S[(size_t)ya * W1 + xb] - v.S[(size_t)yb * W1 + xa] + v.S[(size_t)ya * W1 + xa];
+  const long long tot = (long long)tot_u;
   const double area = (double)((xb - xa) * (yb - ya));
   unsigned val = v.img[(size_t)y * v.pitch + x];
   if (!v.black_on_white) val = 255 - val;

@@ -25,6 +25,7 @@ enum { kScGd = 0, kScDld = 1, kScStep2 = 2, kScX2 = 3, kScG2 = 4, kScCost = 5, k
 constexpr int kTraceCols = 10;     // iteration cost cost_change gmax gnorm step_norm rho radius accepted stage
 
 // termination codes in Ctrl::done (0 = keep running)
+constexpr double kShardMark = 1048576.0;                 // sharded solves: "my pass is void" on top of a rank's failure count in the gathered step scalars
 constexpr unsigned kProgressLikelyLast = 1u << 30;      // progress word, low half: Ctrl::done | this hint
 enum { kRunning = 0, kDoneConvergence = 1, kDoneNoConvergence = 2, kDoneUserSuccess = 3, kDoneFailure = 4,
        kDoneSyncTimeout = 5 };   // a device-flag hand-over between the two streams ran into its bound: the pass is void, the host re-runs it with events
@@ -204,6 +205,9 @@ void launch_reduced(const DevView& v, int mode, hipStream_t s);
 void launch_trial(const DevView& v, hipStream_t s);            // back-substitution + manifold update + trial residual sweep
 void launch_final(const DevView& v, int mode, hipStream_t s);
 int chain_forward_launches(const DevView& v);      // launches of the chain's forward elimination (levels + top)
+// a segment of a packed upload: `bytes` (a multiple of 4) from offset src_off of the staging image to dst; src_off = ~0: zero-fill
+struct UnpackSeg { unsigned long long dst, src_off, bytes; };
+void launch_unpack(const UnpackSeg* segs, int n, const void* image, size_t total_bytes, hipStream_t s);
 void launch_set_ctrl(Ctrl* d, const Ctrl& c, hipStream_t s);      // d[0] <- c, d[1] <- 0
 void launch_wait_flag(const DevView& v, int idx, long long seq, hipStream_t s);      // returns when sync_flags[idx] >= seq
 void launch_signal_flag(const DevView& v, int idx, hipStream_t s);                    // sync_flags[idx] <- sync_seq once everything before it in the stream is done

@@ -143,7 +143,8 @@ template <class T> struct Meas { T w[3], a[3], time; };
 VC_HD int imu_bracket(const ImuView& b, double time, double off, double* t_at = nullptr) {
   const double t0 = b.t[0], span = b.t[b.n - 1] - t0;
   int g = (span > 0.0) ? (int)((((time - off) - t0) / span) * (double)(b.n - 1)) : 0;
-  g = g < 0 ? 0 : (g > b.n - 2 ? b.n - 2 : g);
+  g = g > b.n - 2 ? b.n - 2 : g;
+  g = g < 0 ? 0 : g;                                      // (never below 0; every caller -- imu_range, imu_range_lanes -- returns an empty range for fewer than two samples before it gets here: the reference runs its schedule through with no IMU samples at all, tests/test_robustness_gpu.py)
   // the guess and its neighbours in ONE round of loads (a dependent load is ~1 us on the device): with nearly uniform sampling
   // the answer is among them; the walks below only run for gappy streams.  All four comparisons are taken before any branch, so
   // that the loads cannot be deferred into the branches that use them.

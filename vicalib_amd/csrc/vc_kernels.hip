@@ -1616,9 +1616,13 @@ __device__ void final_phase(const DevView& v, int mode, double* red) {
       double* o = v.scal;
       o[kScGd] = red[0]; o[kScDld] = red[256]; o[kScStep2] = red[512]; o[kScX2] = red[768]; o[kScG2] = red[1024];
       o[kScCost] = 0.5 * red[1280]; o[kScGmax] = red[1536]; o[kScSq] = 0.0;
+      // sharded with flag hand-overs: a rank whose pass is marked void (vc_kutil.hpp) says so with kShardMark on top of its failure
+      // count -- after the all-reduce every rank sees it and none of them judges the pass
+      double mark = 0.0;
+      if (mode == 1 && v.sync_seq > 0) { const long long m = sync_marked(v); if (m != 0 && m <= v.sync_seq) mark = kShardMark; }
       if (mode == 1) {       // sharded: publish this rank's terms (and its numeric-failure flags) in its slot of the gather table
         for (int r = 0; r < v.world; ++r)
-          for (int k = 0; k < kNumScal; ++k) v.gath[r * kNumScal + k] = (r == v.rank) ? (k == kScSq ? (double)(v.flags[4 + 2 * v.par] + v.flags[5 + 2 * v.par]) : o[k]) : 0.0;
+          for (int k = 0; k < kNumScal; ++k) v.gath[r * kNumScal + k] = (r == v.rank) ? (k == kScSq ? (double)(v.flags[4 + 2 * v.par] + v.flags[5 + 2 * v.par]) + mark : o[k]) : 0.0;
       }
     }
   }
@@ -1629,7 +1633,12 @@ __device__ void final_phase(const DevView& v, int mode, double* red) {
       for (int r = 0; r < v.world; ++r) a = (k == kScGmax) ? fmax(a, v.gath[r * kNumScal + k]) : a + v.gath[r * kNumScal + k];
       o[k] = a;
     }
-    v.flags[4 + 2 * v.par] = (o[kScSq] > 0.0) ? 1 : 0; v.flags[5 + 2 * v.par] = 0;
+    if (o[kScSq] >= kShardMark && v.sync_seq > 0) {      // some rank's pass is void: this rank's is, too (lm_decide below withholds the decision)
+      long long expect = 0;
+      if (!__hip_atomic_compare_exchange_strong(v.sync_flags + 6, &expect, v.sync_seq, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        __hip_atomic_fetch_min(v.sync_flags + 6, v.sync_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    v.flags[4 + 2 * v.par] = (fmod(o[kScSq], kShardMark) > 0.0) ? 1 : 0; v.flags[5 + 2 * v.par] = 0;
   }
   if (mode != 1 && tid == 0) lm_decide(v);
 }
@@ -1666,6 +1675,7 @@ __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
     if (threadIdx.x == 0) {
       s_count_base = __hip_atomic_load(v.sync_flags + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       spin_until_flag(v, 4, s_count_base + nwg_imu);
+      __hip_atomic_store(v.sync_flags + 5, s_count_base + nwg_imu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next pass counts on from here
     }
     __syncthreads();
   }
@@ -1675,7 +1685,6 @@ __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
   if (v.final_wait > 0) {
     if (threadIdx.x == 0) {
       spin_until_flag(v, 3, v.final_wait);
-      if (counted) __hip_atomic_store(v.sync_flags + 5, s_count_base + nwg_imu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
   }
@@ -1683,6 +1692,24 @@ __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
   if (threadIdx.x == 0) signal_flag(v, 0);
 }
 
+// One stage's small uploads (vc_calibrator.cpp: upload): the host packs them into one page-locked staging image that goes to the
+// device with ONE copy; this kernel scatters the image's segments to their buffers (several destinations may share a source: both
+// state buffers and the "initial state" copy take the same poses) and zero-fills what a stage starts from zero.  Replaces ~45 small
+// pageable copies / fills per stage (4.1 of the 19 ms of a complete cfg3 calibration).
+__global__ __launch_bounds__(256) void k_unpack(const UnpackSeg* segs, int n, const unsigned* image) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
+  for (int k = 0; k < n; ++k) {
+    const UnpackSeg sg = segs[k];
+    unsigned* dst = (unsigned*)sg.dst;
+    const size_t words = sg.bytes >> 2;
+    if (sg.src_off == ~0ull) { for (size_t i = tid; i < words; i += nt) dst[i] = 0u; }
+    else { const unsigned* src = image + (sg.src_off >> 2); for (size_t i = tid; i < words; i += nt) dst[i] = src[i]; }
+  }
+}
+void launch_unpack(const UnpackSeg* segs, int n, const void* image, size_t total_bytes, hipStream_t s) {
+  const int blocks = (int)std::min<size_t>(512, std::max<size_t>(1, total_bytes / (256 * 16)));
+  hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(256), 0, s, segs, n, (const unsigned*)image);
+}
 // a fresh control record for a solve: record 0 <- the host's (a kernel argument), record 1 blank -- one launch instead of a copy and a fill
 __global__ __launch_bounds__(64) void k_set_ctrl(Ctrl* d, Ctrl c) {
   if (threadIdx.x == 0) { d[0] = c; Ctrl z = Ctrl(); d[1] = z; }

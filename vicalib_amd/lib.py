@@ -237,10 +237,14 @@ class ViCalibrator:
         return out[:n]
 
     def PrintResults(self):
-        n = _check(self.L.vc_print_results(self.h, None, 0), "PrintResults")           # the length first: any number of cameras
-        buf = C.create_string_buffer(n + 1)
-        _check(self.L.vc_print_results(self.h, buf, n + 1), "PrintResults")
-        return buf.value.decode()
+        # the length first (any number of cameras); a worker started with Start() may change the values -- and with them the
+        # length of the %.10g text -- between the two calls: some slack, and another round if that was not enough
+        for _ in range(8):
+            n = _check(self.L.vc_print_results(self.h, None, 0), "PrintResults")
+            buf = C.create_string_buffer(n + 65)
+            if self.L.vc_print_results(self.h, buf, n + 65) >= 0:
+                return buf.value.decode()
+        raise VicalibError("PrintResults: the text kept growing")
     def WriteCameraModels(self, path): _check(self.L.vc_write_camera_models(self.h, path.encode()), "WriteCameraModels")
 
     # ---- engine-level ------------------------------------------------------------------------
