@@ -6,6 +6,14 @@
 //   -cam  detections://cam0.csv[,cam1.csv,...]   one file per camera channel, lines  frame,dot_id,u,v,X,Y,Z[,time]
 //                                                (the format the reference prints with -output_conics,
 //                                                 vicalib-task.cc:313-317; `time` is an optional 8th column)
+//   -cam  file://dir/cam0_*.pgm[,dir/cam1_*.pgm]  (round 4) one glob of 8-bit PGM images per camera channel, sorted by name, one frame per
+//                                                image -- HAL's FileReader URI of the reference's own usage line (main.cc:11).  Every
+//                                                image goes through the GPU dot detector (vc_detector_find_conics) and the grid
+//                                                association (vc_target_find): what VicalibTask::AddImageMeasurements does with
+//                                                calibu::ImageProcessing / ConicFinder / TargetGridDot (vicalib-task.cc:263-330).
+//                                                The target's large / small pattern comes from -grid_pattern_file (rows of 0 / 1), or
+//                                                from -grid_height / -grid_width / -grid_seed through the library's own generator;
+//                                                Calibu's presets and MakePattern are not in the reference tree.
 //   -imu  csv://dir                              HAL CsvDriver layout: dir/accel.txt, dir/gyro.txt, dir/timestamp.txt
 //
 // Everything from "AddFrame" on is the reference's flow: start intrinsics per -models (vicalib-engine.cc:203-257) or
@@ -20,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <glob.h>
 #include <map>
 #include <memory>
 #include <set>
@@ -53,13 +62,14 @@ static void DefineFlags() {
   Define("has_initial_guess", "bool", "false", "Whether or not the given calibration file has a valid guess.");
   Define("output_conics", "bool", "false", "Echo the detections that were used (frame,dot_id,u,v,X,Y,Z).");
   Define("grid_preset", "string", "", "Which grid preset to use: small, large, letter, medium.");
+  Define("grid_pattern_file", "string", "", "(image input) large / small pattern of the target: grid_height rows of grid_width 0 / 1 entries (1 = large dot).");
   Define("max_reprojection_error", "double", "0.15", "Maximum allowed reprojection error (pixels).");
   Define("num_vicalib_frames", "int64", "-1", "Number of frames to process before calibration begins (-1: all).");
   Define("print_poses", "bool", "false", "Output poses to poses.txt");
   Define("print_covariance", "bool", "false", "Print the solution covariance of q_ck / p_ck / params (the reference compiles this in with COMPUTE_VICALIB_COVARIANCE).");
   Define("output", "string", "cameras.xml", "Output XML file to write camera models to.");
   Define("output_log_file", "string", "vicalibrator.log", "Calibration result output log file.");
-  Define("cam", "string", "", "Camera URI: detections://cam0.csv[,cam1.csv...]");
+  Define("cam", "string", "", "Camera URI: detections://cam0.csv[,cam1.csv...] or file://dir/cam0_*.pgm[,dir/cam1_*.pgm...] (8-bit PGM images)");
   Define("imu", "string", "", "IMU URI (if available): csv://directory");
   Define("models", "string", "", "Comma-separated list of camera model types: fov, poly2, poly3, rational6, kb4, linear.");
   Define("model_files", "string", "", "Comma-separated list of camera model files to initialise from.");
@@ -176,6 +186,62 @@ static bool ParseNumbers(const std::string& line, std::vector<double>* v) {
 struct Detection { long frame; int dot; double u, v, X, Y, Z; };
 struct Channel { std::vector<Detection> det; std::map<long, double> frame_time; };
 
+// ---- image channels (vicalib-task.cc:263-330 with files for sensors) ----------------------------------------------------------------
+static bool ReadPgm(const std::string& path, int* w, int* h, std::vector<unsigned char>* px, std::string* err) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) { *err = "cannot open image " + path; return false; }
+  std::string magic; f >> magic;
+  if (magic != "P5") { *err = path + ": not a binary PGM (P5)"; return false; }
+  auto next_int = [&](long* v) {
+    while (true) { f >> std::ws; if (f.peek() == '#') { std::string c; std::getline(f, c); } else break; }
+    return (bool)(f >> *v);
+  };
+  long W = 0, H = 0, M = 0;
+  if (!next_int(&W) || !next_int(&H) || !next_int(&M) || W < 1 || H < 1 || M != 255) { *err = path + ": expected an 8-bit PGM header"; return false; }
+  f.get();                                          // the single whitespace byte behind the header
+  px->resize((size_t)W * H);
+  f.read((char*)px->data(), (std::streamsize)px->size());
+  if ((size_t)f.gcount() != px->size()) { *err = path + ": truncated image data"; return false; }
+  *w = (int)W; *h = (int)H;
+  return true;
+}
+struct TargetSpec { std::vector<int> pattern; int rows = 0, cols = 0; double spacing = 0.0; };
+// one camera channel from a glob of images: frame k = k-th file (sorted); detections carry the target dot's index and position
+static bool ReadImages(const std::string& pattern_glob, const TargetSpec& tg, int device, Channel* ch, int* width, int* height, std::string* err) {
+  glob_t g; std::memset(&g, 0, sizeof(g));
+  if (glob(pattern_glob.c_str(), 0, nullptr, &g) != 0 || g.gl_pathc == 0) { globfree(&g); *err = "no images match " + pattern_glob; return false; }
+  std::vector<std::string> files(g.gl_pathv, g.gl_pathv + g.gl_pathc);
+  globfree(&g);
+  std::sort(files.begin(), files.end());
+  vc_detector* det = nullptr;
+  std::vector<unsigned char> px;
+  const int kMax = 4096;
+  std::vector<double> cen(2 * kMax), con(9 * kMax);
+  std::vector<int> box(4 * kMax), idx(kMax);
+  long placed = 0, skipped = 0;
+  for (size_t k = 0; k < files.size(); ++k) {
+    int w = 0, h = 0;
+    if (!ReadPgm(files[k], &w, &h, &px, err)) { if (det) vc_detector_destroy(det); return false; }
+    if (!det) {
+      const int rc = vc_detector_create(device, w, h, &det);
+      if (rc != VC_OK) { *err = rc == VC_ERR_NO_DEVICE ? "no usable HIP device for the dot detector" : "vc_detector_create failed"; return false; }
+      *width = w; *height = h;
+    } else if (w != *width || h != *height) { *err = files[k] + ": image size differs from the first image of the channel"; vc_detector_destroy(det); return false; }
+    int n = 0, m = 0;
+    if (vc_detector_find_conics(det, px.data(), w, cen.data(), con.data(), box.data(), kMax, &n) != VC_OK ||
+        vc_target_find(cen.data(), con.data(), n, tg.pattern.data(), tg.rows, tg.cols, idx.data(), &m) != VC_OK) { *err = files[k] + ": detection failed"; vc_detector_destroy(det); return false; }
+    if (m == 0) { ++skipped; continue; }                 // "Tracking bad" (vicalib-task.cc:278-281): the frame contributes nothing
+    for (int i = 0; i < n; ++i) {
+      if (idx[i] < 0) continue;
+      const int r = idx[i] / tg.cols, c = idx[i] % tg.cols;
+      ch->det.push_back(Detection{(long)k, idx[i], cen[2 * i], cen[2 * i + 1], c * tg.spacing, r * tg.spacing, 0.0});
+      ++placed;
+    }
+  }
+  if (det) vc_detector_destroy(det);
+  std::fprintf(stderr, "I %s: %zu images, %ld dots associated with the target, %ld images without an unambiguous placement\n", pattern_glob.c_str(), files.size(), placed, skipped);
+  return true;
+}
 static bool ReadDetections(const std::string& path, Channel* ch, std::string* err) {
   std::ifstream f(path);
   if (!f) { *err = "cannot open detections file " + path; return false; }
@@ -337,6 +403,39 @@ int main(int argc, char** argv) {
   // ---- sensors ------------------------------------------------------------------------------------------------------
   const std::vector<std::string> cam_files = Split(StripScheme(FlagString("cam")), ',');
   std::vector<Channel> channels(cam_files.size());
+  const bool from_images = FlagString("cam").compare(0, 7, "file://") == 0;      // HAL's FileReader scheme (main.cc:11)
+  int img_w = 0, img_h = 0;
+  if (from_images) {
+    // the target (vicalib-engine.cc:453-465): its pattern from a file, or generated from -grid_height / -grid_width / -grid_seed
+    TargetSpec tg;
+    tg.rows = grid_h; tg.cols = grid_w; tg.spacing = FlagDouble("grid_spacing");
+    if (!FlagString("grid_pattern_file").empty()) {
+      std::ifstream pf(FlagString("grid_pattern_file"));
+      if (!pf) { std::fprintf(stderr, "F cannot open grid pattern file %s\n", FlagString("grid_pattern_file").c_str()); return 1; }
+      std::string line; std::vector<double> v; tg.rows = 0; tg.cols = 0;
+      while (std::getline(pf, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        if (!ParseNumbers(line, &v) || v.empty()) continue;
+        if (tg.cols && (int)v.size() != tg.cols) { std::fprintf(stderr, "F grid pattern file: rows of different length\n"); return 1; }
+        tg.cols = (int)v.size(); ++tg.rows;
+        for (double x : v) tg.pattern.push_back(x != 0.0 ? 1 : 0);
+      }
+      if (tg.rows < 2 || tg.cols < 2) { std::fprintf(stderr, "F grid pattern file holds no pattern\n"); return 1; }
+      grid_w = tg.cols; grid_h = tg.rows;
+    } else if (!preset.empty()) {
+      std::fprintf(stderr, "F -grid_preset %s with image input: the presets' large / small patterns live in Calibu, which is not part of the reference tree -- "
+                           "pass the printed target's pattern with -grid_pattern_file (or generate a target with -grid_height / -grid_width / -grid_seed)\n", preset.c_str());
+      return 1;
+    } else {
+      tg.pattern.resize((size_t)tg.rows * tg.cols);
+      vc_target_make_pattern(tg.rows, tg.cols, (unsigned)FlagInt("grid_seed"), tg.pattern.data());
+    }
+    for (size_t c = 0; c < cam_files.size(); ++c) {
+      int w = 0, h = 0;
+      if (!ReadImages(cam_files[c], tg, (int)FlagInt("device"), &channels[c], &w, &h, &err)) { std::fprintf(stderr, "F %s\n", err.c_str()); return err.find("HIP device") != std::string::npos ? 3 : 1; }
+      img_w = std::max(img_w, w); img_h = std::max(img_h, h);
+    }
+  } else
   for (size_t c = 0; c < cam_files.size(); ++c)
     if (!ReadDetections(cam_files[c], &channels[c], &err)) { std::fprintf(stderr, "F %s\n", err.c_str()); return 1; }
   const size_t n_cam = channels.size();
@@ -353,7 +452,7 @@ int main(int argc, char** argv) {
     models.resize(n_cam, "poly3");
   }
   std::vector<vic::CameraAndPose> input_cameras;
-  const int W = (int)FlagInt("image_width"), H = (int)FlagInt("image_height");
+  const int W = img_w > 0 ? img_w : (int)FlagInt("image_width"), H = img_h > 0 ? img_h : (int)FlagInt("image_height");      // (images carry their size)
   if (!model_files.empty()) {
     for (const std::string& mf : model_files) {
       vic::CameraAndPose cam;

@@ -230,6 +230,15 @@ int vc_detector_find(vc_detector* d, const unsigned char* image, int pitch, doub
  * boxes (nullable): 4 ints per dot, the dot's bounding box x0, y0, x1, y1 inclusive (calibu::Conic::bbox). */
 int vc_detector_find_conics(vc_detector* d, const unsigned char* image, int pitch, double* centres, double* conics, int* boxes, int max_conics,
                             int* n_found);
+/* Second half of the front-end (vicalib-task.cc:274-277, calibu::TargetGridDot::FindTarget; vicalib-engine.cc:459-461,
+ * calibu::MakePattern): which dot of the target is every detected conic?  Host code, no device needed (a few hundred dots per image).
+ * vc_target_make_pattern: the large (1) / small (0) pattern of a rows x cols target from a seed (own generator: Calibu's is not in the
+ * reference tree -- a printed Calibu target needs its own pattern).  vc_target_find: centres (2 per dot) and image ellipses (9 per dot,
+ * as vc_detector_find_conics returns them) of one image -> dot_index (row * cols + col, or -1) per conic, the reference's
+ * `ellipse_target_map`; *n_matched = 0 when no unambiguous placement exists (the reference then skips the frame).  Calibu's source
+ * being absent, parity with FindTarget is unpinned; tests hold it to rendered views (tests/test_grid_cpu.py). */
+int vc_target_make_pattern(int rows, int cols, unsigned seed, int* pattern);
+int vc_target_find(const double* centres, const double* conics, int n, const int* pattern, int rows, int cols, int* dot_index, int* n_matched);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,7 @@ import numpy as np
 
 
 def render(width=640, height=480, nx=9, ny=6, spacing=0.03, r_large=0.0094, r_small=0.0063, fu=420.0, fv=420.0, seed=0,
-           tilt=(0.25, -0.2, 0.1), dist=0.42, ss=8, white=230, black=25, with_conics=False):
+           tilt=(0.25, -0.2, 0.1), dist=0.42, ss=8, white=230, black=25, with_conics=False, pattern=None, missing=0.0, with_grid=False):
     """Returns (image u8 [h, w], centres [n, 2] in pixel coordinates (x, y), pixel centres at integers); with_conics: also the
     image ellipses as 3 x 3 matrices (unit Frobenius norm, first entry positive)."""
     rng = np.random.default_rng(seed)
@@ -19,9 +19,14 @@ def render(width=640, height=480, nx=9, ny=6, spacing=0.03, r_large=0.0094, r_sm
     Hi = np.linalg.inv(H)
     img = np.full((height, width), float(white))
     centres, conics = [], []
-    big = rng.random((ny, nx)) < 0.4
+    big = rng.random((ny, nx)) < 0.4 if pattern is None else np.asarray(pattern).astype(bool)
+    gone = rng.random((ny, nx)) < missing          # dots that are not drawn (occluded / undetected)
+    grid_idx = []
     for j in range(ny):
         for i in range(nx):
+            if gone[j, i]:
+                continue
+            grid_idx.append(j * nx + i)
             X, Y, r = i * spacing, j * spacing, (r_large if big[j, i] else r_small)
             Cc = np.array([[1, 0, -X], [0, 1, -Y], [-X, -Y, X * X + Y * Y - r * r]], dtype=float)     # circle as a conic in the plane
             Ci = Hi.T @ Cc @ Hi                                                                   # its image
@@ -45,6 +50,8 @@ def render(width=640, height=480, nx=9, ny=6, spacing=0.03, r_large=0.0094, r_sm
             cov /= ss * ss
             img[y0:y1, x0:x1] = np.minimum(img[y0:y1, x0:x1], white - (white - black) * cov)
     out = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    if with_grid:      # also the target-dot index (row * nx + col) of every dot drawn and the large / small pattern used
+        return out, np.array(centres), np.array(conics), np.array(grid_idx), big.astype(np.int32)
     if with_conics:
         return out, np.array(centres), np.array(conics)
     return out, np.array(centres)

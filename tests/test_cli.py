@@ -183,3 +183,33 @@ def test_cli_initial_guess_reproduces_the_reference_exit_status(tmp_path):
     assert r_vi.returncode == 2 and "IMU bias(es) for gyroscope differ" in r_vi.stderr, r_vi.stdout + r_vi.stderr     # '<' 1e9: always
     r_vi2 = _run(vi + ["-imu_diff_sense", "corrected", "-max_imu_gyro_diff", "1e9", "-max_imu_accel_diff", "1e9"])
     assert r_vi2.returncode == 0, r_vi2.stdout + r_vi2.stderr
+
+
+@pytest.mark.gpu
+def test_cli_calibrates_from_images(tmp_path):
+    """images -> dots -> grid -> PnP seed -> solve -> cameras.xml (SURVEY 8 f4 + f1; vicalib-task.cc:263-348 with PGM files for HAL): twelve
+    rendered views of a 13 x 9 two-size dot target (pattern from -grid_seed), pinhole camera with fu = fv = 420."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import dot_images
+    from vicalib_amd import lib
+    pat = lib.target_make_pattern(9, 13, seed=71)
+    rng = np.random.default_rng(4)
+    for k in range(12):
+        tilt = tuple(rng.uniform(-0.45, 0.45, size=2)) + (rng.uniform(-3.0, 3.0),)
+        img, _ = dot_images.render(seed=k, tilt=tilt, dist=rng.uniform(0.36, 0.5), nx=13, ny=9, spacing=0.022, r_large=0.0069, r_small=0.0046,
+                                   pattern=pat, missing=0.05, ss=4)
+        with open(tmp_path / ("view_%03d.pgm" % k), "wb") as f:
+            f.write(b"P5\n# rendered by tests/dot_images.py\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+            f.write(img.tobytes())
+    out = tmp_path / "cameras.xml"
+    r = _run(["-cam", "file://" + str(tmp_path / "view_*.pgm"), "-grid_height", "9", "-grid_width", "13", "-grid_spacing", "0.022", "-grid_seed", "71",
+              "-models", "linear", "-nocalibrate_imu", "-output", str(out)])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "12 images" in r.stderr
+    typ, K, T = _read_xml(str(out))[0]
+    np.testing.assert_allclose(K[:2], [420.0, 420.0], rtol=5e-3)
+    np.testing.assert_allclose(K[2:4], [319.5, 239.5], atol=2.0)
+    # a preset's pattern cannot be known without Calibu: refused with an explanation, not guessed
+    r = _run(["-cam", "file://" + str(tmp_path / "view_*.pgm"), "-grid_preset", "small", "-models", "linear", "-nocalibrate_imu"])
+    assert r.returncode == 1 and "grid_pattern_file" in r.stderr

@@ -122,3 +122,25 @@ def test_gpu_detector_returns_the_conics_and_boxes():
     for i, j in enumerate(d.argmin(axis=1)):
         _, ax = _axes(g_C[i]); _, axt = _axes(conics[j])
         np.testing.assert_allclose(ax, axt, rtol=0.03)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,tilt,blur", [(0, (0.25, -0.2, 0.1), 0.0), (3, (-0.35, 0.3, -0.4), 0.9), (7, (0.4, 0.1, 2.9), 0.6)])
+def test_gpu_detector_to_grid_association(seed, tilt, blur):
+    """The whole image front-end on one rendered view: GPU dot detector -> vc_target_find.  Every dot of the 13 x 9 target (10 % of them
+    not drawn) gets its true index; what FindTarget's `ellipse_target_map` holds in the reference (vicalib-task.cc:274-277)."""
+    from vicalib_amd import lib
+    pat = lib.target_make_pattern(9, 13, seed=71)
+    img, truth, conics, grid_idx, big = dot_images.render(seed=seed, tilt=tilt, dist=0.45, nx=13, ny=9, spacing=0.022, r_large=0.0069, r_small=0.0046,
+                                                          pattern=pat, missing=0.10, with_grid=True, ss=4)
+    if blur:
+        img = _blurred(img, blur)
+    det = lib.ConicDetector(img.shape[1], img.shape[0])
+    cen, con, box = det.find_conics(img)
+    assert len(cen) == len(truth)
+    got, m = lib.target_find(cen, con.reshape(-1, 9), pat)
+    assert m >= len(truth) - 2
+    d = np.linalg.norm(cen[:, None, :] - truth[None, :, :], axis=2)
+    nearest = d.argmin(axis=1)
+    hit = got >= 0
+    np.testing.assert_array_equal(got[hit], grid_idx[nearest][hit])

@@ -27,6 +27,7 @@
 #include "vc_device.h"
 #include "vc_math.hpp"
 #include "vc_pnp.hpp"
+#include "vc_grid.hpp"
 #include "vc_imu.hpp"
 
 using namespace vc;
@@ -1379,6 +1380,17 @@ int vc_pnp_planar_ransac(int model, const double* params, int nparams, int n, co
                          double tol_px, double T_cw[7], double* rms, int* n_inliers, char* inlier) {
   if (!params || !p_w || !p_c || !T_cw || model_nk(model) < 0 || nparams != model_nk(model) || iterations < 0 || !(tol_px >= 0.0)) return VC_ERR_BAD_ARG;
   return pnp_planar_ransac(model, params, n, p_w, p_c, iterations, tol_px, T_cw, rms, n_inliers, inlier) ? VC_OK : VC_ERR_BAD_ARG;
+}
+int vc_target_make_pattern(int rows, int cols, unsigned seed, int* pattern) {
+  if (rows < 1 || cols < 1 || !pattern) return VC_ERR_BAD_ARG;
+  grid_make_pattern(rows, cols, seed, pattern);
+  return VC_OK;
+}
+int vc_target_find(const double* centres, const double* conics, int n, const int* pattern, int rows, int cols, int* dot_index, int* n_matched) {
+  if (!centres || !conics || !pattern || !dot_index || n < 0 || rows < 1 || cols < 1) return VC_ERR_BAD_ARG;
+  const int m = grid_find_target(centres, conics, nullptr, n, pattern, rows, cols, dot_index);
+  if (n_matched) *n_matched = m;
+  return VC_OK;
 }
 int vc_set_pnp_ransac(vc_calibrator* h, int iterations, double tol_px) {
   NOT_RUNNING(h);

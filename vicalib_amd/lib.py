@@ -31,12 +31,31 @@ SYMBOLS = [
     "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
     "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_pnp_planar_ransac", "vc_set_pnp_ransac", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_allreduce_calls", "vc_last_error", "vc_get_imu_weights",
     "vc_solution_covariance_dim", "vc_get_solution_covariance", "vc_get_solution_covariance_names",
+    "vc_target_make_pattern", "vc_target_find",
     "vc_detector_create", "vc_detector_destroy", "vc_detector_set_params", "vc_detector_find", "vc_detector_find_conics",
 ]
 
 
 class VicalibError(RuntimeError):
     pass
+
+
+def target_make_pattern(rows, cols, seed=71):
+    """vc_target_make_pattern: rows x cols array, 1 = large dot."""
+    out = np.zeros((rows, cols), dtype=np.int32)
+    _check(load().vc_target_make_pattern(int(rows), int(cols), C.c_uint(seed), out.ctypes.data_as(C.c_void_p)), "target_make_pattern")
+    return out
+
+
+def target_find(centres, conics, pattern):
+    """vc_target_find: dot index (row * cols + col, or -1) of every conic; an all -1 result means no unambiguous placement."""
+    centres = np.ascontiguousarray(centres, dtype=np.float64); conics = np.ascontiguousarray(conics, dtype=np.float64)
+    pattern = np.ascontiguousarray(pattern, dtype=np.int32)
+    n = len(centres)
+    idx = np.full(n, -1, dtype=np.int32); m = C.c_int(0)
+    _check(load().vc_target_find(_d(centres), _d(conics), n, pattern.ctypes.data_as(C.c_void_p), pattern.shape[0], pattern.shape[1],
+                                 idx.ctypes.data_as(C.c_void_p), C.byref(m)), "target_find")
+    return idx, m.value
 
 
 def pnp_planar(model, params, p_w, p_c):
