@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 4 evidence on the GPU box (one gpurun call): kernel statistics + PMC traffic (cfg3, cfg4), pass timeline, solve boundary,
+# per-rank passes, default bench line.  Outputs under gpurun_out/final_r04/; copy what is to be judged into profiles/.
+set -u
+R=$PWD; O=$R/gpurun_out/final_r04; mkdir -p $O
+tools/profile_round.sh r04 cfg3 > $O/prof_cfg3.log 2>&1
+tools/profile_round.sh r04 cfg4 > $O/prof_cfg4.log 2>&1
+bash tools/timeline_round.sh cfg3 k_final > $O/pass_timeline_cfg3.txt 2>&1
+bash tools/boundary_round.sh cfg3 > $O/solve_boundary_cfg3.txt 2>&1
+tools/perrank_round.sh final_r04 > $O/perrank.txt 2>&1
+python bench.py --workload cfg5 --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline --no-secondary > $O/bench_cfg5_full.json 2> $O/bench_cfg5_full.err
+cd /tmp && export TMPDIR=/tmp
+VICALIB_AMD_FLAG_SYNC=0 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VALU -d $O/pmc2 -o p -- python $R/bench.py --workload cfg4 --frames 2500 --steps 20 --warmup 2 --repeats 1 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc2.err
+python $R/tools/rocpd_pmc.py $(ls $O/pmc2/*results.db | head -1) > $O/sq_sweep_cfg4_2500.txt 2>&1; rm -rf $O/pmc2
+cd $R
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+tail -3 $O/prof_cfg3.log; grep "frames:" $O/perrank.txt; python -c "
+import json
+txt=open('$O/bench_default.json').read(); d=json.loads([l for l in txt.splitlines() if l.startswith('{')][-1]); print(d['ms_per_step'], d['timing'], d['roofline']['kernel'], d['roofline']['frac'], d.get('complete_calibration'))"

@@ -1796,7 +1796,9 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
   // ... and at the bottom level too once the weight update on the other stream starts behind it (vc_calibrator.cpp: enqueue_pass;
   // VICALIB_AMD_CHAIN_TWO_BOTTOM=0: one-sided bottom level)
   static const bool two_bottom = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO_BOTTOM"); return !(e && std::atoi(e) == 0); }();
-  const int two_from = two_bottom ? 0 : 1;
+  // (only in passes that hand over through device flags: there the weight update waits for the bottom level; with event hand-overs it
+  //  runs beside it -- 500 wavefronts that fill a SIMD's register file each -- and the one-sided bottom level is the faster one)
+  const int two_from = (two_bottom && v.sync_seq > 0) ? 0 : 1;
   auto fwd = [&](int groups, int stride, int m, int top, int lvl) {
     const bool side_by_side = cpl > 1 && !columns_per_lane;
     if (cpl <= 1 && two_sided && !top && m >= 4 && lvl >= two_from) hipLaunchKernelGGL(k_chain_fwd2, dim3(groups), dim3(128), 0, s, v, stride, m, lvl);
