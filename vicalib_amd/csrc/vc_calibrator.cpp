@@ -299,6 +299,7 @@ struct vc_calibrator {
   DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_seg[2], d_seg_cost[2],
       d_cW, d_cdelta, d_ct0, d_cg, d_clam, d_cdiag, d_cscale2, d_vel_init, d_imus_init, d_rX[2], d_grp_part, d_wg_trial, d_wg_imu_trial,
       d_imu_delta_blk, d_imu_grav;
+  DBuf<long long> d_cready;
   size_t wsqrt_frames = 0;       // number of frames the device weight_sqrt_ array was initialised for
   size_t imu_uploaded = 0; double imu_uploaded_last = 0.0;      // sample count / last time stamp of the device copy of the IMU samples
   int trace_cap = 0;
@@ -657,6 +658,7 @@ struct vc_calibrator {
       }
       HIP_OK(d_cW.alloc(nf * 9 * dv.ldx)); HIP_OK(d_cdelta.alloc(nf * 9)); HIP_OK(d_ct0.alloc(nf * 9)); HIP_OK(d_cg.alloc(nf * 9)); HIP_OK(d_clam.alloc(nf * 9));
       HIP_OK(d_cdiag.alloc(nf * 9)); HIP_OK(d_cscale2.alloc(nf * 9));
+      HIP_OK(d_cready.alloc(nf)); pack.zero(d_cready.p, nf * sizeof(long long));
       for (int b = 0; b < 2; ++b) HIP_OK(d_rX[b].alloc((nf / std::min(chain_group_size(), chain_group_size_upper()) + 2) * 9 * dv.ldx));
     }
     dv.imu_t = d_imu_t.p; dv.imu_w = d_imu_w.p; dv.imu_a = d_imu_a.p; dv.frame_time = d_frame_time.p;
@@ -665,7 +667,7 @@ struct vc_calibrator {
     dv.imu_delta_blk = d_imu_delta_blk.p; dv.imu_grav = d_imu_grav.p;
     for (int b = 0; b < 2; ++b) { dv.segb[b] = d_seg[b].p; dv.seg_costb[b] = d_seg_cost[b].p; }
     dv.cW = d_cW.p; dv.cdelta = d_cdelta.p; dv.ct0 = d_ct0.p; dv.cg = d_cg.p;
-    dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p;
+    dv.clam = d_clam.p; dv.cdiag = d_cdiag.p; dv.cscale2 = d_cscale2.p; dv.cready = d_cready.p;
     for (int b = 0; b < 2; ++b) dv.rX[b] = d_rX[b].p;
     HIP_OK(pack.flush(stream));
     up_c = up_ms();
@@ -793,6 +795,7 @@ struct vc_calibrator {
       //  other's time slices.  A time-out is lossless there too: the mark travels with the step scalars' all-reduce, all ranks resume)
       const bool fs = flag_sync && !serial_weights && (!sharded() || shard_flag_sync) && !use_graphs && !events_only;      // (a captured pass has fixed arguments and needs the events to fork the capture)
       ++pass_seq;
+      dv.pass_id = pass_seq;
       wr_ring[pass_seq & 15] = wcur;              // (what a resume after a flag time-out restores: the weight buffer this pass reads)
       dv.sync_flags = d_sync.p; dv.sync_seq = fs ? pass_seq : 0; dv.final_wait = 0; dv.block_wait = 0; dv.sync_bound = sync_bound;
       const bool fs_trial = fs && jac_on_stream2 && dv.n_tiles > 0;      // (no tiles: no trial sweep to publish the back-substitution's end)

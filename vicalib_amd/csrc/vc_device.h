@@ -162,6 +162,8 @@ struct DevView {
   double* seg_costb[2];            // (n_frames-1)  imu_mult * rho at the linearisation point
   // delta form of the IMU blocks (vc_imu.hpp): the block's sample intervals, each an RK4 step from the identity state, appended in
   // order -- values + 13 partials (biases, scale factors, time offset).  The interval deltas themselves never reach memory
+  long long* cready;               // n_frames: pass number in which the frame's step of the back-substitution was published (k_chain_back_levels)
+  long long pass_id;               // this pass's number (monotonic over the calibrator's life)
   double* imu_grav;                // 2 x 16: gravity vector and its partials (vc_imu.hpp: imu_gravity_record) of state buffer b, written by k_imu_block, read by k_imu_jac
   double* imu_delta_blk;           // (n_frames - 1) x kBlockDeltaStride, written by k_imu_block, read by k_imu_jac; T = -1: empty range
   // ---- block-tridiagonal frame chain (9 x 9 blocks: pose 6 + velocity 3), cyclic reduction ----------------

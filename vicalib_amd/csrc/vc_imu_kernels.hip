@@ -1459,9 +1459,16 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
 #define BSTAMP(i) do { } while (0)
 #endif
 constexpr int kBackT0Frames = 1;      // frames per extra workgroup of the top-level launch (t0 = z + Y delta_s)
-__global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int top, int lvl, int two) {
-  __shared__ double ds[192 + 8];
-  __shared__ double dl[kChainM * 9];
+// FUSED: all levels below the top one in ONE launch (round 4).  A group needs the steps of its two separators, which a group of a
+// level above produces: instead of a kernel boundary per level (four launches of ~9.5 us at cfg3 whose dependent chain is 2.5-3.6 us;
+// the rest is launch, first loads and memory latency) every producer publishes its frames' steps with device-coherent stores and then
+// raises the frames' ready words (the pass number), and a consumer -- which has requested everything else it needs beforehand --
+// polls the two ready words and takes the steps with device-coherent loads: no fence, no cache write-back (the pattern of the
+// cross-stream hand-overs).  Workgroups are laid out top level first: a group only ever waits for workgroups with a
+// smaller index, which the dispatcher has started before it.
+struct BackLevels { int n; int start[8]; int stride[8]; int m[8]; int two[8]; };
+template <bool FUSED>
+__device__ __forceinline__ void chain_back_group(const DevView& v, int s, int m, int top, int lvl, int two, int group, double* ds, double* dl) {
   const int done = v.ctrl->done;        // looked at once the level's inputs have been requested (see k_chain_fwd)
   const int lane = threadIdx.x;
 #ifdef VC_BACK_STAMPS
@@ -1469,41 +1476,18 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
 #endif
   const int N = v.n_frames, D = v.D, ldw = v.ldw, ldx = v.ldx;
   const long gs = (long)m * s;
-  const int a = top ? -1 : (int)(blockIdx.x * gs);
+  const int a = top ? -1 : (int)(group * gs);
   const int first = top ? 0 : a + s;
   const size_t isz = (size_t)9 * ldx;
-  // The chain-independent part of every right-hand side, t0 = z + Y delta_s, for ALL frames: extra workgroups of the top level's
-  // launch (which has one group and an idle chip beside it), lane = column so that a load instruction covers one row segment --
-  // the levels below read one value per (frame, row) instead of walking D entries of a row per lane, 63 cache lines per load
-  // instruction (2.5 us per level at D = 29, 7-16 us at D = 115; tools/back_stamps.py).
-  if (top && blockIdx.x > 0) {
-    if (done) return;
-    const int f = (int)blockIdx.x - 1;      // one frame per wavefront: its nine rows' loads go out together
-    double dsl[3];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) { const int j = lane + 64 * u; dsl[u] = j < D ? v.delta_s[j] : (j == D ? 1.0 : 0.0); }      // (column D: z itself)
-    double p[9];
-#pragma unroll
-    for (int kk = 0; kk < 9; ++kk) {
-      const double* Wr = v.cW + (size_t)f * isz + (size_t)kk * ldx;
-      double acc = 0.0;
-#pragma unroll
-      for (int w = 0; w < 3; ++w) { const int j = lane + 64 * w; if (j <= D) acc += Wr[j] * dsl[w]; }
-      p[kk] = acc;
-    }
-#pragma unroll
-    for (int kk = 0; kk < 9; ++kk) {
-      const double t0 = wave_sum(p[kk]);
-      if (lane == 0) v.ct0[(size_t)f * 9 + kk] = t0;
-    }
-    return;
-  }
   for (int j = lane; j < D; j += 64) ds[j] = v.delta_s[j];
   const int q = first < N ? (top ? (N - 1) / s + 1 : min(m - 1, (N - 1 - first) / s + 1)) : 0;
   const int r = first + q * s;                                  // right separator (or past the end)
   double da[9], dn[9];
+  const bool has_a = a >= 0 && a < N, has_r = !top && q > 0 && r < N;
+  if (!FUSED) {
 #pragma unroll
-  for (int k = 0; k < 9; ++k) { da[k] = (a >= 0 && a < N) ? v.cdelta[(size_t)a * 9 + k] : 0.0; dn[k] = (!top && q > 0 && r < N) ? v.cdelta[(size_t)r * 9 + k] : 0.0; }
+    for (int k = 0; k < 9; ++k) { da[k] = has_a ? v.cdelta[(size_t)a * 9 + k] : 0.0; dn[k] = has_r ? v.cdelta[(size_t)r * 9 + k] : 0.0; }
+  }
   const int fi = lane / 9, k = lane % 9;
   const bool mine = fi < q;
   const int e = first + (mine ? fi : 0) * s;
@@ -1527,14 +1511,35 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
     double acc;
     if (top) { acc = Wr[D]; for (int j = 0; j < D; ++j) acc += Wr[j] * ds[j]; }      // (its own frames: the extra workgroups run beside it)
     else acc = v.ct0[(size_t)e * 9 + k];
-    if (a >= 0) {
-      const bool right = two_sided && fi > fmid;
-#pragma unroll
-      for (int c = 0; c < 9; ++c) acc += Wr[ldw + c] * (right ? dn[c] : da[c]);       // (dn: still the right separator's step here)
-    }
     t = acc;
   }
+  double Xs[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) Xs[c] = (mine && a >= 0) ? v.cW[(size_t)e * isz + (size_t)k * ldx + ldw + c] : 0.0;
   if (done) return;
+  if (FUSED) {
+    // everything else is on its way: now the separators' steps (the levels above publish them, see the kernel's header)
+    if (lane == 0) {
+      long long n = 0;
+      while ((has_a && __hip_atomic_load(v.cready + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v.pass_id) ||
+             (has_r && __hip_atomic_load(v.cready + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v.pass_id)) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++n > 4000000) { atomicAdd(&v.flags[4 + 2 * v.par], 1); atomicAdd((unsigned long long*)&v.dbg[21], 1ull); break; }      // (never seen: would take a dispatcher that starts workgroups out of order)
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    (void)__builtin_amdgcn_readfirstlane(lane);      // (the wavefront goes on together)
+#pragma unroll
+    for (int k2 = 0; k2 < 9; ++k2) {
+      da[k2] = has_a ? __hip_atomic_load(v.cdelta + (size_t)a * 9 + k2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      dn[k2] = has_r ? __hip_atomic_load(v.cdelta + (size_t)r * 9 + k2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+  }
+  if (mine && a >= 0) {
+    const bool right = two_sided && fi > fmid;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) t += Xs[c] * (right ? dn[c] : da[c]);       // (dn: still the right separator's step here)
+  }
 #ifdef VC_BACK_STAMPS
   if (__builtin_amdgcn_readfirstlane(__double2loint(t)) == 0x7fffffff) return;      // (forces t before the stamp)
   if (blockIdx.x == (top ? 0 : gridDim.x / 2) && threadIdx.x == 0 && lvl < 4) { v.dbg[8 * lvl] = bs0_; v.dbg[8 * lvl + 1] = bs1_; }      // (not in passes that exit early)
@@ -1604,7 +1609,14 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
   if (__builtin_amdgcn_readfirstlane(__double2loint(my)) == 0x7fffffff) return;
 #endif
   BSTAMP(3);
-  if (mine) v.cdelta[(size_t)e * 9 + k] = my;
+  if (lvl != 0 && v.cready) {
+    // frames of this level are separators of the levels below: device-coherent stores, then -- once the wavefront's stores have
+    // been performed -- the frames' ready words
+    if (mine) __hip_atomic_store(v.cdelta + (size_t)e * 9 + k, my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (mine && k == 0) __hip_atomic_store(v.cready + e, v.pass_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (mine) v.cdelta[(size_t)e * 9 + k] = my;
   if (lvl != 0) { BSTAMP(4); return; }
   // ---- level 0: trial poses / velocities of the group's frames and their step terms
   if (mine) dl[(fi + 1) * 9 + k] = my;
@@ -1645,10 +1657,54 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
 #pragma unroll
   for (int o2 = 32; o2 > 0; o2 >>= 1) gmax = fmax(gmax, __shfl_down(gmax, o2, 64));
   if (lane == 0) {
-    double* o = v.grp_part + (size_t)blockIdx.x * kNumScal;
+    double* o = v.grp_part + (size_t)group * kNumScal;
     o[kScGd] = gd; o[kScDld] = dld; o[kScStep2] = step2; o[kScX2] = x2; o[kScG2] = g2; o[kScCost] = 0.0; o[kScGmax] = gmax; o[kScSq] = 0.0;
   }
   BSTAMP(4);
+}
+
+__global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int top, int lvl, int two) {
+  __shared__ double ds[192 + 8];
+  __shared__ double dl[kChainM * 9];
+  const int lane = threadIdx.x;
+  const int D = v.D, ldx = v.ldx;
+  const size_t isz = (size_t)9 * ldx;
+  // The chain-independent part of every right-hand side, t0 = z + Y delta_s, for ALL frames: extra workgroups of the top level's
+  // launch (which has one group and an idle chip beside it), lane = column so that a load instruction covers one row segment --
+  // the levels below read one value per (frame, row) instead of walking D entries of a row per lane, 63 cache lines per load
+  // instruction (2.5 us per level at D = 29, 7-16 us at D = 115; tools/back_stamps.py).
+  if (top && blockIdx.x > 0) {
+    if (v.ctrl->done) return;
+    const int f = (int)blockIdx.x - 1;      // one frame per wavefront: its nine rows' loads go out together
+    double dsl[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { const int j = lane + 64 * u; dsl[u] = j < D ? v.delta_s[j] : (j == D ? 1.0 : 0.0); }      // (column D: z itself)
+    double p[9];
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk) {
+      const double* Wr = v.cW + (size_t)f * isz + (size_t)kk * ldx;
+      double acc = 0.0;
+#pragma unroll
+      for (int w = 0; w < 3; ++w) { const int j = lane + 64 * w; if (j <= D) acc += Wr[j] * dsl[w]; }
+      p[kk] = acc;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk) {
+      const double t0 = wave_sum(p[kk]);
+      if (lane == 0) v.ct0[(size_t)f * 9 + kk] = t0;
+    }
+    return;
+  }
+  chain_back_group<false>(v, s, m, top, lvl, two, (int)blockIdx.x, ds, dl);
+}
+__global__ __launch_bounds__(64) void k_chain_back_levels(DevView v, BackLevels L) {
+  __shared__ double ds[192 + 8];
+  __shared__ double dl[kChainM * 9];
+  int li = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) if (i < L.n && (int)blockIdx.x >= L.start[i]) li = i;
+  const int lvl = L.n - 1 - li;                       // (the table runs from the highest level down to level 0)
+  chain_back_group<true>(v, L.stride[li], L.m[li], 0, lvl, L.two[li], (int)blockIdx.x - L.start[li], ds, dl);
 }
 
 // sum over all frames of [Y | z]^T [Y | z]: part[chunk] = [ D x D | D ]  (same layout as the vision path)
@@ -1796,9 +1852,9 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
   // ... and at the bottom level too once the weight update on the other stream starts behind it (vc_calibrator.cpp: enqueue_pass;
   // VICALIB_AMD_CHAIN_TWO_BOTTOM=0: one-sided bottom level)
   static const bool two_bottom = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO_BOTTOM"); return !(e && std::atoi(e) == 0); }();
-  // (only in passes that hand over through device flags: there the weight update waits for the bottom level; with event hand-overs it
-  //  runs beside it -- 500 wavefronts that fill a SIMD's register file each -- and the one-sided bottom level is the faster one)
-  const int two_from = (two_bottom && v.sync_seq > 0) ? 0 : 1;
+  // (whatever the hand-over mode: a solve resumed with events after a flag time-out must repeat the withheld passes with the same
+  //  arithmetic -- with events the weight update runs beside the bottom level and the pass is ~4 us slower than one-sided would be)
+  const int two_from = two_bottom ? 0 : 1;
   auto fwd = [&](int groups, int stride, int m, int top, int lvl) {
     const bool side_by_side = cpl > 1 && !columns_per_lane;
     if (cpl <= 1 && two_sided && !top && m >= 4 && lvl >= two_from) hipLaunchKernelGGL(k_chain_fwd2, dim3(groups), dim3(128), 0, s, v, stride, m, lvl);
@@ -1817,6 +1873,23 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
     fwd(1, top_stride, m_top, 1, nl);
   } else {
     hipLaunchKernelGGL(k_chain_back, dim3(1 + (nl > 0 ? (N + kBackT0Frames - 1) / kBackT0Frames : 0)), dim3(64), 0, s, v, top_stride, m_top, 1, nl, 0);
+    // the levels below: one launch (k_chain_back_levels: ready words instead of kernel boundaries); VICALIB_AMD_BACK_FUSED=0: one launch per level
+    static const bool fused = [] { const char* e = std::getenv("VICALIB_AMD_BACK_FUSED"); return !(e && std::atoi(e) == 0); }();
+    // (only while every workgroup of the launch can be resident at once -- 119 registers, 4 wavefronts per SIMD, 4096 on the chip; half of
+    //  that here: a group that waits for its separators then never keeps a producer from starting, whatever order the dispatcher picks)
+    int total_groups = 0;
+    for (int l = 0; l < nl; ++l) total_groups += (int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1);
+    if (fused && nl > 0 && nl <= 8 && v.cready && total_groups <= 2048) {
+      BackLevels L; L.n = nl;
+      int at = 0;
+      for (int i = 0; i < nl; ++i) {
+        const int l = nl - 1 - i;
+        L.start[i] = at; L.stride[i] = strides[l]; L.m[i] = ms[l]; L.two[i] = (two_sided && ms[l] >= 4 && l >= two_from) ? 1 : 0;
+        at += (int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1);
+      }
+      for (int i = nl; i < 8; ++i) { L.start[i] = 1 << 30; L.stride[i] = 1; L.m[i] = 2; L.two[i] = 0; }
+      hipLaunchKernelGGL(k_chain_back_levels, dim3(at), dim3(64), 0, s, v, L);
+    } else
     for (int l = nl - 1; l >= 0; --l)
       hipLaunchKernelGGL(k_chain_back, dim3((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1)), dim3(64), 0, s, v, strides[l], ms[l], 0, l,
                          (two_sided && ms[l] >= 4 && l >= two_from) ? 1 : 0);
