@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-R=$PWD; O=$R/gpurun_out/${1:-r04i}; mkdir -p $O
+R=$PWD; O=$R/gpurun_out/${1:-quick}; mkdir -p $O
 timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_flag_sync_gpu.py -x -q -m gpu > $O/tests.log 2>&1; tail -3 $O/tests.log
 show() { python - <<PY
 import json

@@ -1315,7 +1315,8 @@ int vc_create(vc_calibrator** out, int device) {
   const char* prio_env = std::getenv("VICALIB_AMD_STREAM2_PRIORITY");      // "default": plain hipStreamCreate (A/B measurements)
   const bool plain2 = prio_env && std::strcmp(prio_env, "default") == 0;
   auto make_stream2 = [&]() -> hipError_t {
-    if (!plain2 && prio_least != prio_greatest && hipStreamCreateWithPriority(&h->stream2, hipStreamDefault, prio_least) == hipSuccess) { h->flag_sync = true; return hipSuccess; }
+    const bool high2 = prio_env && std::strcmp(prio_env, "high") == 0;      // (A/B: the second stream in the HIGHEST priority class instead of the lowest)
+    if (!plain2 && prio_least != prio_greatest && hipStreamCreateWithPriority(&h->stream2, hipStreamDefault, high2 ? prio_greatest : prio_least) == hipSuccess) { h->flag_sync = true; return hipSuccess; }
     (void)hipGetLastError();
     return hipStreamCreate(&h->stream2);          // (a runtime without stream priorities: plain stream, same results)
   };
