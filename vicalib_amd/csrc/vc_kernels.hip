@@ -1472,9 +1472,10 @@ __device__ __forceinline__ void publish_progress(const DevView& v, const Ctrl& c
   if (v.host_progress) {
     // a finished solve: the record itself goes to the host's page-locked copy, then -- after a system-scope fence -- the progress word
     // says `done`; the host reads the result from there while the passes queued past the end drain (no copy, no synchronisation)
-    if (c.done && v.host_ctrl) *v.host_ctrl = c;
-    __threadfence_system();
-    __hip_atomic_store(v.host_progress, ((unsigned long long)(unsigned)c.passes << 32) | (unsigned)c.done | (c.likely_last ? kProgressLikelyLast : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (the fence only then: it waits for the stores to host memory to be performed -- a round trip over the host link -- and the host
+    //  reads the record and the trace rows only once it has seen `done`; the rows of earlier passes were completed by their kernels' ends)
+    if (c.done && v.host_ctrl) { *v.host_ctrl = c; __threadfence_system(); }
+    __hip_atomic_store(v.host_progress, ((unsigned long long)(unsigned)c.passes << 32) | (unsigned)c.done | (c.likely_last ? kProgressLikelyLast : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 __device__ void lm_decide(const DevView& v) {
