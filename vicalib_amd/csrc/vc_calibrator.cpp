@@ -209,6 +209,33 @@ struct RcclApi {
   }
 };
 static RcclApi g_rccl;
+
+// roctx ranges around the stages, solves and passes (tracing hooks), bound at run time and only on request
+// (VICALIB_AMD_ROCTX=1): `rocprofv3 --marker-trace --kernel-trace` then shows which kernels belong to which LM pass of which stage.
+struct RoctxApi {
+  int (*Push)(const char*) = nullptr;
+  int (*Pop)() = nullptr;
+  bool tried = false, on = false;
+  bool load() {
+    if (tried) return on;
+    tried = true;
+    const char* e = std::getenv("VICALIB_AMD_ROCTX");
+    if (!e || e[0] != '1') return false;
+    void* lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return false;
+    Push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+    Pop = (int (*)())dlsym(lib, "roctxRangePop");
+    on = Push && Pop;
+    return on;
+  }
+};
+static RoctxApi g_roctx;
+struct RoctxRange {
+  bool live;
+  explicit RoctxRange(const char* name) : live(g_roctx.load()) { if (live) (void)g_roctx.Push(name); }
+  ~RoctxRange() { if (live) (void)g_roctx.Pop(); }
+};
 // text of the last failure of an entry point that has more to say than its status code (vc_last_error; per thread)
 static thread_local std::string g_last_error;
 constexpr int kNcclDouble = 8, kNcclSum = 0, kNcclMax = 2;     // ncclDataType_t / ncclRedOp_t values of nccl.h
@@ -391,6 +418,7 @@ struct vc_calibrator {
   }
 
   int upload() {
+    RoctxRange rr("vicalib_amd: upload (SetupProblem of a stage)");
     HIP_OK(hipSetDevice(device));
     drop_graphs();
     const bool up_timing = std::getenv("VICALIB_AMD_TIMING") != nullptr;
@@ -779,6 +807,7 @@ struct vc_calibrator {
   // first_pass: the pass right after init_ctrl (the only one that needs k_reproj_jac when k_trial carries the sweep)
   // events_only: a stand-alone pass outside a solve (parity hooks, timing): nobody would resume it after a flag time-out
   int enqueue_pass(bool first_pass = true, bool events_only = false) {
+    RoctxRange rr(first_pass ? "vicalib_amd: LM pass (first of a solve: + linearisation)" : "vicalib_amd: LM pass");
     const int D = dv.D;
     dv.merged = 0; dv.par = 0; dv.ctrl = d_ctrl.p; dv.ctrl_prev = d_ctrl.p + 1;
     if (dv.imu_on) {
@@ -980,6 +1009,7 @@ struct vc_calibrator {
   // The trust-region loop (ceres::Solve :956 with LEVENBERG_MARQUARDT).  The loop itself runs
   // on the device (lm_decide in vc_kernels.hip); the host enqueues passes in batches and polls Ctrl::done.
   int solve_once(Termination* term, double* final_cost, long* nres) {
+    RoctxRange rr("vicalib_amd: solve (ceres::Solve of one stage)");
     if (device_dirty) { int rc = upload(); if (rc) return rc; }
     *nres = 2L * ((long)dv.n_obs * vis_mult - n_one_less) + (dv.imu_on ? 9L * imu_mult * std::max(0, dv.n_frames - 1) : 0L);
     if (sharded()) {
