@@ -594,8 +594,8 @@ struct vc_calibrator {
     const int n_chunks = std::max(1, (N + chunk_frames - 1) / chunk_frames);
     const int part_stride = D * D + D + C * kGStride + (imu_on() ? kGStride : 0) + 2;     // ... + [x2 of observation-less frames, chunk cost] (vision path)
     for (int b = 0; b < 2; ++b) {
-      HIP_OK(d_G[b].alloc((size_t)std::max(T, 1) * kGStride)); HIP_OK(d_tile_cost[b].alloc(std::max(T, 1)));
-      HIP_OK(hipMemsetAsync(d_G[b].p, 0, (size_t)std::max(T, 1) * kGStride * sizeof(double), stream));   // sub-blocks a model never writes stay 0
+      HIP_OK(d_G[b].alloc((size_t)std::max(T, 1) * kGPack)); HIP_OK(d_tile_cost[b].alloc(std::max(T, 1)));
+      HIP_OK(hipMemsetAsync(d_G[b].p, 0, (size_t)std::max(T, 1) * kGPack * sizeof(double), stream));   // sub-blocks a model never writes stay 0
     } HIP_OK(d_tile_trial.alloc((size_t)std::max(T, 1) * 2));
     HIP_OK(d_Y.alloc((size_t)std::max(T, 1) * kYStride)); HIP_OK(d_fr.alloc((size_t)std::max(N, 1) * kFrStride));
     HIP_OK(d_fdiag.alloc((size_t)std::max(N, 1) * 6)); HIP_OK(d_fscale2.alloc((size_t)std::max(N, 1) * 6));

@@ -101,7 +101,7 @@ struct DevView {
   // Linearisation of the vision terms, double-buffered like the state: Gb[b] / tile_costb[b] belong to state buffer b.
   // Vision-only passes evaluate the Jacobian sweep AT THE TRIAL POINT inside k_trial (one projection sweep per LM
   // iteration instead of two); accepting the step flips `cur` and the linearisation is already there.
-  double* Gb[2];                   // n_tiles x kGStride
+  double* Gb[2];                   // n_tiles x kGPack (packed upper triangle + side vector, vc_math.hpp)
   double* tile_costb[2];           // n_tiles   (Jacobian sweep: cost at the linearisation point)
   int fused;                       // 1: the trial point is evaluated by the Jacobian sweeps themselves (k_trial on vision-only passes,
                                    // k_reproj_jac / k_imu_jac in trial mode with the IMU), which leave the next linearisation in buffer 1-cur

@@ -716,8 +716,9 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
       double val[5];
 #pragma unroll
       for (int q = 0; q < 5; ++q) {
-        const int o = (q < 4) ? q * 64 + lane : kGGrad + (lane & 15);
-        val[q] = (q < 4 || lane < 16) ? v.Gb[cur][(size_t)(t0 + t) * kGStride + o] : 0.0;
+        const int e = q * 64 + lane;
+        const int o = (q < 4) ? g_pack_idx(e >> 4, e & 15) : kGPackGrad + (lane & 15);      // (packed record in HBM: expanded on load)
+        val[q] = (q < 4 || lane < 16) ? v.Gb[cur][(size_t)(t0 + t) * kGPack + o] : 0.0;
       }
 #pragma unroll
       for (int q = 0; q < 5; ++q) {

@@ -211,21 +211,22 @@ __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* 
     }
   }
   JSTAMP(4);
-  // D lane = 16 i + 4 b + j holds G[4 I_b + i][4 J_b + j]; both triangles are written (unused blocks stay zero from upload)
+  // D lane = 16 i + 4 b + j holds G[4 I_b + i][4 J_b + j]; the packed record takes the upper triangle only (unused blocks stay zero
+  // from upload)
   {
     const int i = lane >> 4, j = lane & 3;
     const double d0 = acc[0][0] + acc[1][0], d1 = acc[0][1] + acc[1][1], d2 = acc[0][2] + acc[1][2];
     const int r0 = 4 * b + i, c0 = 4 * b + j;
-    G[r0 * 16 + c0] = d0;
+    if (i <= j) G[g_pack_idx(r0, c0)] = d0;
     const int r1 = 4 * (kThreeCols ? xb : b) + i, c1 = 4 * (kThreeCols ? xc : ((b + 1) & 3)) + j;
-    G[r1 * 16 + c1] = d1; G[c1 * 16 + r1] = d1;
+    G[g_pack_idx(r1, c1)] = d1;                      // (an off-diagonal block: g_pack_idx orders the pair)
     if (!kThreeCols) {
       // blocks 2, 3 hold the odd steps' share of (0,2), (1,3): added to blocks 0, 1 (eight lanes further on in the row of 16)
       const double d2o = dpp_row_f64<0x128, 0xF>(d2, d2);      // row_ror:8
       if (b < 2) {
         const double d2t = d2 + d2o;
         const int r2 = 4 * b + i, c2 = 4 * (b + 2) + j;
-        G[r2 * 16 + c2] = d2t; G[c2 * 16 + r2] = d2t;
+        G[g_pack_idx(r2, c2)] = d2t;
       }
     }
   }
@@ -233,7 +234,7 @@ __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* 
 #pragma unroll
     for (int i = 0; i < (kSideGrad ? 16 : 1); ++i) {
       const double t = wave_sum(gacc[i]);
-      if (lane == 0) G[kGGrad + i] = t;
+      if (lane == 0) G[kGPackGrad + i] = t;
     }
   }
   JSTAMP(5);
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void k_reproj_jac(DevView v, int trial) {
     const int cur = trial ? 1 - ct->cur : ct->cur;
     const int f = v.tile_frame[tile], c = v.tile_cam[tile];
     cost = jac_tile_dispatch(v, v.cd[c].model, v.poses[cur] + (size_t)f * kPoseStride, v.cams[cur] + (size_t)c * kCamStride, ct->mult,
-                             tile, lane, wl, v.Gb[cur] + (size_t)tile * kGStride);
+                             tile, lane, wl, v.Gb[cur] + (size_t)tile * kGPack);
     if (lane == 0) v.tile_costb[cur][tile] = cost;
   }
   if (trial) {               // the workgroup's share of the trial cost, in fixed order
@@ -452,8 +453,8 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
       for (int t = 0; t < nt; ++t) {           // full 16x16 Gram block of every tile of the frame
         double val[5];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) val[q] = v.Gb[cur][(size_t)(t0 + t) * kGStride + q * 64 + lane];
-        val[4] = (lane < 16) ? v.Gb[cur][(size_t)(t0 + t) * kGStride + kGGrad + lane] : 0.0;
+        for (int q = 0; q < 4; ++q) { const int e = q * 64 + lane; val[q] = v.Gb[cur][(size_t)(t0 + t) * kGPack + g_pack_idx(e >> 4, e & 15)]; }      // (packed record: expanded on load)
+        val[4] = (lane < 16) ? v.Gb[cur][(size_t)(t0 + t) * kGPack + kGPackGrad + lane] : 0.0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) Gw[t * kGStride + q * 64 + lane] = val[q];
         if (lane < 16) Gw[t * kGStride + kGGrad + lane] = val[4];
@@ -1319,7 +1320,7 @@ __device__ __forceinline__ void trial_tile(const DevView& v, int cur, double mul
     // Jacobian sweep at the trial point: its cost is the trial cost, its Gram block is the next linearisation if the
     // step is accepted (k_final flips `cur`); a rejected step leaves Gb[cur] untouched
     cost = jac_tile_dispatch(v, h.model, Tout, camr, mult, tile, lane, lds_rows + wave * 64 * kDotStride,
-                             v.Gb[1 - cur] + (size_t)tile * kGStride, h.off, h.cnt);
+                             v.Gb[1 - cur] + (size_t)tile * kGPack, h.off, h.cnt);
     if (lane == 0) v.tile_costb[1 - cur][tile] = cost;
   } else {
     TileXf x;

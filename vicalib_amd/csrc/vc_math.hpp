@@ -33,6 +33,11 @@ constexpr int kUCols = 16;        // padded width of a unique-column row
 // nk <= 9 the residual column r sits inside the block (column 6 + nk).  rational6 has nk = 10: its 16 Jacobian columns fill the
 // block and the products with r (J^T r, 16 values) live in the side vector at kGGrad.
 constexpr int kGGrad = 256;
+// In HBM the record is PACKED (round 4): the block's upper triangle row by row (136 doubles) + the side vector = kGPack doubles --
+// the symmetric block was written and read in full before (2176 -> 1216 B per tile and buffer).  Readers expand it on load (LDS images and
+// chunk partials keep the 16 x 16 layout above).
+constexpr int kGPack = 152, kGPackGrad = 136;
+VC_HD int g_pack_idx(int r, int c) { const int a = r <= c ? r : c, b = r <= c ? c : r; return a * 16 - (a * (a - 1)) / 2 + (b - a); }
 VC_HD double gram_grad(const double* G, int row, int nk) { return nk < 10 ? G[row * kUCols + 6 + nk] : G[kGGrad + row]; }
 constexpr int kSoftL1A = 0;       // loss ids
 constexpr double kSophusEps = 1e-10;
