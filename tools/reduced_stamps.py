@@ -23,7 +23,9 @@ tot = st[6] - st[0]
 for i in range(1, 7):
     print("%-28s +%8.0f cycles  %5.1f %%" % (names[i], st[i] - st[i - 1], 100.0 * (st[i] - st[i - 1]) / tot))
 print("total %.0f cycles" % tot)
-if st[8:14].sum() > 0:
+if st[8:14].sum() > 0 and st[8] > 1e9:
+    print("one-wavefront solve (D <= 32): load %.0f, factor %.0f, L to LDS %.0f, back-substitution %.0f cycles" % (st[9]-st[8], st[10]-st[9], st[11]-st[10], st[12]-st[11]))
+elif st[8:14].sum() > 0:
     print("inside the blocked solve (D > 32), cycles summed over the panels:")
     for n, c in zip(["load + damping", "diagonal blocks (one wavefront)", "rows below the panel", "trailing update", "back-substitution: partial sums", "back-substitution: panel solves"], st[8:14]):
         print("  %-36s %8.0f cycles" % (n, c))

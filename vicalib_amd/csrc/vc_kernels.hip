@@ -654,6 +654,7 @@ __global__ __launch_bounds__(kSumEntries * kSumSlices) void k_part_sum(DevView v
   }
 }
 
+constexpr int kSmallD = 32;   // reduced systems up to this width are solved by one wavefront; above it the workgroup-wide LDS factorisation is faster
 // Phase A of the reduced system (one workgroup):
 // Sbuf = [ S = H_ss - sum Y^T Y (full symmetric, undamped) | g_red | diag(H_ss) | g_s | cost, 0 ]
 struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[kMaxCams * 256]; double T1[kMaxCams * 256]; double red[256]; double camq[kMaxCams * 4]; double gc[kMaxCams * 16]; };
@@ -664,10 +665,18 @@ struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[kMaxCams * 25
 #else
 #define VC_STAMP(i) do { } while (0)
 #endif
-__device__ __forceinline__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */) {
+// S: v.Sbuf, or (single process, D <= kSmallD) an LDS image of it that this phase fills first -- every read-modify-write of the
+// phase and the solve's row loads then stay on chip (three L2 round trips less on the critical path); the kernel writes it back.
+__device__ __forceinline__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */, double* S, bool s_in_lds) {
   VC_STAMP(0);
   const int tid = threadIdx.x, D = v.D, C = v.n_cams;
-  double* S = v.Sbuf;
+  // (all of a thread's loads go out before the first is stored to LDS: a plain copy loop is one memory round trip per iteration)
+  constexpr int kSIter = (kSmallD * kSmallD + kSmallD + 255) / 256;
+  double s_in[kSIter];
+  if (s_in_lds) {      // S and g_red as k_part_sum left them
+#pragma unroll
+    for (int q = 0; q < kSIter; ++q) { const int e = tid + 256 * q; s_in[q] = e < D * D + D ? v.Sbuf[e] : 0.0; }
+  }
   double* gred = S + D * D;
   double* hd = gred + D;
   double* gs = hd + D;
@@ -678,10 +687,20 @@ __device__ __forceinline__ void schur_final_phase(const DevView& v, int cur, Fin
   const double* ptot = v.part_total;
   // camera rotations: fetched now, under the loads' latency, instead of one dependent global load per camera later
   if (tid < C * 4) L.camq[tid] = v.cams[cur][(size_t)(tid >> 2) * kCamStride + (tid & 3)];
-  for (int e = D * D + D + tid; e < stride - 1; e += 256) {
-    const double t = ptot[e];
-    if (e < stride - 2) L.gsum[e - D * D - D] = t;
-    else *x2_noobs = t;                 // x2 of observation-less frames
+  for (int e0 = D * D + D + tid; e0 < stride - 1; e0 += 4 * 256) {
+    double t[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int e = e0 + 256 * q; t[q] = e < stride - 1 ? ptot[e] : 0.0; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + 256 * q;
+      if (e < stride - 2) L.gsum[e - D * D - D] = t[q];
+      else if (e == stride - 2) *x2_noobs = t[q];                 // x2 of observation-less frames
+    }
+  }
+  if (s_in_lds) {
+#pragma unroll
+    for (int q = 0; q < kSIter; ++q) { const int e = tid + 256 * q; if (e < D * D + D) S[e] = s_in[q]; }
   }
   VC_STAMP(1);
   for (int i = tid; i < D; i += 256) { hd[i] = 0.0; gs[i] = 0.0; }
@@ -800,20 +819,28 @@ __device__ __forceinline__ void schur_final_phase(const DevView& v, int cur, Fin
 // (cams[1-cur] <- Plus(cams[cur], delta_s)) and their scalar terms scal[8..15].
 //   D <= 32: one wavefront, rows in registers, pivots exchanged with v_readlane (no barriers);
 //   D  > 32: workgroup-wide in LDS.
-constexpr int kSmallD = 32;   // above this the workgroup-wide LDS factorisation is faster
 // Lane i keeps row i of the augmented matrix in registers (static indices: all loops over columns are
-// unrolled to DMAX); the freshly scaled pivot column is exchanged through LDS as one contiguous vector
-// (broadcast reads, no dependent read-modify-write chains).  Lt: DMAX x ldt, x: D.
+// unrolled to DMAX), pivots and pivot columns travel through v_readlane; the factor goes to LDS (Lt: DMAX x ldt) for the
+// back-substitution only.  x: D.
+// (the arguments by value: a function that is not inlined and takes the DevView by reference makes its caller keep a copy of the
+//  whole record in scratch memory -- 1 KB per lane and a slower launch)
+struct SmallSolveArgs { int D; double* sscale2; double* sdiag; double* slam; int* bad_flag; long long* dbg; };
 template <int DMAX>
-__device__ void solve_small_wave(const DevView& v, const Ctrl* ct, int lane, double* Lt, double* x, double pre_sc2, double pre_dg) {
+__device__ __forceinline__ void solve_small_wave(const SmallSolveArgs v, const Ctrl* ct, int lane, double* Lt, double* x, double pre_sc2, double pre_dg, const double* S /* v.Sbuf or its LDS image */) {
   const int D = v.D;
   constexpr int ldt = DMAX + 2;
-  const double* S = v.Sbuf;
   const double* gred = S + D * D;
   const double* hd = gred + D;
+#ifdef VC_REDUCED_STAMPS
+  if (lane == 0) v.dbg[8] = (long long)__builtin_readcyclecounter();
+#endif
   double row[DMAX];
+  {
+    // one base address per lane (row `lane` of S; g_red for lane D and, harmlessly, beyond), the column as an immediate offset
+    const double* rp = lane < D ? S + lane * D : gred;
 #pragma unroll
-  for (int k = 0; k < DMAX; ++k) row[k] = (k < D && lane <= D) ? (lane < D ? S[lane * D + k] : gred[k]) : 0.0;
+    for (int k = 0; k < DMAX; ++k) { double t = 0.0; if (k < D) t = rp[k]; row[k] = lane <= D ? t : 0.0; }
+  }
   double lam = 0.0;
   if (lane < D) {
     double sc2, dg;
@@ -828,6 +855,12 @@ __device__ void solve_small_wave(const DevView& v, const Ctrl* ct, int lane, dou
   }
 #pragma unroll
   for (int k = 0; k < DMAX; ++k) row[k] += (k == lane) ? lam : 0.0;
+#ifdef VC_REDUCED_STAMPS
+#define VC_SS(i) do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); if (lane == 0) v.dbg[8 + (i)] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define VC_SS(i) do { } while (0)
+#endif
+  VC_SS(1);
   // Every loop below is fully unrolled (j, k compile-time): register indices are static, pivots and pivot columns travel
   // as scalars through v_readlane -- no LDS round trip and no select chains inside the dependent chain.  The column loop
   // has no branch and no store (one scheduling region): the trailing updates of column j fill the latency of column
@@ -843,35 +876,50 @@ __device__ void solve_small_wave(const DevView& v, const Ctrl* ct, int lane, dou
     d = ok ? d : 1.0;
     const double ipiv = fast_rsqrt(d);
     const double lij = (lane == j) ? d * ipiv : mine * ipiv;
-    row[j] = lij;
+    row[j] = lij * ipiv;      // what the back-substitution wants: column j of L over its diagonal entry (off the dependent chain)
 #pragma unroll
     for (int k = j + 1; k < DMAX; ++k) row[k] -= lij * readlane_f64(lij, k);
   }
-  if (bad && lane == 0) v.flags[5 + 2 * v.par] = 1;
-  // column j of L, contiguous over the rows (entries above the diagonal / beyond row D are never read; lanes past the
+  VC_SS(2);
+  if (bad && lane == 0) *v.bad_flag = 1;
+  // column j of L / L_jj, contiguous over the rows (entries above the diagonal / beyond row D are never read; lanes past the
   // padded row length all write the last padding slot)
   {
     const int slot = lane < ldt - 1 ? lane : ldt - 1;
 #pragma unroll
     for (int j = 0; j < DMAX; ++j) Lt[j * ldt + slot] = row[j];
   }
-  // delta_s = -L^-T y.  Lt row i is column i of L: L[j][i] for j >= i, and y_i = L[D][i] at index D.
+  // delta_s = -L^-T y.  Lt row i is column i of L over L_ii: c_ij = L[j][i] / L[i][i] for j > i, and y_i / L[i][i] at index D:
+  // x_i = -y_i / L_ii - sum_{j > i} c_ij x_j.  Lane i keeps its running sum s; the unknowns are resolved four at a time: the four
+  // lanes' sums are broadcast (v_readlane, independent of each other), every lane solves the 4 x 4 triangle itself (its six
+  // coefficients are wave-uniform LDS reads, requested ahead) and applies the four unknowns to its sum -- one scalar round trip
+  // per four unknowns on the dependent chain instead of one per unknown.  A lane inside the block ends up with its own unknown:
+  // the terms the broadcast value was still missing are exactly the ones the update adds (c_ij = 0 for j <= i).
   wave_lds_sync();
+  VC_SS(3);
   double c[DMAX];
 #pragma unroll
-  for (int j = 0; j < DMAX; ++j) c[j] = (j < D && lane < D && j >= lane) ? Lt[lane * ldt + j] : 0.0;
+  for (int j = 0; j < DMAX; ++j) c[j] = (j < D && lane < D && j > lane) ? Lt[lane * ldt + j] : 0.0;
   double s = (lane < D) ? -Lt[lane * ldt + D] : 0.0;
-  const double dinv = (lane < D) ? 1.0 / Lt[lane * ldt + lane] : 1.0;
-  double mine = 0.0;
 #pragma unroll
-  for (int j = DMAX - 1; j >= 0; --j) {
-    if (j < D) {
-      const double xj = readlane_f64(s * dinv, j);
-      if (lane == j) mine = xj;
-      s -= c[j] * xj;              // c[j] = 0 for j < lane; lane j's own s is not needed any more
-    }
+  for (int hi = DMAX; hi > 0; hi -= 4) {
+    const int lo = hi >= 4 ? hi - 4 : 0, n = hi - lo;
+    double t[4], xb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (q < n) t[q] = readlane_f64(s, lo + q);
+#pragma unroll
+    for (int q = 3; q >= 0; --q)
+      if (q < n) {
+        double a = t[q];
+#pragma unroll
+        for (int r = 3; r > q; --r) if (r < n) a -= ((lo + r < D) ? Lt[(lo + q) * ldt + lo + r] : 0.0) * xb[r];      // oldest unknown first
+        xb[q] = a;
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (q < n) s -= c[lo + q] * xb[q];
   }
-  if (lane < D) x[lane] = mine;
+  if (lane < D) x[lane] = s;
+  VC_SS(4);
 }
 
 // Workgroup-wide factorisation for D > 32.  Only the lower triangle (plus the right-hand-side row D) is kept, packed:
@@ -1056,15 +1104,21 @@ __device__ __forceinline__ void solve_large_blocked(const DevView& v, const Ctrl
 }
 
 __device__ __forceinline__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dyn, double* red /* 6 x 256 */, const double* s_cam,
-                                    double pre_sc2, double pre_dg, const double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */) {
+                                    double pre_sc2, double pre_dg, const double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */,
+                                    const double* Sb /* v.Sbuf or its LDS image */, double pre_imu) {
   const int tid = threadIdx.x, D = v.D, cur = ct->cur;
   double* x;
   VC_STAMP(4);
   if (D <= kSmallD) {
     x = dyn + (kSmallD + 1) * (kSmallD + 2);
     if (tid < 64 && D > 0) {
-      if (D <= 16) solve_small_wave<16>(v, ct, tid, dyn, x, pre_sc2, pre_dg);
-      else solve_small_wave<32>(v, ct, tid, dyn, x, pre_sc2, pre_dg);
+      // (every column up to DMAX is eliminated whether the matrix has it or not: instances close to the common widths)
+      const SmallSolveArgs a = {D, v.sscale2, v.sdiag, v.slam, v.flags + 5 + 2 * v.par, v.dbg};
+      if (D <= 16) solve_small_wave<16>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb);
+      else if (D <= 24) solve_small_wave<24>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb);
+      else if (D <= 28) solve_small_wave<28>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb);
+      else if (D <= 30) solve_small_wave<30>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb);
+      else solve_small_wave<32>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb);
     }
     __syncthreads();
   } else {
@@ -1109,14 +1163,16 @@ __device__ __forceinline__ void reduced_solve_phase(const DevView& v, const Ctrl
       for (int i = 0; i < nk; ++i) { const double d = x[cc + i], o = cin[kCamK + i]; step2 += d * d; x2 += o * o; cout[kCamK + i] = o + d; }
     }
   }
+  double o[16];      // accepted IMU parameters: requested at kernel entry by lanes 0..15 of this thread's wavefront
+  if (v.imu_on && (tid >> 6) == (one_wave ? 0 : 1)) {
+#pragma unroll
+    for (int a = 0; a < 16; ++a) o[a] = readlane_f64(pre_imu, a);
+  }
   if (v.imu_on && tid == (one_wave ? 63 : 64)) {     // g(2) b(6) sf(6) toff(1): plain additive parameters
-    const double* iin = v.imus[cur];
     double* iout = v.imus[1 - cur];
     // all loads first, then the arithmetic, then the stores: interleaved, every store would hold back the next element's loads
     // (the compiler cannot tell the two buffers apart) -- 15 dependent memory round trips in the tail of a critical-path kernel
-    double o[16], dlt[15];
-#pragma unroll
-    for (int a = 0; a < 16; ++a) o[a] = iin[a];
+    double dlt[15];
 #pragma unroll
     for (int a = 0; a < 15; ++a) { const int col = v.imu_param_col[a]; dlt[a] = (col >= 0) ? x[col >= 0 ? col : 0] : 0.0; }
 #pragma unroll
@@ -1182,13 +1238,22 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   const Ctrl* ct = v.ctrl;
   if (ct->done) { if (threadIdx.x == 0 && mode != 1) signal_flag(v, 1); return; }
   if (threadIdx.x < kMaxCams) s_cd[threadIdx.x] = v.cd[threadIdx.x];
+  __shared__ double s_S[kSmallD * kSmallD + 3 * kSmallD + 2];      // single process, D <= kSmallD: the reduced system stays in LDS between the phases
   double pre_sc2 = 1.0, pre_dg = 1.0;      // damping inputs of the small solve: requested now, consumed after phase A
+  double pre_imu = 0.0;                    // accepted IMU parameters (lane a of the wavefront whose thread forms the trial ones): the tail's
   if (mode != 1) {
     for (int i = threadIdx.x; i < v.n_cams * kCamStride; i += 256) s_cam[i] = v.cams[ct->cur][i];
     if (v.D <= kSmallD && (int)threadIdx.x < v.D) { pre_sc2 = v.sscale2[threadIdx.x]; pre_dg = v.sdiag[threadIdx.x]; }
+    if (v.imu_on && (int)(threadIdx.x >> 6) == (v.D <= 64 ? 0 : 1) && (threadIdx.x & 63) < 16) pre_imu = v.imus[ct->cur][threadIdx.x & 63];
   }
-  if (mode != 2) { schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2, s_cd); __syncthreads(); }
-  if (mode != 1) reduced_solve_phase(v, ct, dyn, red, s_cam, pre_sc2, pre_dg, mode == 0 ? &s_x2 : nullptr, s_cd);
+  const bool s_in_lds = mode == 0 && v.D <= kSmallD;
+  if (s_in_lds) {
+    schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2, s_cd, s_S, true);
+    __syncthreads();
+    // Sbuf keeps its meaning for k_final (cost slot) and the parity hooks: written back off the critical path
+    for (int e = threadIdx.x; e < v.D * v.D + 3 * v.D + 2; e += 256) v.Sbuf[e] = s_S[e];
+  } else if (mode != 2) { schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2, s_cd, v.Sbuf, false); __syncthreads(); }
+  if (mode != 1) reduced_solve_phase(v, ct, dyn, red, s_cam, pre_sc2, pre_dg, mode == 0 ? &s_x2 : nullptr, s_cd, s_in_lds ? s_S : v.Sbuf, pre_imu);
   if (mode != 1) { __syncthreads(); if (threadIdx.x == 0) signal_flag(v, 1); }      // the trial IMU parameters exist (stream B's deltas wait for this)
 }
 
