@@ -6,7 +6,7 @@
 #include "../../vicalib_amd/csrc/vc_math.hpp"
 #include <vector>
 #include "../../vicalib_amd/csrc/vc_imu.hpp"
-#include "../../vicalib_amd/csrc/vc_imu_weights.hpp"
+#include "seq_weights.hpp"
 using namespace vc;
 
 template <int MODEL>

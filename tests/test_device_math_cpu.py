@@ -21,7 +21,7 @@ def hh():
         src = os.path.join(HERE, "host_harness", "harness.cpp")
         so = os.path.join(HERE, "host_harness", "libvc_host_harness.so")
         csrc = os.path.join(HERE, "..", "vicalib_amd", "csrc")
-        deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".h"))]
+        deps = [src, os.path.join(HERE, "host_harness", "seq_weights.hpp")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".h"))]
         if not os.path.exists(so) or max(os.path.getmtime(f) for f in deps) > os.path.getmtime(so):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
         _hh = C.CDLL(so)

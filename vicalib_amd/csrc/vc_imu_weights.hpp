@@ -49,276 +49,6 @@ VC_HD void w_dqx_dq(const double* q, const double* vec, double* m) {   // 3x4
   m[8] = 2 * qz * x + 2 * qw * y - 4 * qx * z; m[9] = 2 * qz * y - 2 * qw * x - 4 * qy * z;
   m[10] = 2 * qy * y + 2 * qx * x;           m[11] = 2 * qx * y - 2 * qy * x;
 }
-VC_HD void w_dlog_dq(const double* q, double* m) {      // 3x4
-  const double v[3] = {q[0], q[1], q[2]}, w = q[3];
-  const double n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], n = sqrt(n2);
-  if (n < 1e-9) {
-    const double s1 = 2 * n2, s2 = 1.0 / (w * w * w), s3 = (3 * s1) / (w * w * w * w) - 2 / (w * w), s4 = 2 / w;
-    for (int i = 0; i < 3; ++i) {
-      for (int j = 0; j < 3; ++j) m[i * 4 + j] = (i == j) ? -4 * s2 * v[i] * v[i] + s4 - s1 * s2 : -4 * v[i] * v[j] * s2;
-      m[i * 4 + 3] = v[i] * s3;
-    }
-  } else {
-    const double s1 = n2, s2 = 1 / (s1 / (w * w) + 1), s3 = atan(sqrt(s1) / w), s4 = 1 / (s1 * sqrt(s1)), s5 = 1 / s1, s6 = 1 / w;
-    const double s7 = (2 * s3) / sqrt(s1);
-    for (int i = 0; i < 3; ++i) {
-      for (int j = 0; j < 3; ++j) {
-        const double off = 2 * v[i] * v[j] * s2 * s5 * s6 - 2 * v[i] * v[j] * s3 * s4;
-        m[i * 4 + j] = (i == j) ? s7 - 2 * v[i] * v[i] * s3 * s4 + 2 * v[i] * v[i] * s2 * s5 * s6 : off;
-      }
-      m[i * 4 + 3] = -(2 * v[i] * s2) / (w * w);
-    }
-  }
-}
-// SO3 log of a quaternion (value only) with theta
-VC_HD void w_so3_log(const double* q, double* w, double* theta) {
-  const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2], n = sqrt(n2), qw = q[3];
-  double c;
-  if (n < kSophusEps) c = 2.0 / qw - 2.0 * n2 / (qw * qw * qw);
-  else if (fabs(qw) < kSophusEps) c = (qw > 0.0) ? 3.14159265358979323846 / n : -3.14159265358979323846 / n;
-  else c = 2.0 * atan(n / qw) / n;
-  *theta = c * n;
-  w[0] = c * q[0]; w[1] = c * q[1]; w[2] = c * q[2];
-}
-// d log(T)/dT, 6x7, T as [t(3), q(4)]; input storage [q, t]
-VC_HD void w_dlog_dse3(const double* T, double* dl) {
-  double dw_dq[12];
-  w_dlog_dq(T, dw_dq);
-  const double x = T[4], y = T[5], z = T[6];
-  double w[3], theta;
-  w_so3_log(T, w, &theta);
-  const double wx = w[0], wy = w[1], wz = w[2];
-  const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
-  double O2[9];
-  mm(O, O, O2, 3, 3, 3);
-  const bool small = fabs(theta) < kSophusEps;
-  const double c = small ? 1.0 / 12.0 : (1.0 - theta / (2.0 * tan(theta / 2.0))) / (theta * theta);
-  for (int i = 0; i < 42; ++i) dl[i] = 0.0;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dl[i * 7 + j] = (i == j ? 1.0 : 0.0) - 0.5 * O[3 * i + j] + c * O2[3 * i + j];
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) dl[(3 + i) * 7 + 3 + j] = dw_dq[i * 4 + j];
-  double dw[9];
-  if (small) {
-    const double d12 = 1. / 12, d6 = 1. / 6.;
-    dw[0] = d12 * (wy * y + wz * z); dw[1] = d12 * wx * y - d6 * wy * x - 0.5 * z; dw[2] = 0.5 * y - d6 * wz * x + d12 * wx * z;
-    dw[3] = 0.5 * z + d12 * wy * x - d6 * wx * y; dw[4] = d12 * (wx * x + wz * z); dw[5] = d12 * wy * z - d6 * wz * y - 0.5 * x;
-    dw[6] = d12 * wz * x - d6 * wx * z - 0.5 * y; dw[7] = 0.5 * x + d12 * wz * y - d6 * wy * z; dw[8] = d12 * ((wx * x) * (wy * y));
-  } else {
-    const double s1 = wx * wx + wy * wy + wz * wz, rs1 = sqrt(s1), s2 = tan(rs1 / 2), s3 = rs1 / (2 * s2) - 1;
-    const double s4 = wz / (2 * rs1 * s2) - (wz * (s2 * s2 + 1)) / (4 * s2 * s2);
-    const double s5 = wy / (2 * rs1 * s2) - (wy * (s2 * s2 + 1)) / (4 * s2 * s2);
-    const double s6 = wx / (2 * rs1 * s2) - (wx * (s2 * s2 + 1)) / (4 * s2 * s2);
-    const double s7 = 1 / s1, s8 = 1 / (s1 * s1), s9 = wx * wx + wy * wy, s10 = wx * wx + wz * wz, s11 = wy * wy + wz * wz;
-    const double s12 = 2 * s3 * s8 * wx * wy * wz;
-    const double s13 = -2 * s3 * s8 * wy * wz * wz + s4 * s7 * wy * wz + s3 * s7 * wy;
-    const double s14 = -2 * s3 * s8 * wx * wz * wz + s4 * s7 * wx * wz + s3 * s7 * wx;
-    const double s15 = -2 * s3 * s8 * wz * wy * wy + s5 * s7 * wz * wy + s3 * s7 * wz;
-    const double s16 = -2 * s3 * s8 * wz * wx * wx + s6 * s7 * wz * wx + s3 * s7 * wz;
-    const double s17 = -2 * s3 * s8 * wx * wy * wy + s5 * s7 * wx * wy + s3 * s7 * wx;
-    const double s18 = -2 * s3 * s8 * wy * wx * wx + s6 * s7 * wy * wx + s3 * s7 * wy;
-    const double s19 = 2 * s3 * s7 * wy, s20 = 2 * s3 * s7 * wx;
-    dw[0] = x * (s6 * s7 * s11 - 2 * s3 * s8 * s11 * wx) - s18 * y - s16 * z;
-    dw[1] = x * (s19 + s5 * s7 * s11 - 2 * s3 * s8 * s11 * wy) - s17 * y - z * (s5 * s7 * wx * wz - 2 * s3 * s8 * wx * wy * wz + 0.5);
-    dw[2] = x * (s4 * s7 * s11 + 2 * s3 * s7 * wz - 2 * s3 * s8 * s11 * wz) - s14 * z + y * (s12 - s4 * s7 * wx * wy + 0.5);
-    dw[3] = y * (s20 + s6 * s7 * s10 - 2 * s3 * s8 * s10 * wx) - s18 * x + z * (s12 - s6 * s7 * wy * wz + 0.5);
-    dw[4] = y * (s5 * s7 * s10 - 2 * s3 * s8 * s10 * wy) - s17 * x - s15 * z;
-    dw[5] = y * (s4 * s7 * s10 + 2 * s3 * s7 * wz - 2 * s3 * s8 * s10 * wz) - s13 * z - x * (s4 * s7 * wx * wy - s12 + 0.5);
-    dw[6] = z * (s20 + s6 * s7 * s9 - 2 * s3 * s8 * s9 * wx) - s16 * x - y * (s6 * s7 * wy * wz - s12 + 0.5);
-    dw[7] = z * (s19 + s5 * s7 * s9 - 2 * s3 * s8 * s9 * wy) - s15 * y + x * (s12 - s5 * s7 * wx * wz + 0.5);
-    dw[8] = z * (s4 * s7 * s9 - 2 * s3 * s8 * s9 * wz) - s14 * x - s13 * y;
-  }
-  double blk[12];
-  mm(dw, dw_dq, blk, 3, 3, 4);
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) dl[i * 7 + 3 + j] = blk[i * 4 + j];
-}
-
-struct WState { double q[4], p[3], v[3]; };
-// IntegratePose with dy/dk (10x9) and dy/dy (10x10)
-VC_HD void w_integrate_pose(const WState& s, const double* k, double dt, WState* y, double* dy_dk, double* dy_dy) {
-  const double wdt[3] = {k[3] * dt, k[4] * dt, k[5] * dt};
-  double rq[4];
-  so3_exp(wdt, rq);
-  for (int i = 0; i < 3; ++i) { y->p[i] = s.p[i] + k[i] * dt; y->v[i] = s.v[i] + k[6 + i] * dt; }
-  quat_mul(rq, s.q, y->q);
-  for (int i = 0; i < 90; ++i) dy_dk[i] = 0.0;
-  for (int i = 0; i < 100; ++i) dy_dy[i] = 0.0;
-  for (int i = 0; i < 3; ++i) { dy_dk[i * 9 + i] = dt; dy_dk[(7 + i) * 9 + 6 + i] = dt; dy_dy[i * 10 + i] = 1.0; dy_dy[(7 + i) * 10 + 7 + i] = 1.0; }
-  double a[16], e[12], ae[12], d2[16];
-  w_dq1q2_dq1(s.q, a); w_dqexp_dw(wdt, e);
-  mm(a, e, ae, 4, 4, 3);
-  for (int i = 0; i < 4; ++i) for (int j = 0; j < 3; ++j) dy_dk[(3 + i) * 9 + 3 + j] = ae[i * 3 + j] * dt;
-  w_dq1q2_dq2(rq, d2);
-  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) dy_dy[(3 + i) * 10 + 3 + j] = d2[i * 4 + j];
-}
-// GetPoseDerivative with dk/db (9x6) and dk/dx (9x10)
-VC_HD void w_pose_derivative(const WState& s, const double* g_w, const Meas<double>& z0, const Meas<double>& z1, const double* b,
-                             const double* sf, double dt, double* k, double* dk_db, double* dk_dx) {
-  const double alpha = (z1.time - (z0.time + dt)) / (z1.time - z0.time);
-  double zg[3], za[3], u[3], o[3], R[9];
-  for (int i = 0; i < 3; ++i) { zg[i] = z0.w[i] * alpha + z1.w[i] * (1.0 - alpha); za[i] = z0.a[i] * alpha + z1.a[i] * (1.0 - alpha); }
-  for (int i = 0; i < 3; ++i) k[i] = s.v[i];
-  quat_to_R(s.q, R);
-  for (int i = 0; i < 3; ++i) u[i] = zg[i] * sf[i] + b[i];
-  for (int i = 0; i < 3; ++i) k[3 + i] = R[3 * i] * u[0] + R[3 * i + 1] * u[1] + R[3 * i + 2] * u[2];
-  for (int i = 0; i < 3; ++i) u[i] = za[i] * sf[3 + i] + b[3 + i];
-  quat_rotate(s.q, u, o);
-  for (int i = 0; i < 3; ++i) k[6 + i] = o[i] - g_w[i];
-  for (int i = 0; i < 54; ++i) dk_db[i] = 0.0;
-  for (int i = 0; i < 90; ++i) dk_dx[i] = 0.0;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { dk_db[(3 + i) * 6 + j] = R[3 * i + j]; dk_db[(6 + i) * 6 + 3 + j] = R[3 * i + j]; }
-  for (int i = 0; i < 3; ++i) dk_dx[i * 10 + 7 + i] = 1.0;
-  double m1[12], m2[12];
-  w_dqx_dq(s.q, zg, m1); w_dqx_dq(s.q, b, m2);
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) dk_dx[(3 + i) * 10 + 3 + j] = m1[i * 4 + j] + m2[i * 4 + j];
-  w_dqx_dq(s.q, za, m1); w_dqx_dq(s.q, b + 3, m2);
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) dk_dx[(6 + i) * 10 + 3 + j] = m1[i * 4 + j] + m2[i * 4 + j];
-}
-// one RK4 step with Jacobians; Sigma (10x10) <- F Sigma F^T + G R G^T
-VC_HD void w_integrate_imu(WState* st, const Meas<double>& z0, const Meas<double>& z1, const double* b, const double* sf,
-                           const double* g, double* Sigma, double sg2, double sa2) {
-  const double dt = z1.time - z0.time;
-  if (dt == 0) return;
-  double dy_db[60], dy_dy0[100], dk_db[54], dk_dy[90], dy_dk[90], dy_dy[100];
-  double kt_db[54], kt_dy[90], kc_db[54], kc_dy[90], tmp[100], tmp2[100];
-  double k1[9], kk[9], ksum[9];
-  WState y;
-  for (int i = 0; i < 60; ++i) dy_db[i] = 0.0;
-  for (int i = 0; i < 100; ++i) dy_dy0[i] = (i % 11 == 0) ? 1.0 : 0.0;
-  const double tau[4] = {0.0, dt / 2, dt / 2, dt}, hh[3] = {dt * 0.5, dt * 0.5, dt}, wgt[4] = {1.0, 2.0, 2.0, 1.0};
-  WState cur = *st;
-  for (int i = 0; i < 54; ++i) kt_db[i] = 0.0;
-  for (int i = 0; i < 90; ++i) kt_dy[i] = 0.0;
-  for (int i = 0; i < 9; ++i) ksum[i] = 0.0;
-  for (int stage = 0; stage < 4; ++stage) {
-    w_pose_derivative(cur, g, z0, z1, b, sf, tau[stage], stage == 0 ? k1 : kk, dk_db, dk_dy);
-    const double* kc = stage == 0 ? k1 : kk;
-    // total derivatives of this stage's k: dk/db = dk_db + dk_dy dy_db ; dk/dy0 = dk_dy dy_dy0
-    mm(dk_dy, dy_db, tmp, 9, 10, 6);
-    for (int i = 0; i < 54; ++i) kc_db[i] = dk_db[i] + tmp[i];
-    mm(dk_dy, dy_dy0, kc_dy, 9, 10, 10);
-    for (int i = 0; i < 54; ++i) kt_db[i] += wgt[stage] * kc_db[i];
-    for (int i = 0; i < 90; ++i) kt_dy[i] += wgt[stage] * kc_dy[i];
-    for (int i = 0; i < 9; ++i) ksum[i] += wgt[stage] * kc[i];
-    if (stage < 3) {
-      w_integrate_pose(*st, kc, hh[stage], &y, dy_dk, dy_dy);
-      mm(dy_dk, kc_db, dy_db, 10, 9, 6);
-      mm(dy_dk, kc_dy, tmp, 10, 9, 10);
-      for (int i = 0; i < 100; ++i) dy_dy0[i] = dy_dy[i] + tmp[i];
-      cur = y;
-    }
-  }
-  w_integrate_pose(*st, ksum, dt / 6.0, &y, dy_dk, dy_dy);
-  mm(dy_dk, kt_db, dy_db, 10, 9, 6);
-  mm(dy_dk, kt_dy, tmp, 10, 9, 10);
-  for (int i = 0; i < 100; ++i) dy_dy0[i] = dy_dy[i] + tmp[i];
-  // Sigma <- F Sigma F^T + G R G^T, R = diag(sg2 x3, sa2 x3)
-  mm(dy_dy0, Sigma, tmp, 10, 10, 10);
-  mmt(tmp, dy_dy0, tmp2, 10, 10, 10);
-  for (int i = 0; i < 10; ++i)
-    for (int j = 0; j < 10; ++j) {
-      double s = 0.0;
-      for (int q = 0; q < 6; ++q) s += dy_db[i * 6 + q] * (q < 3 ? sg2 : sa2) * dy_db[j * 6 + q];
-      Sigma[i * 10 + j] = tmp2[i * 10 + j] + s;
-    }
-  *st = y;
-}
-VC_HD bool w_inverse9(const double* M, double* inv) {
-  const int n = 9;
-  double a[81];
-  for (int i = 0; i < 81; ++i) { a[i] = M[i]; inv[i] = (i % 10 == 0) ? 1.0 : 0.0; }
-  for (int c = 0; c < n; ++c) {
-    int p = c;
-    for (int r = c + 1; r < n; ++r) if (fabs(a[r * n + c]) > fabs(a[p * n + c])) p = r;
-    if (a[p * n + c] == 0.0) return false;
-    if (p != c) for (int j = 0; j < n; ++j) { double t = a[p * n + j]; a[p * n + j] = a[c * n + j]; a[c * n + j] = t; t = inv[p * n + j]; inv[p * n + j] = inv[c * n + j]; inv[c * n + j] = t; }
-    const double d = 1.0 / a[c * n + c];
-    for (int r = 0; r < n; ++r) {
-      if (r == c) continue;
-      const double f = a[r * n + c] * d;
-      if (f == 0.0) continue;
-      for (int j = 0; j < n; ++j) { a[r * n + j] -= f * a[c * n + j]; inv[r * n + j] -= f * inv[c * n + j]; }
-    }
-    for (int j = 0; j < n; ++j) { a[c * n + j] *= d; inv[c * n + j] *= d; }
-  }
-  return true;
-}
-// principal square root of a symmetric PSD 9x9: cyclic Jacobi on the symmetrised input
-VC_HD void w_sqrt_spd9(const double* M, double* out) {
-  const int n = 9;
-  double a[81], v[81];
-  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { a[i * n + j] = 0.5 * (M[i * n + j] + M[j * n + i]); v[i * n + j] = (i == j) ? 1.0 : 0.0; }
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0, dg = 0;
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { if (i != j) off += a[i * n + j] * a[i * n + j]; else dg += a[i * n + i] * a[i * n + i]; }
-    if (off <= 1e-60 * dg || off == 0) break;
-    for (int p = 0; p < n - 1; ++p) for (int q = p + 1; q < n; ++q) {
-      if (a[p * n + q] == 0.0) continue;
-      const double th = (a[q * n + q] - a[p * n + p]) / (2.0 * a[p * n + q]);
-      const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-      const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-      for (int k = 0; k < n; ++k) { const double akp = a[k * n + p], akq = a[k * n + q]; a[k * n + p] = cs * akp - sn * akq; a[k * n + q] = sn * akp + cs * akq; }
-      for (int k = 0; k < n; ++k) { const double apk = a[p * n + k], aqk = a[q * n + k]; a[p * n + k] = cs * apk - sn * aqk; a[q * n + k] = sn * apk + cs * aqk; }
-      for (int k = 0; k < n; ++k) { const double vkp = v[k * n + p], vkq = v[k * n + q]; v[k * n + p] = cs * vkp - sn * vkq; v[k * n + q] = sn * vkp + cs * vkq; }
-    }
-  }
-  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
-    double s = 0;
-    for (int k = 0; k < n; ++k) s += v[i * n + k] * sqrt(fmax(a[k * n + k], 0.0)) * v[j * n + k];
-    out[i * n + j] = s;
-  }
-}
-
-// weight_sqrt_ of the segment (frames j-1 -> j). Leaves w_sqrt untouched if the range is empty (:731-733).
-VC_HD void imu_weight_sqrt(const ImuView& buf, double t_start, double t_end, double toff, const double* T1, const double* v1,
-                           const double* T2, const double* b, const double* sf, const double* gdir, double gyro_sigma,
-                           double accel_sigma, double* w_sqrt) {
-  const ImuRange rg = imu_range(buf, t_start, t_end, toff);
-  if (!rg.valid) return;
-  double gw[3];
-  imu_gravity(gdir, gw);
-  double Sigma[100];
-  for (int i = 0; i < 100; ++i) Sigma[i] = 0.0;
-  WState s;
-  for (int i = 0; i < 4; ++i) s.q[i] = T1[i];
-  for (int i = 0; i < 3; ++i) { s.p[i] = T1[4 + i]; s.v[i] = v1[i]; }
-  const int n_meas = (rg.k1 - rg.k0 + 1) + 2;
-  Meas<double> z0, z1;
-  imu_range_get(buf, rg, toff, t_start, t_end, 0, &z0);
-  for (int m = 1; m < n_meas; ++m) {
-    imu_range_get(buf, rg, toff, t_start, t_end, m, &z1);
-    w_integrate_imu(&s, z0, z1, b, sf, gw, Sigma, gyro_sigma * gyro_sigma, accel_sigma * accel_sigma);
-    z0 = z1;
-  }
-  // rel = T_pred * T2^-1
-  const double qc[4] = {-T2[0], -T2[1], -T2[2], T2[3]}, nt[3] = {-T2[4], -T2[5], -T2[6]};
-  double t2w[7], rel[7], tr[3];
-  quat_rotate(qc, nt, t2w + 4);
-  for (int i = 0; i < 4; ++i) t2w[i] = qc[i];
-  quat_mul(s.q, qc, rel);
-  const double nrm = sqrt(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2] + rel[3] * rel[3]);
-  for (int i = 0; i < 4; ++i) rel[i] /= nrm;
-  quat_rotate(s.q, t2w + 4, tr);
-  for (int i = 0; i < 3; ++i) rel[4 + i] = s.p[i] + tr[i];
-  // J = dLog_dSE3(rel) * dt1t2_dt1(T_pred, T2^-1)   (6x7 . 7x7), then the 9x10 with the velocity identity
-  double dl[42], dt12[49], J67[42];
-  w_dlog_dse3(rel, dl);
-  for (int i = 0; i < 49; ++i) dt12[i] = 0.0;
-  dt12[0] = dt12[8] = dt12[16] = 1.0;
-  double m34[12], m44[16];
-  w_dqx_dq(s.q, t2w + 4, m34);
-  w_dq1q2_dq1(t2w, m44);
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) dt12[i * 7 + 3 + j] = m34[i * 4 + j];
-  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) dt12[(3 + i) * 7 + 3 + j] = m44[i * 4 + j];
-  mm(dl, dt12, J67, 6, 7, 7);
-  double J[90], JS[90], P[81], cov[81];
-  for (int i = 0; i < 90; ++i) J[i] = 0.0;
-  for (int i = 0; i < 6; ++i) for (int j = 0; j < 7; ++j) J[i * 10 + j] = J67[i * 7 + j];
-  J[6 * 10 + 7] = J[7 * 10 + 8] = J[8 * 10 + 9] = 1.0;
-  mm(J, Sigma, JS, 9, 10, 10);
-  mmt(JS, J, P, 9, 10, 9);
-  if (!w_inverse9(P, cov)) return;
-  w_sqrt_spd9(cov, w_sqrt);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // Interval-parallel form of the same propagation (what k_imu_weights runs since round 3).
 //
@@ -331,7 +61,7 @@ VC_HD void imu_weight_sqrt(const ImuView& buf, double t_start, double t_end, dou
 //        [ I   Fpq  fpv I ]         [ Gp_bg  Gp_ba ]        the four q columns and the three gyro-bias columns are the only ones
 //    F = [ 0   Fqq    0   ]     G = [ Gq_bg    0   ]        that pass through the dense 4 x 4 quaternion blocks; the accelerometer
 //        [ 0   Fvq    I   ]         [ Gv_bg  Gv_ba ]        bias columns are running sums of the stage rotations
-// (p columns: identity; v columns: fpv = (dt / 6) * 6).  Same numbers as w_integrate_imu up to rounding: every product the
+// (p columns: identity; v columns: fpv = (dt / 6) * 6).  Same numbers as the sequential dense form (tests/host_harness/seq_weights.hpp: w_integrate_imu) up to rounding: every product the
 // dense form takes with an exact 0 or 1 is dropped, nothing else is reordered inside a column.
 // Interval record: f = [Fpq 3x4 | Fqq 4x4 | Fvq 3x4 | fpv] (41), g = [Gp_bg 3x3 | Gq_bg 4x3 | Gv_bg 3x3 | Gp_ba 3x3 | Gv_ba 3x3] (48),
 // all row-major.  Symmetric 10 x 10 matrices (Sigma, G R G^T) travel as packed lower triangles: entry (a >= b) at a (a + 1) / 2 + b.
@@ -571,7 +301,8 @@ VC_HD void w_noise_term(const double* P, const double* g, double sg2, double sa2
       term[a * (a + 1) / 2 + c] = x;
     }
 }
-// dLog_dSE3 as w_dlog_dse3 above (vicalibrator-utils.h:107-154, :308-434), arranged for the device: the arctangent of
+// dLog_dSE3 (vicalibrator-utils.h:107-154, :308-434), arranged for the device (the only copy in the product; the formula as the
+// reference writes it is kept with the tests, tests/host_harness/seq_weights.hpp: w_dlog_dse3): the arctangent of
 // dLog_dq and of the SO3 logarithm is one value, tan(theta / 2) is |q_v| / |q_w| on the logarithm's regular branch (theta =
 // 2 atan(|q_v| / q_w)), and the quotients that share a denominator share one reciprocal.  Same numbers up to rounding
 // (tests/test_device_math_cpu.py compares the two).
@@ -668,7 +399,7 @@ VC_HD void w_dlog_dse3_lean(const double* T, double* dl) {
     for (int j = 0; j < 4; ++j) dl[i * 7 + 3 + j] = blk[i * 4 + j];
 }
 // Row i (< 6) of J67 = dLog_dSE3(T_pred T2^-1) dt1t2_dt1(T_pred, T2^-1) (vicalibrator.h:762-775); dt1t2_dt1 = [I3, dqx_dq(q, t);
-// 0, dq1q2_dq1] is sparse, so the product is taken row by row.  rel / t2w as imu_weight_sqrt builds them.
+// 0, dq1q2_dq1] is sparse, so the product is taken row by row.  rel / t2w as w_projection_prepare builds them.
 VC_HD void w_projection_prepare(const double* q_pred, const double* p_pred, const double* T2, double* rel, double* t2w) {
   const double qc[4] = {-T2[0], -T2[1], -T2[2], T2[3]}, nt[3] = {-T2[4], -T2[5], -T2[6]};
   double tr[3];
