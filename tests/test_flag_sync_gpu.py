@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _run(tmp_path, name, **env):
     out = str(tmp_path / (name + ".npz"))
     e = dict(os.environ)
-    for k in ("VICALIB_AMD_FLAG_SYNC", "VICALIB_AMD_SYNC_BOUND", "VICALIB_AMD_STREAM2_PRIORITY", "GPU_MAX_HW_QUEUES", "VICALIB_AMD_BATCHED"):
+    for k in ("VICALIB_AMD_FLAG_SYNC", "VICALIB_AMD_SYNC_BOUND", "VICALIB_AMD_SYNC_BOUND_FROM_PASS", "VICALIB_AMD_STREAM2_PRIORITY", "GPU_MAX_HW_QUEUES", "VICALIB_AMD_BATCHED"):
         e.pop(k, None)
     e.update({k: str(v) for k, v in env.items()})
     r = subprocess.run([sys.executable, os.path.join(HERE, "sync_worker.py"), out], env=e, capture_output=True, text=True, timeout=600)
@@ -48,6 +48,23 @@ def test_a_timed_out_flag_wait_is_loud_and_lossless(events_run, tmp_path, bound)
     got, err = _run(tmp_path, "bound%d" % bound, VICALIB_AMD_SYNC_BOUND=bound)
     assert int(got["timeouts"]) >= 1, "bound %d never hit" % bound
     assert "ran into its bound" in err
+    _same(got, events_run)
+
+
+@pytest.mark.parametrize("from_pass,batched", [(n, b) for b in (0, 1) for n in range(3, 49, 5)])
+def test_a_time_out_in_the_middle_of_a_solve_is_lossless(events_run, tmp_path, from_pass, batched):
+    """The time-out hits a pass whose accepted state differs from its predecessor's (the waits of the first passes succeed: the tiny
+    bound only applies from pass `from_pass` of the calibrator on).  What the resumed pass reads -- the IMU weights its predecessor
+    left, in particular -- must not have been touched by the void pass or by the passes queued behind it (round 4: those passes'
+    weight kernels copied / rewrote the buffer the resumed pass linearises with; a first-pass time-out never showed it, both buffers
+    hold the same numbers there), and inside a streak of rejected steps the resumed pass must keep the linearisation in place (made with
+    the weights of the pass that accepted the state) instead of linearising again with the current ones.  Passes 3, 8, .. 48 of the
+    calibrator's ~55: every stage, first passes, accepted and rejected steps, passes queued past a stage's end."""
+    env = dict(VICALIB_AMD_SYNC_BOUND=1, VICALIB_AMD_SYNC_BOUND_FROM_PASS=from_pass)
+    if batched:
+        env["VICALIB_AMD_BATCHED"] = 1
+    got, err = _run(tmp_path, "mid%d_%d" % (from_pass, batched), **env)
+    assert int(got["timeouts"]) >= 1 and "ran into its bound" in err, (int(got["timeouts"]), err[-300:])
     _same(got, events_run)
 
 

@@ -252,6 +252,7 @@ struct vc_calibrator {
   bool weights_behind_l0 = !(std::getenv("VICALIB_AMD_WEIGHTS_BEHIND_L0") && std::getenv("VICALIB_AMD_WEIGHTS_BEHIND_L0")[0] == '0');
   bool shard_flag_sync = std::getenv("VICALIB_AMD_SHARD_FLAG_SYNC") && std::getenv("VICALIB_AMD_SHARD_FLAG_SYNC")[0] == '1';
   long long sync_bound = 400000;        // polls before a flag wait gives up (~0.2 s); VICALIB_AMD_SYNC_BOUND (test hook: a tiny bound forces the time-out path)
+  int sync_bound_from_pass = 0;         // VICALIB_AMD_SYNC_BOUND_FROM_PASS (test hook): the tiny bound only from this pass of the calibrator on -- a time-out in the middle of a solve
   int wr_ring[16] = {0};                // weight buffer read by pass (pass_seq & 15)
   int sync_timeouts = 0;                // flag hand-overs that ran into their bound (each one reported on stderr, the solve resumed with events)
   long long pass_seq = 0;               // passes enqueued (the value the flags carry)
@@ -826,7 +827,7 @@ struct vc_calibrator {
       ++pass_seq;
       dv.pass_id = pass_seq;
       wr_ring[pass_seq & 15] = wcur;              // (what a resume after a flag time-out restores: the weight buffer this pass reads)
-      dv.sync_flags = d_sync.p; dv.sync_seq = fs ? pass_seq : 0; dv.final_wait = 0; dv.block_wait = 0; dv.sync_bound = sync_bound;
+      dv.sync_flags = d_sync.p; dv.sync_seq = fs ? pass_seq : 0; dv.final_wait = 0; dv.block_wait = 0; dv.sync_bound = (pass_seq >= sync_bound_from_pass) ? sync_bound : 400000;
       const bool fs_trial = fs && jac_on_stream2 && dv.n_tiles > 0;      // (no tiles: no trial sweep to publish the back-substitution's end)
       dv.final_wait = fs_trial ? pass_seq : 0;      // (k_imu_jac(trial) and k_final both look at it)
       dv.block_wait = fs_trial ? pass_seq : 0;      // (k_imu_block(trial))
@@ -999,7 +1000,11 @@ struct vc_calibrator {
     if (d_sync.p) HIP_OK(hipMemsetAsync(d_sync.p, 0, 8 * sizeof(long long), stream));
     HIP_OK(hipMemsetAsync(dv.flags + 4, 0, 4 * sizeof(int), stream));      // numeric-failure marks of the void passes
     Ctrl r = c;
-    r.done = 0; r.abort_seq = 0; r.need_lin = 1;
+    // need_lin stays as the last decision left it: after a rejected step the linearisation in place is the one made when the state was
+    // accepted, with the IMU weights of THAT pass -- the weights have moved on since (they are updated every pass), so linearising
+    // again here would not reproduce it (costs of the following rejected steps off by 1e-7 relative: the time-out test in the middle of
+    // a rejected streak); the void passes only wrote the trial-side buffers, the accepted state's records are intact
+    r.done = 0; r.abort_seq = 0;
     HIP_OK(hipMemcpyAsync(d_ctrl.p, &r, sizeof(Ctrl), hipMemcpyHostToDevice, stream));
     HIP_OK(hipStreamSynchronize(stream));
     pin->down.done = 0;
@@ -1033,6 +1038,7 @@ struct vc_calibrator {
     { int rcu = upload_ctrl(&pin->up); if (rcu) return rcu; }
     if (dv.imu_on && dv.weights_on) {     // UpdateImuWeights() before ceres::Solve (vicalibrator.h:955)
       if (!serial_weights && stream2) { HIP_OK(hipEventRecord(ev_pre, stream)); pre_weights_pending = true; }
+      dv.sync_seq = 0;      // (not a pass: a sticky time-out mark left by the previous solve's last pass must not make this update skip itself)
       launch_imu_weights(dv, wcur, stream); wcur = 1 - wcur;
     }
     const size_t trace_bytes = (size_t)std::min(trace_cap, 64) * kTraceCols * 8;
@@ -1360,6 +1366,7 @@ int vc_create(vc_calibrator** out, int device) {
   // (=1 forces the flags on whatever the second stream's priority class: the test that puts both streams on one hardware queue)
   { const char* e = std::getenv("VICALIB_AMD_FLAG_SYNC"); if (e && e[0] == '0') h->flag_sync = false; if (e && e[0] == '1') h->flag_sync = true; }
   { const char* e = std::getenv("VICALIB_AMD_SYNC_BOUND"); if (e && std::atoll(e) > 0) h->sync_bound = std::atoll(e); }      // (test hook: a tiny bound forces the time-out path)
+  { const char* e = std::getenv("VICALIB_AMD_SYNC_BOUND_FROM_PASS"); if (e) h->sync_bound_from_pass = std::atoi(e); }
   if (h->flag_sync && (h->d_sync.alloc(8) != hipSuccess || hipMemset(h->d_sync.p, 0, 8 * sizeof(long long)) != hipSuccess)) h->flag_sync = false;
   *out = h;
   return VC_OK;

@@ -383,6 +383,13 @@ __global__ __launch_bounds__(64) void k_imu_weights(DevView v, int wr) {
   double* L = w_lds + grp * kWLds;
   // the buffer being written must end up complete: blocks that keep their weight (no samples, singular projection) and passes
   // queued behind a finished solve copy the current one -- at the end, off the path of the blocks that get a new weight
+  // A pass that is void after a flag time-out (vc_kutil.hpp), and every pass queued behind it, must leave BOTH buffers alone: the
+  // resumed pass linearises with the weights its predecessor left in wsqrtb[wr of the void pass], which is the buffer the next
+  // queued pass would write (round 4: a time-out in the middle of a solve resumed with the void pass's own weights there -- same
+  // state, one update too far: costs off by 1e-5 .. 5e-4 for a few iterations.  A first-pass time-out hides it: both buffers
+  // hold the same numbers).  The host takes the buffer index back from its ring (resume_after_sync_timeout).
+  if (v.sync_seq > 0) { const long long m = sync_marked(v); if (m != 0 && m <= v.sync_seq) return; }      // wave-uniform
+  if (ct->done == kDoneSyncTimeout) return;
   if (ct->done || !v.weights_on) {               // wave-uniform
     if (exists) for (int e = c; e < 81; e += 16) v.wsqrtb[1 - wr][(size_t)s * 81 + e] = v.wsqrtb[wr][(size_t)s * 81 + e];
     return;
