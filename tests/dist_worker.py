@@ -172,6 +172,8 @@ def _guarded(fn, *a, **k):
 if __name__ == "__main__":
     if sys.argv[1] == "gpu_imu":
         _guarded(main_imu)
+    elif sys.argv[1] == "gpu_imu4":     # cfg4's rig: 4 cameras + IMU, reduced dimension 67 + 9 per shard boundary: two wavefronts per sweep in the chain's upper levels
+        _guarded(main_imu, models=("poly3",) * 4, n_total=200, max_iters=200, prior=True)
     elif sys.argv[1] == "gpu_imu8":      # cfg5's rig: 8 cameras + IMU, reduced dimension 115 + 9 per shard boundary; well conditioned
         _guarded(main_imu, models=("fov", "kb4") * 4, n_total=240, max_iters=200, oracle=True, prior=True)
     else:

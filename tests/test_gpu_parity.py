@@ -451,10 +451,11 @@ def test_imu_blocks_match_oracle_across_sample_rates_and_offsets(frame_rate, imu
 
 
 @pytest.mark.parametrize("n_frames,models", [(n, ("kb4",)) for n in (2, 3, 7, 8, 9, 15, 16, 17, 57, 63, 64, 65, 130)] +
-                         [(17, ("poly3",) * 4), (9, ("fov", "kb4") * 4), (66, ("fov", "kb4") * 4)])
+                         [(17, ("poly3",) * 4), (66, ("poly3",) * 4), (130, ("poly3",) * 4), (260, ("poly3",) * 4), (9, ("fov", "kb4") * 4), (66, ("fov", "kb4") * 4)])
 def test_chain_elimination_matches_dense_schur_complement(n_frames, models):
     """The partitioned elimination of the frame chain (groups of 8, levels, top level; vc_imu_kernels.hip) for frame counts on
-    every side of its group boundaries, and for one, two and three image columns per lane (D = 29, 67, 115): the reduced system
+    every side of its group boundaries, and for one, two and three image columns per lane (D = 29, 67, 115; at D = 67 with enough frames
+    for two and three levels of the two-sided elimination with two wavefronts per sweep): the reduced system
     it leaves on the shared parameters -- S = H_ss - W^T M^-1 W, g_red = g_s - W^T M^-1 g_f with M the block-tridiagonal frame
     matrix -- against a dense solve of the oracle's normal equations (visual + inertial blocks, all parameters free)."""
     p = synth.generate(synth.Config(models=models, n_frames=n_frames, imu=True, seed=5))

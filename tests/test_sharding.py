@@ -91,6 +91,14 @@ def test_three_rank_sharded_visual_inertial_solve_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_two_rank_four_camera_visual_inertial_solve_on_one_gpu():
+    """cfg4's rig (4 x poly3 + IMU), 100 frames per rank: reduced dimension 67 + 9 -> two image columns per lane's worth of border, the
+    chain's upper level eliminated from both ends by two wavefronts per sweep (round 4), with a separator / ghost frame at the shard
+    boundary.  Sharded == single process on every iteration's cost and on the final parameters."""
+    _run("gpu_imu4", 900)
+
+
+@pytest.mark.gpu
 def test_four_rank_eight_camera_visual_inertial_solve_on_one_gpu():
     """cfg5's rig (8 cameras fov / kb4 + IMU), 240 frames, every stage converges: reduced dimension 115 + 3 x 9 = 142 -> packed-triangle
     reduced solve, 10 column tiles in the chain Gram.  Strict: every iteration's cost equals the single-process solve's at 1e-7 and the

@@ -1202,17 +1202,24 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(DevView v, int s, int m, 
 // Images of the right sweep's frames hold [Y | z | X_s (coupling to r) | L | X_n (coupling to the frame on the LEFT)]; the
 // back-substitution (k_chain_back, two = 1) mirrors the order.  The short group at the chain's end works the same way without r.
 #ifdef VC_F2_STAMPS
-#define F2STAMP(i) do { if (blockIdx.x == 0 && lvl == 1 && (threadIdx.x & 63) == 0 && (i) < 16) v.dbg[(i) + 16 * (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define F2STAMP(i) do { if (NW == 1 && blockIdx.x == 0 && lvl == 1 && (threadIdx.x & 63) == 0 && (i) < 16) v.dbg[(i) + 16 * (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define F2STAMP(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int lvl) {
+// NW > 1 (round 4): borders wider than one column per lane -- every sweep is NW wavefronts side by side (column c = lane + 64 u, as in
+// chain_fwd_group), the group a workgroup of 2 NW wavefronts; the exchanges inside a sweep go through workgroup barriers, which both
+// sweeps then meet in lockstep (a sweep with one frame less runs an empty round).  ~370 registers: one wavefront per SIMD, so NW = 2 fills
+// a CU -- used on levels whose groups the chip holds at once (chain_levels).
+template <int NW>
+__global__ __launch_bounds__(128 * NW) void k_chain_fwd2(DevView v, int s, int m, int lvl) {
+  constexpr int W = 64 * NW;
   __shared__ __attribute__((aligned(16))) double XS2[2][9 * kXsLd];
   __shared__ double An2[2][81], Ls2[2][81];
-  __shared__ double MID[9 * 64];      // right sweep -> wavefront 0: its update of the middle frame (W, A columns) and the middle's coupling to r
-  __shared__ double SEPR[9 * 64];     // the right sweep's accumulated update of r
+  __shared__ double MID[9 * W];      // right sweep -> wavefront 0: its update of the middle frame (W, A columns) and the middle's coupling to r
+  __shared__ double SEPR[9 * W];     // the right sweep's accumulated update of r
   // (the wavefront's index as a scalar: everything that depends on it -- sweep direction, frame count, addresses -- stays uniform)
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, group = blockIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wave = wv / NW /* the sweep */, lane = threadIdx.x & 63, group = blockIdx.x;
+  auto gsync = [&]() { if (NW > 1) __syncthreads(); else wave_lds_sync_local(); };
   const int N = v.n_frames, D = v.D, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
 #ifdef VC_F2_STAMPS
   const long long f2_t0 = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1225,7 +1232,7 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
   const double* rp = v.rX[(lvl + 1) & 1];
   double* rw = v.rX[lvl & 1];
   const size_t isz = (size_t)9 * ldx;
-  const int c = lane, e0 = c - nW;
+  const int c = lane + 64 * (wv % NW), e0 = c - nW;
   const int role = c < nW ? 0 : (e0 < 9 ? 1 : e0 < 18 ? 2 : e0 < 27 ? 3 : 4);     // 0 border (W | g), 1 C, 2 A, 3 B, 4 none
   const int pc = c < nW ? c : (c < ncol ? ldw + e0 : 0);
   const int sub = e0 < 9 ? e0 : e0 < 18 ? e0 - 9 : e0 - 18;
@@ -1292,7 +1299,7 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
   load_cols(a + (cnt > 0 ? i0 : mid) * s, true, cnt > 0 || wave == 0, xin);
   if (done) return;
 #ifdef VC_F2_STAMPS
-  if (blockIdx.x == 0 && lvl == 1 && (threadIdx.x & 63) == 0) v.dbg[16 * (threadIdx.x >> 6)] = f2_t0;
+  if (NW == 1 && blockIdx.x == 0 && lvl == 1 && (threadIdx.x & 63) == 0) v.dbg[16 * (threadIdx.x >> 6)] = f2_t0;
 #endif
   F2STAMP(1);
   if (role == 2) {
@@ -1301,7 +1308,7 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
   }
   // one elimination: A (in An) = L L^T, all columns solved, image stored, [X_s | X_n] to XS, out = [X_s | X_n]^T (column)
   auto eliminate = [&](int e, double* x, double* out) {
-    wave_lds_sync_local();
+    gsync();
     // A = L L^T in EVERY lane, from registers (round 4; before: nine lanes, one row each, pivots and pivot columns through
     // v_readlane -- ~240 cycles per pivot, 0.9 us per frame, and the factor went through LDS to the lanes that solve with it).  All
     // lanes read the lower triangle (broadcast LDS reads) and run the same scalar factorisation: per pivot one v_rsq_f64 chain,
@@ -1330,7 +1337,7 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
           for (int k = j + 1; k <= i; ++k) Lr[i * (i + 1) / 2 + k] -= Lr[i * (i + 1) / 2 + j] * Lr[k * (k + 1) / 2 + j];
       }
       if (bad) {               // wave-uniform (every lane holds the same numbers): the frame gets an identity block, the pass is flagged
-        if (lane == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
+        if (c == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
           dinv[i] = 1.0;
@@ -1361,7 +1368,7 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
 #pragma unroll
       for (int k = 0; k < 9; ++k) XS[k * kXsLd + xc] = x[k];
     }
-    wave_lds_sync_local();
+    gsync();
     if (role == 2) {
       double* img = v.cW + (size_t)e * isz + pc;
 #pragma unroll
@@ -1385,13 +1392,14 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
     const bool at_mid = j == cnt;
     F2STAMP(2 + 2 * j);
     if (at_mid) {
+      if (NW > 1) for (int jj = cnt; jj < max(nl, nr); ++jj) { gsync(); gsync(); }      // the other sweep's extra elimination: its barriers
       if (wave == 1) {
         if (cnt == 0) {
 #pragma unroll
-          for (int k = 0; k < 9; ++k) MID[k * 64 + lane] = 0.0;
+          for (int k = 0; k < 9; ++k) MID[k * W + c] = 0.0;
         }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) SEPR[k * 64 + lane] = dacc[k];
+        for (int k = 0; k < 9; ++k) SEPR[k * W + c] = dacc[k];
       }
       F2STAMP(12);
       __syncthreads();
@@ -1399,8 +1407,8 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
       if (wave == 1) return;
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        if (role == 0 || role == 2) xin[k] += MID[k * 64 + lane];
-        else if (role == 3 && nr > 0) xin[k] = MID[k * 64 + nW + sub];      // (no right sweep: the middle's own B block stays)
+        if (role == 0 || role == 2) xin[k] += MID[k * W + c];
+        else if (role == 3 && nr > 0) xin[k] = MID[k * W + nW + sub];      // (no right sweep: the middle's own B block stays)
       }
       if (role == 2) {
 #pragma unroll
@@ -1422,9 +1430,9 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
       if (has_r && role < 4) {
         double* ri = rw + (size_t)(r / gs) * isz + pc;
         const bool keep = role == 0 || role == 2;
-        const int src = role == 2 ? nW + sub : lane;
+        const int src = role == 2 ? nW + sub : c;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) ri[k * ldx] = keep ? -out[9 + k] - SEPR[k * 64 + src] : 0.0;
+        for (int k = 0; k < 9; ++k) ri[k * ldx] = keep ? -out[9 + k] - SEPR[k * W + src] : 0.0;
       }
       if (role == 3) {                 // the separator's coupling to the right separator at the next level (none where the chain ends)
         double* img = v.cW + (size_t)a * isz + pc;
@@ -1435,7 +1443,7 @@ __global__ __launch_bounds__(128) void k_chain_fwd2(DevView v, int s, int m, int
     }
     if (wave == 1 && j + 1 == cnt) {    // the next frame is the middle, which wavefront 0 eliminates: hand the update over
 #pragma unroll
-      for (int k = 0; k < 9; ++k) MID[k * 64 + lane] = -out[9 + k];
+      for (int k = 0; k < 9; ++k) MID[k * W + c] = -out[9 + k];
     } else {
 #pragma unroll
       for (int k = 0; k < 9; ++k) xin[k] = o[k] - (role == 3 ? 0.0 : out[9 + k]);
@@ -1856,16 +1864,27 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
   // wavefronts of ~370 registers next to the weight update's 500 on the other stream, and queue behind them (42 vs 32 us).
   // VICALIB_AMD_CHAIN_TWO=0: one-sided throughout
   static const bool two_env = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO"); return !(e && std::atoi(e) == 0); }();
-  const bool two_sided = two_env && cpl <= 1;
+  const bool two_sided = two_env && cpl <= 2;
   // ... and at the bottom level too once the weight update on the other stream starts behind it (vc_calibrator.cpp: enqueue_pass;
   // VICALIB_AMD_CHAIN_TWO_BOTTOM=0: one-sided bottom level)
   static const bool two_bottom = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO_BOTTOM"); return !(e && std::atoi(e) == 0); }();
   // (whatever the hand-over mode: a solve resumed with events after a flag time-out must repeat the withheld passes with the same
   //  arithmetic -- with events the weight update runs beside the bottom level and the pass is ~4 us slower than one-sided would be)
   const int two_from = two_bottom ? 0 : 1;
+  // (two columns per lane's worth of border, D <= 100: two wavefronts per sweep, a whole CU per group -- on levels whose groups the chip
+  //  holds at once; a function of the frame count and the level only: forward, backward and every hand-over mode agree on it)
+  auto two_at = [&](int l) {
+    if (!(two_sided && ms[l] >= 4 && l >= two_from)) return false;
+    if (cpl <= 1) return true;
+    const long groups = ((long)N - 1) / ((long)strides[l] * ms[l]) + 1;
+    return groups <= 256;
+  };
   auto fwd = [&](int groups, int stride, int m, int top, int lvl) {
     const bool side_by_side = cpl > 1 && !columns_per_lane;
-    if (cpl <= 1 && two_sided && !top && m >= 4 && lvl >= two_from) hipLaunchKernelGGL(k_chain_fwd2, dim3(groups), dim3(128), 0, s, v, stride, m, lvl);
+    if (!top && two_at(lvl)) {
+      if (cpl <= 1) hipLaunchKernelGGL(k_chain_fwd2<1>, dim3(groups), dim3(128), 0, s, v, stride, m, lvl);
+      else hipLaunchKernelGGL(k_chain_fwd2<2>, dim3(groups), dim3(256), 0, s, v, stride, m, lvl);
+    }
     else if (cpl <= 1) hipLaunchKernelGGL((k_chain_fwd<1, 1>), dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
     else if (side_by_side) {
       if (cpl <= 2) hipLaunchKernelGGL((k_chain_fwd<1, 2>), dim3(groups), dim3(128), 0, s, v, stride, m, top, lvl);
@@ -1892,7 +1911,7 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
       int at = 0;
       for (int i = 0; i < nl; ++i) {
         const int l = nl - 1 - i;
-        L.start[i] = at; L.stride[i] = strides[l]; L.m[i] = ms[l]; L.two[i] = (two_sided && ms[l] >= 4 && l >= two_from) ? 1 : 0;
+        L.start[i] = at; L.stride[i] = strides[l]; L.m[i] = ms[l]; L.two[i] = two_at(l) ? 1 : 0;
         at += (int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1);
       }
       for (int i = nl; i < 8; ++i) { L.start[i] = 1 << 30; L.stride[i] = 1; L.m[i] = 2; L.two[i] = 0; }
@@ -1900,7 +1919,7 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
     } else
     for (int l = nl - 1; l >= 0; --l)
       hipLaunchKernelGGL(k_chain_back, dim3((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1)), dim3(64), 0, s, v, strides[l], ms[l], 0, l,
-                         (two_sided && ms[l] >= 4 && l >= two_from) ? 1 : 0);
+                         two_at(l) ? 1 : 0);
   }
 }
 // launches of the forward elimination (levels + the top level)
