@@ -246,6 +246,7 @@ struct vc_calibrator {
   hipStream_t stream2 = nullptr;        // the IMU weight update of a pass runs here, under the pass's Jacobian sweeps and chain solve
   hipEvent_t ev_state = nullptr, ev_weights = nullptr, ev_imujac = nullptr, ev_reduced = nullptr, ev_back = nullptr, ev_pre = nullptr;
   bool pre_weights_pending = false;     // solve_once has recorded ev_pre ahead of the weight update that precedes a solve
+  bool pre_weights_fresh = false;       // ... and nothing has moved the state since: the first pass's own update would repeat it
   int wcur = 0;                         // weight buffer holding the current weight_sqrt_
   Packer pack;                          // staging image of a stage's small uploads
   bool flag_sync = false;               // hand-overs to the second stream through device flags instead of event records (set at creation)
@@ -819,7 +820,11 @@ struct vc_calibrator {
       // is a few hundred latency-bound wavefronts, far from filling the chip on its own.  Everything on the critical path --
       // chain, both trial sweeps, decision -- stays on the main stream: kernels of one stream follow each other without a gap,
       // an event hand-over costs 5-13 us.
-      const bool upd = dv.weights_on != 0;
+      // (the first pass of a solve: UpdateImuWeights() has just run on this very state (solve_once) -- the pass's own update would write the
+      //  same numbers into the other buffer, 30 us on the second stream beside the first linearisation and the bottom chain level: the pass
+      //  evaluates its trial point with the buffer it linearises with, and the buffers do not swap)
+      const bool upd = dv.weights_on != 0 && !(first_pass && pre_weights_fresh);
+      if (first_pass) pre_weights_fresh = false;
       // (sharded solves: flags when every rank has a device of its own -- vc_set_shard_rccl with more than one rank, or
       //  VICALIB_AMD_SHARD_FLAG_SYNC=1; the one-GPU gloo tests keep the events: several processes' waiting kernels would burn each
       //  other's time slices.  A time-out is lossless there too: the mark travels with the step scalars' all-reduce, all ranks resume)
@@ -1040,6 +1045,7 @@ struct vc_calibrator {
       if (!serial_weights && stream2) { HIP_OK(hipEventRecord(ev_pre, stream)); pre_weights_pending = true; }
       dv.sync_seq = 0;      // (not a pass: a sticky time-out mark left by the previous solve's last pass must not make this update skip itself)
       launch_imu_weights(dv, wcur, stream); wcur = 1 - wcur;
+      pre_weights_fresh = true;
     }
     const size_t trace_bytes = (size_t)std::min(trace_cap, 64) * kTraceCols * 8;
     int guard = 0, n_enq = 0;
