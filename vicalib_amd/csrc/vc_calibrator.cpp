@@ -852,6 +852,9 @@ struct vc_calibrator {
         if (fs && !first_pass && prev_pass_signals) launch_wait_flag(dv, 0, pass_seq - 1, stream2);      // the previous pass's k_final
         else {
           HIP_OK(hipEventRecord(ev_state, stream));
+          // the vision linearisation of a first pass depends on nothing the second stream does: it goes out before that stream's
+          // launches (five runtime calls: the main stream would sit idle behind the preceding weight update for as long as they take)
+          if (first_pass) KT("k_reproj_jac", launch_reproj_jac(dv, stream, 0));
           HIP_OK(hipStreamWaitEvent(stream2, ev_state, 0));
         }
         if (first_pass) {
@@ -863,10 +866,7 @@ struct vc_calibrator {
         // the chain elimination, whose two-sided form needs the chip to itself; it is not needed before k_imu_jac(trial)
         if (upd && fs && !first_pass && weights_behind_l0 && chain_forward_launches(dv) >= 2) launch_wait_flag(dv, 7, pass_seq, stream2);
         if (upd) KT2("k_imu_weights", launch_imu_weights(dv, wcur, stream2));
-        if (first_pass) {
-          KT("k_reproj_jac", launch_reproj_jac(dv, stream, 0));
-          HIP_OK(hipStreamWaitEvent(stream, ev_imujac, 0));
-        }
+        if (first_pass) HIP_OK(hipStreamWaitEvent(stream, ev_imujac, 0));
       } else {
         if (upd) KT("k_imu_weights", launch_imu_weights(dv, wcur, stream));
         if (first_pass) {
