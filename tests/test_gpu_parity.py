@@ -744,6 +744,30 @@ def test_visual_inertial_without_time_offset_estimation():
     assert cal.time_offset() == 0.0
 
 
+@pytest.mark.parametrize("model,D", [("linear", 25), ("fov", 26), ("poly3", 28), ("kb4", 29)])
+def test_visual_inertial_solve_at_every_width_of_the_one_wavefront_reduced_solve(model, D):
+    """Mono camera + IMU, all parameters free in the last stage: the reduced system has 25 .. 29 columns -- the instances of the
+    one-wavefront reduced solve of width 28 (with D = 28: the right-hand-side row is the instance's last) and 30, its LDS-resident
+    reduced system and the four-at-a-time back-substitution (round 4); full schedule against the oracle.  (mono rational6 + IMU,
+    D = 31, is not in the list: that solve amplifies 2e-8 of rounding to 3e-6 within two iterations -- rejected steps at rho = 0.1,
+    radius 1e7 -- and the oracle's own trace length changes with its thread count; width 32 is covered by the vision rigs below.)"""
+    p = _vi_problem(60, seed=5, models=(model,))
+    cal, orc = _load_both(p)
+    cal.Solve(); orc.solve()
+    assert cal.shared_dim() == D
+    _compare_vi(p, cal, orc)
+
+
+@pytest.mark.parametrize("models,D", [(("poly3", "poly3", "fov"), 31), (("poly3", "poly3", "poly2"), 32), (("kb4", "fov", "fov"), 30)])
+def test_vision_solve_at_the_widest_one_wavefront_reduced_solves(models, D):
+    """Three-camera rigs without IMU whose reduced systems have 30, 31 and 32 columns: the width-30 instance with the right-hand-side
+    row as its last, and the width-32 instance up to the widest system the one-wavefront solve takes."""
+    p, cal, orc = _pair(synth.Config(models=models, n_frames=30, seed=19))
+    cal.Solve(); orc.solve()
+    assert cal.shared_dim() == D
+    _compare_solution(p, cal, orc)
+
+
 def test_rotation_only_stage_matches_oracle():
     """Stages A (visual) + B (inertial, rotation only): 2x visual + 1x IMU multiplicities, block-tridiagonal chain."""
     p = _vi_problem(24)
