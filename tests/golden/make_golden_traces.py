@@ -23,6 +23,11 @@ CASES = {
     "mono_rational6_40": (dict(models=("rational6",), n_frames=40, seed=9), dict(calibrate_imu=False)),
     "rig4_mixed_imu_80": (dict(models=("fov", "poly3", "kb4", "rational6"), n_frames=80, imu=True, seed=13, extrinsics_prior=True),
                           dict(calibrate_imu=True, max_iters=100)),
+    # BASELINE cfg3 at FULL size (the configuration every bench number is quoted on): mono kb4 + IMU, 2000 frames, 373 493
+    # corners, complete A->D schedule.  The oracle needs a few minutes for it; the GPU test reads the fixture only.
+    "cfg3_full": (dict(models=("kb4",), grid="small", n_frames=2000, imu=True), dict(calibrate_imu=True)),
+    # BASELINE cfg4's rig and grid (4 x poly3 + IMU, 900-dot grid) at 400 frames, D = 67
+    "cfg4_rig_400": (dict(models=("poly3",) * 4, grid="large", n_frames=400, imu=True, seed=21), dict(calibrate_imu=True)),
 }
 
 

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _run(tmp_path, name, **env):
     out = str(tmp_path / (name + ".npz"))
     e = dict(os.environ)
-    for k in ("VICALIB_AMD_FLAG_SYNC", "VICALIB_AMD_SYNC_BOUND", "VICALIB_AMD_SYNC_BOUND_FROM_PASS", "VICALIB_AMD_STREAM2_PRIORITY", "GPU_MAX_HW_QUEUES", "VICALIB_AMD_BATCHED"):
+    for k in ("VICALIB_AMD_FLAG_SYNC", "VICALIB_AMD_SYNC_BOUND", "VICALIB_AMD_SYNC_BOUND_FROM_PASS", "VICALIB_AMD_STREAM2_PRIORITY", "GPU_MAX_HW_QUEUES", "VICALIB_AMD_BATCHED", "VICALIB_AMD_GRAPHS", "VICALIB_AMD_BACK_FUSED"):
         e.pop(k, None)
     e.update({k: str(v) for k, v in env.items()})
     r = subprocess.run([sys.executable, os.path.join(HERE, "sync_worker.py"), out], env=e, capture_output=True, text=True, timeout=600)
@@ -80,3 +80,17 @@ def test_both_streams_on_one_hardware_queue(events_run, tmp_path):
     got, err = _run(tmp_path, "one_queue", GPU_MAX_HW_QUEUES=1, VICALIB_AMD_STREAM2_PRIORITY="default", VICALIB_AMD_FLAG_SYNC=1, VICALIB_AMD_SYNC_BOUND=20000)
     _same(got, events_run)
     print("one hardware queue: %d time-out(s)" % int(got["timeouts"]))
+
+
+def test_graph_replay_of_the_visual_inertial_pass_gives_the_same_iterates(events_run, tmp_path):
+    """VICALIB_AMD_GRAPHS=1 replays a captured pass: its kernel arguments are frozen, the pass number among them.  The fused
+    back-substitution (k_chain_back_levels) orders producers and consumers by comparing per-frame ready words with that number, so from
+    the second replay on its consumers would not wait (advice r4) -- a captured pass runs one launch per level instead
+    (the arithmetic of VICALIB_AMD_BACK_FUSED=0: that run must be reproduced bit for bit, and the event run at rounding level)."""
+    got, err = _run(tmp_path, "graphs", VICALIB_AMD_GRAPHS=1)
+    assert int(got["timeouts"]) == 0, err
+    per_level, _ = _run(tmp_path, "per_level", VICALIB_AMD_FLAG_SYNC=0, VICALIB_AMD_BACK_FUSED=0, VICALIB_AMD_BATCHED=1)
+    _same(got, per_level)
+    assert got["trace"].shape == events_run["trace"].shape
+    for k in ("trace", "K", "T", "frames", "biases", "toff"):
+        np.testing.assert_allclose(got[k], events_run[k], rtol=1e-11, atol=1e-13)

@@ -423,6 +423,7 @@ struct vc_calibrator {
     RoctxRange rr("vicalib_amd: upload (SetupProblem of a stage)");
     HIP_OK(hipSetDevice(device));
     drop_graphs();
+    pre_weights_fresh = false; pre_weights_pending = false;      // (the state is about to change under them)
     const bool up_timing = std::getenv("VICALIB_AMD_TIMING") != nullptr;
     const auto up_t0 = std::chrono::steady_clock::now();
     auto up_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - up_t0).count(); };
@@ -823,7 +824,7 @@ struct vc_calibrator {
       // (the first pass of a solve: UpdateImuWeights() has just run on this very state (solve_once) -- the pass's own update would write the
       //  same numbers into the other buffer, 30 us on the second stream beside the first linearisation and the bottom chain level: the pass
       //  evaluates its trial point with the buffer it linearises with, and the buffers do not swap)
-      const bool upd = dv.weights_on != 0 && !(first_pass && pre_weights_fresh);
+      const bool upd = dv.weights_on != 0 && !(first_pass && pre_weights_fresh && !events_only);      // (a stand-alone pass always updates)
       if (first_pass) pre_weights_fresh = false;
       // (sharded solves: flags when every rank has a device of its own -- vc_set_shard_rccl with more than one rank, or
       //  VICALIB_AMD_SHARD_FLAG_SYNC=1; the one-GPU gloo tests keep the events: several processes' waiting kernels would burn each
@@ -896,7 +897,14 @@ struct vc_calibrator {
         }
         KT2("k_imu_block(trial)", launch_imu_delta(dv, stream2, 1));
       }
-      KT("k_chain_back", launch_chain_solve_b(dv, stream));
+      {
+        // (a captured pass freezes its arguments, pass_id among them: from the second replay on the ready words of the fused
+        //  back-substitution would already hold a number >= it and its consumers would not wait -- one launch per level there)
+        long long* const ready = dv.cready;
+        if (use_graphs) dv.cready = nullptr;
+        KT("k_chain_back", launch_chain_solve_b(dv, stream));
+        dv.cready = ready;
+      }
       // trial point: both sweeps in trial mode on the main stream, the IMU blocks with the weights this pass has just updated
       // (second stream: weight update, then the deltas -- ev_weights covers both); the decision follows without another
       // cross-stream hop (each costs 6-13 us on the device's timeline)
@@ -1041,6 +1049,10 @@ struct vc_calibrator {
     if (!pin) HIP_OK(hipHostMalloc((void**)&pin, sizeof(Pinned), hipHostMallocCoherent | hipHostMallocMapped));
     init_ctrl(&pin->up);
     { int rcu = upload_ctrl(&pin->up); if (rcu) return rcu; }
+    // a wait that ran into its bound in a pass queued past the end of the previous solve (nobody judged it, nobody reported it) must
+    // not void this solve's first pass: the sticky word starts every solve clear
+    if (d_sync.p) HIP_OK(hipMemsetAsync(d_sync.p + 6, 0, sizeof(long long), stream));
+    pre_weights_fresh = false; pre_weights_pending = false;
     if (dv.imu_on && dv.weights_on) {     // UpdateImuWeights() before ceres::Solve (vicalibrator.h:955)
       if (!serial_weights && stream2) { HIP_OK(hipEventRecord(ev_pre, stream)); pre_weights_pending = true; }
       dv.sync_seq = 0;      // (not a pass: a sticky time-out mark left by the previous solve's last pass must not make this update skip itself)
@@ -1151,6 +1163,7 @@ struct vc_calibrator {
     n_enq = pin->down.passes; first_enq = true; guard = 0;
     }
     const Ctrl c = pin->down;
+    pre_weights_fresh = false; pre_weights_pending = false;      // (a solve that queued no pass must not leave them to a later stand-alone pass)
     if (std::getenv("VICALIB_AMD_TIMING") && enqueue_ms > 0.0)
       std::fprintf(stderr, "[vicalib_amd]   solve: %d passes enqueued in %.3f ms of host time (batched schedule), %d decided; waited %.3f ms for the device, %.3f ms in all\n",
                    n_enq, enqueue_ms, c.passes, wait_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tso0).count());

@@ -1540,7 +1540,13 @@ __device__ __forceinline__ void chain_back_group(const DevView& v, int s, int m,
       while ((has_a && __hip_atomic_load(v.cready + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v.pass_id) ||
              (has_r && __hip_atomic_load(v.cready + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v.pass_id)) {
         __builtin_amdgcn_s_sleep(2);
-        if (++n > 4000000) { atomicAdd(&v.flags[4 + 2 * v.par], 1); atomicAdd((unsigned long long*)&v.dbg[21], 1ull); break; }      // (never seen: would take a dispatcher that starts workgroups out of order)
+        // (never seen: would take a dispatcher that starts workgroups out of order.  Loud and lossless like the cross-stream waits where a
+        //  resume exists -- the pass is marked void, the host reports it and repeats the pass with events; a numeric-failure mark otherwise)
+        if (++n > 4000000) {
+          if (v.sync_seq > 0) mark_sync_timeout(v, v.sync_seq); else atomicAdd(&v.flags[4 + 2 * v.par], 1);
+          atomicAdd((unsigned long long*)&v.dbg[21], 1ull);
+          break;
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1906,7 +1912,15 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
     //  that here: a group that waits for its separators then never keeps a producer from starting, whatever order the dispatcher picks)
     int total_groups = 0;
     for (int l = 0; l < nl; ++l) total_groups += (int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1);
-    if (fused && nl > 0 && nl <= 8 && v.cready && total_groups <= 2048) {
+    // (half of what the device can hold of this kernel -- asked once, not a constant of one chip: the other half is left to whatever the
+    //  second stream runs beside it)
+    static const int resident_limit = [] {
+      int dev = 0, per_cu = 0; hipDeviceProp_t pr;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_chain_back_levels, 64, 0) != hipSuccess || per_cu <= 0) return 2048;
+      return std::max(64, per_cu * pr.multiProcessorCount / 2);
+    }();
+    if (fused && nl > 0 && nl <= 8 && v.cready && total_groups <= resident_limit) {
       BackLevels L; L.n = nl;
       int at = 0;
       for (int i = 0; i < nl; ++i) {

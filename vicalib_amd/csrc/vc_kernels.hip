@@ -1544,19 +1544,23 @@ __device__ __forceinline__ void publish_progress(const DevView& v, const Ctrl& c
     __hip_atomic_store(v.host_progress, ((unsigned long long)(unsigned)c.passes << 32) | (unsigned)c.done | (c.likely_last ? kProgressLikelyLast : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
-__device__ void lm_decide(const DevView& v) {
+// void_pass: another rank of a sharded solve has marked this pass void (final_phase, mode 2) -- honoured whatever THIS rank's
+// hand-over mode: a rank on events must withhold the decision the flag ranks withhold, or the ranks' states and collective
+// schedules diverge
+__device__ void lm_decide(const DevView& v, bool void_pass = false) {
   Ctrl local = *v.ctrl;          // one burst of loads, one burst of stores
   // device-flag hand-overs: a wait of this pass (or of one before it, noticed after that pass's decision) ran into its bound --
   // what this pass computed cannot be trusted.  No judgement: the record stays as the last valid decision left it, the solve ends
   // with kDoneSyncTimeout and the host resumes it with event hand-overs (vc_kutil.hpp: spin_until_flag)
-  if (v.sync_seq > 0) {
+  if (v.sync_seq > 0 && !void_pass) {
     const long long m = sync_marked(v);
-    if (m != 0 && m <= v.sync_seq) {
-      local.done = kDoneSyncTimeout; local.abort_seq = (int)(v.sync_seq & 0x7fffffff);      // (this pass is the first one without a decision)
-      *v.ctrl = local;
-      publish_progress(v, local);
-      return;
-    }
+    void_pass = m != 0 && m <= v.sync_seq;
+  }
+  if (void_pass) {
+    local.done = kDoneSyncTimeout; local.abort_seq = (int)(v.pass_id & 0x7fffffff);      // (this pass is the first one without a decision; pass_id == sync_seq where flags are on)
+    *v.ctrl = local;
+    publish_progress(v, local);
+    return;
   }
   const bool fail = (v.flags[4 + 2 * v.par] != 0) || (v.flags[5 + 2 * v.par] != 0);
   v.flags[4 + 2 * v.par] = 0; v.flags[5 + 2 * v.par] = 0;
@@ -1693,6 +1697,7 @@ __device__ void final_phase(const DevView& v, int mode, double* red) {
       }
     }
   }
+  bool void_pass = false;
   if (mode == 2 && tid == 0) {   // after the all-reduce: combine the ranks in fixed order, identically everywhere
     double* o = v.scal;
     for (int k = 0; k < kNumScal; ++k) {
@@ -1700,14 +1705,13 @@ __device__ void final_phase(const DevView& v, int mode, double* red) {
       for (int r = 0; r < v.world; ++r) a = (k == kScGmax) ? fmax(a, v.gath[r * kNumScal + k]) : a + v.gath[r * kNumScal + k];
       o[k] = a;
     }
-    if (o[kScSq] >= kShardMark && v.sync_seq > 0) {      // some rank's pass is void: this rank's is, too (lm_decide below withholds the decision)
-      long long expect = 0;
-      if (!__hip_atomic_compare_exchange_strong(v.sync_flags + 6, &expect, v.sync_seq, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        __hip_atomic_fetch_min(v.sync_flags + 6, v.sync_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // some rank's pass is void: this rank's is, too -- lm_decide below withholds the decision, on a rank that hands over through
+    // events as well (ranks may disagree on the mode: a failed priority stream, a per-rank environment, a rank that fell back earlier)
+    void_pass = o[kScSq] >= kShardMark;
+    if (void_pass && v.sync_seq > 0) mark_sync_timeout(v, v.sync_seq);
     v.flags[4 + 2 * v.par] = (fmod(o[kScSq], kShardMark) > 0.0) ? 1 : 0; v.flags[5 + 2 * v.par] = 0;
   }
-  if (mode != 1 && tid == 0) lm_decide(v);
+  if (mode != 1 && tid == 0) lm_decide(v, void_pass);
 }
 // The waiting side as a kernel of its own: one wavefront on the second stream; the kernels behind it in that stream start when it
 // returns (vc_kutil.hpp: spin_until_flag).

@@ -94,18 +94,19 @@ __device__ __forceinline__ void signal_flag(const DevView& v, int idx) {
 __device__ __forceinline__ long long sync_marked(const DevView& v) {
   return __hip_atomic_load(v.sync_flags + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// marks pass `seq` (and everything queued behind it) void: the sticky word keeps the smallest pass number
+__device__ __forceinline__ void mark_sync_timeout(const DevView& v, long long seq) {
+  long long expect = 0;
+  if (!__hip_atomic_compare_exchange_strong(v.sync_flags + 6, &expect, seq, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    __hip_atomic_fetch_min(v.sync_flags + 6, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void spin_until_flag(const DevView& v, int idx, long long seq) {      // one thread
   long long n = 0;
   while (__hip_atomic_load(v.sync_flags + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
     __builtin_amdgcn_s_sleep(16);
     const long long m = sync_marked(v);
     if (m != 0 && m <= v.sync_seq) return;             // this pass is void already
-    if (++n > v.sync_bound) {
-      long long expect = 0;
-      if (!__hip_atomic_compare_exchange_strong(v.sync_flags + 6, &expect, v.sync_seq, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        __hip_atomic_fetch_min(v.sync_flags + 6, v.sync_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
+    if (++n > v.sync_bound) { mark_sync_timeout(v, v.sync_seq); return; }
   }
 }
 // ... and for a whole workgroup at its entry: thread 0 waits, then every wavefront drops what it may hold of the other stream's
