@@ -17,6 +17,8 @@ it run first (untimed); complete final-stage solves are then run back to back fr
 done.  N > 1: one process per GPU, frames sharded, one all-reduce of the reduced system and one of the step scalars per
 iteration over RCCL.  `python bench.py --gpus N` launches its own N ranks when it is not already running under
 torch.distributed.run.  Prints ONE JSON line on rank 0.
+`--transport gloo` (or VICALIB_AMD_BENCH_TRANSPORT=gloo) runs the same multi-rank branch with the ranks sharing the visible device(s)
+and the all-reduces through torch.distributed's gloo backend: what tests/test_bench_multirank_gpu.py executes on a one-GPU box.
 """
 import argparse
 import json
@@ -65,7 +67,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (cfg2 / at-scale) measurements")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps iterations each; ms_per_step is their median")
+    ap.add_argument("--transport", default=os.environ.get("VICALIB_AMD_BENCH_TRANSPORT", "auto"), choices=["auto", "rccl", "gloo"],
+                    help="multi-rank runs: rccl = one GPU per rank, the library's own RCCL communicator (auto: the same); gloo = torch.distributed "
+                         "gloo + the FrameShardComm callback, ranks share the visible device(s) -- executes the whole multi-rank branch of this "
+                         "script on a one-GPU box (a functional check, not a scaling measurement)")
     args = ap.parse_args()
+    gloo = args.transport == "gloo"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # self-launch: one rank per GPU over RCCL
@@ -87,12 +94,19 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # gloo transport: the ranks share whatever devices there are (all of them device 0 on a one-GPU box)
+    device = local_rank % torch.cuda.device_count() if gloo else local_rank
+    torch.cuda.set_device(device)
     # VICALIB_AMD_FORCE_SHARD_PATH=1 (test hook): one rank, but through the sharded code path (split kernels + RCCL)
     force_shard = world == 1 and os.environ.get("VICALIB_AMD_FORCE_SHARD_PATH") == "1"
     if world > 1 or force_shard:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    # the bench's own small collectives (agreement on the transport, MAX of the block times, gathers for the JSON line)
+    coll_dev = "cpu" if gloo else "cuda"
 
     wl = default_workload(world) if args.workload == "auto" else args.workload
     base = synth.BASELINE_CONFIGS[wl]
@@ -103,35 +117,53 @@ def main():
     vi = bool(base.imu)
 
     rccl_errors = []      # native RCCL path failed on this rank: the texts go into the JSON line's comm object
+    # ONE library communicator per process, lent to the three calibrators below (a first 8-GPU run must not also be the debut of
+    # three ncclCommInitRank / two ncclCommDestroy in a row whose relative order across the ranks nobody has seen)
+    shared = {"comm": None, "kind": None}
 
-    def attach(c):
+    def transport():
+        """Decided once, collectively: 'rccl' (shared library communicator), 'torch' (callback on torch.distributed) or 'none'."""
+        if shared["kind"] is not None:
+            return shared["kind"]
         if world == 1 and not force_shard:
+            shared["kind"] = "none"
             return "none"
-        if os.environ.get("VICALIB_AMD_SHARD_COMM", "rccl") == "rccl":
+        kind = "torch"
+        if not gloo and os.environ.get("VICALIB_AMD_SHARD_COMM", "rccl") == "rccl":
+            from vicalib_amd.lib import ShardComm
             ok = 1
             try:
-                c.set_shard_rccl(rank, world)
+                shared["comm"] = ShardComm(device, rank, world)
             except Exception as e:      # noqa: BLE001
                 # the exception text carries vc_last_error(): which RCCL call failed and RCCL's own error string
                 ok = 0
                 rccl_errors.append(str(e))
             # every rank must end up on the same transport: one failed rank sends all of them to the torch.distributed callback
             if world > 1:
-                flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+                flag = torch.tensor([ok], device=coll_dev, dtype=torch.int32)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 all_ok = int(flag.item())
             else:
                 all_ok = ok
             if all_ok:
-                return "rccl"
-            if ok:
-                rccl_errors.append("native RCCL communicator dropped: another rank failed to create its own")
+                kind = "rccl"
             else:
-                e = rccl_errors[-1]
-                print("bench[rank %d]: native RCCL path unavailable (%s); using the torch.distributed callback" % (rank, e), file=sys.stderr)
-        from vicalib_amd.parallel import FrameShardComm
-        c.set_shard(rank, world, FrameShardComm(device="cuda:%d" % local_rank, stream_ptr=c.stream()))
-        return "torch"
+                if ok:
+                    rccl_errors.append("native RCCL communicator dropped: another rank failed to create its own")
+                    shared["comm"].close(); shared["comm"] = None
+                else:
+                    print("bench[rank %d]: native RCCL path unavailable (%s); using the torch.distributed callback" % (rank, rccl_errors[-1]), file=sys.stderr)
+        shared["kind"] = kind
+        return kind
+
+    def attach(c):
+        kind = transport()
+        if kind == "rccl":
+            c.set_shard_comm(shared["comm"])
+        elif kind == "torch":
+            from vicalib_amd.parallel import FrameShardComm
+            c.set_shard(rank, world, FrameShardComm(device="cuda:%d" % device, stream_ptr=c.stream()))
+        return "gloo" if (kind == "torch" and gloo) else kind
 
     def barrier():
         torch.cuda.synchronize()
@@ -144,7 +176,7 @@ def main():
     # then on.
     full = None
     for rep in range(2):
-        cal2 = ViCalibrator(local_rank).load_problem(prob)
+        cal2 = ViCalibrator(device).load_problem(prob)
         cal2.SetCalibrateImu(vi)
         attach(cal2)
         barrier(); t0 = time.perf_counter()
@@ -161,10 +193,11 @@ def main():
             gt = prob.imu_gt
             full["time_offset_error_s"] = abs(cal2.time_offset() - gt["time_offset"])
             full["gyro_bias_error"] = float(np.abs(cal2.GetBiases()[:3] - gt["bg"]).max())
+    cal2.close()
     del cal2
 
     # ---- the timed loop: LM iterations of the final stage --------------------------------------------------------
-    cal = ViCalibrator(local_rank).load_problem(prob)
+    cal = ViCalibrator(device).load_problem(prob)
     cal.SetCalibrateImu(vi)
     comm_kind = attach(cal)
     if vi:
@@ -186,18 +219,18 @@ def main():
         d = time.perf_counter() - t0
         block_local.append(d)
         if world > 1:
-            tt = torch.tensor([d], device="cuda", dtype=torch.float64)
+            tt = torch.tensor([d], device=coll_dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             d = float(tt.item())
         block_dt.append(d)
     dt = float(np.median(block_dt))
     per_rank_ms = None
     if world > 1:
-        mine = torch.tensor([1e3 * float(np.median(block_local)) / max(done, 1)], device="cuda", dtype=torch.float64)
+        mine = torch.tensor([1e3 * float(np.median(block_local)) / max(done, 1)], device=coll_dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank_ms = [float(x.item()) for x in allr]
-        no = torch.tensor([float(n_obs_local)], device="cuda", dtype=torch.float64)
+        no = torch.tensor([float(n_obs_local)], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(no)
         n_obs_total = int(no.item())
     else:
@@ -339,7 +372,7 @@ def main():
             "critical_path": critical_path, "comm": comm, "kernels_in_loop": kernels,
         }
         if not args.no_secondary and world == 1 and not force_shard:
-            out["secondary"] = secondary(local_rank)
+            out["secondary"] = secondary(device)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, prob)
     if rank == 0:
@@ -353,8 +386,11 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1 or force_shard:
         # leave together, and without the interpreter's teardown order deciding which of the two RCCL users (torch's process
-        # group, the library's own communicators) is torn down first
+        # group, the library's one communicator) is torn down first: calibrators, then the shared communicator, then the barrier
         try:
+            cal.close()
+            if shared["comm"] is not None:
+                shared["comm"].close()
             dist.barrier()
         except Exception:      # noqa: BLE001
             pass

@@ -166,6 +166,14 @@ void* vc_get_stream(vc_calibrator* h);    /* hipStream_t */
  * the host distributes it by whatever means it has, every rank calls vc_set_shard_rccl (collective: ncclCommInitRank). */
 int vc_rccl_unique_id(void* out128);
 int vc_set_shard_rccl(vc_calibrator* h, int rank, int world_size, const void* unique_id128);
+/* One RCCL communicator for several calibrators of a process (a launcher that solves more than once: one ncclCommInitRank and
+ * one ncclCommDestroy per process instead of one pair per calibrator).  vc_shard_comm_create is collective like
+ * vc_set_shard_rccl; vc_set_shard_comm lends the communicator to a calibrator on the same device (rank / world size are the
+ * communicator's); the caller destroys it after the calibrators that used it. */
+typedef struct vc_shard_comm vc_shard_comm;
+int vc_shard_comm_create(int device, int rank, int world_size, const void* unique_id128, vc_shard_comm** out);
+int vc_set_shard_comm(vc_calibrator* h, vc_shard_comm* comm);
+void vc_shard_comm_destroy(vc_shard_comm* comm);
 long long vc_allreduce_calls(vc_calibrator* h);    /* all-reduces issued through the library's own communicator */
 /* Text behind the last failing status of vc_set_shard_rccl on this thread (which library call failed, RCCL's error string and
  * last-error text): what a launcher prints before it falls back to another transport.  Empty if nothing failed. */

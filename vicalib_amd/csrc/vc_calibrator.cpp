@@ -310,7 +310,12 @@ struct vc_calibrator {
   long global_first = 0, global_total = 0;     // this rank's frame range in the sharded problem (known after gather_shard_info)
   vc_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
-  void* rccl_comm = nullptr;        // own communicator (vc_set_shard_rccl): all-reduces go straight onto `stream`
+  void* rccl_comm = nullptr;        // RCCL communicator (vc_set_shard_rccl: own; vc_set_shard_comm: borrowed): all-reduces go straight onto `stream`
+  bool rccl_comm_owned = false;     // this calibrator created it and destroys it
+  void drop_comm() {
+    if (rccl_comm && rccl_comm_owned && g_rccl.CommDestroy) { (void)hipStreamSynchronize(stream); (void)g_rccl.CommDestroy(rccl_comm); }
+    rccl_comm = nullptr; rccl_comm_owned = false;
+  }
   long rccl_calls = 0;
   // ---- device -----------------------------------------------------------------------------
   bool device_dirty = true;      // host problem changed since the last upload
@@ -345,7 +350,7 @@ struct vc_calibrator {
 
   ~vc_calibrator() {
     stop();
-    if (rccl_comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(stream); (void)g_rccl.CommDestroy(rccl_comm); }
+    drop_comm();
     drop_graphs();
     kt_free();
     if (stream2) (void)hipStreamDestroy(stream2);
@@ -1771,7 +1776,7 @@ int vc_set_shard(vc_calibrator* h, int rank, int world_size, vc_allreduce_fn fn,
   if (world_size < 1 || rank < 0 || rank >= world_size || (world_size > 1 && !fn)) return VC_ERR_BAD_ARG;
   // a callback replaces the library's own communicator (a caller that falls back after vc_set_shard_rccl succeeded on this rank but
   // failed on another one must end up on the same transport everywhere)
-  if (h->rccl_comm) { (void)g_rccl.CommDestroy(h->rccl_comm); h->rccl_comm = nullptr; }
+  h->drop_comm();
   h->rank = rank; h->world = world_size; h->allreduce = fn; h->allreduce_ctx = ctx; h->device_dirty = true;
   { const char* e = std::getenv("VICALIB_AMD_FORCE_SHARD_PATH"); h->force_shard_path = e && e[0] == '1'; }
   return VC_OK;
@@ -1784,32 +1789,72 @@ int vc_rccl_unique_id(void* out128) {
   std::memcpy(out128, &id, sizeof(id));
   return VC_OK;
 }
-int vc_set_shard_rccl(vc_calibrator* h, int rank, int world_size, const void* unique_id128) {
+// ncclCommInitRank with the failure text a launcher prints before it falls back (vc_last_error)
+static int rccl_comm_init(int device, int rank, int world_size, const void* unique_id128, void** comm) {
   g_last_error.clear();          // (vc_last_error() is about THIS call from here on)
-  NOT_RUNNING(h);
+  *comm = nullptr;
   if (world_size < 1 || rank < 0 || rank >= world_size || !unique_id128) return VC_ERR_BAD_ARG;
   if (!g_rccl.load()) {
     const char* de = dlerror();      // (one call: dlerror() clears the message it returns)
     g_last_error = std::string("librccl could not be loaded: ") + (de ? de : "ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy not all found");
     return VC_ERR_UNSUPPORTED;
   }
-  if (hipSetDevice(h->device) != hipSuccess) { g_last_error = "hipSetDevice(" + std::to_string(h->device) + ") failed"; return VC_ERR_NO_DEVICE; }
+  if (hipSetDevice(device) != hipSuccess) { g_last_error = "hipSetDevice(" + std::to_string(device) + ") failed"; return VC_ERR_NO_DEVICE; }
   RcclUniqueId id;
   std::memcpy(&id, unique_id128, sizeof(id));
-  if (h->rccl_comm) { (void)g_rccl.CommDestroy(h->rccl_comm); h->rccl_comm = nullptr; }
-  const int nrc = g_rccl.CommInitRank(&h->rccl_comm, world_size, id, rank);
+  const int nrc = g_rccl.CommInitRank(comm, world_size, id, rank);
   if (nrc != 0) {
-    g_last_error = "ncclCommInitRank(rank " + std::to_string(rank) + " of " + std::to_string(world_size) + ", device " + std::to_string(h->device) + ") = " + std::to_string(nrc);
+    g_last_error = "ncclCommInitRank(rank " + std::to_string(rank) + " of " + std::to_string(world_size) + ", device " + std::to_string(device) + ") = " + std::to_string(nrc);
     if (g_rccl.GetErrorString) g_last_error += std::string(" (") + g_rccl.GetErrorString(nrc) + ")";
     if (g_rccl.GetLastError) { const char* le = g_rccl.GetLastError(nullptr); if (le && le[0]) g_last_error += std::string(": ") + le; }
-    h->rccl_comm = nullptr; return VC_ERR_NO_DEVICE;
+    *comm = nullptr; return VC_ERR_NO_DEVICE;
   }
+  return VC_OK;
+}
+static void attach_rccl(vc_calibrator* h, int rank, int world_size, void* comm, bool owned) {
+  h->drop_comm();
+  h->rccl_comm = comm; h->rccl_comm_owned = owned;
   h->rank = rank; h->world = world_size; h->allreduce = nullptr; h->allreduce_ctx = nullptr; h->device_dirty = true;
   { const char* e = std::getenv("VICALIB_AMD_FORCE_SHARD_PATH"); h->force_shard_path = e && e[0] == '1'; }
   // an RCCL communicator of several ranks has one device per rank: this process has its device to itself, the cross-stream hand-overs of
   // the pass can go through device flags as in a single-process solve (-25 us per pass and rank; VICALIB_AMD_SHARD_FLAG_SYNC=0 keeps events)
   { const char* e = std::getenv("VICALIB_AMD_SHARD_FLAG_SYNC"); if (world_size > 1 && !(e && e[0] == '0')) h->shard_flag_sync = true; }
+}
+int vc_set_shard_rccl(vc_calibrator* h, int rank, int world_size, const void* unique_id128) {
+  g_last_error.clear();
+  NOT_RUNNING(h);
+  h->drop_comm();
+  void* comm = nullptr;
+  const int rc = rccl_comm_init(h->device, rank, world_size, unique_id128, &comm);
+  if (rc) return rc;
+  attach_rccl(h, rank, world_size, comm, true);
   return VC_OK;
+}
+// One communicator for all calibrators of a process (a launcher that runs several solves in a row -- bench.py builds three
+// calibrators -- pays ONE ncclCommInitRank and one ncclCommDestroy, and their order across the ranks is the launcher's, not that
+// of three destructors): created once, lent to calibrators with vc_set_shard_comm, destroyed by the caller after the calibrators.
+struct vc_shard_comm { void* comm; int device, rank, world; };
+int vc_shard_comm_create(int device, int rank, int world_size, const void* unique_id128, vc_shard_comm** out) {
+  if (!out) return VC_ERR_BAD_ARG;
+  *out = nullptr;
+  void* comm = nullptr;
+  const int rc = rccl_comm_init(device, rank, world_size, unique_id128, &comm);
+  if (rc) return rc;
+  *out = new vc_shard_comm{comm, device, rank, world_size};
+  return VC_OK;
+}
+int vc_set_shard_comm(vc_calibrator* h, vc_shard_comm* c) {
+  g_last_error.clear();
+  NOT_RUNNING(h);
+  if (!c || !c->comm) return VC_ERR_BAD_ARG;
+  if (c->device != h->device) { g_last_error = "vc_set_shard_comm: the communicator lives on device " + std::to_string(c->device) + ", the calibrator on " + std::to_string(h->device); return VC_ERR_BAD_ARG; }
+  attach_rccl(h, c->rank, c->world, c->comm, false);
+  return VC_OK;
+}
+void vc_shard_comm_destroy(vc_shard_comm* c) {
+  if (!c) return;
+  if (c->comm && g_rccl.CommDestroy) { (void)hipSetDevice(c->device); (void)hipDeviceSynchronize(); (void)g_rccl.CommDestroy(c->comm); }
+  delete c;
 }
 long long vc_allreduce_calls(vc_calibrator* h) { return h ? h->rccl_calls : 0; }
 const char* vc_last_error(void) { return g_last_error.c_str(); }

@@ -29,7 +29,7 @@ SYMBOLS = [
     "vc_get_biases", "vc_get_scale_factor", "vc_get_gravity", "vc_time_offset", "vc_mean_squared_error", "vc_get_camera_proj_rmse",
     "vc_get_num_iterations", "vc_num_imu_measurements", "vc_get_imu_measurements", "vc_get_integration_poses", "vc_print_results", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
     "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
-    "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_pnp_planar_ransac", "vc_set_pnp_ransac", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_allreduce_calls", "vc_last_error", "vc_get_imu_weights",
+    "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_pnp_planar_ransac", "vc_set_pnp_ransac", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_shard_comm_create", "vc_set_shard_comm", "vc_shard_comm_destroy", "vc_allreduce_calls", "vc_last_error", "vc_get_imu_weights",
     "vc_solution_covariance_dim", "vc_get_solution_covariance", "vc_get_solution_covariance_names",
     "vc_target_make_pattern", "vc_target_find",
     "vc_detector_create", "vc_detector_destroy", "vc_detector_set_params", "vc_detector_find", "vc_detector_find_conics",
@@ -96,7 +96,7 @@ def load():
         L.vc_num_observations.restype = C.c_longlong
         L.vc_allreduce_calls.restype = C.c_longlong
         L.vc_last_error.restype = C.c_char_p
-        for name in ("vc_destroy", "vc_detector_destroy"):
+        for name in ("vc_destroy", "vc_detector_destroy", "vc_shard_comm_destroy"):
             getattr(L, name).restype = None
         _lib = L
     return _lib
@@ -110,6 +110,32 @@ def _check(rc, what):
 
 def _d(a):
     return np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.c_void_p)
+
+
+class ShardComm:
+    """One RCCL communicator for all calibrators of this process (vc_shard_comm_create): created once -- collective, the 128-byte id
+    travels through torch.distributed --, lent to calibrators with ViCalibrator.set_shard_comm, destroyed with close() after them."""
+
+    def __init__(self, device, rank, world, group=None):
+        import torch.distributed as dist
+        self.L = load()
+        self.rank, self.world = int(rank), int(world)
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _check(self.L.vc_rccl_unique_id(buf), "rccl_unique_id")
+        box = [bytes(buf.raw)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        self.h = C.c_void_p()
+        rc = self.L.vc_shard_comm_create(int(device), self.rank, self.world, C.create_string_buffer(box[0], 128), C.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise VicalibError("shard_comm_create: status %d: %s" % (rc, (self.L.vc_last_error() or b"").decode(errors="replace")))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vc_shard_comm_destroy(self.h)
+            self.h = None
 
 
 class ViCalibrator:
@@ -306,6 +332,12 @@ class ViCalibrator:
         rc = self.L.vc_set_shard_rccl(self.h, int(rank), int(world), C.create_string_buffer(box[0], 128))
         if rc != 0:          # say which RCCL call failed and why (vc_last_error) before the caller falls back to another transport
             raise VicalibError("set_shard_rccl: status %d: %s" % (rc, (self.L.vc_last_error() or b"").decode(errors="replace")))
+
+    def set_shard_comm(self, comm):
+        """Frame sharding over a communicator shared with the process's other calibrators (ShardComm); not owned by this calibrator."""
+        rc = self.L.vc_set_shard_comm(self.h, comm.h)
+        if rc != 0:
+            raise VicalibError("set_shard_comm: status %d: %s" % (rc, (self.L.vc_last_error() or b"").decode(errors="replace")))
 
     def allreduce_calls(self): return int(self.L.vc_allreduce_calls(self.h))
 
