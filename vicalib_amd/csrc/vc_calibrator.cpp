@@ -668,6 +668,12 @@ struct vc_calibrator {
     for (int a = 0; a < 15; ++a) dv.imu_param_col[a] = imu_param_col[a];
     dv.ldw = (((D + 1 + 15) / 16) * 16 % 32 == 0) ? ((D + 1 + 15) / 16) * 16 + 16 : ((D + 1 + 15) / 16) * 16;
     dv.ldx = dv.ldw + 32;
+    {
+      // early Gram (vc_device.h): narrow reduced systems of a single process; a function of the problem only, never of the hand-over
+      // mode -- a solve resumed with events after a flag time-out must repeat the withheld passes with the same arithmetic
+      static const bool early_env = [] { const char* e = std::getenv("VICALIB_AMD_EARLY_GRAM"); return !(e && e[0] == '0'); }();
+      dv.gram_top_stride = (early_env && dv.imu_on && D <= kSmallD && !sharded() && N >= 1) ? chain_top_stride(N) : 0;
+    }
     dv.pin_first = (shard_imu && rank > 0) ? 1 : 0; dv.pin_last = ghost ? 1 : 0;
     dv.sep_col0 = D0 + 9 * (rank - 1); dv.sep_col1 = D0 + 9 * rank;
     HIP_OK(d_sep_strip.alloc((size_t)2 * 9 * dv.ldw)); dv.sep_strip = d_sep_strip.p;
@@ -882,7 +888,7 @@ struct vc_calibrator {
       }
       KT("k_chain_init", launch_chain_init(dv, stream));
       KT("k_chain_fwd", launch_chain_fwd(dv, stream));
-      KT("k_chain_gram", launch_chain_gram(dv, stream));
+      if (dv.gram_top_stride == 0) KT("k_chain_gram", launch_chain_gram(dv, stream));      // (early Gram: the sums ride in the top level's launch)
       KT("k_part_sum", launch_part_sum(dv, stream));
       int rc = VC_OK;
       if (sharded()) {
@@ -1015,7 +1021,7 @@ struct vc_calibrator {
                          "solve with event hand-overs, which this calibrator keeps from now on (VICALIB_AMD_FLAG_SYNC=0 selects them from the start)\n",
                  c.passes + 1);
     wcur = wr_ring[c.abort_seq & 15];
-    if (d_sync.p) HIP_OK(hipMemsetAsync(d_sync.p, 0, 8 * sizeof(long long), stream));
+    if (d_sync.p) HIP_OK(hipMemsetAsync(d_sync.p, 0, kSyncWords * sizeof(long long), stream));
     HIP_OK(hipMemsetAsync(dv.flags + 4, 0, 4 * sizeof(int), stream));      // numeric-failure marks of the void passes
     Ctrl r = c;
     // need_lin stays as the last decision left it: after a rejected step the linearisation in place is the one made when the state was
@@ -1391,7 +1397,8 @@ int vc_create(vc_calibrator** out, int device) {
   { const char* e = std::getenv("VICALIB_AMD_FLAG_SYNC"); if (e && e[0] == '0') h->flag_sync = false; if (e && e[0] == '1') h->flag_sync = true; }
   { const char* e = std::getenv("VICALIB_AMD_SYNC_BOUND"); if (e && std::atoll(e) > 0) h->sync_bound = std::atoll(e); }      // (test hook: a tiny bound forces the time-out path)
   { const char* e = std::getenv("VICALIB_AMD_SYNC_BOUND_FROM_PASS"); if (e) h->sync_bound_from_pass = std::atoi(e); }
-  if (h->flag_sync && (h->d_sync.alloc(8) != hipSuccess || hipMemset(h->d_sync.p, 0, 8 * sizeof(long long)) != hipSuccess)) h->flag_sync = false;
+  // (the flag words are there whatever the hand-over mode: the counted hand-over inside k_reduced's launch uses two of them)
+  if (h->d_sync.alloc(kSyncWords) != hipSuccess || hipMemset(h->d_sync.p, 0, kSyncWords * sizeof(long long)) != hipSuccess) { delete h; return VC_ERR_NO_DEVICE; }
   *out = h;
   return VC_OK;
 }

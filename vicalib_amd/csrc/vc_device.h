@@ -23,6 +23,8 @@ constexpr int kFrL = 0, kFrZ = 21, kFrG = 27, kFrLam = 33, kFrDinv = 39;
 constexpr int kNumScal = 8;
 enum { kScGd = 0, kScDld = 1, kScStep2 = 2, kScX2 = 3, kScG2 = 4, kScCost = 5, kScGmax = 6, kScSq = 7 };
 constexpr int kTraceCols = 10;     // iteration cost cost_change gmax gnorm step_norm rho radius accepted stage
+constexpr int kSmallD = 32;        // reduced systems up to this width are solved by one wavefront; above it the workgroup-wide LDS factorisation is faster
+constexpr int kSyncWords = 16;     // DevView::sync_flags
 
 // termination codes in Ctrl::done (0 = keep running)
 constexpr double kShardMark = 1048576.0;                 // sharded solves: "my pass is void" on top of a rank's failure count in the gathered step scalars
@@ -185,6 +187,13 @@ struct DevView {
   // pin_first: local frame 0 is this rank's separator; pin_last: local frame n_frames-1 is a copy ("ghost") of the next
   // rank's separator (columns sep_col1..+8), kept here because the IMU block that ends in it belongs to this rank.
   int pin_first, pin_last, sep_col0, sep_col1;
+  // Early Gram (visual-inertial, single process, D <= kSmallD): sum [Y | z]^T [Y | z] of every frame below the chain's top level is formed by
+  // extra workgroups of the top level's launch (beside its one group); the top level's own frames (index = 0 mod gram_top_stride, at most
+  // 7) are added by k_reduced itself from their images.  0: k_chain_gram is a launch of its own and covers every frame.
+  // (Tried: the partial sums as extra workgroups of k_reduced's launch, delivered with device-coherent stores and a count the first
+  //  workgroup waits for -- 36 us against 7.4 + 23 for the two launches: coherent stores, the count and the coherent loads behind it cost
+  //  more than a kernel boundary)
+  int gram_top_stride;
   int rank, world;                 // frame sharding: this process's rank, number of ranks
   // Merged decision (vision-only, single process): the accept/reject decision on pass k's trial point is taken at the head
   // of pass k+1's k_frame_schur -- by every workgroup, redundantly and identically -- instead of a k_final launch per pass.
@@ -207,6 +216,7 @@ void launch_reduced(const DevView& v, int mode, hipStream_t s);
 void launch_trial(const DevView& v, hipStream_t s);            // back-substitution + manifold update + trial residual sweep
 void launch_final(const DevView& v, int mode, hipStream_t s);
 int chain_forward_launches(const DevView& v);      // launches of the chain's forward elimination (levels + top)
+int chain_top_stride(int n_frames);                // stride of the frames the chain's top level eliminates
 // a segment of a packed upload: `bytes` (a multiple of 4) from offset src_off of the staging image to dst; src_off = ~0: zero-fill
 struct UnpackSeg { unsigned long long dst, src_off, bytes; };
 void launch_unpack(const UnpackSeg* segs, int n, const void* image, size_t total_bytes, hipStream_t s);

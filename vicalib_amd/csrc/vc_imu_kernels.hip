@@ -610,6 +610,11 @@ __global__ __launch_bounds__(64) void k_imu_weights(DevView v, int wr) {
 // takes part in (compact records, vc_device.h: kSeg*), the right-hand side, the separator couplings of a sharded chain -- instead
 // of zero-filling the image and scattering into it (round 2: 22 of 45 MB per launch at BASELINE cfg3 were the zero-fill and the
 // unread parts of the 33 x 33 blocks).  The padding columns between D + 1 and ldw and behind the blocks are never read.
+#ifdef VC_INIT_STAMPS
+#define ISTAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0 && (i) < 16) v.dbg[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ISTAMP(i) do { } while (0)
+#endif
 constexpr int kInitPad = 160;            // per wavefront behind the Gram records: Hs 42 | A 81 | g 9 | lambda 9 | tile cameras 8 | pad
 __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two workgroups per CU: the kernel waits on memory)
   extern __shared__ __attribute__((aligned(16))) double sh[];
@@ -617,7 +622,13 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
   __shared__ double s_R[kMaxCams * 9];   // the cameras' rotations R_ck, once per workgroup
   __shared__ int s_ci[256];              // what every image column is: owning camera (255: none) | column inside its block << 8 | "comes from the IMU records" << 16
   const Ctrl* ct = v.ctrl;
+#ifdef VC_INIT_STAMPS
+  const long long ist0_ = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   if (ct->done) return;
+#ifdef VC_INIT_STAMPS
+  if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) v.dbg[0] = ist0_;      // (not in passes that exit early)
+#endif
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int C = v.n_cams, D = v.D, N = v.n_frames, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
   const int cur = ct->cur;
@@ -660,6 +671,7 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
 #pragma unroll
   for (int a = 0; a < 15; ++a) sp_col = (lane == a) ? v.imu_param_col[a] : sp_col;
   __syncthreads();
+  ISTAMP(1);
 
   for (int fg = f0; fg < f1; fg += 4) {
     const int f = fg + wave;
@@ -715,6 +727,7 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
     }
     if (lane < kMaxCams) { tcam[lane] = my_tc; tinv[lane] = -1; }
     wave_lds_sync();
+    ISTAMP(2);
     if (lane < nt) tinv[my_tc] = lane;             // the frame's tile of every camera
     for (int t = 0; t < nt; ++t) {
       // (the tile's camera as a scalar: the per-camera sums take one add per loaded value behind a scalar branch, not a select
@@ -740,6 +753,7 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
         }
     }
     wave_lds_sync();
+    ISTAMP(3);
     // ---- visual part of the frame's own block: H_pp (6 x 6) and g_p (6) from the tiles (lanes 0..41)
     if (lane < 42) {
       double hval = 0.0;
@@ -767,6 +781,7 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
       Hs[lane] = hval;
     }
     wave_lds_sync();
+    ISTAMP(4);
     // ---- own block A (lane e = 9 i + j, two slots), right-hand side, damping
     double aval[2];
 #pragma unroll
@@ -795,6 +810,7 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
       gs[lane] = gval; ls[lane] = lam;
     }
     wave_lds_sync();
+    ISTAMP(5);
     // ---- the image: every column written once.  First the columns that come from the IMU records (lanes 0..23) ...
     if (sp_col >= 0) {
 #pragma unroll
@@ -871,9 +887,11 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
       }
     }
     wave_lds_sync();
+    ISTAMP(6);
   }
   // chunk sums of the camera Gram blocks and of the IMU shared block (4 wavefronts combined in fixed order)
   __syncthreads();
+  ISTAMP(7);
   const int slot = C * kGStride + kGStride;
 #pragma unroll
   for (int c = 0; c < kMaxCams; ++c)
@@ -897,6 +915,10 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
     for (int w = 0; w < 4; ++w) { double tw = 0.0; for (int k = 0; k < 9; ++k) tw += sh[w * 9 + k]; t += tw; }
     part[v.part_stride - 1] = t;
   }
+#ifdef VC_INIT_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  ISTAMP(8);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ chain elimination
@@ -1742,17 +1764,16 @@ constexpr int kMaxPairsPerWaveI = 9;
 // group of four frames at D = 115; here the NQ chains advance side by side).  Rows of the next group are requested before the
 // current group's MFMAs and land in registers meanwhile.
 // NL: entries of the 36 x ld row image per thread (36 ld / 256, rounded up).
+// mask_stride > 0: frames with index 0 (mod mask_stride) contribute nothing (the chain's top level: still being eliminated while this
+// runs beside it; k_reduced adds them from their finished images, see DevView::gram_top_stride)
 template <int NQ, int NL>
-__global__ __launch_bounds__(256, 2) void k_chain_gram(DevView v) {
-  extern __shared__ __attribute__((aligned(16))) double R[];    // 36 x ld
-  __shared__ unsigned short s_pair[128];                         // pair p -> I | J << 8
+__device__ __forceinline__ void chain_gram_chunk(const DevView& v, int chunk, double* R /* 36 x ld */, unsigned short* s_pair /* 128 */, int mask_stride) {
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
   GSTAMP(0);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int D = v.D, ld = v.ldw, N = v.n_frames;
   const int nT = (D + 1 + 15) / 16, nPairs = nT * (nT + 1) / 2;
-  const int chunk = blockIdx.x;
   const int f0 = chunk * v.chunk_frames, f1 = min(f0 + v.chunk_frames, N);
   double* part = v.part + (size_t)chunk * v.part_stride;
   if (tid < nPairs) {
@@ -1773,10 +1794,16 @@ __global__ __launch_bounds__(256, 2) void k_chain_gram(DevView v) {
     auto request = [&](int fg) {
       const int nrow = min(4, f1 - fg) * 9;
       const double* src = v.cW + (size_t)fg * 9 * v.ldx;
+      unsigned mbits = 0u;                  // bit q: frame fg + q is masked (wave-uniform)
+      if (mask_stride > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mbits |= ((fg + q) % mask_stride == 0) ? (1u << q) : 0u;
+      }
       int row = row0, col = col0;
 #pragma unroll
       for (int u = 0; u < NL; ++u) {
-        tmp[u] = (row < nrow) ? src[(unsigned)(row * v.ldx + col)] : 0.0;      // (uniform base + 32-bit offset: one register per entry if hoisted)
+        const bool masked = (mbits >> ((row * 57) >> 9)) & 1u;      // (row / 9 for rows below 36)
+        tmp[u] = (row < nrow && !masked) ? src[(unsigned)(row * v.ldx + col)] : 0.0;      // (uniform base + 32-bit offset: one register per entry if hoisted)
         row += step_r; col += step_c;
         if (col >= ld) { col -= ld; ++row; }
       }
@@ -1820,6 +1847,29 @@ __global__ __launch_bounds__(256, 2) void k_chain_gram(DevView v) {
   __builtin_amdgcn_s_waitcnt(0);
   GSTAMP(15);
 #endif
+}
+template <int NQ, int NL>
+__global__ __launch_bounds__(256, 2) void k_chain_gram(DevView v) {
+  extern __shared__ __attribute__((aligned(16))) double R[];    // 36 x ld
+  __shared__ unsigned short s_pair[128];                         // pair p -> I | J << 8
+  chain_gram_chunk<NQ, NL>(v, (int)blockIdx.x, R, s_pair, 0);
+}
+// The chain's top level (one group, one wavefront, 4-7 dependent eliminations: ~13 us at BASELINE cfg3 with the chip idle beside it) and, in
+// the same launch, the Gram sums of every frame below it -- final since the launch before: workgroup 0 eliminates, workgroups 1 .. n_chunks
+// are k_chain_gram's with the top level's frames masked out (DevView::gram_top_stride).  Narrow borders only (one image column per lane).
+template <int NQ>
+__global__ __launch_bounds__(256) void k_chain_top_gram(DevView v, int s, int m, int lvl) {
+  extern __shared__ __attribute__((aligned(16))) double R[];    // 36 x ld
+  __shared__ unsigned short s_pair[128];
+  __shared__ __attribute__((aligned(16))) double XS[9 * kXsLd];
+  __shared__ double An[81];
+  __shared__ double Ls_all[81];
+  if (blockIdx.x == 0) {
+    if (threadIdx.x >= 64) return;
+    chain_fwd_group<1, 1>(v, s, m, 1, lvl, 0, 0, XS, An, Ls_all);
+    return;
+  }
+  chain_gram_chunk<NQ, 7>(v, (int)blockIdx.x - 1, R, s_pair, v.gram_top_stride);
 }
 
 // ------------------------------------------------------------------------------------------ launchers
@@ -1903,7 +1953,13 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
   };
   if (forward) {
     for (int l = 0; l < nl; ++l) fwd((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1), strides[l], ms[l], 0, l);
-    fwd(1, top_stride, m_top, 1, nl);
+    if (v.gram_top_stride > 0 && cpl <= 1) {
+      // early Gram: the top level's one group and the Gram sums of all frames below it in one launch
+      const size_t lds = (size_t)36 * v.ldw * sizeof(double);
+      const int nT = (v.D + 1 + 15) / 16, nPairs = nT * (nT + 1) / 2;
+      if (nPairs <= 4) hipLaunchKernelGGL(k_chain_top_gram<1>, dim3(1 + v.n_chunks), dim3(256), lds, s, v, top_stride, m_top, nl);
+      else hipLaunchKernelGGL(k_chain_top_gram<2>, dim3(1 + v.n_chunks), dim3(256), lds, s, v, top_stride, m_top, nl);
+    } else fwd(1, top_stride, m_top, 1, nl);
   } else {
     hipLaunchKernelGGL(k_chain_back, dim3(1 + (nl > 0 ? (N + kBackT0Frames - 1) / kBackT0Frames : 0)), dim3(64), 0, s, v, top_stride, m_top, 1, nl, 0);
     // the levels below: one launch (k_chain_back_levels: ready words instead of kernel boundaries); VICALIB_AMD_BACK_FUSED=0: one launch per level
@@ -1935,6 +1991,17 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
       hipLaunchKernelGGL(k_chain_back, dim3((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1)), dim3(64), 0, s, v, strides[l], ms[l], 0, l,
                          two_at(l) ? 1 : 0);
   }
+}
+// stride of the frames the top level eliminates (1: no level below it)
+int chain_top_stride(int n_frames) {
+  if (n_frames < 1) return 1;
+  int nl = 0; long st = 1;
+  while (true) {
+    const int m = nl == 0 ? chain_group_size() : chain_group_size_upper();
+    if (!((n_frames - 1) / st + 1 > m - 1)) break;
+    ++nl; st *= m;
+  }
+  return (int)st;
 }
 // launches of the forward elimination (levels + the top level)
 int chain_forward_launches(const DevView& v) {

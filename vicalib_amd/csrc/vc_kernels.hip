@@ -627,10 +627,10 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
 // through one CU plus a D^2 loop of dependent round trips, 24 + 8 us at D = 67.  (A two-level version whose last workgroup per
 // column added the slab totals behind a device-scope fence was 14x slower: every release fence writes the L2 back.)
 constexpr int kSumEntries = 16, kSumSlices = 32;
-__global__ __launch_bounds__(kSumEntries * kSumSlices) void k_part_sum(DevView v) {
-  __shared__ double sl[kSumEntries * kSumSlices];
+template <int SLICES>
+__device__ __forceinline__ void part_sum_block(const DevView& v, int block, double* sl /* 16 x SLICES */) {
   if (v.ctrl->done) return;
-  const int tid = threadIdx.x, e = blockIdx.x * kSumEntries + (tid & (kSumEntries - 1)), ks = tid / kSumEntries;
+  const int tid = threadIdx.x, e = block * kSumEntries + (tid & (kSumEntries - 1)), ks = tid / kSumEntries;
   const int stride = v.part_stride, D = v.D, DD = D * D, n = v.n_chunks;
   int i = 0, j = 0;
   bool live = e < stride;
@@ -639,22 +639,26 @@ __global__ __launch_bounds__(kSumEntries * kSumSlices) void k_part_sum(DevView v
   if (live) {
     const double* src = v.part + e;
 #pragma unroll 16
-    for (int k = ks; k < n; k += kSumSlices) s += src[(size_t)k * stride];
+    for (int k = ks; k < n; k += SLICES) s += src[(size_t)k * stride];
   }
   sl[tid] = s;
   __syncthreads();
   if (tid < kSumEntries && live) {
     double t = sl[tid];
 #pragma unroll
-    for (int q = 1; q < kSumSlices; ++q) t += sl[q * kSumEntries + tid];
+    for (int q = 1; q < SLICES; ++q) t += sl[q * kSumEntries + tid];
     double* S = v.Sbuf;
     if (e < DD) { S[e] = -t; if ((i >> 4) < (j >> 4)) S[j * D + i] = -t; }
     else if (e < DD + D) S[e] = -t;        // g_red follows S
     else v.part_total[e] = t;
   }
 }
+__global__ __launch_bounds__(kSumEntries * kSumSlices) void k_part_sum(DevView v) {
+  __shared__ double sl[kSumEntries * kSumSlices];
+  part_sum_block<kSumSlices>(v, (int)blockIdx.x, sl);
+}
 
-constexpr int kSmallD = 32;   // reduced systems up to this width are solved by one wavefront; above it the workgroup-wide LDS factorisation is faster
+// (kSmallD, vc_device.h: reduced systems up to this width are solved by one wavefront; above it the workgroup-wide LDS factorisation is faster)
 // Phase A of the reduced system (one workgroup):
 // Sbuf = [ S = H_ss - sum Y^T Y (full symmetric, undamped) | g_red | diag(H_ss) | g_s | cost, 0 ]
 struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[kMaxCams * 256]; double T1[kMaxCams * 256]; double red[256]; double camq[kMaxCams * 4]; double gc[kMaxCams * 16]; };
@@ -667,7 +671,11 @@ struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[kMaxCams * 25
 #endif
 // S: v.Sbuf, or (single process, D <= kSmallD) an LDS image of it that this phase fills first -- every read-modify-write of the
 // phase and the solve's row loads then stay on chip (three L2 round trips less on the critical path); the kernel writes it back.
-__device__ __forceinline__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */, double* S, bool s_in_lds) {
+// top / top_rows (early Gram, DevView::gram_top_stride): the [Y | z] rows of the chain's top-level frames (LDS, 64 rows x kTopLd, zero
+// beyond the rows and beyond column D) -- their Gram sums are subtracted here
+constexpr int kTopLd = 34;
+__device__ __forceinline__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */, double* S, bool s_in_lds,
+                                                  const double* top = nullptr, int top_rows = 0) {
   VC_STAMP(0);
   const int tid = threadIdx.x, D = v.D, C = v.n_cams;
   // (all of a thread's loads go out before the first is stored to LDS: a plain copy loop is one memory round trip per iteration)
@@ -701,6 +709,39 @@ __device__ __forceinline__ void schur_final_phase(const DevView& v, int cur, Fin
   if (s_in_lds) {
 #pragma unroll
     for (int q = 0; q < kSIter; ++q) { const int e = tid + 256 * q; if (e < D * D + D) S[e] = s_in[q]; }
+    if (top) {
+      // S -= sum over the top-level frames of Y^T Y, g_red -= Y^T z, on the matrix pipe: the (at most 64, zero-padded) rows are the k
+      // dimension, the column tiles (0,0), (0,1), (1,1) of the D + 1 <= 33 columns one wavefront each (v_mfma_f64_16x16x4; entries (i, j)
+      // and (j, i) are the same products in the same order: S stays symmetric to the bit).  (As a scalar loop -- thread per entry, two LDS
+      // reads per row and entry -- this took 6 us: 0.7 MB through the LDS pipe.)
+      __syncthreads();
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+      if (wave < 3) {
+        const int I = wave == 2 ? 1 : 0, J = wave == 0 ? 0 : 1;
+        const double* pa = top + (lane >> 4) * kTopLd + I * 16 + (lane & 15);
+        const double* pb = top + (lane >> 4) * kTopLd + J * 16 + (lane & 15);
+        // (four accumulators over the 16 k-steps of the 64 padded rows: the instruction's ~300 cycles of latency four times, not sixteen)
+        v4d ac[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ac[u] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 4) {
+          if (4 * ks < top_rows) {      // (wave-uniform)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ac[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(ks + u) * 4 * kTopLd], pb[(ks + u) * 4 * kTopLd], ac[u], 0, 0, 0);
+          }
+        }
+        const v4d acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = I * 16 + (lane >> 4) + 4 * g, col = J * 16 + (lane & 15);
+          if (row < D) {
+            if (col < D) { S[row * D + col] -= acc[g]; if (I != J) S[col * D + row] -= acc[g]; }
+            else if (col == D) S[D * D + row] -= acc[g];
+          }
+        }
+      }
+    }
   }
   VC_STAMP(1);
   for (int i = tid; i < D; i += 256) { hd[i] = 0.0; gs[i] = 0.0; }
@@ -1239,6 +1280,22 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   if (ct->done) { if (threadIdx.x == 0 && mode != 1) signal_flag(v, 1); return; }
   if (threadIdx.x < kMaxCams) s_cd[threadIdx.x] = v.cd[threadIdx.x];
   __shared__ double s_S[kSmallD * kSmallD + 3 * kSmallD + 2];      // single process, D <= kSmallD: the reduced system stays in LDS between the phases
+  // early Gram: [Y | z] rows of the chain's top-level frames, behind phase A's record in the dynamic region (static LDS is at its limit
+  // where the packed matrix of a D = 178 system takes 137 KB of the dynamic one)
+  double* s_top = dyn + (sizeof(FinalLds) + 7) / 8;
+  const bool early = v.gram_top_stride > 0 && mode == 0 && v.D <= kSmallD;
+  const int top_rows = early ? 9 * min(7, (v.n_frames - 1) / v.gram_top_stride + 1) : 0;
+  if (early) {
+    // the top-level frames' rows (final since the launch before the partial sums): requested first, their latency under everything below
+    double tin[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int idx = threadIdx.x + 256 * u, r = idx / kTopLd, c = idx - r * kTopLd;
+      tin[u] = (idx < 64 * kTopLd && r < top_rows && c <= v.D) ? v.cW[((size_t)(r / 9) * v.gram_top_stride * 9 + (r % 9)) * v.ldx + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 9; ++u) { const int idx = threadIdx.x + 256 * u; if (idx < 64 * kTopLd) s_top[idx] = tin[u]; }
+  }
   double pre_sc2 = 1.0, pre_dg = 1.0;      // damping inputs of the small solve: requested now, consumed after phase A
   double pre_imu = 0.0;                    // accepted IMU parameters (lane a of the wavefront whose thread forms the trial ones): the tail's
   if (mode != 1) {
@@ -1248,7 +1305,7 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   }
   const bool s_in_lds = mode == 0 && v.D <= kSmallD;
   if (s_in_lds) {
-    schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2, s_cd, s_S, true);
+    schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2, s_cd, s_S, true, early ? s_top : nullptr, top_rows);
     __syncthreads();
     // Sbuf keeps its meaning for k_final (cost slot) and the parity hooks: written back off the critical path
     for (int e = threadIdx.x; e < v.D * v.D + 3 * v.D + 2; e += 256) v.Sbuf[e] = s_S[e];
@@ -1847,7 +1904,8 @@ void launch_frame_schur(const DevView& v, hipStream_t s) {
 static inline size_t reduced_lds(const DevView& v) {
   const size_t solve = v.D <= kSmallD ? ((size_t)(kSmallD + 1) * (kSmallD + 2) + 3 * (kSmallD + 1)) * sizeof(double)
                                       : ((size_t)(v.D + 1) * (v.D + 2) / 2 + 3 * (v.D + 1) + 256 + 16 + 256) * sizeof(double);
-  return std::max(solve, sizeof(FinalLds));
+  const size_t top = (v.gram_top_stride > 0 && v.D <= kSmallD) ? (size_t)64 * kTopLd * sizeof(double) : 0;      // (k_reduced: s_top)
+  return std::max(solve, (sizeof(FinalLds) + 7) / 8 * 8 + top);
 }
 void launch_reduced(const DevView& v, int mode, hipStream_t s) {
   const size_t lds = reduced_lds(v);
