@@ -41,6 +41,8 @@ WORKLOADS = {
 }
 # HBM bytes per launch from rocprofv3 --pmc passes on the N = 1 default workload (profiles/, see README there)
 PMC_TRAFFIC = {}
+TRAFFIC_SOURCE = ("profiles/pmc_traffic_latest.json: HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc passes of this command "
+                  "taken on an earlier run and committed) -- NOT measured in this run")
 try:
     with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as _f:
         PMC_TRAFFIC = json.load(_f)
@@ -286,6 +288,9 @@ def main():
             "k_chain_init": ("hbm", flops_init, bytes_init), "k_chain_fwd": ("fp64-valu", flops_fwd, bytes_fwd),
             "k_chain_back": ("fp64-valu", flops_back, bytes_back), "k_chain_gram": ("mfma", flops_gram, bytes_gram),
             "k_reduced": ("fp64-valu", flops_red, bytes_red)}
+    if vi and "k_chain_gram" not in kt and "k_chain_fwd" in kt:
+        # early Gram: the Gram sums ride in the top level's launch -- the group k_chain_fwd carries their flops and bytes
+        algo["k_chain_fwd"] = ("fp64-valu", flops_fwd + flops_gram, bytes_fwd + bytes_gram)
     # launch groups that run on the second stream next to the critical path (vc_calibrator.cpp: enqueue_pass)
     overlapped = {"k_imu_weights", "k_imu_block(trial)", "k_imu_block", "k_imu_jac"} if vi else set()
     if vi and os.environ.get("VICALIB_AMD_JAC_STREAM2", "1") != "0" and os.environ.get("VICALIB_AMD_OVERLAP_WEIGHTS", "1") != "0":
@@ -325,9 +330,9 @@ def main():
         hbm = bound == "hbm"
         roofline = {"kernel": dom, "bound": bound, "achieved": e["hbm_gbs"] if hbm else e["tflops"], "peak": 8000.0 if hbm else 78.6,
                     "unit": "GB/s" if hbm else "TFLOP/s", "frac": e["hbm_frac"] if hbm else e["fp64_frac"],
-                    "traffic": pmc_traffic(dom) if world == 1 and not args.frames else None, "avg_ms": e["avg_ms"],
+                    "traffic": pmc_traffic(dom) if world == 1 and not args.frames else None, "traffic_source": TRAFFIC_SOURCE, "avg_ms": e["avg_ms"],
                     "algorithmic_flops": fl, "algorithmic_bytes": by, "hbm_gbs": e["hbm_gbs"], "hbm_frac": e["hbm_frac"],
-                    "launches_in_group": "one launch per level of the partitioned elimination" if "chain_fwd" in dom or "chain_back" in dom else 1,
+                    "launches_in_group": ("one launch per level of the partitioned elimination" + ("; the top level's launch also forms the chain's Gram sums" if "chain_fwd" in dom and "k_chain_gram" not in kt else "")) if "chain_fwd" in dom or "chain_back" in dom else 1,
                     "timing": "HIP events around every launch group of this kernel inside the timed LM loop (decisions live)"}
     # the step's critical path: the groups of the main stream in launch order, from the same in-loop events
     crit = [(k, e["ms_per_step"]) for k, e in kernels.items() if e["stream"].startswith("A")]
@@ -343,7 +348,20 @@ def main():
         e = kernels[nm]
         roofline_sweep = {"kernel": nm + " (residual + Jacobian + tile normal equations sweep)", "avg_ms": e["avg_ms"], "tflops": e["tflops"],
                           "fp64_frac": e["fp64_frac"], "hbm_gbs": e["hbm_gbs"], "hbm_frac": e["hbm_frac"],
-                          "traffic": PMC_TRAFFIC.get(wl, {}).get(nm.replace("(trial)", "")) if world == 1 and not args.frames else None}
+                          "traffic": PMC_TRAFFIC.get(wl, {}).get(nm.replace("(trial)", "")) if world == 1 and not args.frames else None,
+                          "traffic_source": TRAFFIC_SOURCE}
+    # the residual-only sweep (k_reproj_res; replaces Problem::Evaluate at vicalibrator.h:959-971, :873-898).  The LM
+    # loop no longer runs it (residual_sweeps: 0 -- the trial point is judged by the Jacobian sweeps themselves); the RMSE and outlier
+    # passes do.  Timed stand-alone, launches back to back on the calibrator's stream (vc_time_kernels).
+    roofline_res = None
+    if world == 1 and n_tiles > 0:
+        jac_alone_ms, res_ms = cal.time_kernels(50)
+        roofline_res = {"kernel": "k_reproj_res (residual-only sweep: RMSE / outlier passes)", "bound": "hbm", "avg_ms": res_ms,
+                        "algorithmic_bytes": bytes_res, "achieved": bytes_res / (res_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": bytes_res / (res_ms * 1e-3) / 8e12, "corners_per_sec": n_obs_local / (res_ms * 1e-3),
+                        "traffic": PMC_TRAFFIC.get(wl, {}).get("k_reproj_res") if not args.frames else None, "traffic_source": TRAFFIC_SOURCE,
+                        "timing": "50 stand-alone launches back to back between two HIP events on the calibrator's stream",
+                        "jacobian_sweep_alone_ms": jac_alone_ms, "jacobian_sweep_alone_fp64_frac": flops_jac / (jac_alone_ms * 1e-3) / 78.6e12}
     comm = None
     if world > 1 or force_shard:
         ar = {k: kernels[k] for k in kernels if k.startswith("allreduce")}
@@ -368,7 +386,7 @@ def main():
                        "reduced_dim": cal.shared_dim(),
                        "parallelism": "frames sharded x%d, all-reduce of reduced system per LM iteration (%s)" % (world, comm_kind)},
             "lm_iters_per_sec": iters_per_s, "jacobian_sweeps": jac_sweeps, "residual_sweeps": res_sweeps, "allreduce_calls": allreduce_calls,
-            "final_rmse_px": rmse, "complete_calibration": full, "roofline": roofline, "roofline_jacobian_sweep": roofline_sweep,
+            "final_rmse_px": rmse, "complete_calibration": full, "roofline": roofline, "roofline_jacobian_sweep": roofline_sweep, "roofline_residual_sweep": roofline_res,
             "critical_path": critical_path, "comm": comm, "kernels_in_loop": kernels,
         }
         if not args.no_secondary and world == 1 and not force_shard:
@@ -415,10 +433,18 @@ def secondary(device):
     t0 = time.perf_counter(); done, _, _ = cal.run_iterations(12); dt = time.perf_counter() - t0
     cal.set_kernel_timing(True); cal.run_iterations(12); kt = cal.kernel_timing(); cal.set_kernel_timing(False)
     jac = kt.get("k_reproj_jac(trial)", (0, float("nan")))[1]
-    out["cfg4_one_gpu"] = {"frames": len(p.frame_time), "corners": n, "reduced_dim": cal.shared_dim(), "ms_per_lm_iteration": 1e3 * dt / done,
+    jac_alone_ms, res_ms = cal.time_kernels(10)
+    n_tiles4 = cal.num_tiles()
+    bytes_res4 = 18.0 * n + n_tiles4 * (64 + 8)
+    out["cfg4_one_gpu"] = {"roofline_residual_sweep": {"kernel": "k_reproj_res", "avg_ms": res_ms, "algorithmic_bytes": bytes_res4, "hbm_gbs": bytes_res4 / (res_ms * 1e-3) / 1e9,
+                                                       "hbm_frac": bytes_res4 / (res_ms * 1e-3) / 8e12, "traffic": PMC_TRAFFIC.get("cfg4", {}).get("k_reproj_res"),
+                                                       "traffic_source": TRAFFIC_SOURCE, "jacobian_sweep_alone_ms": jac_alone_ms,
+                                                       "jacobian_sweep_alone_fp64_frac": 1050.0 * n / (jac_alone_ms * 1e-3) / 78.6e12},
+                           "frames": len(p.frame_time), "corners": n, "reduced_dim": cal.shared_dim(), "ms_per_lm_iteration": 1e3 * dt / done,
                            "corner_residuals_per_sec": n * done / dt, "kernels_in_loop_us": {k: 1e3 * v[1] for k, v in kt.items()},
                            "jacobian_sweep_tflops": 1050.0 * n / (jac * 1e-3) / 1e12, "jacobian_sweep_fp64_frac": 1050.0 * n / (jac * 1e-3) / 78.6e12,
                            "jacobian_sweep_hbm_frac": 18.0 * n / (jac * 1e-3) / 8e12}
+    out["cfg4_one_gpu"] = dict(sorted(out["cfg4_one_gpu"].items()))
     del cal, p
     for tag, frames in (("cfg2", 500), ("cfg2_x10", 5000)):
         p = synth.generate_native(synth.Config(models=("fov", "fov"), grid="small", n_frames=frames, imu=False))
@@ -477,6 +503,18 @@ def cpu_baseline(wl, prob):
 
     orc, nobs = build(threads)
     iters, t = run(orc, 12.0)
+    # "sweeps also timed alone" -- the residual-only sweep (Problem::Evaluate: every residual block, reprojection and IMU, no
+    # Jacobians) and the residual + Jacobian sweep (dual numbers, normal-equation blocks), same sample, same threads
+    def sweep_alone(fn, budget=2.0):
+        fn(); k = 0; t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget and k < 50:
+            fn(); k += 1
+        return k / (time.perf_counter() - t0)
+    res_rate = sweep_alone(orc.evaluate_cost)
+    jac_rate = sweep_alone(orc.linearize)
+    sweeps_alone = {"residual_only_corner_residuals_per_sec": nobs * res_rate, "residual_jacobian_corner_residuals_per_sec": nobs * jac_rate, "cores": threads,
+                    "what": "one sweep over all residual blocks of the sample (reprojection + IMU); the Jacobian leg forms the dual-number blocks and the normal-equation "
+                            "blocks (and copies them out: oracle linearize())"}
     ncpu = os.cpu_count() or threads
     all_cores = best = None
     if ncpu > threads:
@@ -501,7 +539,7 @@ def cpu_baseline(wl, prob):
             "sample": "%d LM-iteration work units of the %s (IMU weight update, dual-number Jacobian sweep, IMU blocks, block solve, cost sweep) on the "
                       "first %d of %d frames (%d corners) of %s, %.1f s" % (iters, "final stage" if vi else "vision-only solve", n_sub, len(prob.frame_time), nobs, wl, t),
             "lm_iters_per_sec_extrapolated_to_full": (nobs * iters / t) / prob.n_obs,
-            "all_cores": all_cores, "closed_form_cpu": best, "host": {"nproc": ncpu, "cpu": cpu_model}}
+            "sweeps_alone": sweeps_alone, "all_cores": all_cores, "closed_form_cpu": best, "host": {"nproc": ncpu, "cpu": cpu_model}}
 
 
 if __name__ == "__main__":
