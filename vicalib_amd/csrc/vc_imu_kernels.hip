@@ -616,12 +616,33 @@ __global__ __launch_bounds__(64) void k_imu_weights(DevView v, int wr) {
 #define ISTAMP(i) do { } while (0)
 #endif
 constexpr int kInitPad = 160;            // per wavefront behind the Gram records: Hs 42 | A 81 | g 9 | lambda 9 | tile cameras 8 | pad
+// Round 5: the loads of a frame are two dependent round trips instead of four (the frame's tile of every camera comes from
+// frame_cam_tile[f][c] -- requested before the control record has arrived; then everything else in one go: the tiles' Gram records, the
+// two IMU records, costs, damping state -- where round 4 walked frame_tile_off -> tile_cam -> IMU records -> Gram records), and a
+// wavefront that owns several frames of its chunk (large problems: the chunk grows with the frame count so that the whole grid is
+// resident at once) requests frame i + 1's data before it forms frame i's columns: a frame costs its arithmetic, not arithmetic + latency.
+// Stamps (tools/init_stamps.py) before the change: ~10 us of the ~20 us a frame took at every size were the four round trips.
+// CMAX: cameras the instance holds registers for (1, 2, 4, 8).
+template <int CMAX>
+struct InitLoads {
+  double gv[CMAX][3];          // Gram record of the frame's tile of camera c as it lies in HBM (packed upper triangle + side vector: entries lane, lane + 64, lane + 128 of kGPack)
+  double pre[9];               // lanes 0..14: couplings of IMU parameter `lane`; lanes 15..23: column lane - 15 of B
+  double a_imu[2], g_imu, sc2_in, dg_in, isum_in[4], cost_in;
+};
+template <int CMAX>
 __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two workgroups per CU: the kernel waits on memory)
   extern __shared__ __attribute__((aligned(16))) double sh[];
   __shared__ CamDesc s_cd[kMaxCams];
   __shared__ double s_R[kMaxCams * 9];   // the cameras' rotations R_ck, once per workgroup
   __shared__ int s_ci[256];              // what every image column is: owning camera (255: none) | column inside its block << 8 | "comes from the IMU records" << 16
   const Ctrl* ct = v.ctrl;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int C = v.n_cams, D = v.D, N = v.n_frames, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
+  const int chunk = blockIdx.x;
+  const int f0 = chunk * v.chunk_frames, f1 = min(f0 + v.chunk_frames, N);
+  // the first frame's tile list does not depend on the control record: requested ahead of it
+  auto load_fct = [&](int f) { return (lane < C && f < f1) ? v.frame_cam_tile[(size_t)f * C + lane] : -1; };
+  int fct = load_fct(f0 + wave);
 #ifdef VC_INIT_STAMPS
   const long long ist0_ = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -629,11 +650,97 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
 #ifdef VC_INIT_STAMPS
   if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) v.dbg[0] = ist0_;      // (not in passes that exit early)
 #endif
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int C = v.n_cams, D = v.D, N = v.n_frames, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
   const int cur = ct->cur;
   const int init_scale = ct->init_scale, reuse = ct->reuse_diag;
   const double radius = ct->radius;
+  int sp_col = -1;                                 // lanes 0..14: the column of IMU parameter `lane` (or none)
+#pragma unroll
+  for (int a = 0; a < 15; ++a) sp_col = (lane == a) ? v.imu_param_col[a] : sp_col;
+  // ---- everything a frame needs from memory, requested in one go (fct_f: lane c's tile of camera c in frame f, or -1)
+  auto issue = [&](int f, int fct_f, InitLoads<CMAX>& R) {
+    const bool live = f < f1;
+    const bool pin_f = (f == 0 && v.pin_first), pin_l = (f == N - 1 && v.pin_last), pin_self = pin_f || pin_l;
+    const bool pin_next = (f + 1 == N - 1 && v.pin_last);
+#if defined(VC_INIT_EXP) && (VC_INIT_EXP & 1)
+    const double* rc = nullptr; const double* rp = nullptr;      // experiment: no IMU-record loads
+#else
+    const double* rc = (live && f >= 1) ? v.segb[cur] + (size_t)(f - 1) * kSegStride : nullptr;
+    const double* rp = (live && f + 1 < N) ? v.segb[cur] + (size_t)f * kSegStride : nullptr;
+#endif
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+#if defined(VC_INIT_EXP) && (VC_INIT_EXP & 4)
+      const int tc = -1;                                                          // experiment: no Gram-record loads
+#else
+      const int tc = __builtin_amdgcn_readfirstlane(__shfl(fct_f, c, 64));      // (wave-uniform: a scalar branch per camera)
+#endif
+#pragma unroll
+      for (int q = 0; q < 3; ++q) R.gv[c][q] = 0.0;
+      if (c < C && tc >= 0) {
+        const double* g = v.Gb[cur] + (size_t)tc * kGPack;      // (three contiguous loads per tile; expanded to the 16 x 16 form on the way into LDS)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const int e = q * 64 + lane; const double x = g[e < kGPack ? e : 0]; R.gv[c][q] = e < kGPack ? x : 0.0; }
+      }
+    }
+    // Branch-free from here on: every lane loads from a valid address (a lane without an entry reads the start of record 0) and keeps
+    // the value or a zero by a select.  Loads under divergent branches are not hoisted out of them: round 4's form -- `if (lane has this
+    // entry) x += record[..]`, ~40 masked loads per frame -- ran them as a chain of dependent round trips, 8 of the 17 us a wavefront
+    // took at BASELINE cfg3 and 60 of 124 us at cfg5's per-rank size (tools/init_stamps.py with -DVC_INIT_EXP=1: the kernel without them).
+    const double* safe = v.cg;                 // (always there; only its first entry is ever read through `safe`, and the value is dropped)
+    const double* rcs = rc ? rc : safe;
+    const double* rps = rp ? rp : safe;
+    const bool has_c = rc != nullptr, has_p = rp != nullptr;      // wave-uniform
+    const int oc = has_c ? 1 : 0, op = has_p ? 1 : 0;             // offsets into an absent record collapse to 0
+    {
+      const bool tile_cost = lane < C && fct_f >= 0, blk_cost = lane == 8 && has_c;      // every block counted once, by its "cur" frame
+      const double* pcst = tile_cost ? v.tile_costb[cur] + fct_f : (blk_cost ? v.seg_costb[cur] + (f - 1) : safe);      // (has_c: f >= 1 and a block f - 1 exists)
+      const double x = *pcst;
+      R.cost_in = (tile_cost || blk_cost) ? x : 0.0;
+    }
+    {
+      // lanes 0..14: IMU parameter `lane`'s couplings with this frame (from both records); lanes 15..23: column lane - 15 of B
+      const bool isB = lane >= 15 && lane < 24 && has_p && !pin_self && !pin_next;
+      const bool par = lane < 15 && sp_col >= 0;
+      const int a = lane < 15 ? lane : 0, jb = lane >= 15 && lane < 24 ? lane - 15 : 0;
+      const double* pa = par ? rcs + (kSegWc + a) * oc : (isB ? rps + kSegBpc + jb : safe);
+      const int sa = par ? 15 * oc : (isB ? 9 : 0);
+      const bool va = (par && has_c) || isB;
+      const double* pb = par ? rps + (kSegWp + a) * op : safe;
+      const int sb = par ? 15 * op : 0;
+      const bool vb = par && has_p;
+      double xa[9], xb[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { xa[i] = pa[i * sa]; xb[i] = pb[i * sb]; }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R.pre[i] = (va ? xa[i] : 0.0) + (vb ? xb[i] : 0.0);
+    }
+    {
+      double xc[2], xp[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { const int e = lane + 64 * q, ee = e < 81 ? e : 0; xc[q] = rcs[(kSegAcc + ee) * oc]; xp[q] = rps[(kSegApp + ee) * op]; }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { const bool in = lane + 64 * q < 81; R.a_imu[q] = ((in && has_c) ? xc[q] : 0.0) + ((in && has_p) ? xp[q] : 0.0); }
+    }
+    {
+      const int l9 = lane < 9 ? lane : 0;
+      const size_t fo = (size_t)(live ? f : 0) * 9 + l9;
+      const double gc = rcs[(kSegGc + l9) * oc], gp = rps[(kSegGp + l9) * op], s2 = v.cscale2[fo], dgv = v.cdiag[fo];
+      const bool in = lane < 9 && live;
+      R.g_imu = ((in && has_c) ? gc : 0.0) + ((in && has_p) ? gp : 0.0);
+      R.sc2_in = (in && !init_scale) ? s2 : 0.0;
+      R.dg_in = (in && reuse) ? dgv : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {      // IMU shared block of block f-1 (every block counted once, by its "cur" frame)
+      const int e = lane + 64 * q, a = e >> 4, b2 = e & 15;
+      const bool in = a < 15;
+      const double x = rcs[(in ? ((b2 < 15) ? kSegHii + a * 15 + b2 : kSegGi + a) : 0) * oc];
+      R.isum_in[q] = (in && has_c) ? x : 0.0;
+    }
+  };
+  InitLoads<CMAX> R;
+  issue(f0 + wave, fct, R);
+  int fct_next = load_fct(f0 + wave + 4);          // the tile list of the frame after this one (one load, a frame ahead of its use)
   if (tid < kMaxCams) s_cd[tid] = v.cd[tid];
   if (tid < C) { double Rm[9]; quat_to_R(v.cams[cur] + (size_t)tid * kCamStride, Rm); for (int k = 0; k < 9; ++k) s_R[tid * 9 + k] = Rm[k]; }
   double* Gw = sh + wave * (C * kGStride + kInitPad);
@@ -643,16 +750,26 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
   double* ls = gs + 9;                   // its damping
   int* tcam = reinterpret_cast<int*>(ls + 9);      // cameras of the frame's tiles [8], then the frame's tile of every camera [8]
   int* tinv = tcam + kMaxCams;
-  const int chunk = blockIdx.x;
-  const int f0 = chunk * v.chunk_frames, f1 = min(f0 + v.chunk_frames, N);
-  double gsum[kMaxCams][5];     // [4]: the Gram record's side vector (lanes < 16)
+  double gsum[CMAX][3];         // per-camera sums of the chunk's Gram records, packed like the records
+  // where the lane's packed entries go in the 16 x 16 + 16 record: offset of (r, c), of (c, r), -1: no such entry
+  int po[3], pm[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int e = q * 64 + lane;
+    int r = 0;
+#pragma unroll
+    for (int a = 1; a < 16; ++a) r += (e >= a * 16 - (a * (a - 1)) / 2) ? 1 : 0;      // row of packed entry e (< kGPackGrad)
+    const int cidx = r + (e - (r * 16 - (r * (r - 1)) / 2));
+    po[q] = e < kGPackGrad ? r * 16 + cidx : (e < kGPack ? kGGrad + (e - kGPackGrad) : -1);
+    pm[q] = (e < kGPackGrad && cidx != r) ? cidx * 16 + r : -1;
+  }
   double isum[4] = {0.0, 0.0, 0.0, 0.0};      // IMU shared block: Hii[a][b] at a*16+b (a,b<15), g_i[a] at a*16+15
   double csum = 0.0;            // cost at the linearisation point: the frames' tiles (lanes 0..7) and IMU blocks (lane 8), summed per chunk here
                                 // instead of over all tiles and blocks by the one workgroup of k_reduced (32 of its 214 us at 50 000 tiles)
 #pragma unroll
-  for (int c = 0; c < kMaxCams; ++c)
+  for (int c = 0; c < CMAX; ++c)
 #pragma unroll
-    for (int q = 0; q < 5; ++q) gsum[c][q] = 0.0;
+    for (int q = 0; q < 3; ++q) gsum[c][q] = 0.0;
   // what each image column is, once for all frames of the chunk: owning camera and column inside its block; the columns that come
   // from the IMU records -- the (at most 15) IMU-parameter columns and the 9 columns of B -- belong to lanes 0..23 whatever their
   // position in the image, so that their values can be requested before anything else happens
@@ -667,16 +784,12 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
     }
     s_ci[col] = cam | (loc << 8) | (skip << 16);
   }
-  int sp_col = -1;                                 // lanes 0..14: the column of IMU parameter `lane` (or none)
-#pragma unroll
-  for (int a = 0; a < 15; ++a) sp_col = (lane == a) ? v.imu_param_col[a] : sp_col;
   __syncthreads();
   ISTAMP(1);
 
   for (int fg = f0; fg < f1; fg += 4) {
     const int f = fg + wave;
     if (f >= f1) continue;
-    const int t0 = v.frame_tile_off[f], nt = v.frame_tile_off[f + 1] - t0;
     double* Wf = v.cW + (size_t)f * 9 * ldx;     // the frame's image: [W | g] in columns 0..D, then (from ldw) C (zero) | A | B
     // pinned frames (separator / ghost, see DevView): their rows go to sep_strip, the chain sees an isolated identity block
     const bool pin_f = (f == 0 && v.pin_first), pin_l = (f == N - 1 && v.pin_last), pin_self = pin_f || pin_l;
@@ -684,75 +797,56 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
     double* Wt = pin_self ? v.sep_strip + (size_t)(pin_f ? 0 : 1) * 9 * ldw : Wf;
     const int ldt = pin_self ? ldw : ldx;         // row stride of Wt
     const int sep_self = pin_f ? v.sep_col0 : v.sep_col1;
-    // IMU blocks: block f-1 has this frame as "cur", block f as "prev"
-    const double* rc = (f >= 1) ? v.segb[cur] + (size_t)(f - 1) * kSegStride : nullptr;
+    const double* rc = (f >= 1) ? v.segb[cur] + (size_t)(f - 1) * kSegStride : nullptr;      // (the separator couplings below read them again: L2 hits)
     const double* rp = (f + 1 < N) ? v.segb[cur] + (size_t)f * kSegStride : nullptr;
-    // ---- everything the frame needs from memory is requested here, in one go: the tiles' Gram records (to LDS and into the
-    // chunk's per-camera sums), the parts of the two IMU records, the per-column couplings, the damping state
-    const int my_tc = (lane < nt) ? v.tile_cam[t0 + lane] : -1;
-    if (lane < nt) csum += v.tile_costb[cur][t0 + lane];
-    if (lane == 8 && rc) csum += v.seg_costb[cur][f - 1];          // every block counted once, by its "cur" frame
-    double pre[9];                                 // lanes 0..14: couplings of IMU parameter `lane`; lanes 15..23: column lane - 15 of B
-    {
-      const bool isB = lane >= 15 && lane < 24 && rp && !pin_self && !pin_next;
-      const int a = lane < 15 ? lane : 0, jb = lane >= 15 && lane < 24 ? lane - 15 : 0;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        double x = 0.0;
-        if (sp_col >= 0 && rc) x += rc[kSegWc + i * 15 + a];
-        if (sp_col >= 0 && rp) x += rp[kSegWp + i * 15 + a];
-        if (isB) x = rp[kSegBpc + i * 9 + jb];
-        pre[i] = x;
-      }
+    // ---- this frame's values out of the load registers: Gram records to LDS and into the chunk's per-camera sums, the rest to locals
+    const unsigned long long present = __ballot(lane < C && fct >= 0);
+    const int nt = __popcll(present);
+    if (lane < kMaxCams) {
+      const bool have = lane < C && fct >= 0;
+      const int slot = __popcll(present & ((1ull << lane) - 1ull));
+      tinv[lane] = have ? slot : -1;                       // the frame's tile slot of every camera
     }
-    double a_imu[2] = {0.0, 0.0}, g_imu = 0.0, sc2_in = 0.0, dg_in = 0.0;
+    wave_lds_sync_local();      // (wavefront scope: a workgroup-scope fence would wait for the next frame's loads)
+    if (lane < C && fct >= 0) tcam[tinv[lane]] = lane;     // camera of every slot
+    csum += R.cost_in;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int e = lane + 64 * q;
-      if (e < 81) { if (rc) a_imu[q] += rc[kSegAcc + e]; if (rp) a_imu[q] += rp[kSegApp + e]; }
-    }
-    if (lane < 9) {
-      if (rc) g_imu += rc[kSegGc + lane];
-      if (rp) g_imu += rp[kSegGp + lane];
-      if (!init_scale) sc2_in = v.cscale2[(size_t)f * 9 + lane];
-      if (reuse) dg_in = v.cdiag[(size_t)f * 9 + lane];
-    }
-    // IMU shared block of block f-1 (every block counted once, by its "cur" frame)
-    if (rc) {
+    for (int q = 0; q < 4; ++q) isum[q] += R.isum_in[q];
+    int slot_c = 0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int e = lane + 64 * q, a = e >> 4, b = e & 15;
-        if (a < 15) isum[q] += (b < 15) ? rc[kSegHii + a * 15 + b] : rc[kSegGi + a];
-      }
-    }
-    if (lane < kMaxCams) { tcam[lane] = my_tc; tinv[lane] = -1; }
-    wave_lds_sync();
-    ISTAMP(2);
-    if (lane < nt) tinv[my_tc] = lane;             // the frame's tile of every camera
-    for (int t = 0; t < nt; ++t) {
-      // (the tile's camera as a scalar: the per-camera sums take one add per loaded value behind a scalar branch, not a select
-      // over all cameras x slots -- 1600 selects per frame at 8 cameras)
-      const int c = __builtin_amdgcn_readfirstlane(__shfl(my_tc, t, 64));
-      double val[5];
+    for (int c = 0; c < CMAX; ++c) {
+      const bool have = c < C && ((present >> c) & 1ull);      // wave-uniform
+      if (have) {
 #pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        const int e = q * 64 + lane;
-        const int o = (q < 4) ? g_pack_idx(e >> 4, e & 15) : kGPackGrad + (lane & 15);      // (packed record in HBM: expanded on load)
-        val[q] = (q < 4 || lane < 16) ? v.Gb[cur][(size_t)(t0 + t) * kGPack + o] : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        const int o = (q < 4) ? q * 64 + lane : kGGrad + (lane & 15);
-        if (q < 4 || lane < 16) Gw[t * kGStride + o] = val[q];
-      }
-#pragma unroll
-      for (int k = 0; k < kMaxCams; ++k)
-        if (c == k) {
-#pragma unroll
-          for (int q = 0; q < 5; ++q) gsum[k][q] += val[q];
+        for (int q = 0; q < 3; ++q) {
+          if (po[q] >= 0) Gw[slot_c * kGStride + po[q]] = R.gv[c][q];
+          if (pm[q] >= 0) Gw[slot_c * kGStride + pm[q]] = R.gv[c][q];
+          gsum[c][q] += R.gv[c][q];
         }
+        ++slot_c;
+      }
     }
-    wave_lds_sync();
+    // the image columns that come straight from the IMU records (lanes 0..23) are written now: their registers are free for the next
+    // frame's loads
+    if (sp_col >= 0) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Wt[i * ldt + sp_col] = R.pre[i];
+      if (pin_self) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Wf[i * ldx + sp_col] = 0.0;
+      }
+    }
+    if (lane >= 15 && lane < 24) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Wf[i * ldx + ldw + 18 + (lane - 15)] = R.pre[i];
+    }
+    const double a_imu[2] = {R.a_imu[0], R.a_imu[1]};
+    const double g_imu = R.g_imu, sc2_in = R.sc2_in, dg_in = R.dg_in;
+    wave_lds_sync_local();
+    ISTAMP(2);
+    // ---- the next frame of this wavefront: its loads go out now, under this frame's arithmetic and stores
+    fct = fct_next;
+    if (f + 4 < f1) { issue(f + 4, fct, R); fct_next = load_fct(f + 8); }
     ISTAMP(3);
     // ---- visual part of the frame's own block: H_pp (6 x 6) and g_p (6) from the tiles (lanes 0..41)
     if (lane < 42) {
@@ -780,7 +874,7 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
       }
       Hs[lane] = hval;
     }
-    wave_lds_sync();
+    wave_lds_sync_local();
     ISTAMP(4);
     // ---- own block A (lane e = 9 i + j, two slots), right-hand side, damping
     double aval[2];
@@ -809,22 +903,9 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
       v.cg[(size_t)f * 9 + lane] = pin_self ? 0.0 : gval;
       gs[lane] = gval; ls[lane] = lam;
     }
-    wave_lds_sync();
+    wave_lds_sync_local();
     ISTAMP(5);
-    // ---- the image: every column written once.  First the columns that come from the IMU records (lanes 0..23) ...
-    if (sp_col >= 0) {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) Wt[i * ldt + sp_col] = pre[i];
-      if (pin_self) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Wf[i * ldx + sp_col] = 0.0;
-      }
-    }
-    if (lane >= 15 && lane < 24) {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) Wf[i * ldx + ldw + 18 + (lane - 15)] = pre[i];
-    }
-    // ... then all the others, one column per lane and round
+    // ---- the image: every column written once (the columns that come from the IMU records went out above); one column per lane and round
     for (int col = lane; col < ncol; col += 64) {
       const int ci = s_ci[col];
       if (ci >> 16) continue;
@@ -874,6 +955,9 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
 #pragma unroll
         for (int i = 0; i < 9; ++i) val[i] = pin_self ? ((i == jb) ? 1.0 : 0.0) : As[i * 9 + jb] + ((i == jb) ? ls[i] : 0.0);
       }
+#if defined(VC_INIT_EXP) && (VC_INIT_EXP & 2)
+      if (val[0] == 123.456)                       // experiment: no image stores
+#endif
       if (col < nW) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) Wt[i * ldt + col] = val[i];
@@ -886,7 +970,7 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
         for (int i = 0; i < 9; ++i) Wf[i * ldx + ldw + e] = val[i];
       }
     }
-    wave_lds_sync();
+    wave_lds_sync_local();
     ISTAMP(6);
   }
   // chunk sums of the camera Gram blocks and of the IMU shared block (4 wavefronts combined in fixed order)
@@ -894,11 +978,13 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
   ISTAMP(7);
   const int slot = C * kGStride + kGStride;
 #pragma unroll
-  for (int c = 0; c < kMaxCams; ++c)
+  for (int c = 0; c < CMAX; ++c)
     if (c < C) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) sh[wave * slot + c * kGStride + q * 64 + lane] = gsum[c][q];
-      if (lane < 16) sh[wave * slot + c * kGStride + kGGrad + lane] = gsum[c][4];
+      for (int q = 0; q < 3; ++q) {
+        if (po[q] >= 0) sh[wave * slot + c * kGStride + po[q]] = gsum[c][q];
+        if (pm[q] >= 0) sh[wave * slot + c * kGStride + pm[q]] = gsum[c][q];
+      }
     }
 #pragma unroll
   for (int q = 0; q < 4; ++q) sh[wave * slot + C * kGStride + q * 64 + lane] = isum[q];
@@ -2018,9 +2104,11 @@ int chain_forward_launches(const DevView& v) {
 void launch_chain_init(const DevView& v, hipStream_t s) {
   const size_t slot = (size_t)v.n_cams * kGStride + kGStride;
   const size_t lds = std::max((size_t)4 * (v.n_cams * kGStride + kInitPad), 4 * slot) * sizeof(double);
-  static size_t granted = 0;
-  if (lds > 65536 && lds > granted) { (void)hipFuncSetAttribute((const void*)k_chain_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
-  hipLaunchKernelGGL(k_chain_init, dim3(v.n_chunks), dim3(256), lds, s, v);
+  auto go = [&](auto kern) {
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(v.n_chunks), dim3(256), lds, s, v);
+  };
+  if (v.n_cams <= 1) go(k_chain_init<1>); else if (v.n_cams <= 2) go(k_chain_init<2>); else if (v.n_cams <= 4) go(k_chain_init<4>); else go(k_chain_init<8>);
 }
 void launch_chain_fwd(const DevView& v, hipStream_t s) { chain_levels(v, s, true); }
 void launch_chain_gram(const DevView& v, hipStream_t s) {
