@@ -245,6 +245,7 @@ struct vc_calibrator {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;        // the IMU weight update of a pass runs here, under the pass's Jacobian sweeps and chain solve
   hipEvent_t ev_state = nullptr, ev_weights = nullptr, ev_imujac = nullptr, ev_reduced = nullptr, ev_back = nullptr, ev_pre = nullptr;
+  bool top_gram_launch = false;         // early Gram: the chain's top-level frames need a Gram launch of their own (upload)
   bool pre_weights_pending = false;     // solve_once has recorded ev_pre ahead of the weight update that precedes a solve
   bool pre_weights_fresh = false;       // ... and nothing has moved the state since: the first pass's own update would repeat it
   int wcur = 0;                         // weight buffer holding the current weight_sqrt_
@@ -607,12 +608,12 @@ struct vc_calibrator {
     } HIP_OK(d_tile_trial.alloc((size_t)std::max(T, 1) * 2));
     HIP_OK(d_Y.alloc((size_t)std::max(T, 1) * kYStride)); HIP_OK(d_fr.alloc((size_t)std::max(N, 1) * kFrStride));
     HIP_OK(d_fdiag.alloc((size_t)std::max(N, 1) * 6)); HIP_OK(d_fscale2.alloc((size_t)std::max(N, 1) * 6));
-    HIP_OK(d_part.alloc((size_t)n_chunks * ((size_t)Dmax * Dmax + Dmax + C * kGStride + kGStride + 2)));
-    HIP_OK(d_part.alloc((size_t)n_chunks * part_stride)); HIP_OK(d_part_total.alloc((size_t)part_stride)); HIP_OK(d_Sbuf.alloc((size_t)D * D + 3 * D + 2));
+    HIP_OK(d_part.alloc((size_t)(n_chunks + 1) * ((size_t)Dmax * Dmax + Dmax + C * kGStride + kGStride + 2)));      // (+ 1: the chain's top level, early Gram)
+    HIP_OK(d_part.alloc((size_t)(n_chunks + 1) * part_stride)); HIP_OK(d_part_total.alloc((size_t)part_stride)); HIP_OK(d_Sbuf.alloc((size_t)D * D + 3 * D + 2));
     HIP_OK(d_sdiag.alloc(D)); HIP_OK(d_sscale2.alloc(D)); HIP_OK(d_slam.alloc(D)); HIP_OK(d_delta_s.alloc(D));
     HIP_OK(d_fpart.alloc((size_t)std::max(N, 1) * kNumScal));
     trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); HIP_OK(d_ctrl.alloc(2));
-    HIP_OK(hipMemsetAsync(d_part.p, 0, (size_t)n_chunks * part_stride * sizeof(double), stream));
+    HIP_OK(hipMemsetAsync(d_part.p, 0, (size_t)(n_chunks + 1) * part_stride * sizeof(double), stream));
     pack.zero(d_fpart.p, (size_t)std::max(N, 1) * kNumScal * sizeof(double));
     HIP_OK(d_scal.alloc(2 * kNumScal)); HIP_OK(d_flags.alloc(8));
     HIP_OK(d_wgpart.alloc((size_t)std::max(1, (T + 3) / 4) * kNumScal));
@@ -625,7 +626,7 @@ struct vc_calibrator {
     for (int c = 0; c < kMaxCams; ++c) { dv.cd[c].model = 0; dv.cd[c].flags = 0; dv.cd[c].col0 = 0; dv.cd[c].ncols = 0; }
     for (int c = 0; c < C; ++c) { dv.cd[c].model = cams[c].model; dv.cd[c].flags = cam_flags[c]; dv.cd[c].col0 = cam_col0[c]; dv.cd[c].ncols = cam_ncols(cam_flags[c], cams[c].nk); }
     dv.n_frames = N; dv.n_cams = C; dv.n_tiles = T; dv.n_points = n_points_dev; dv.D = D;
-    dv.n_chunks = n_chunks; dv.chunk_frames = chunk_frames; dv.n_obs = (long long)n_active;
+    dv.n_chunks = n_chunks; dv.n_part = n_chunks; dv.chunk_frames = chunk_frames; dv.n_obs = (long long)n_active;
     dv.obs_uv = d_uv.p; dv.obs_pt = d_pt.p; dv.points = d_points.p;
     dv.tile_hdr = d_tile_hdr.p;
     dv.tile_frame = d_tile_frame.p; dv.tile_cam = d_tile_cam.p; dv.tile_off = d_tile_off.p;
@@ -672,7 +673,13 @@ struct vc_calibrator {
       // early Gram (vc_device.h): narrow reduced systems of a single process; a function of the problem only, never of the hand-over
       // mode -- a solve resumed with events after a flag time-out must repeat the withheld passes with the same arithmetic
       static const bool early_env = [] { const char* e = std::getenv("VICALIB_AMD_EARLY_GRAM"); return !(e && e[0] == '0'); }();
-      dv.gram_top_stride = (early_env && dv.imu_on && D <= kSmallD && !sharded() && N >= 1) ? chain_top_stride(N) : 0;
+      // (where it pays: the top level's one group must outlast the Gram sums beside it -- at 6250 frames x 8 cameras, D = 115, the top
+      //  level is two frames and the sums take 50 us: 0.906 -> 0.938 ms per pass with them in its launch; at 2500 frames, D = 67: -4.5 us)
+      const bool narrow = D + 1 + 27 <= 128;      // at most two image columns per lane
+      dv.gram_top_stride = (early_env && dv.imu_on && N >= 1 && N <= 4096 && narrow) ? chain_top_stride(N) : 0;
+      // the top level's own frames: added by k_reduced (single process, narrow system) or a partial record of their own
+      top_gram_launch = dv.gram_top_stride > 0 && !(D <= kSmallD && !sharded());
+      dv.n_part = dv.n_chunks + (top_gram_launch ? 1 : 0);
     }
     dv.pin_first = (shard_imu && rank > 0) ? 1 : 0; dv.pin_last = ghost ? 1 : 0;
     dv.sep_col0 = D0 + 9 * (rank - 1); dv.sep_col1 = D0 + 9 * rank;
@@ -889,6 +896,7 @@ struct vc_calibrator {
       KT("k_chain_init", launch_chain_init(dv, stream));
       KT("k_chain_fwd", launch_chain_fwd(dv, stream));
       if (dv.gram_top_stride == 0) KT("k_chain_gram", launch_chain_gram(dv, stream));      // (early Gram: the sums ride in the top level's launch)
+      else if (top_gram_launch) KT("k_chain_gram(top)", launch_chain_gram_top(dv, stream));
       KT("k_part_sum", launch_part_sum(dv, stream));
       int rc = VC_OK;
       if (sharded()) {

@@ -83,6 +83,7 @@ struct TileHdr { int frame, cam, t0, nt, off, cnt, model, pad; unsigned long lon
 struct DevView {
   CamDesc cd[kMaxCams];
   int n_frames, n_cams, n_tiles, n_points, D, n_chunks, chunk_frames;
+  int n_part;                      // partial records k_part_sum adds: n_chunks, + 1 where the chain's top level has a record of its own (launch_chain_gram_top)
   long long n_obs;
   const double2* obs_uv;
   const unsigned short* obs_pt;
@@ -187,9 +188,10 @@ struct DevView {
   // pin_first: local frame 0 is this rank's separator; pin_last: local frame n_frames-1 is a copy ("ghost") of the next
   // rank's separator (columns sep_col1..+8), kept here because the IMU block that ends in it belongs to this rank.
   int pin_first, pin_last, sep_col0, sep_col1;
-  // Early Gram (visual-inertial, single process, D <= kSmallD): sum [Y | z]^T [Y | z] of every frame below the chain's top level is formed by
-  // extra workgroups of the top level's launch (beside its one group); the top level's own frames (index = 0 mod gram_top_stride, at most
-  // 7) are added by k_reduced itself from their images.  0: k_chain_gram is a launch of its own and covers every frame.
+  // Early Gram (visual-inertial passes): sum [Y | z]^T [Y | z] of every frame below the chain's top level is formed by extra workgroups of
+  // the top level's launch (beside its one group); the top level's own frames (index = 0 mod gram_top_stride, at most 7) are added by
+  // k_reduced itself from their images (single process, D <= kSmallD) or summed by a one-workgroup launch into partial record n_chunks
+  // (n_part = n_chunks + 1).  0: k_chain_gram is a launch of its own and covers every frame.
   // (Tried: the partial sums as extra workgroups of k_reduced's launch, delivered with device-coherent stores and a count the first
   //  workgroup waits for -- 36 us against 7.4 + 23 for the two launches: coherent stores, the count and the coherent loads behind it cost
   //  more than a kernel boundary)
@@ -240,6 +242,7 @@ void launch_chain_solve_a(const DevView& v, hipStream_t s);                 // t
 void launch_chain_init(const DevView& v, hipStream_t s);                    // frame images from the tile Gram records and the IMU blocks
 void launch_chain_fwd(const DevView& v, hipStream_t s);                     // forward elimination, one launch per level
 void launch_chain_gram(const DevView& v, hipStream_t s);                    // sum of [Y | z]^T [Y | z] per chunk
+void launch_chain_gram_top(const DevView& v, hipStream_t s);                // early Gram: the top level's frames as one more partial record
 void launch_chain_solve_b(const DevView& v, hipStream_t s);                 // back-substitution + trial frame state
 
 }  // namespace vc

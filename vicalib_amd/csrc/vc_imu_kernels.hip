@@ -1852,15 +1852,18 @@ constexpr int kMaxPairsPerWaveI = 9;
 // NL: entries of the 36 x ld row image per thread (36 ld / 256, rounded up).
 // mask_stride > 0: frames with index 0 (mod mask_stride) contribute nothing (the chain's top level: still being eliminated while this
 // runs beside it; k_reduced adds them from their finished images, see DevView::gram_top_stride)
+// gather_stride > 0: the chunk is the top level itself -- frames 0, gather_stride, 2 gather_stride, ... (at most 7), summed into the partial
+// record behind the dense chunks' (a launch of its own after the top level, where k_reduced does not add these frames itself)
 template <int NQ, int NL>
-__device__ __forceinline__ void chain_gram_chunk(const DevView& v, int chunk, double* R /* 36 x ld */, unsigned short* s_pair /* 128 */, int mask_stride) {
+__device__ __forceinline__ void chain_gram_chunk(const DevView& v, int chunk, double* R /* 36 x ld */, unsigned short* s_pair /* 128 */, int mask_stride, int gather_stride = 0) {
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
   GSTAMP(0);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int D = v.D, ld = v.ldw, N = v.n_frames;
   const int nT = (D + 1 + 15) / 16, nPairs = nT * (nT + 1) / 2;
-  const int f0 = chunk * v.chunk_frames, f1 = min(f0 + v.chunk_frames, N);
+  const int fstep = gather_stride > 0 ? gather_stride : 1;      // frame slot q of a group is frame (fg + q) fstep
+  const int f0 = gather_stride > 0 ? 0 : chunk * v.chunk_frames, f1 = gather_stride > 0 ? (N - 1) / gather_stride + 1 : min(f0 + v.chunk_frames, N);
   double* part = v.part + (size_t)chunk * v.part_stride;
   if (tid < nPairs) {
     int I = 0, J = 0;
@@ -1879,7 +1882,8 @@ __device__ __forceinline__ void chain_gram_chunk(const DevView& v, int chunk, do
     double tmp[NL];
     auto request = [&](int fg) {
       const int nrow = min(4, f1 - fg) * 9;
-      const double* src = v.cW + (size_t)fg * 9 * v.ldx;
+      const double* src = v.cW + (size_t)fg * fstep * 9 * v.ldx;
+      const unsigned skip = (unsigned)(fstep - 1) * 9u * (unsigned)v.ldx;      // extra offset per frame slot (0 for consecutive frames)
       unsigned mbits = 0u;                  // bit q: frame fg + q is masked (wave-uniform)
       if (mask_stride > 0) {
 #pragma unroll
@@ -1888,8 +1892,9 @@ __device__ __forceinline__ void chain_gram_chunk(const DevView& v, int chunk, do
       int row = row0, col = col0;
 #pragma unroll
       for (int u = 0; u < NL; ++u) {
-        const bool masked = (mbits >> ((row * 57) >> 9)) & 1u;      // (row / 9 for rows below 36)
-        tmp[u] = (row < nrow && !masked) ? src[(unsigned)(row * v.ldx + col)] : 0.0;      // (uniform base + 32-bit offset: one register per entry if hoisted)
+        const unsigned qf = (unsigned)(row * 57) >> 9;               // (row / 9 for rows below 36)
+        const bool masked = (mbits >> qf) & 1u;
+        tmp[u] = (row < nrow && !masked) ? src[(unsigned)(row * v.ldx + col) + qf * skip] : 0.0;      // (uniform base + 32-bit offset: one register per entry if hoisted)
         row += step_r; col += step_c;
         if (col >= ld) { col -= ld; ++row; }
       }
@@ -1934,28 +1939,31 @@ __device__ __forceinline__ void chain_gram_chunk(const DevView& v, int chunk, do
   GSTAMP(15);
 #endif
 }
+// gather = 0: one workgroup per chunk of consecutive frames (the top level's frames masked out where DevView::gram_top_stride is set);
+// gather = 1: one workgroup, the top level's frames into the partial record behind the dense chunks'
 template <int NQ, int NL>
-__global__ __launch_bounds__(256, 2) void k_chain_gram(DevView v) {
+__global__ __launch_bounds__(256, 2) void k_chain_gram(DevView v, int gather) {
   extern __shared__ __attribute__((aligned(16))) double R[];    // 36 x ld
   __shared__ unsigned short s_pair[128];                         // pair p -> I | J << 8
-  chain_gram_chunk<NQ, NL>(v, (int)blockIdx.x, R, s_pair, 0);
+  if (gather) chain_gram_chunk<NQ, NL>(v, v.n_chunks, R, s_pair, 0, v.gram_top_stride);
+  else chain_gram_chunk<NQ, NL>(v, (int)blockIdx.x, R, s_pair, v.gram_top_stride);
 }
-// The chain's top level (one group, one wavefront, 4-7 dependent eliminations: ~13 us at BASELINE cfg3 with the chip idle beside it) and, in
-// the same launch, the Gram sums of every frame below it -- final since the launch before: workgroup 0 eliminates, workgroups 1 .. n_chunks
-// are k_chain_gram's with the top level's frames masked out (DevView::gram_top_stride).  Narrow borders only (one image column per lane).
-template <int NQ>
+// The chain's top level (one group of NW wavefronts side by side, 4-7 dependent eliminations: ~13 us at BASELINE cfg3, 25-50 us with wide
+// borders, the chip idle beside it) and, in the same launch, the Gram sums of every frame below it -- final since the launch before:
+// workgroup 0 eliminates, workgroups 1 .. n_chunks are k_chain_gram's with the top level's frames masked out (DevView::gram_top_stride).
+template <int NW, int NQ, int NL>
 __global__ __launch_bounds__(256) void k_chain_top_gram(DevView v, int s, int m, int lvl) {
   extern __shared__ __attribute__((aligned(16))) double R[];    // 36 x ld
   __shared__ unsigned short s_pair[128];
   __shared__ __attribute__((aligned(16))) double XS[9 * kXsLd];
   __shared__ double An[81];
-  __shared__ double Ls_all[81];
+  __shared__ double Ls_all[NW * 81];
   if (blockIdx.x == 0) {
-    if (threadIdx.x >= 64) return;
-    chain_fwd_group<1, 1>(v, s, m, 1, lvl, 0, 0, XS, An, Ls_all);
+    if ((int)threadIdx.x >= 64 * NW) return;      // (a barrier counts the wavefronts that are still there)
+    chain_fwd_group<1, NW>(v, s, m, 1, lvl, 0, (int)(threadIdx.x >> 6), XS, An, Ls_all);
     return;
   }
-  chain_gram_chunk<NQ, 7>(v, (int)blockIdx.x - 1, R, s_pair, v.gram_top_stride);
+  chain_gram_chunk<NQ, NL>(v, (int)blockIdx.x - 1, R, s_pair, v.gram_top_stride);
 }
 
 // ------------------------------------------------------------------------------------------ launchers
@@ -1984,6 +1992,7 @@ int chain_group_size_upper() {
   if (!m) { const char* e = std::getenv("VICALIB_AMD_CHAIN_M_UPPER"); m = e ? std::max(2, std::min(kChainM, std::atoi(e))) : chain_group_size(); }
   return m;
 }
+void launch_chain_gram(const DevView& v, hipStream_t s);
 // Level schedule of the partitioned chain elimination: strides 1, m0, m0 m1, ... while more than m - 1 frames are active, then
 // the top level (one wavefront eliminates the rest).  forward: bottom-up; backward: top-down.
 static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
@@ -2039,13 +2048,25 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
   };
   if (forward) {
     for (int l = 0; l < nl; ++l) fwd((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1), strides[l], ms[l], 0, l);
-    if (v.gram_top_stride > 0 && cpl <= 1) {
+    const bool side_by_side_top = cpl <= 1 || !columns_per_lane;
+    if (v.gram_top_stride > 0 && side_by_side_top) {
       // early Gram: the top level's one group and the Gram sums of all frames below it in one launch
       const size_t lds = (size_t)36 * v.ldw * sizeof(double);
-      const int nT = (v.D + 1 + 15) / 16, nPairs = nT * (nT + 1) / 2;
-      if (nPairs <= 4) hipLaunchKernelGGL(k_chain_top_gram<1>, dim3(1 + v.n_chunks), dim3(256), lds, s, v, top_stride, m_top, nl);
-      else hipLaunchKernelGGL(k_chain_top_gram<2>, dim3(1 + v.n_chunks), dim3(256), lds, s, v, top_stride, m_top, nl);
-    } else fwd(1, top_stride, m_top, 1, nl);
+      const int nT = (v.D + 1 + 15) / 16, nPairs = nT * (nT + 1) / 2, nq = std::min(kMaxPairsPerWaveI, (nPairs + 3) / 4);
+      const int nlr = (36 * v.ldw + 255) / 256;
+      auto go = [&](auto kern) {
+        if (lds > 40000) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(1 + v.n_chunks), dim3(256), lds, s, v, top_stride, m_top, nl);
+      };
+      // (wavefronts of the top group by the border's width, Gram instance by the row image's size: the pairs that occur)
+      if (cpl <= 1) { if (nq <= 1) go(k_chain_top_gram<1, 1, 7>); else go(k_chain_top_gram<1, 2, 7>); }
+      else if (cpl <= 2) { if (nlr <= 12) go(k_chain_top_gram<2, 4, 12>); else if (nq <= 6) go(k_chain_top_gram<2, 6, 16>); else go(k_chain_top_gram<2, 9, 16>); }
+      else if (cpl <= 3) { if (nlr <= 16) go(k_chain_top_gram<3, 9, 16>); else if (nlr <= 21) go(k_chain_top_gram<3, 9, 21>); else go(k_chain_top_gram<3, 9, 25>); }
+      else { if (nlr <= 25) go(k_chain_top_gram<4, 9, 25>); else go(k_chain_top_gram<4, 9, 30>); }
+    } else {
+      fwd(1, top_stride, m_top, 1, nl);
+      if (v.gram_top_stride > 0) launch_chain_gram(v, s);      // (A/B hook VICALIB_AMD_CHAIN_WAVES=0: the same masked sums, a launch of their own)
+    }
   } else {
     hipLaunchKernelGGL(k_chain_back, dim3(1 + (nl > 0 ? (N + kBackT0Frames - 1) / kBackT0Frames : 0)), dim3(64), 0, s, v, top_stride, m_top, 1, nl, 0);
     // the levels below: one launch (k_chain_back_levels: ready words instead of kernel boundaries); VICALIB_AMD_BACK_FUSED=0: one launch per level
@@ -2111,12 +2132,12 @@ void launch_chain_init(const DevView& v, hipStream_t s) {
   if (v.n_cams <= 1) go(k_chain_init<1>); else if (v.n_cams <= 2) go(k_chain_init<2>); else if (v.n_cams <= 4) go(k_chain_init<4>); else go(k_chain_init<8>);
 }
 void launch_chain_fwd(const DevView& v, hipStream_t s) { chain_levels(v, s, true); }
-void launch_chain_gram(const DevView& v, hipStream_t s) {
+static void chain_gram_go(const DevView& v, hipStream_t s, int gather) {
   const size_t lds = (size_t)36 * v.ldw * sizeof(double);
   const int nT = (v.D + 1 + 15) / 16, nPairs = nT * (nT + 1) / 2, nq = std::min(kMaxPairsPerWaveI, (nPairs + 3) / 4);
   auto go = [&](auto kern) {
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(v.n_chunks), dim3(256), lds, s, v);
+    hipLaunchKernelGGL(kern, dim3(gather ? 1 : v.n_chunks), dim3(256), lds, s, v, gather);
   };
   // (pairs per wavefront, row-image entries per thread) by the number of column tiles: ld = 48, 80, 112, 144, 176, 208
   const int nl = (36 * v.ldw + 255) / 256;
@@ -2127,6 +2148,9 @@ void launch_chain_gram(const DevView& v, hipStream_t s) {
   else if (nl <= 25) go(k_chain_gram<9, 25>);
   else go(k_chain_gram<9, 30>);
 }
+void launch_chain_gram(const DevView& v, hipStream_t s) { chain_gram_go(v, s, 0); }
+// early Gram where k_reduced does not add the top level's frames itself (D > kSmallD, sharded passes): their sums as one more partial record
+void launch_chain_gram_top(const DevView& v, hipStream_t s) { chain_gram_go(v, s, 1); }
 void launch_chain_solve_a(const DevView& v, hipStream_t s) { launch_chain_init(v, s); launch_chain_fwd(v, s); launch_chain_gram(v, s); }
 void launch_chain_solve_b(const DevView& v, hipStream_t s) { chain_levels(v, s, false); }
 

@@ -631,7 +631,7 @@ template <int SLICES>
 __device__ __forceinline__ void part_sum_block(const DevView& v, int block, double* sl /* 16 x SLICES */) {
   if (v.ctrl->done) return;
   const int tid = threadIdx.x, e = block * kSumEntries + (tid & (kSumEntries - 1)), ks = tid / kSumEntries;
-  const int stride = v.part_stride, D = v.D, DD = D * D, n = v.n_chunks;
+  const int stride = v.part_stride, D = v.D, DD = D * D, n = v.n_part;
   int i = 0, j = 0;
   bool live = e < stride;
   if (e < DD) { i = e / D; j = e - i * D; live = (i >> 4) <= (j >> 4); }
