@@ -1518,10 +1518,12 @@ __device__ void trace_push(const DevView& v, Ctrl* c, const double* rec, bool wr
 }
 // s: the frame-side step scalars of the judged pass, fail: a factorisation of that pass broke down, writer: this caller owns
 // the global side effects (trace rows)
-__device__ void lm_decide_local(const DevView& v, Ctrl* c, const double* s, bool fail, bool writer) {
+// t: the shared parameters' terms (k_reduced: scal[8..15]), R_cost: cost at the linearisation point (Sbuf's cost slot) -- nullptr / NaN-free
+// defaults read them here; k_final's single-process path hands in what it requested at its entry
+__device__ void lm_decide_local(const DevView& v, Ctrl* c, const double* s, bool fail, bool writer, const double* t_in = nullptr, const double* cost_in = nullptr) {
   const int D = v.D;
-  const double* t = v.scal + kNumScal;
-  const double R_cost = v.Sbuf[(size_t)D * D + 3 * D];
+  const double* t = t_in ? t_in : v.scal + kNumScal;
+  const double R_cost = cost_in ? *cost_in : v.Sbuf[(size_t)D * D + 3 * D];
   const double R_gd = s[kScGd] + t[kScGd], R_dld = s[kScDld] + t[kScDld];
   const double R_step2 = s[kScStep2] + t[kScStep2], R_x2 = s[kScX2] + t[kScX2];
   const double R_gnorm = sqrt(s[kScG2] + t[kScG2]), R_gmax = fmax(s[kScGmax], t[kScGmax]);
@@ -1604,26 +1606,39 @@ __device__ __forceinline__ void publish_progress(const DevView& v, const Ctrl& c
 // void_pass: another rank of a sharded solve has marked this pass void (final_phase, mode 2) -- honoured whatever THIS rank's
 // hand-over mode: a rank on events must withhold the decision the flag ranks withhold, or the ranks' states and collective
 // schedules diverge
-__device__ void lm_decide(const DevView& v, bool void_pass = false) {
-  Ctrl local = *v.ctrl;          // one burst of loads, one burst of stores
+// Everything the deciding thread reads that this launch does not produce itself: the control record, the failure marks (set by the
+// chain kernels of the main stream, long done), the shared parameters' terms and the linearisation cost (k_reduced).  One burst of loads.
+struct DecideInputs { Ctrl c; double t[kNumScal]; double lin_cost; int f4, f5; };
+__device__ __forceinline__ void load_decide_inputs(const DevView& v, DecideInputs* in) {
+  in->c = *v.ctrl;
+  in->f4 = v.flags[4 + 2 * v.par]; in->f5 = v.flags[5 + 2 * v.par];
+#pragma unroll
+  for (int k = 0; k < kNumScal; ++k) in->t[k] = v.scal[kNumScal + k];
+  in->lin_cost = v.Sbuf[(size_t)v.D * v.D + 3 * v.D];
+}
+// s: the step scalars of the pass (v.scal, or registers of the launch that has just reduced them)
+__device__ void lm_decide_with(const DevView& v, DecideInputs& in, bool void_pass, const double* s) {
+  Ctrl& local = in.c;
   // device-flag hand-overs: a wait of this pass (or of one before it, noticed after that pass's decision) ran into its bound --
   // what this pass computed cannot be trusted.  No judgement: the record stays as the last valid decision left it, the solve ends
   // with kDoneSyncTimeout and the host resumes it with event hand-overs (vc_kutil.hpp: spin_until_flag)
-  if (v.sync_seq > 0 && !void_pass) {
-    const long long m = sync_marked(v);
-    void_pass = m != 0 && m <= v.sync_seq;
-  }
+  if (v.sync_seq > 0 && !void_pass) { const long long m = sync_marked(v); void_pass = m != 0 && m <= v.sync_seq; }
   if (void_pass) {
     local.done = kDoneSyncTimeout; local.abort_seq = (int)(v.pass_id & 0x7fffffff);      // (this pass is the first one without a decision; pass_id == sync_seq where flags are on)
     *v.ctrl = local;
     publish_progress(v, local);
     return;
   }
-  const bool fail = (v.flags[4 + 2 * v.par] != 0) || (v.flags[5 + 2 * v.par] != 0);
+  const bool fail = (in.f4 != 0) || (in.f5 != 0);
   v.flags[4 + 2 * v.par] = 0; v.flags[5 + 2 * v.par] = 0;
-  lm_decide_local(v, &local, v.scal, fail, true);
+  lm_decide_local(v, &local, s, fail, true, in.t, &in.lin_cost);
   *v.ctrl = local;
   publish_progress(v, local);
+}
+__device__ void lm_decide(const DevView& v, bool void_pass = false) {
+  DecideInputs in;
+  load_decide_inputs(v, &in);
+  lm_decide_with(v, in, void_pass, v.scal);
 }
 // ---- merged decision --------------------------------------------------------------------------------------------
 // The control record of the current pass from the previous pass's record: judge the pending trial point, or carry a finished
@@ -1740,6 +1755,9 @@ __device__ void final_phase(const DevView& v, int mode, double* red) {
       }
       __syncthreads();
     }
+#ifdef VC_FINAL_STAMPS
+    if (tid == 0) v.dbg[3] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     if (tid == 0) {
       double* o = v.scal;
       o[kScGd] = red[0]; o[kScDld] = red[256]; o[kScStep2] = red[512]; o[kScX2] = red[768]; o[kScG2] = red[1024];
@@ -1768,7 +1786,83 @@ __device__ void final_phase(const DevView& v, int mode, double* red) {
     if (void_pass && v.sync_seq > 0) mark_sync_timeout(v, v.sync_seq);
     v.flags[4 + 2 * v.par] = (fmod(o[kScSq], kShardMark) > 0.0) ? 1 : 0; v.flags[5 + 2 * v.par] = 0;
   }
+#ifdef VC_FINAL_STAMPS
+  if (tid == 0) v.dbg[4] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   if (mode != 1 && tid == 0) lm_decide(v, void_pass);
+}
+// Single-process visual-inertial pass (k_final, mode 0): the same sums, arranged around the wait.  The main stream's terms -- the
+// chain groups' step terms, the vision sweep's trial cost -- are reduced BEFORE the wait for the second stream's workgroup count
+// (wave shuffles + one LDS exchange instead of an eight-level tree of barriers), the second stream's trial cost behind it, and the deciding
+// thread takes the totals from registers.  Stamps (tools/final_stamps.py, round 4 form): 3.4 us reduction + 4.1 us decision behind the
+// count, all of it on the critical path at the end of every pass.
+__device__ void final_phase_vi(const DevView& v, double* red /* >= 40 */, bool counted, long long nwg_imu) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // (the deciding thread's inputs: requested first, 2.4 us of round trips that used to follow the last barrier)
+  DecideInputs din;
+  if (tid == 0) load_decide_inputs(v, &din);
+  double s[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+  for (int g = tid; g < v.n_chain_groups; g += 256) {
+    const double* p = v.grp_part + (size_t)g * kNumScal;
+    s[0] += p[kScGd]; s[1] += p[kScDld]; s[2] += p[kScStep2]; s[3] += p[kScX2]; s[4] += p[kScG2];
+    s[6] = fmax(s[6], p[kScGmax]);
+  }
+#pragma unroll 16
+  for (int t = tid; t < (v.n_tiles + 3) / 4; t += 256) s[5] += v.wg_trial[t];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) s[k] = wave_sum(s[k]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s[6] = fmax(s[6], __shfl_down(s[6], o, 64));
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) red[wave * 8 + k] = s[k];
+  }
+#ifdef VC_FINAL_STAMPS
+  if (tid == 0) v.dbg[8] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+  if (counted && tid == 0) {
+    // the count is a running one (never reset inside a solve: a reset could race with workgroups still adding); this kernel keeps
+    // the count at the end of the last judged pass in sync_flags[5]
+    const long long base = __hip_atomic_load(v.sync_flags + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    spin_until_flag(v, 4, base + nwg_imu);
+    __hip_atomic_store(v.sync_flags + 5, base + nwg_imu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next pass counts on from here
+  }
+  __syncthreads();
+  double b = 0.0;
+  if (v.final_wait > 0) {      // delivered by device-coherent stores while k_imu_jac still runs (see k_final)
+#pragma unroll 4
+    for (int t = tid; t < (v.n_frames - 1 + 7) / 8; t += 256) b += __hip_atomic_load(v.wg_imu_trial + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+#pragma unroll 4
+    for (int t = tid; t < (v.n_frames - 1 + 7) / 8; t += 256) b += v.wg_imu_trial[t];
+  }
+  b = wave_sum(b);
+  if (lane == 0) red[32 + wave] = b;
+#ifdef VC_FINAL_STAMPS
+  if (tid == 0) { v.dbg[3] = (long long)__builtin_amdgcn_s_memrealtime(); }
+#endif
+  __syncthreads();
+  if (tid == 0) {
+#ifdef VC_FINAL_STAMPS
+    v.dbg[4] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    double o[kNumScal];
+    const int idx[6] = {kScGd, kScDld, kScStep2, kScX2, kScG2, kScCost};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[idx[k]] = (red[k] + red[8 + k]) + (red[16 + k] + red[24 + k]);
+    o[kScCost] = 0.5 * (o[kScCost] + ((red[32] + red[33]) + (red[34] + red[35])));
+    o[kScGmax] = fmax(fmax(red[6], red[14]), fmax(red[22], red[30])); o[kScSq] = 0.0;
+#pragma unroll
+    for (int k = 0; k < kNumScal; ++k) v.scal[k] = o[k];      // (parity hooks read them)
+#ifdef VC_FINAL_STAMPS
+    v.dbg[9] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    lm_decide_with(v, din, false, o);
+#ifdef VC_FINAL_STAMPS
+    v.dbg[10] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+  }
 }
 // The waiting side as a kernel of its own: one wavefront on the second stream; the kernels behind it in that stream start when it
 // returns (vc_kutil.hpp: spin_until_flag).
@@ -1780,8 +1874,16 @@ __global__ __launch_bounds__(64) void k_wait_flag(DevView v, int idx, long long 
 __global__ __launch_bounds__(64) void k_signal_flag(DevView v, int idx) {
   if (threadIdx.x == 0) signal_flag(v, idx);
 }
+#ifdef VC_FINAL_STAMPS
+#define FSTAMP(i) do { if (threadIdx.x == 0 && !over_) v.dbg[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
   __shared__ double red[256 * 7];
+#ifdef VC_FINAL_STAMPS
+  const long long fs0_ = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   // the second stream's share of the trial cost (k_imu_jac's workgroup sums): wait for its flag here, inside the kernel, instead of
   // behind a cross-stream event (12 us between the second stream's last kernel and this one on the timeline); every wavefront
   // then drops what it may have cached of the other stream's results.  Also when the solve is over: the main stream must not
@@ -1794,10 +1896,16 @@ __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
   // Sharded (mode 1: reduce, all-reduce, mode 2: decide): the first wait belongs to the reducing launch, the second wait and the
   // flag to the deciding one.
   const bool over = v.ctrl->done != 0;
+  [[maybe_unused]] const bool over_ = over;
+#ifdef VC_FINAL_STAMPS
+  if (threadIdx.x == 0 && !over) v.dbg[0] = fs0_;
+#endif
+  FSTAMP(1);
   __shared__ long long s_count_base;
   const long long nwg_imu = (long long)((v.n_frames - 1 + 7) / 8);
   const bool counted = v.final_wait > 0 && !over && v.n_frames > 1 && mode != 2;
-  if (counted) {
+  const bool vi_single = mode == 0 && v.imu_on && !over;      // the count is waited for inside final_phase_vi, behind the main stream's sums
+  if (counted && !vi_single) {
     // the count is a running one (never reset inside a solve: a reset could race with workgroups still adding); this kernel keeps
     // the count at the end of the last judged pass in sync_flags[5]
     if (threadIdx.x == 0) {
@@ -1807,8 +1915,11 @@ __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
     }
     __syncthreads();
   }
-  if (!over) final_phase(v, mode, red);
+  FSTAMP(2);
+  if (vi_single) final_phase_vi(v, red, counted, nwg_imu);
+  else if (!over) final_phase(v, mode, red);
   if (mode == 1) return;
+  FSTAMP(5);
   __syncthreads();
   if (v.final_wait > 0) {
     if (threadIdx.x == 0) {
@@ -1816,8 +1927,10 @@ __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
     }
     __syncthreads();
   }
+  FSTAMP(6);
   // (a pass that has been marked void still signals: the next pass's waiters return at once anyway, and the host takes over)
   if (threadIdx.x == 0) signal_flag(v, 0);
+  FSTAMP(7);
 }
 
 // One stage's small uploads (vc_calibrator.cpp: upload): the host packs them into one page-locked staging image that goes to the
@@ -1881,7 +1994,19 @@ static inline int tiles_grid(const DevView& v) { return (v.n_tiles + 3) / 4; }
 
 void launch_reproj_jac(const DevView& v, hipStream_t s, int trial) {
   if (v.n_tiles == 0) return;
-  const size_t lds = 4 * 64 * kDotStride * sizeof(double);
+  size_t lds = 4 * 64 * kDotStride * sizeof(double);
+  // Visual-inertial trial sweep: k_imu_jac(trial) starts on the second stream a few microseconds behind this kernel.  Both take ~230
+  // registers; two workgroups of this kernel per CU (two wavefronts per SIMD) leave no room for a wavefront of the other, which then runs
+  // behind this kernel's first round instead of beside it (26 instead of 17 us, and the pass ends with it).  One workgroup per CU here --
+  // a larger LDS request is the lever a launch has -- lets the two share every SIMD from the start: k_imu_jac 18 us, this kernel 24 us
+  // instead of 16 and now the last to end, with k_final's start-up no longer hidden behind the other stream: 0.2075 against 0.2035 ms per
+  // iteration.  Off; VICALIB_AMD_TRIAL_ONE_WG=1 for A/B runs
+  static const bool one_wg = [] { const char* e = std::getenv("VICALIB_AMD_TRIAL_ONE_WG"); return e && e[0] == '1'; }();
+  if (trial && v.imu_on && one_wg && tiles_grid(v) <= 1024) {
+    lds = 88 * 1024;
+    static bool granted = false;
+    if (!granted) { (void)hipFuncSetAttribute((const void*)k_reproj_jac, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = true; }
+  }
   hipLaunchKernelGGL(k_reproj_jac, dim3(tiles_grid(v)), dim3(256), lds, s, v, trial);
 }
 void launch_part_sum(const DevView& v, hipStream_t s) {
