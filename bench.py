@@ -313,7 +313,7 @@ def main():
         t = PMC_TRAFFIC.get(wl, {})
         base = group.replace("(trial)", "")
         if base == "k_chain_fwd":
-            parts = [t.get("k_chain_fwd@pass"), t.get("k_chain_fwd2@pass")]
+            parts = [t.get("k_chain_fwd@pass"), t.get("k_chain_fwd2@pass"), t.get("k_chain_top_gram@pass", t.get("k_chain_top_gram"))]
             return sum(x for x in parts if x) if any(parts) else t.get(base)
         if base == "k_chain_back":
             return t.get("k_chain_back@pass", t.get(base))

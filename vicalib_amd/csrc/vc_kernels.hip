@@ -629,7 +629,9 @@ __global__ __launch_bounds__(256, MINW) void k_frame_schur(DevView v) {
 constexpr int kSumEntries = 16, kSumSlices = 32;
 template <int SLICES>
 __device__ __forceinline__ void part_sum_block(const DevView& v, int block, double* sl /* 16 x SLICES */) {
-  if (v.ctrl->done) return;
+  // (the control record is requested here and looked at once the partials have been requested as well: a finished solve costs a few
+  //  wasted loads, a running one saves the record's round trip ahead of the sum's)
+  const int done = v.ctrl->done;
   const int tid = threadIdx.x, e = block * kSumEntries + (tid & (kSumEntries - 1)), ks = tid / kSumEntries;
   const int stride = v.part_stride, D = v.D, DD = D * D, n = v.n_part;
   int i = 0, j = 0;
@@ -641,6 +643,7 @@ __device__ __forceinline__ void part_sum_block(const DevView& v, int block, doub
 #pragma unroll 16
     for (int k = ks; k < n; k += SLICES) s += src[(size_t)k * stride];
   }
+  if (done) return;
   sl[tid] = s;
   __syncthreads();
   if (tid < kSumEntries && live) {
