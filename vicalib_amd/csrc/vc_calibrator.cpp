@@ -940,8 +940,7 @@ struct vc_calibrator {
           HIP_OK(hipStreamWaitEvent(stream2, ev_back, 0));
         }
         KT2("k_imu_jac(trial)", launch_imu_jac(dv, wcur, stream2, 1));
-        if (fs_trial) launch_signal_flag(dv, 3, stream2);
-        else HIP_OK(hipEventRecord(ev_weights, stream2));
+        if (!fs_trial) HIP_OK(hipEventRecord(ev_weights, stream2));      // (flag hand-overs: k_final ends on the second count of k_imu_jac's workgroups)
         KT("k_reproj_jac(trial)", launch_reproj_jac(dv, stream, 1));
         if (!fs_trial) HIP_OK(hipStreamWaitEvent(stream, ev_weights, 0));      // (flag hand-overs: k_final waits for the second stream itself)
       } else {

@@ -135,7 +135,7 @@ struct DevView {
   int* flags;                      // [0]: frame Cholesky failures, [1]: reduced Cholesky failure (per pass)
   // cross-stream hand-overs without event records on the main stream (visual-inertial pass, single process): single-workgroup
   // kernels publish the pass number when they are done, a one-wavefront kernel on the second stream waits for it
-  long long* sync_flags;           // [0]: k_final, [1]: k_reduced, [2]: back-substitution done (k_reproj_jac(trial) has started), [3]: second stream's trial-point kernels done, [4]: workgroups of k_imu_jac(trial) that have delivered their cost share (a running count, never reset inside a solve), [5]: that count at the end of the last judged pass (k_final's own book-keeping), [6]: STICKY -- number of the first pass in which a wait ran into its bound (0: none), [7]: bottom level of the chain elimination complete
+  long long* sync_flags;           // [0]: k_final, [1]: k_reduced, [2]: back-substitution done (k_reproj_jac(trial) has started), [3]: second stream's trial-point kernels done, [4]: workgroups of k_imu_jac(trial) that have delivered their cost share (a running count, never reset inside a solve), [5]: that count at the end of the last judged pass (k_final's own book-keeping), [6]: STICKY -- number of the first pass in which a wait ran into its bound (0: none), [7]: bottom level of the chain elimination complete, [11]: workgroups of k_imu_jac(trial) whose records have been performed (running count), [12]: that count at the end of the last judged pass
   long long sync_seq;              // this pass's number (0: no signalling)
   long long block_wait;            // k_imu_block(trial): one thread waits for sync_flags[2] >= block_wait before the kernel ends (0: no)
   long long final_wait;            // k_final waits for sync_flags[3] >= final_wait before it reads the second stream's sums (0: ordered by an event)

@@ -57,7 +57,12 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   __shared__ double sh[8 * kImuJacLds];
   IJSTAMP(0);
   const Ctrl* ct = v.ctrl;
-  if (ct->done || (!trial && !ct->need_lin)) return;
+  if (ct->done || (!trial && !ct->need_lin)) {
+    // (a finished solve: the workgroup still counts itself in the second count -- k_final of this pass waits for it, so that the main
+    //  stream never runs ahead of this one into the next solve)
+    if (trial && v.final_wait > 0 && threadIdx.x == 0) __hip_atomic_fetch_add(v.sync_flags + 11, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int half = lane >> 5, l = lane & 31;
   const int n_blocks = v.n_frames - 1;
@@ -119,7 +124,11 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
     }
   }
   IJSTAMP(3);
-  if (!exists) return;
+  // flag hand-overs, trial sweep: the records go out as device-coherent stores and the workgroup counts itself a second time once they
+  // have been performed -- k_final ends on that count (round 4: on a flag a one-thread kernel raised behind this one, 6 us after this
+  // kernel's end, which since round 5's leaner k_final was what the pass ended on)
+  const bool counted2 = trial && v.final_wait > 0;
+  if (exists) {
   // J^T J and J^T r of the block in the compact record: entry e = w * <column a, column b> with the residual as column 33
   // (statically unrolled, the (row, column) pairs of the lane's 25 entries requested at the kernel's entry: as a loop every entry
   //  waited for its own table look-up -- 25 dependent global round trips, 10 of the kernel's 24 us at cfg3)
@@ -131,9 +140,15 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc += Jl[a * 9 + k] * Jl[bb * 9 + k];
-    if (e < kSegLen) rec[e] = w * acc;
+    if (e < kSegLen) { if (counted2) __hip_atomic_store(rec + e, w * acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else rec[e] = w * acc; }
   }
-  if (l == 0) v.seg_costb[cur][s] = ct->imu_mult * rho;
+  if (l == 0) { if (counted2) __hip_atomic_store(v.seg_costb[cur] + s, ct->imu_mult * rho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else v.seg_costb[cur][s] = ct->imu_mult * rho; }
+  }
+  if (counted2) {
+    __builtin_amdgcn_s_waitcnt(0);          // this wavefront's stores have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(v.sync_flags + 11, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   IJSTAMP(4);
 }
 

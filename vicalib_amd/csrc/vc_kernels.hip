@@ -1620,12 +1620,13 @@ __device__ __forceinline__ void load_decide_inputs(const DevView& v, DecideInput
   in->lin_cost = v.Sbuf[(size_t)v.D * v.D + 3 * v.D];
 }
 // s: the step scalars of the pass (v.scal, or registers of the launch that has just reduced them)
-__device__ void lm_decide_with(const DevView& v, DecideInputs& in, bool void_pass, const double* s) {
+// marked: the sticky time-out word if the caller has read it already (behind its last wait), -1: read here
+__device__ void lm_decide_with(const DevView& v, DecideInputs& in, bool void_pass, const double* s, long long marked = -1) {
   Ctrl& local = in.c;
   // device-flag hand-overs: a wait of this pass (or of one before it, noticed after that pass's decision) ran into its bound --
   // what this pass computed cannot be trusted.  No judgement: the record stays as the last valid decision left it, the solve ends
   // with kDoneSyncTimeout and the host resumes it with event hand-overs (vc_kutil.hpp: spin_until_flag)
-  if (v.sync_seq > 0 && !void_pass) { const long long m = sync_marked(v); void_pass = m != 0 && m <= v.sync_seq; }
+  if (v.sync_seq > 0 && !void_pass) { const long long m = marked >= 0 ? marked : sync_marked(v); void_pass = m != 0 && m <= v.sync_seq; }
   if (void_pass) {
     local.done = kDoneSyncTimeout; local.abort_seq = (int)(v.pass_id & 0x7fffffff);      // (this pass is the first one without a decision; pass_id == sync_seq where flags are on)
     *v.ctrl = local;
@@ -1832,6 +1833,8 @@ __device__ void final_phase_vi(const DevView& v, double* red /* >= 40 */, bool c
     __hip_atomic_store(v.sync_flags + 5, base + nwg_imu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next pass counts on from here
   }
   __syncthreads();
+  // (the sticky time-out word: behind this launch's last wait that could set it, requested together with the second stream's costs)
+  const long long marked = (tid == 0 && v.sync_seq > 0) ? sync_marked(v) : 0;
   double b = 0.0;
   if (v.final_wait > 0) {      // delivered by device-coherent stores while k_imu_jac still runs (see k_final)
 #pragma unroll 4
@@ -1861,7 +1864,7 @@ __device__ void final_phase_vi(const DevView& v, double* red /* >= 40 */, bool c
 #ifdef VC_FINAL_STAMPS
     v.dbg[9] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    lm_decide_with(v, din, false, o);
+    lm_decide_with(v, din, false, o, marked);
 #ifdef VC_FINAL_STAMPS
     v.dbg[10] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -1924,9 +1927,14 @@ __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
   if (mode == 1) return;
   FSTAMP(5);
   __syncthreads();
-  if (v.final_wait > 0) {
+  if (v.final_wait > 0 && v.n_frames > 1) {
+    // the second stream's records are complete: every workgroup of k_imu_jac(trial) has counted itself a second time behind its
+    // (device-coherent) stores -- a running count like the first, this kernel's book-keeping in sync_flags[12].  Also when the solve is
+    // over (the workgroups count themselves at their exit): the main stream must not run ahead of the second one into the next solve.
     if (threadIdx.x == 0) {
-      spin_until_flag(v, 3, v.final_wait);
+      const long long base = __hip_atomic_load(v.sync_flags + 12, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      spin_until_flag(v, 11, base + nwg_imu);
+      __hip_atomic_store(v.sync_flags + 12, base + nwg_imu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
   }
