@@ -291,7 +291,7 @@ def main():
     if vi and "k_chain_gram" not in kt and "k_chain_fwd" in kt:
         # early Gram: the Gram sums ride in the top level's launch -- the group k_chain_fwd carries their flops and bytes
         algo["k_chain_fwd"] = ("fp64-valu", flops_fwd + flops_gram, bytes_fwd + bytes_gram)
-    # launch groups that run on the second stream next to the critical path (vc_calibrator.cpp: enqueue_pass)
+    # launch groups that run on the second stream next to the critical path (vc_pass.cpp: enqueue_pass)
     overlapped = {"k_imu_weights", "k_imu_block(trial)", "k_imu_block", "k_imu_jac"} if vi else set()
     if vi and os.environ.get("VICALIB_AMD_JAC_STREAM2", "1") != "0" and os.environ.get("VICALIB_AMD_OVERLAP_WEIGHTS", "1") != "0":
         overlapped.add("k_imu_jac(trial)")      # beside the vision sweep of the trial point (round 3)
@@ -446,6 +446,35 @@ def secondary(device):
                            "jacobian_sweep_hbm_frac": 18.0 * n / (jac * 1e-3) / 8e12}
     out["cfg4_one_gpu"] = dict(sorted(out["cfg4_one_gpu"].items()))
     del cal, p
+    # (c) the image front-end (dot detection ahead of the solver; vc_detect.hip): images per second through the C ABI --
+    # host image in, dot centres out (upload, integral image, adaptive threshold, labelling, statistics, one conic fit per dot, download).
+    # Untuned kernels of a few hundred wavefronts each; informational.
+    try:
+        from vicalib_amd.lib import ConicDetector
+        det_out = {}
+        for (w, h, nx, ny, r) in ((640, 480, 13, 9, 9.0), (1280, 960, 26, 18, 9.0)):
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = np.full((h, w), 230.0)
+            for j in range(ny):
+                for i in range(nx):
+                    cx, cy = (i + 1.0) * w / (nx + 1.0), (j + 1.0) * h / (ny + 1.0)
+                    rr = r if (i * 7 + j * 3) % 3 else 0.66 * r
+                    x0, x1, y0, y1 = int(cx - rr - 2), int(cx + rr + 3), int(cy - rr - 2), int(cy + rr + 3)
+                    d2 = (xx[y0:y1, x0:x1] - cx) ** 2 + (yy[y0:y1, x0:x1] - cy) ** 2
+                    img[y0:y1, x0:x1] = np.where(d2 < rr * rr, 25.0, img[y0:y1, x0:x1])
+            img8 = img.astype(np.uint8)
+            det = ConicDetector(w, h, device); det.set_params()
+            found = det.find(img8)
+            reps = 40
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                det.find(img8)
+            dt = time.perf_counter() - t0
+            det_out["%dx%d" % (w, h)] = {"dots_rendered": nx * ny, "dots_found": int(len(found)), "images_per_sec": reps / dt, "ms_per_image": 1e3 * dt / reps}
+            det.close()
+        out["detector"] = det_out
+    except Exception as e:      # noqa: BLE001
+        out["detector"] = {"error": str(e)}
     for tag, frames in (("cfg2", 500), ("cfg2_x10", 5000)):
         p = synth.generate_native(synth.Config(models=("fov", "fov"), grid="small", n_frames=frames, imu=False))
         cal = ViCalibrator(device).load_problem(p); cal.SetCalibrateImu(False); cal.prepare()

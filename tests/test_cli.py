@@ -213,3 +213,17 @@ def test_cli_calibrates_from_images(tmp_path):
     # a preset's pattern cannot be known without Calibu: refused with an explanation, not guessed
     r = _run(["-cam", "file://" + str(tmp_path / "view_*.pgm"), "-grid_preset", "small", "-models", "linear", "-nocalibrate_imu"])
     assert r.returncode == 1 and "grid_pattern_file" in r.stderr
+    # ... and with the printed target's pattern supplied (-grid_pattern_file: rows of 0 / 1, 1 = large dot) a preset's target is usable with
+    # images: the file's rows / columns replace the preset's, the preset keeps its spacing default unless -grid_spacing says otherwise
+    # (vicalib-engine.cc:453-465 resolve the pattern inside Calibu; this is the escape hatch for a tree without it)
+    pf = tmp_path / "pattern.txt"
+    with open(pf, "w") as f:
+        f.write("# 13 x 9 two-size dot target, the pattern of -grid_seed 71\n")
+        for row in np.asarray(pat).reshape(9, 13):
+            f.write(" ".join(str(int(x)) for x in row) + "\n")
+    out2 = tmp_path / "cameras_pattern.xml"
+    r = _run(["-cam", "file://" + str(tmp_path / "view_*.pgm"), "-grid_preset", "small", "-grid_pattern_file", str(pf), "-grid_spacing", "0.022",
+              "-models", "linear", "-nocalibrate_imu", "-output", str(out2)])
+    assert r.returncode == 0, r.stderr[-3000:]
+    typ2, K2, T2 = _read_xml(str(out2))[0]
+    np.testing.assert_allclose(K2, K, rtol=1e-9)          # the same target, the same calibration

@@ -5,7 +5,7 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT="$HERE/../libvicalib_amd.so"
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
-  -o "$OUT" "$HERE/vc_kernels.hip" "$HERE/vc_imu_kernels.hip" "$HERE/vc_detect.hip" "$HERE/vc_calibrator.cpp" "$@"
+  -o "$OUT" "$HERE/vc_kernels.hip" "$HERE/vc_imu_kernels.hip" "$HERE/vc_detect.hip" "$HERE/vc_upload.cpp" "$HERE/vc_pass.cpp" "$HERE/vc_solve.cpp" "$HERE/vc_capi.cpp" "$@"
 echo "built $OUT"
 # the synthetic-problem generator (host only; test / bench infrastructure): vicalib_amd/libvicalib_synth.so
 ${CXX:-g++} -O2 -std=c++17 -fPIC -shared -Wall -pthread -o "$HERE/../libvicalib_synth.so" "$HERE/vc_synth.cpp"

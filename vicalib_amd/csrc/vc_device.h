@@ -1,4 +1,4 @@
-// vc_device.h -- device-side views shared by the host driver (vc_calibrator.cpp)
+// vc_device.h -- device-side views shared by the host driver (vc_calibrator.hpp and its translation units)
 // and the HIP kernels (vc_kernels.hip).  HBM layout (see DESIGN.md "Data layout"):
 //   observations  tile-sorted SoA: obs_uv[n] (16 B) + obs_pt[n] (u16 index into points[]) = 18 B / corner
 //   tiles         (frame, camera) groups: tile_frame, tile_cam, tile_off[n_tiles+1]

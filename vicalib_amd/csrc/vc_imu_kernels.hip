@@ -2031,7 +2031,7 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
   // VICALIB_AMD_CHAIN_TWO=0: one-sided throughout
   static const bool two_env = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO"); return !(e && std::atoi(e) == 0); }();
   const bool two_sided = two_env && cpl <= 2;
-  // ... and at the bottom level too once the weight update on the other stream starts behind it (vc_calibrator.cpp: enqueue_pass;
+  // ... and at the bottom level too once the weight update on the other stream starts behind it (vc_pass.cpp: enqueue_pass;
   // VICALIB_AMD_CHAIN_TWO_BOTTOM=0: one-sided bottom level)
   static const bool two_bottom = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO_BOTTOM"); return !(e && std::atoi(e) == 0); }();
   // (whatever the hand-over mode: a solve resumed with events after a flag time-out must repeat the withheld passes with the same

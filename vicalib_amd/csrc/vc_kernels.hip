@@ -1574,7 +1574,7 @@ __device__ void lm_decide_local(const DevView& v, Ctrl* c, const double* s, bool
   rec[6] = rec[2] / model_change;
   if (rec[6] > 1e-3) {
     {
-      // convergence predictor for the feeding host (vc_calibrator.cpp: solve_once): quadratic-looking approach to the function tolerance
+      // convergence predictor for the feeding host (vc_solve.cpp: solve_once): quadratic-looking approach to the function tolerance
       const double rel = fabs(rec[2]) / c->cost;
       c->likely_last = (rel < 1e3 * c->ftol && rel < 0.1 * c->last_rel) ? 1 : 0;
       c->last_rel = rel;
@@ -1595,7 +1595,7 @@ __device__ void lm_decide_local(const DevView& v, Ctrl* c, const double* s, bool
   }
 }
 
-// the host's view of the loop: one system-scope store per decision (vc_calibrator.cpp: solve_once feeds passes against it)
+// the host's view of the loop: one system-scope store per decision (vc_solve.cpp: solve_once feeds passes against it)
 __device__ __forceinline__ void publish_progress(const DevView& v, const Ctrl& c) {
   if (v.host_progress) {
     // a finished solve: the record itself goes to the host's page-locked copy, then -- after a system-scope fence -- the progress word
@@ -1944,7 +1944,7 @@ __global__ __launch_bounds__(256) void k_final(DevView v, int mode) {
   FSTAMP(7);
 }
 
-// One stage's small uploads (vc_calibrator.cpp: upload): the host packs them into one page-locked staging image that goes to the
+// One stage's small uploads (vc_upload.cpp: upload): the host packs them into one page-locked staging image that goes to the
 // device with ONE copy; this kernel scatters the image's segments to their buffers (several destinations may share a source: both
 // state buffers and the "initial state" copy take the same poses) and zero-fills what a stage starts from zero.  Replaces ~45 small
 // pageable copies / fills per stage (4.1 of the 19 ms of a complete cfg3 calibration).

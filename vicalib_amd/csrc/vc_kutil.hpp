@@ -89,7 +89,7 @@ __device__ __forceinline__ void signal_flag(const DevView& v, int idx) {
 // data there is: everything that can be wrong from here on lives in the trial-side buffers of that pass and the passes behind
 // it, and the deciding thread of a marked pass (lm_decide) does not judge -- it ends the solve with kDoneSyncTimeout, the accepted
 // state and the control record exactly as the last valid decision left them.  The host reports the time-out, switches to
-// event hand-overs and resumes from there (vc_calibrator.cpp: solve_once): same iterates as a run without flags.  Once a pass is
+// event hand-overs and resumes from there (vc_solve.cpp: solve_once): same iterates as a run without flags.  Once a pass is
 // marked every later wait returns at once (no cascade of 0.2 s bounds through the passes already queued).
 __device__ __forceinline__ long long sync_marked(const DevView& v) {
   return __hip_atomic_load(v.sync_flags + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
