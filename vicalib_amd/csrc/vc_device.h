@@ -196,6 +196,7 @@ struct DevView {
   //  workgroup waits for -- 36 us against 7.4 + 23 for the two launches: coherent stores, the count and the coherent loads behind it cost
   //  more than a kernel boundary)
   int gram_top_stride;
+  int fold_l0;                     // 1: k_chain_init's work rides in the bottom level's launch (k_chain_l0; chunk = group of 8 frames)
   int rank, world;                 // frame sharding: this process's rank, number of ranks
   // Merged decision (vision-only, single process): the accept/reject decision on pass k's trial point is taken at the head
   // of pass k+1's k_frame_schur -- by every workgroup, redundantly and identically -- instead of a k_final launch per pass.
@@ -219,6 +220,7 @@ void launch_trial(const DevView& v, hipStream_t s);            // back-substitut
 void launch_final(const DevView& v, int mode, hipStream_t s);
 int chain_forward_launches(const DevView& v);      // launches of the chain's forward elimination (levels + top)
 int chain_top_stride(int n_frames);                // stride of the frames the chain's top level eliminates
+bool chain_fold_supported(int n_frames, int D, int n_cams);      // k_chain_l0 can serve this problem (vc_imu_kernels.hip)
 // a segment of a packed upload: `bytes` (a multiple of 4) from offset src_off of the staging image to dst; src_off = ~0: zero-fill
 struct UnpackSeg { unsigned long long dst, src_off, bytes; };
 void launch_unpack(const UnpackSeg* segs, int n, const void* image, size_t total_bytes, hipStream_t s);

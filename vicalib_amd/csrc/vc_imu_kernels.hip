@@ -1586,6 +1586,560 @@ __global__ __launch_bounds__(128 * NW) void k_chain_fwd2(DevView v, int s, int m
   F2STAMP(14);
 }
 
+// ---- bottom level with the chain assembly folded in (round 5; verdict r3 / r4 item 1a) ---------------------------------------------------
+// One workgroup of FOUR wavefronts per group of 8 frames [a | e_1 .. e_7 | (r)]: wavefronts 0 / 1 are k_chain_fwd2<1>'s two sweeps,
+// wavefronts 2 / 3 are BUILDERS that do k_chain_init's work for the group's frames in the order the sweeps need them (builder 2: the left
+// sweep's frames, then the middle; builder 3: the right sweep's frames, then the separator a) and hand every frame over through LDS: the
+// border [W | g] and the block A of an unsolved frame never touch HBM (k_chain_init wrote the image, the bottom level read it back, a kernel
+// boundary between them).  The 9 x 9 couplings B -- all an image needs besides -- are read by the sweeps straight from the IMU block records.
+// A builder requests its next frame's records before it forms the current frame's columns, so the sweeps wait ~one frame's build at their
+// start and the builders stay ahead from there.  The frame's solved image, the damping state and the chunk sums (chunk = group) go to HBM as
+// before.  Narrow borders (one image column per lane), at most two cameras, single process (no pinned frames), groups of 8, two-sided.
+constexpr int kL0Ld = 48;      // row stride of a frame's LDS image: border (D + 1 <= 37 columns), then the 9 columns of A
+template <int CMAX>
+__global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
+  constexpr int W = 64;
+  __shared__ __attribute__((aligned(16))) double XS2[2][9 * kXsLd];
+  __shared__ double An2[2][81], Ls2[2][81];
+  __shared__ double MID[9 * W], SEPR[9 * W];
+  __shared__ double IMG[8][9 * kL0Ld];
+  __shared__ int READY[10];              // [slot]: the frame's image is in IMG; [8]: builder 3's chunk sums are in SUM3
+  __shared__ double BW[2][CMAX * kGStride + kInitPad];
+  __shared__ double SUM3[CMAX * kGStride + kGStride + 16];
+  __shared__ CamDesc s_cd[kMaxCams];
+  __shared__ double s_R[kMaxCams * 9];
+  __shared__ int s_ci[128];
+  const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, group = blockIdx.x;
+  const int N = v.n_frames, D = v.D, C = v.n_cams, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
+  const Ctrl* ct = v.ctrl;
+  const int a = group * 8, first = a + 1;
+  const int q = first < N ? min(7, N - 1 - first + 1) : 0;     // interior frames e_1 .. e_q
+  const int r = first + q;
+  const bool has_r = q == 7 && r < N;
+  const int nl = q > 0 ? (q - 1) / 2 : 0, mid = nl + 1, nr = q > 0 ? q - 1 - nl : 0;
+  const size_t isz = (size_t)9 * ldx;
+  auto wait_ready = [&](int slot) {
+    while (__hip_atomic_load(&READY[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  auto set_ready = [&](int slot) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_store(&READY[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  if (ct->done) return;                                          // (uniform over the workgroup)
+  const int cur = ct->cur;
+  const double* segc = v.segb[cur];
+  if (tid < 10) READY[tid] = 0;
+  if (wv >= 2) {       // the builders prepare the tables both of them use
+    const int t2 = tid - 128;
+    if (t2 < kMaxCams) s_cd[t2] = v.cd[t2];
+    if (t2 < C) { double Rm[9]; quat_to_R(v.cams[cur] + (size_t)t2 * kCamStride, Rm); for (int k = 0; k < 9; ++k) s_R[t2 * 9 + k] = Rm[k]; }
+    if (t2 < ncol) {
+      const int col = t2, e = col - nW;
+      int cam = 255, loc = 0, skip = (e >= 18 && e < 27) ? 1 : 0;
+      if (col < D) {
+        const int cc = v.col_cam[col];
+        cam = cc >= 0 ? cc : 255; loc = v.col_local[col];
+#pragma unroll
+        for (int a2 = 0; a2 < 15; ++a2) skip |= (v.imu_param_col[a2] == col) ? 1 : 0;
+      }
+      s_ci[col] = cam | (loc << 8) | (skip << 16);
+    }
+  }
+  __syncthreads();
+  if (wv < 2) {
+    // ======================================================= the two sweeps (k_chain_fwd2<1> at s = 1, level 0) =======================
+    const int wave = wv;
+    auto gsync = [&]() { wave_lds_sync_local(); };
+    const int c = lane, e0 = c - nW;
+    const int role = c < nW ? 0 : (e0 < 9 ? 1 : e0 < 18 ? 2 : e0 < 27 ? 3 : 4);     // 0 border (W | g), 1 C, 2 A, 3 B, 4 none
+    const int pc = c < nW ? c : (c < ncol ? ldw + e0 : 0);
+    const int sub = e0 < 9 ? e0 : e0 < 18 ? e0 - 9 : e0 - 18;
+    const int icol = role == 0 ? c : nW + sub;                                       // the lane's column in an LDS image (roles 0, 2; role 1 lanes: A's column `sub`)
+    if (q == 0) {              // a separator without interior frames: its image as the builders formed it, no coupling to the right
+      if (wave == 0 && a < N) {
+        wait_ready(0);
+        double* img = v.cW + (size_t)a * isz;
+        if (role == 0 || role == 2) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) img[k * ldx + pc] = IMG[0][k * kL0Ld + icol];
+        } else if (role == 3) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) img[k * ldx + pc] = 0.0;
+        }
+      }
+      return;
+    }
+    const int dir = wave == 0 ? 1 : -1, cnt = wave == 0 ? nl : nr, i0 = wave == 0 ? 1 : q;
+    double* XS = XS2[wave]; double* An = An2[wave]; double* Ls = Ls2[wave];
+    // the image columns of frame e as this sweep needs them: border and A from the builders' LDS image, the couplings from the IMU block
+    // records (B of frame f = the `prev x cur` block of record f, rows = frame f); branch-free, a lane without a value reads a valid
+    // address and keeps a zero
+    auto load_b = [&](int e, bool first_of_sweep, bool with_image, double* xb) {
+      const double* p = segc; int st = 0; bool ok = false;
+      if (with_image) {
+        if (role == 1 && first_of_sweep) {
+          if (dir > 0) { p = segc + (size_t)a * kSegStride + kSegBpc + sub * 9; st = 1; ok = true; }                       // row `sub` of B_a
+          else { ok = e + 1 < N; p = ok ? segc + (size_t)e * kSegStride + kSegBpc + sub : segc; st = ok ? 9 : 0; }        // column `sub` of B_e
+        } else if (role == 3) {
+          if (dir > 0) { ok = e + 1 < N; p = ok ? segc + (size_t)e * kSegStride + kSegBpc + sub : segc; st = ok ? 9 : 0; }
+          else { p = segc + (size_t)(e - 1) * kSegStride + kSegBpc + sub * 9; st = 1; ok = true; }                          // row `sub` of B_{e-1}
+        }
+      }
+      double y[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) y[k] = p[k * st];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) xb[k] = ok ? y[k] : 0.0;
+    };
+    auto take_img = [&](int e, bool with_image, double* x) {      // border and A columns, once the builder says so; added to the couplings
+      if (!with_image) return;                                       // (wave-uniform)
+      wait_ready(e - a);
+      const double* im = IMG[e - a];
+      if (role == 0 || role == 2) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) x[k] = im[k * kL0Ld + icol];
+      }
+    };
+    double xin[9], o[9], dacc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { dacc[k] = 0.0; o[k] = 0.0; }
+    {
+      const int e = a + (cnt > 0 ? i0 : mid);
+      const bool wi = cnt > 0 || wave == 0;
+      load_b(e, true, wi, xin);
+      take_img(e, wi, xin);
+    }
+    if (role == 2) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) An[k * 9 + sub] = xin[k];
+    }
+    // one elimination: A (in An) = L L^T, all columns solved, image stored, [X_s | X_n] to XS, out = [X_s | X_n]^T (column)
+    auto eliminate = [&](int e, double* x, double* out) {
+      gsync();
+      double Lr[45], dinv[9];
+      {
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) Lr[i * (i + 1) / 2 + j] = An[i * 9 + j];
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+          double d = Lr[j * (j + 1) / 2 + j];
+          const bool ok = d > 0.0;
+          bad |= !ok;
+          d = ok ? d : 1.0;
+          const double ip = fast_rsqrt(d);
+          dinv[j] = ip;
+          Lr[j * (j + 1) / 2 + j] = d * ip;
+#pragma unroll
+          for (int i = j + 1; i < 9; ++i) Lr[i * (i + 1) / 2 + j] *= ip;
+#pragma unroll
+          for (int i = j + 1; i < 9; ++i)
+#pragma unroll
+            for (int k = j + 1; k <= i; ++k) Lr[i * (i + 1) / 2 + k] -= Lr[i * (i + 1) / 2 + j] * Lr[k * (k + 1) / 2 + j];
+        }
+        if (bad) {
+          if (c == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            dinv[i] = 1.0;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Lr[i * (i + 1) / 2 + j] = (i == j) ? 1.0 : 0.0;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        x[k] *= dinv[k];
+#pragma unroll
+        for (int rr = k + 1; rr < 9; ++rr) x[rr] -= Lr[rr * (rr + 1) / 2 + k] * x[k];
+      }
+      if (role == 2) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ls[k * 9 + sub] = (k <= sub) ? x[k] : 0.0;
+      }
+      if (role == 0 || role == 1 || role == 3) {
+        double* img = v.cW + (size_t)e * isz + pc;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) img[k * ldx] = x[k];
+      }
+      if (role == 1 || role == 3) {
+        const int xc = sub + (role == 3 ? 9 : 0);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) XS[k * kXsLd + xc] = x[k];
+      }
+      gsync();
+      if (role == 2) {
+        double* img = v.cW + (size_t)e * isz + pc;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) img[k * ldx] = Ls[sub * 9 + k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) x[k] = XS[k * kXsLd + 9 + sub];
+      }
+#pragma unroll
+      for (int rr = 0; rr < 18; ++rr) out[rr] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const double xk = x[k];
+#pragma unroll
+        for (int rr = 0; rr < 18; ++rr) out[rr] += XS[k * kXsLd + rr] * xk;
+      }
+    };
+    for (int j = 0; ; ++j) {
+      const bool at_mid = j == cnt;
+      if (at_mid) {
+        if (wave == 1) {
+          if (cnt == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) MID[k * W + c] = 0.0;
+          }
+#pragma unroll
+          for (int k = 0; k < 9; ++k) SEPR[k * W + c] = dacc[k];
+        }
+        __syncthreads();                 // (all four wavefronts: the builders arrive when their frames are built)
+        if (wave == 1) return;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          if (role == 0 || role == 2) xin[k] += MID[k * W + c];
+          else if (role == 3 && nr > 0) xin[k] = MID[k * W + nW + sub];
+        }
+        if (role == 2) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) An[k * 9 + sub] = xin[k];
+        }
+      }
+      const int e = a + (at_mid ? mid : i0 + dir * j);
+      int en = 0; bool wn = false;
+      if (!at_mid) {                      // the frame after this one: its couplings requested now, its image taken behind the elimination
+        en = a + (j + 1 < cnt ? i0 + dir * (j + 1) : mid); wn = j + 1 < cnt || wave == 0;
+        load_b(en, false, wn, o);
+      }
+      double x[9], out[18];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) x[k] = xin[k];
+      eliminate(e, x, out);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) dacc[k] += out[k];
+      if (at_mid) {
+        if (has_r && role < 4) {
+          double* ri = v.rX[0] + (size_t)(r / 8) * isz + pc;
+          const bool keep = role == 0 || role == 2;
+          const int src = role == 2 ? nW + sub : c;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) ri[k * ldx] = keep ? -out[9 + k] - SEPR[k * W + src] : 0.0;
+        }
+        if (role == 3) {
+          double* img = v.cW + (size_t)a * isz + pc;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) img[k * ldx] = has_r ? -out[k] : 0.0;
+        }
+        break;
+      }
+      if (wave == 1 && j + 1 == cnt) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) MID[k * W + c] = -out[9 + k];
+      } else {
+        take_img(en, wn, o);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) xin[k] = o[k] - (role == 3 ? 0.0 : out[9 + k]);
+        if (role == 2) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) An[k * 9 + sub] = xin[k];
+        }
+      }
+    }
+    // ---- the left separator absorbs its group: its border and A as builder 3 formed them, minus the group's update
+    wait_ready(0);
+    if (role == 0 || role == 1) {
+      const int pcd = role == 1 ? ldw + 9 + sub : pc;
+      double* img = v.cW + (size_t)a * isz + pcd;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) img[k * ldx] = IMG[0][k * kL0Ld + icol] - dacc[k];
+    }
+    return;
+  }
+  // ============================================================ the two builders (k_chain_init's work, frame by frame) ===============
+  const int b = wv - 2;
+  const int init_scale = ct->init_scale, reuse = ct->reuse_diag;
+  const double radius = ct->radius;
+  // frames of this builder, in the order they are needed: slots 1 .. nl, mid  |  q .. mid + 1, 0
+  const int nmine = q == 0 ? (b == 1 ? 1 : 0) : (b == 0 ? nl + 1 : nr + 1);
+  auto slot_of = [&](int i) { return q == 0 ? 0 : (b == 0 ? (i < nl ? 1 + i : mid) : (i < nr ? q - i : 0)); };
+  int sp_col = -1;
+#pragma unroll
+  for (int a2 = 0; a2 < 15; ++a2) sp_col = (lane == a2) ? v.imu_param_col[a2] : sp_col;
+  auto load_fct = [&](int f) { return (lane < C && f < N) ? v.frame_cam_tile[(size_t)f * C + lane] : -1; };
+  auto issue = [&](int f, int fct_f, InitLoads<CMAX>& R) {
+    const double* rc = (f >= 1) ? segc + (size_t)(f - 1) * kSegStride : nullptr;
+    const double* rp = (f + 1 < N) ? segc + (size_t)f * kSegStride : nullptr;
+#pragma unroll
+    for (int cc = 0; cc < CMAX; ++cc) {
+      const int tc = __builtin_amdgcn_readfirstlane(__shfl(fct_f, cc, 64));
+#pragma unroll
+      for (int qq = 0; qq < 3; ++qq) R.gv[cc][qq] = 0.0;
+      if (cc < C && tc >= 0) {
+        const double* g = v.Gb[cur] + (size_t)tc * kGPack;
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) { const int e = qq * 64 + lane; const double x = g[e < kGPack ? e : 0]; R.gv[cc][qq] = e < kGPack ? x : 0.0; }
+      }
+    }
+    const double* safe = v.cg;
+    const double* rcs = rc ? rc : safe;
+    const double* rps = rp ? rp : safe;
+    const bool has_c = rc != nullptr, has_p = rp != nullptr;
+    const int oc = has_c ? 1 : 0, op = has_p ? 1 : 0;
+    {
+      const bool tile_cost = lane < C && fct_f >= 0, blk_cost = lane == 8 && has_c;
+      const double* pcst = tile_cost ? v.tile_costb[cur] + fct_f : (blk_cost ? v.seg_costb[cur] + (f - 1) : safe);
+      const double x = *pcst;
+      R.cost_in = (tile_cost || blk_cost) ? x : 0.0;
+    }
+    {
+      const bool par = lane < 15 && sp_col >= 0;      // (the B columns are the sweeps' own loads here)
+      const int a2 = lane < 15 ? lane : 0;
+      const double* pa = par ? rcs + (kSegWc + a2) * oc : safe;
+      const int sa = par ? 15 * oc : 0;
+      const double* pb = par ? rps + (kSegWp + a2) * op : safe;
+      const int sb = par ? 15 * op : 0;
+      double xa[9], xb[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { xa[i] = pa[i * sa]; xb[i] = pb[i * sb]; }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R.pre[i] = ((par && has_c) ? xa[i] : 0.0) + ((par && has_p) ? xb[i] : 0.0);
+    }
+    {
+      double xc[2], xp[2];
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) { const int e = lane + 64 * qq, ee = e < 81 ? e : 0; xc[qq] = rcs[(kSegAcc + ee) * oc]; xp[qq] = rps[(kSegApp + ee) * op]; }
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) { const bool in = lane + 64 * qq < 81; R.a_imu[qq] = ((in && has_c) ? xc[qq] : 0.0) + ((in && has_p) ? xp[qq] : 0.0); }
+    }
+    {
+      const int l9 = lane < 9 ? lane : 0;
+      const size_t fo = (size_t)f * 9 + l9;
+      const double gc = rcs[(kSegGc + l9) * oc], gp = rps[(kSegGp + l9) * op], s2 = v.cscale2[fo], dgv = v.cdiag[fo];
+      const bool in = lane < 9;
+      R.g_imu = ((in && has_c) ? gc : 0.0) + ((in && has_p) ? gp : 0.0);
+      R.sc2_in = (in && !init_scale) ? s2 : 0.0;
+      R.dg_in = (in && reuse) ? dgv : 0.0;
+    }
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int e = lane + 64 * qq, a2 = e >> 4, b2 = e & 15;
+      const bool in = a2 < 15;
+      const double x = rcs[(in ? ((b2 < 15) ? kSegHii + a2 * 15 + b2 : kSegGi + a2) : 0) * oc];
+      R.isum_in[qq] = (in && has_c) ? x : 0.0;
+    }
+  };
+  double* Gw = BW[b];
+  double* Hs = Gw + C * kGStride;
+  double* As = Hs + 42;
+  double* gs = As + 81;
+  double* ls = gs + 9;
+  int* tcam = reinterpret_cast<int*>(ls + 9);
+  int* tinv = tcam + kMaxCams;
+  double gsum[CMAX][3];
+  double isum[4] = {0.0, 0.0, 0.0, 0.0};
+  double csum = 0.0;
+  int po[3], pm[3];
+#pragma unroll
+  for (int qq = 0; qq < 3; ++qq) {
+    const int e = qq * 64 + lane;
+    int rr = 0;
+#pragma unroll
+    for (int a2 = 1; a2 < 16; ++a2) rr += (e >= a2 * 16 - (a2 * (a2 - 1)) / 2) ? 1 : 0;
+    const int cidx = rr + (e - (rr * 16 - (rr * (rr - 1)) / 2));
+    po[qq] = e < kGPackGrad ? rr * 16 + cidx : (e < kGPack ? kGGrad + (e - kGPackGrad) : -1);
+    pm[qq] = (e < kGPackGrad && cidx != rr) ? cidx * 16 + rr : -1;
+  }
+#pragma unroll
+  for (int cc = 0; cc < CMAX; ++cc)
+#pragma unroll
+    for (int qq = 0; qq < 3; ++qq) gsum[cc][qq] = 0.0;
+  InitLoads<CMAX> R;
+  int fct = -1, fct_next = -1;
+  if (nmine > 0) { fct = load_fct(a + slot_of(0)); issue(a + slot_of(0), fct, R); if (nmine > 1) fct_next = load_fct(a + slot_of(1)); }
+  for (int it = 0; it < nmine; ++it) {
+    const int slot = slot_of(it), f = a + slot;
+    double* im = IMG[slot];
+    const unsigned long long present = __ballot(lane < C && fct >= 0);
+    const int nt = __popcll(present);
+    if (lane < kMaxCams) {
+      const bool have = lane < C && fct >= 0;
+      tinv[lane] = have ? __popcll(present & ((1ull << lane) - 1ull)) : -1;
+    }
+    wave_lds_sync_local();
+    if (lane < C && fct >= 0) tcam[tinv[lane]] = lane;
+    csum += R.cost_in;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) isum[qq] += R.isum_in[qq];
+    int slot_c = 0;
+#pragma unroll
+    for (int cc = 0; cc < CMAX; ++cc) {
+      const bool have = cc < C && ((present >> cc) & 1ull);
+      if (have) {
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) {
+          if (po[qq] >= 0) Gw[slot_c * kGStride + po[qq]] = R.gv[cc][qq];
+          if (pm[qq] >= 0) Gw[slot_c * kGStride + pm[qq]] = R.gv[cc][qq];
+          gsum[cc][qq] += R.gv[cc][qq];
+        }
+        ++slot_c;
+      }
+    }
+    if (sp_col >= 0) {          // the IMU-parameter columns of the border, straight from the records
+#pragma unroll
+      for (int i = 0; i < 9; ++i) im[i * kL0Ld + sp_col] = R.pre[i];
+    }
+    const double a_imu[2] = {R.a_imu[0], R.a_imu[1]};
+    const double g_imu = R.g_imu, sc2_in = R.sc2_in, dg_in = R.dg_in;
+    wave_lds_sync_local();
+    fct = fct_next;
+    if (it + 1 < nmine) { issue(a + slot_of(it + 1), fct, R); if (it + 2 < nmine) fct_next = load_fct(a + slot_of(it + 2)); }
+    if (lane < 42) {
+      double hval = 0.0;
+      for (int t = 0; t < nt; ++t) {
+        const int cc = tcam[t];
+        const double* Rm = s_R + cc * 9;
+        const double* g = Gw + t * kGStride;
+        if (lane < 36) {
+          const int i = lane / 6, j = lane % 6, a2 = i / 3, ii = i % 3, b2 = j / 3, jj = j % 3;
+          double sacc = 0.0;
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq) sacc += Rm[3 * pp + ii] * g[(3 * a2 + pp) * 16 + 3 * b2 + qq] * Rm[3 * qq + jj];
+          hval += (a2 == b2) ? sacc : -sacc;
+        } else {
+          const int i = lane - 36, a2 = i / 3, ii = i % 3;
+          const int nk = model_nk(s_cd[cc].model);
+          double sacc = 0.0;
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) sacc += Rm[3 * pp + ii] * gram_grad(g, 3 * a2 + pp, nk);
+          hval += (a2 == 0) ? -sacc : sacc;
+        }
+      }
+      Hs[lane] = hval;
+    }
+    wave_lds_sync_local();
+    double aval[2];
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int e = lane + 64 * qq, i = e / 9, j = e % 9;
+      aval[qq] = a_imu[qq] + ((e < 81 && i < 6 && j < 6) ? Hs[i * 6 + j] : 0.0);
+      if (e < 81) As[e] = aval[qq];
+    }
+    const double gval = g_imu + ((lane < 6) ? Hs[36 + lane] : 0.0);
+    double hd = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int e = i * 10;
+      const double d = readlane_f64(aval[e >> 6], e & 63);
+      if (lane == i) hd = d;
+    }
+    if (lane < 9) {
+      double sc2 = sc2_in, dg = dg_in;
+      if (init_scale) { sc2 = jacobi_scale2(hd); v.cscale2[(size_t)f * 9 + lane] = sc2; }
+      if (!reuse) { dg = lm_clamped_diag(hd, sc2); v.cdiag[(size_t)f * 9 + lane] = dg; }
+      const double lam = dg / (radius * sc2);
+      v.clam[(size_t)f * 9 + lane] = lam;
+      v.cg[(size_t)f * 9 + lane] = gval;
+      gs[lane] = gval; ls[lane] = lam;
+    }
+    wave_lds_sync_local();
+    // the image's border and A columns -> LDS
+    for (int col = lane; col < ncol; col += 64) {
+      const int ci = s_ci[col];
+      const int e = col - nW;
+      if ((ci >> 16) || (e >= 0 && e < 9)) continue;            // IMU-record columns (done / the sweeps' own), C (nothing)
+      double val[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) val[i] = 0.0;
+      const int jb = (e >= 0) ? e % 9 : 0;
+      const int cc = ci & 255, j = (ci >> 8) & 255;
+      const int t = (cc < kMaxCams) ? tinv[cc] : -1;
+      if (col < D && t >= 0) {
+        const int flags = s_cd[cc].flags, nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
+        const double* Rm = s_R + cc * 9;
+        const double* g = Gw + t * kGStride;
+        double u[6];
+        if (j < nrot) {
+#pragma unroll
+          for (int rr = 0; rr < 6; ++rr) u[rr] = -(g[rr * 16 + 3] * Rm[j] + g[rr * 16 + 4] * Rm[3 + j] + g[rr * 16 + 5] * Rm[6 + j]);
+        } else {
+          const int jj = (j < nrot + ntr) ? j - nrot : 6 + (j - nrot - ntr);
+#pragma unroll
+          for (int rr = 0; rr < 6; ++rr) u[rr] = g[rr * 16 + jj];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          val[i] = -(Rm[i] * u[0] + Rm[3 + i] * u[1] + Rm[6 + i] * u[2]);
+          val[3 + i] = Rm[i] * u[3] + Rm[3 + i] * u[4] + Rm[6 + i] * u[5];
+        }
+      }
+      if (col == D) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) val[i] = gs[i];
+      }
+      if (e >= 9 && e < 18) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) val[i] = As[i * 9 + jb] + ((i == jb) ? ls[i] : 0.0);
+      }
+      const int ic = col < nW ? col : nW + jb;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) im[i * kL0Ld + ic] = val[i];
+    }
+    set_ready(slot);
+  }
+  // ---- chunk sums (chunk = group): builder 3 hands its sums over through LDS, builder 2 adds its own in front and writes the record
+  __syncthreads();                       // (the sweeps' hand-over barrier: counts all four wavefronts)
+  const int nsum = C * kGStride + kGStride;
+  if (b == 1) {
+#pragma unroll
+    for (int cc = 0; cc < CMAX; ++cc)
+      if (cc < C) {
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) {
+          if (po[qq] >= 0) SUM3[cc * kGStride + po[qq]] = gsum[cc][qq];
+          if (pm[qq] >= 0) SUM3[cc * kGStride + pm[qq]] = gsum[cc][qq];
+        }
+      }
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) SUM3[C * kGStride + qq * 64 + lane] = isum[qq];
+    if (lane < 9) SUM3[nsum + lane] = csum;
+    set_ready(8);
+    return;
+  }
+  // builder 2: its own sums through its (now free) Gram scratch, expanded like builder 3's
+#pragma unroll
+  for (int cc = 0; cc < CMAX; ++cc)
+    if (cc < C) {
+#pragma unroll
+      for (int qq = 0; qq < 3; ++qq) {
+        if (po[qq] >= 0) Gw[cc * kGStride + po[qq]] = gsum[cc][qq];
+        if (pm[qq] >= 0) Gw[cc * kGStride + pm[qq]] = gsum[cc][qq];
+      }
+    }
+  wave_lds_sync_local();
+  wait_ready(8);
+  double* part = v.part + (size_t)group * v.part_stride;
+  for (int e = lane; e < C * kGStride; e += 64) part[D * D + D + e] = Gw[e] + SUM3[e];
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) part[D * D + D + C * kGStride + qq * 64 + lane] = isum[qq] + SUM3[C * kGStride + qq * 64 + lane];
+  for (int e = C * kGStride + 256 + lane; e < nsum; e += 64) part[D * D + D + e] = 0.0;
+  {
+    double t0 = (lane < 9) ? csum : 0.0, t1 = (lane < 9) ? SUM3[nsum + lane] : 0.0;
+    // fixed order: builder 2's nine lanes, then builder 3's
+    double tw0 = 0.0, tw1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { tw0 += readlane_f64(t0, k); tw1 += readlane_f64(t1, k); }
+    if (lane == 0) part[v.part_stride - 1] = tw0 + tw1;
+  }
+}
+
 // Back-substitution of one level: delta_e = -L^-T (z + Y delta_s + X_s delta_a + X_n delta_next), right to left inside
 // the group.  Everything that does not depend on the chain (z + Y delta_s + X_s delta_a, the rows of X_n, the columns of L)
 // is formed by lane (frame i, row k) beforehand; the dependent part is one 9 x 9 product and a triangular solve per frame,
@@ -2062,7 +2616,13 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
     else hipLaunchKernelGGL((k_chain_fwd<4, 1>), dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
   };
   if (forward) {
-    for (int l = 0; l < nl; ++l) fwd((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1), strides[l], ms[l], 0, l);
+    for (int l = 0; l < nl; ++l) {
+      const int groups = (int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1);
+      if (l == 0 && v.fold_l0) {      // the chain assembly rides in the bottom level's launch (k_chain_l0)
+        if (v.n_cams <= 1) hipLaunchKernelGGL(k_chain_l0<1>, dim3(groups), dim3(256), 0, s, v);
+        else hipLaunchKernelGGL(k_chain_l0<2>, dim3(groups), dim3(256), 0, s, v);
+      } else fwd(groups, strides[l], ms[l], 0, l);
+    }
     const bool side_by_side_top = cpl <= 1 || !columns_per_lane;
     if (v.gram_top_stride > 0 && side_by_side_top) {
       // early Gram: the top level's one group and the Gram sums of all frames below it in one launch
@@ -2113,6 +2673,13 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
       hipLaunchKernelGGL(k_chain_back, dim3((int)(((long)N - 1) / ((long)strides[l] * ms[l]) + 1)), dim3(64), 0, s, v, strides[l], ms[l], 0, l,
                          two_at(l) ? 1 : 0);
   }
+}
+// k_chain_l0 (the chain assembly folded into the bottom level) serves narrow borders, at most two cameras, groups of 8 eliminated from
+// both ends -- and at least one level below the top one
+bool chain_fold_supported(int n_frames, int D, int n_cams) {
+  static const bool two_env = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO"); return !(e && std::atoi(e) == 0); }();
+  static const bool two_bottom = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO_BOTTOM"); return !(e && std::atoi(e) == 0); }();
+  return two_env && two_bottom && chain_group_size() == kChainM && D + 1 + 27 <= 64 && n_cams <= 2 && (n_frames - 1) + 1 > kChainM - 1;
 }
 // stride of the frames the top level eliminates (1: no level below it)
 int chain_top_stride(int n_frames) {

@@ -91,7 +91,7 @@ int vc_calibrator::enqueue_pass(bool first_pass, bool events_only) {
         KT("k_imu_block", launch_imu_delta(dv, stream, 0)); KT("k_imu_jac", launch_imu_jac(dv, wcur, stream, 0));
       }
     }
-    KT("k_chain_init", launch_chain_init(dv, stream));
+    if (!dv.fold_l0) KT("k_chain_init", launch_chain_init(dv, stream));      // (fold: the bottom level's launch assembles its frames itself)
     KT("k_chain_fwd", launch_chain_fwd(dv, stream));
     if (dv.gram_top_stride == 0) KT("k_chain_gram", launch_chain_gram(dv, stream));      // (early Gram: the sums ride in the top level's launch)
     else if (top_gram_launch) KT("k_chain_gram(top)", launch_chain_gram_top(dv, stream));

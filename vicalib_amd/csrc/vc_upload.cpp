@@ -207,6 +207,11 @@ int vc_calibrator::upload() {
   // (8 cameras, 6250 frames per rank: 197 MB at 4 frames per chunk, k_part_sum 47 -> 19 us at 16)
   while (chunk_frames < 16 && (double)((N + chunk_frames - 1) / chunk_frames) * ((double)D * D + D + (C + 1) * kGStride) * 8.0 > 64e6) chunk_frames *= 2;
   { const char* e = std::getenv("VICALIB_AMD_CHUNK_FRAMES"); if (e && std::atoi(e) >= 4) chunk_frames = std::atoi(e) / 4 * 4; }      // (A/B hook)
+  // the chain assembly folded into the bottom level of the elimination (k_chain_l0): a function of the problem only, never of the
+  // hand-over mode; its chunk of the partial sums is the group of 8 frames.  VICALIB_AMD_FOLD_L0=0: the two kernels apart (A/B)
+  static const bool fold_env = [] { const char* e = std::getenv("VICALIB_AMD_FOLD_L0"); return !(e && e[0] == '0'); }();
+  const bool fold = fold_env && imu_on() && !sharded() && !shard_imu && chain_fold_supported(N, D, C);
+  if (fold) chunk_frames = 8;
   const int n_chunks = std::max(1, (N + chunk_frames - 1) / chunk_frames);
   const int part_stride = D * D + D + C * kGStride + (imu_on() ? kGStride : 0) + 2;     // ... + [x2 of observation-less frames, chunk cost] (vision path)
   for (int b = 0; b < 2; ++b) {
@@ -284,6 +289,7 @@ int vc_calibrator::upload() {
     //  level is two frames and the sums take 50 us: 0.906 -> 0.938 ms per pass with them in its launch; at 2500 frames, D = 67: -4.5 us)
     const bool narrow = D + 1 + 27 <= 128;      // at most two image columns per lane
     dv.gram_top_stride = (early_env && dv.imu_on && N >= 1 && N <= 4096 && narrow) ? chain_top_stride(N) : 0;
+    dv.fold_l0 = fold ? 1 : 0;
     // the top level's own frames: added by k_reduced (single process, narrow system) or a partial record of their own
     top_gram_launch = dv.gram_top_stride > 0 && !(D <= kSmallD && !sharded());
     dv.n_part = dv.n_chunks + (top_gram_launch ? 1 : 0);
