@@ -1610,6 +1610,15 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
   __shared__ double s_R[kMaxCams * 9];
   __shared__ int s_ci[128];
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, group = blockIdx.x;
+#ifdef VC_L0_STAMPS
+  const long long l0t0_ = (long long)__builtin_amdgcn_s_memrealtime();
+  int l0n_ = 1;
+#define L0STAMP() do { if (blockIdx.x == gridDim.x / 2 && lane == 0 && l0n_ < 16) { v.dbg[(wv == 0 ? 0 : 16) + l0n_] = (long long)__builtin_amdgcn_s_memrealtime(); ++l0n_; } } while (0)
+#define L0B(i) do { if (blockIdx.x == gridDim.x / 2 && lane == 0 && wv == 2 && it == 1) v.dbg[24 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define L0STAMP() do { } while (0)
+#define L0B(i) do { } while (0)
+#endif
   const int N = v.n_frames, D = v.D, C = v.n_cams, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
   const Ctrl* ct = v.ctrl;
   const int a = group * 8, first = a + 1;
@@ -1627,9 +1636,75 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) __hip_atomic_store(&READY[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
+  // ---- the builders' first requests go out before anything else: the tile list of their first frame ahead of the control record, the
+  // frame's records as soon as that record says which linearisation buffer is current -- under the tables and the barrier below
+  const int b = wv - 2;                                            // (builders: 0 / 1)
+  // frames of this builder, in the order they are needed: slots 1 .. nl, mid  |  q .. mid + 1, 0
+  const int nmine = wv < 2 ? 0 : (q == 0 ? (b == 1 ? 1 : 0) : (b == 0 ? nl + 1 : nr + 1));
+  auto slot_of = [&](int i) { return q == 0 ? 0 : (b == 0 ? (i < nl ? 1 + i : mid) : (i < nr ? q - i : 0)); };
+  int sp_col = -1;
+#pragma unroll
+  for (int a2 = 0; a2 < 15; ++a2) sp_col = (lane == a2) ? v.imu_param_col[a2] : sp_col;
+  auto load_fct = [&](int f) { return (lane < C && f < N) ? v.frame_cam_tile[(size_t)f * C + lane] : -1; };
+  int fct = -1, fct_next = -1;
+  if (nmine > 0) fct = load_fct(a + slot_of(0));
   if (ct->done) return;                                          // (uniform over the workgroup)
   const int cur = ct->cur;
   const double* segc = v.segb[cur];
+  const int init_scale = ct->init_scale, reuse = ct->reuse_diag;
+  const double radius = ct->radius;
+  // per-lane offsets into a frame's two IMU records, once for all frames (the records' bases are wave-uniform: scalar base + 32-bit
+  // lane offset per load, no 64-bit address arithmetic per lane and load -- issuing a frame's ~45 loads took 1.2 us of the builder's 4)
+  const bool par = lane < 15 && sp_col >= 0;
+  const int o_wc = par ? kSegWc + lane : 0, o_wp = par ? kSegWp + lane : 0, s_par = par ? 15 : 0;
+  const int o_acc0 = kSegAcc + lane, o_acc1 = kSegAcc + (lane + 64 < 81 ? lane + 64 : 0), o_app0 = kSegApp + lane, o_app1 = kSegApp + (lane + 64 < 81 ? lane + 64 : 0);
+  const int l9 = lane < 9 ? lane : 0;
+  int o_ii[4];
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) { const int e = lane + 64 * qq, a2 = e >> 4, b2 = e & 15; o_ii[qq] = a2 < 15 ? ((b2 < 15) ? kSegHii + a2 * 15 + b2 : kSegGi + a2) : 0; }
+  auto issue = [&](int f_in, int fct_f, InitLoads<CMAX>& R) {
+    const int f = __builtin_amdgcn_readfirstlane(f_in);
+    const bool has_c = f >= 1, has_p = f + 1 < N;                               // wave-uniform
+    // (an absent record: the base falls back to record 0 -- always there for N >= 2 -- and every value is dropped by its select)
+    const double* rcs = segc + (size_t)(has_c ? f - 1 : 0) * kSegStride;
+    const double* rps = segc + (size_t)(has_p ? f : 0) * kSegStride;
+#pragma unroll
+    for (int cc = 0; cc < CMAX; ++cc) {
+      const int tc = __builtin_amdgcn_readfirstlane(__shfl(fct_f, cc, 64));
+#pragma unroll
+      for (int qq = 0; qq < 3; ++qq) R.gv[cc][qq] = 0.0;
+      if (cc < C && tc >= 0) {
+        const double* g = v.Gb[cur] + (size_t)tc * kGPack;
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) { const int e = qq * 64 + lane; const double x = g[e < kGPack ? e : 0]; R.gv[cc][qq] = e < kGPack ? x : 0.0; }
+      }
+    }
+    {
+      const bool tile_cost = lane < C && fct_f >= 0, blk_cost = lane == 8 && has_c;
+      const double* pcst = tile_cost ? v.tile_costb[cur] + fct_f : (blk_cost ? v.seg_costb[cur] + (f - 1) : v.cg);
+      const double x = *pcst;
+      R.cost_in = (tile_cost || blk_cost) ? x : 0.0;
+    }
+    double xa[9], xb[9], xc0, xc1, xp0, xp1, xi[4];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { xa[i] = rcs[o_wc + i * s_par]; xb[i] = rps[o_wp + i * s_par]; }
+    xc0 = rcs[o_acc0]; xc1 = rcs[o_acc1]; xp0 = rps[o_app0]; xp1 = rps[o_app1];
+    const double gc = rcs[kSegGc + l9], gp = rps[kSegGp + l9], s2 = v.cscale2[(size_t)f * 9 + l9], dgv = v.cdiag[(size_t)f * 9 + l9];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) xi[qq] = rcs[o_ii[qq]];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R.pre[i] = ((par && has_c) ? xa[i] : 0.0) + ((par && has_p) ? xb[i] : 0.0);
+    const bool in1 = lane + 64 < 81, in9 = lane < 9;
+    R.a_imu[0] = (has_c ? xc0 : 0.0) + (has_p ? xp0 : 0.0);
+    R.a_imu[1] = ((in1 && has_c) ? xc1 : 0.0) + ((in1 && has_p) ? xp1 : 0.0);
+    R.g_imu = ((in9 && has_c) ? gc : 0.0) + ((in9 && has_p) ? gp : 0.0);
+    R.sc2_in = (in9 && !init_scale) ? s2 : 0.0;
+    R.dg_in = (in9 && reuse) ? dgv : 0.0;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) R.isum_in[qq] = ((lane + 64 * qq) < 240 && has_c) ? xi[qq] : 0.0;
+  };
+  InitLoads<CMAX> R;
+  if (nmine > 0) { issue(a + slot_of(0), fct, R); if (nmine > 1) fct_next = load_fct(a + slot_of(1)); }
   if (tid < 10) READY[tid] = 0;
   if (wv >= 2) {       // the builders prepare the tables both of them use
     const int t2 = tid - 128;
@@ -1648,6 +1723,10 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
     }
   }
   __syncthreads();
+#ifdef VC_L0_STAMPS
+  if (blockIdx.x == gridDim.x / 2 && lane == 0 && (wv == 0 || wv == 2)) v.dbg[wv == 0 ? 0 : 16] = l0t0_;
+  if (wv == 0 || wv == 2) L0STAMP();      // 1: behind the first barrier
+#endif
   if (wv < 2) {
     // ======================================================= the two sweeps (k_chain_fwd2<1> at s = 1, level 0) =======================
     const int wave = wv;
@@ -1820,7 +1899,9 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
       double x[9], out[18];
 #pragma unroll
       for (int k = 0; k < 9; ++k) x[k] = xin[k];
+      if (wv == 0) L0STAMP();               // sweep 0: frame taken, elimination starts
       eliminate(e, x, out);
+      if (wv == 0) L0STAMP();               // ... and is done
 #pragma unroll
       for (int k = 0; k < 9; ++k) dacc[k] += out[k];
       if (at_mid) {
@@ -1859,81 +1940,13 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) img[k * ldx] = IMG[0][k * kL0Ld + icol] - dacc[k];
     }
+#ifdef VC_L0_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    if (wv == 0) L0STAMP();
+#endif
     return;
   }
   // ============================================================ the two builders (k_chain_init's work, frame by frame) ===============
-  const int b = wv - 2;
-  const int init_scale = ct->init_scale, reuse = ct->reuse_diag;
-  const double radius = ct->radius;
-  // frames of this builder, in the order they are needed: slots 1 .. nl, mid  |  q .. mid + 1, 0
-  const int nmine = q == 0 ? (b == 1 ? 1 : 0) : (b == 0 ? nl + 1 : nr + 1);
-  auto slot_of = [&](int i) { return q == 0 ? 0 : (b == 0 ? (i < nl ? 1 + i : mid) : (i < nr ? q - i : 0)); };
-  int sp_col = -1;
-#pragma unroll
-  for (int a2 = 0; a2 < 15; ++a2) sp_col = (lane == a2) ? v.imu_param_col[a2] : sp_col;
-  auto load_fct = [&](int f) { return (lane < C && f < N) ? v.frame_cam_tile[(size_t)f * C + lane] : -1; };
-  auto issue = [&](int f, int fct_f, InitLoads<CMAX>& R) {
-    const double* rc = (f >= 1) ? segc + (size_t)(f - 1) * kSegStride : nullptr;
-    const double* rp = (f + 1 < N) ? segc + (size_t)f * kSegStride : nullptr;
-#pragma unroll
-    for (int cc = 0; cc < CMAX; ++cc) {
-      const int tc = __builtin_amdgcn_readfirstlane(__shfl(fct_f, cc, 64));
-#pragma unroll
-      for (int qq = 0; qq < 3; ++qq) R.gv[cc][qq] = 0.0;
-      if (cc < C && tc >= 0) {
-        const double* g = v.Gb[cur] + (size_t)tc * kGPack;
-#pragma unroll
-        for (int qq = 0; qq < 3; ++qq) { const int e = qq * 64 + lane; const double x = g[e < kGPack ? e : 0]; R.gv[cc][qq] = e < kGPack ? x : 0.0; }
-      }
-    }
-    const double* safe = v.cg;
-    const double* rcs = rc ? rc : safe;
-    const double* rps = rp ? rp : safe;
-    const bool has_c = rc != nullptr, has_p = rp != nullptr;
-    const int oc = has_c ? 1 : 0, op = has_p ? 1 : 0;
-    {
-      const bool tile_cost = lane < C && fct_f >= 0, blk_cost = lane == 8 && has_c;
-      const double* pcst = tile_cost ? v.tile_costb[cur] + fct_f : (blk_cost ? v.seg_costb[cur] + (f - 1) : safe);
-      const double x = *pcst;
-      R.cost_in = (tile_cost || blk_cost) ? x : 0.0;
-    }
-    {
-      const bool par = lane < 15 && sp_col >= 0;      // (the B columns are the sweeps' own loads here)
-      const int a2 = lane < 15 ? lane : 0;
-      const double* pa = par ? rcs + (kSegWc + a2) * oc : safe;
-      const int sa = par ? 15 * oc : 0;
-      const double* pb = par ? rps + (kSegWp + a2) * op : safe;
-      const int sb = par ? 15 * op : 0;
-      double xa[9], xb[9];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) { xa[i] = pa[i * sa]; xb[i] = pb[i * sb]; }
-#pragma unroll
-      for (int i = 0; i < 9; ++i) R.pre[i] = ((par && has_c) ? xa[i] : 0.0) + ((par && has_p) ? xb[i] : 0.0);
-    }
-    {
-      double xc[2], xp[2];
-#pragma unroll
-      for (int qq = 0; qq < 2; ++qq) { const int e = lane + 64 * qq, ee = e < 81 ? e : 0; xc[qq] = rcs[(kSegAcc + ee) * oc]; xp[qq] = rps[(kSegApp + ee) * op]; }
-#pragma unroll
-      for (int qq = 0; qq < 2; ++qq) { const bool in = lane + 64 * qq < 81; R.a_imu[qq] = ((in && has_c) ? xc[qq] : 0.0) + ((in && has_p) ? xp[qq] : 0.0); }
-    }
-    {
-      const int l9 = lane < 9 ? lane : 0;
-      const size_t fo = (size_t)f * 9 + l9;
-      const double gc = rcs[(kSegGc + l9) * oc], gp = rps[(kSegGp + l9) * op], s2 = v.cscale2[fo], dgv = v.cdiag[fo];
-      const bool in = lane < 9;
-      R.g_imu = ((in && has_c) ? gc : 0.0) + ((in && has_p) ? gp : 0.0);
-      R.sc2_in = (in && !init_scale) ? s2 : 0.0;
-      R.dg_in = (in && reuse) ? dgv : 0.0;
-    }
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-      const int e = lane + 64 * qq, a2 = e >> 4, b2 = e & 15;
-      const bool in = a2 < 15;
-      const double x = rcs[(in ? ((b2 < 15) ? kSegHii + a2 * 15 + b2 : kSegGi + a2) : 0) * oc];
-      R.isum_in[qq] = (in && has_c) ? x : 0.0;
-    }
-  };
   double* Gw = BW[b];
   double* Hs = Gw + C * kGStride;
   double* As = Hs + 42;
@@ -1959,12 +1972,37 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
   for (int cc = 0; cc < CMAX; ++cc)
 #pragma unroll
     for (int qq = 0; qq < 3; ++qq) gsum[cc][qq] = 0.0;
-  InitLoads<CMAX> R;
-  int fct = -1, fct_next = -1;
-  if (nmine > 0) { fct = load_fct(a + slot_of(0)); issue(a + slot_of(0), fct, R); if (nmine > 1) fct_next = load_fct(a + slot_of(1)); }
+  // what this lane's image column is (one column per lane: D + 28 <= 64), once for all frames -- the column phase then runs without a
+  // divergent branch: a camera's column is three weighted entries per row of its tile's Gram block (a rotation column: -R's column over
+  // entries 3..5; a unit column: one entry with weight 1), A's and g's columns come from the frame's own block; everybody loads from valid
+  // addresses and keeps what is his by selects.  (As `if (camera column) { if (rotation) .. else .. } if (g) .. if (A) ..` the phase took
+  // 2.2 of the ~4 us a builder needs per frame: five serialised branch regions, each with its own LDS round trips.)
+  int ckind = 0, ccam = 0, cjb = 0, cidx0 = 0, cidx1 = 0, cidx2 = 0, cic = 0;
+  double cw0 = 0.0, cw1 = 0.0, cw2 = 0.0, cR[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) cR[i] = 0.0;
+  if (wv >= 2 && lane < ncol) {
+    const int col = lane, ci = s_ci[col], e = col - nW;
+    const int cc = ci & 255, j = (ci >> 8) & 255;
+    cic = col < nW ? col : nW + (e >= 0 ? e % 9 : 0);
+    cjb = (e >= 0) ? e % 9 : 0;
+    if ((ci >> 16) || (e >= 0 && e < 9)) ckind = 0;             // IMU-record columns (written with the records' values), C, B
+    else if (col == D) ckind = 2;
+    else if (e >= 9 && e < 18) ckind = 3;
+    else if (col < D && cc < kMaxCams) {
+      ckind = 1; ccam = cc;
+      const int flags = s_cd[cc].flags, nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
+      const double* Rm = s_R + cc * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) cR[i] = Rm[i];
+      if (j < nrot) { cidx0 = 3; cidx1 = 4; cidx2 = 5; cw0 = -Rm[j]; cw1 = -Rm[3 + j]; cw2 = -Rm[6 + j]; }
+      else { const int jj = (j < nrot + ntr) ? j - nrot : 6 + (j - nrot - ntr); cidx0 = jj; cidx1 = jj; cidx2 = jj; cw0 = 1.0; }
+    } else if (col < nW) ckind = 4;                                // a border column nobody owns: zeros
+  }
   for (int it = 0; it < nmine; ++it) {
     const int slot = slot_of(it), f = a + slot;
     double* im = IMG[slot];
+    L0B(0);
     const unsigned long long present = __ballot(lane < C && fct >= 0);
     const int nt = __popcll(present);
     if (lane < kMaxCams) {
@@ -1997,8 +2035,10 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
     const double a_imu[2] = {R.a_imu[0], R.a_imu[1]};
     const double g_imu = R.g_imu, sc2_in = R.sc2_in, dg_in = R.dg_in;
     wave_lds_sync_local();
+    L0B(1);
     fct = fct_next;
     if (it + 1 < nmine) { issue(a + slot_of(it + 1), fct, R); if (it + 2 < nmine) fct_next = load_fct(a + slot_of(it + 2)); }
+    L0B(2);
     if (lane < 42) {
       double hval = 0.0;
       for (int t = 0; t < nt; ++t) {
@@ -2025,6 +2065,7 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
       Hs[lane] = hval;
     }
     wave_lds_sync_local();
+    L0B(3);
     double aval[2];
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) {
@@ -2050,49 +2091,38 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
       gs[lane] = gval; ls[lane] = lam;
     }
     wave_lds_sync_local();
-    // the image's border and A columns -> LDS
-    for (int col = lane; col < ncol; col += 64) {
-      const int ci = s_ci[col];
-      const int e = col - nW;
-      if ((ci >> 16) || (e >= 0 && e < 9)) continue;            // IMU-record columns (done / the sweeps' own), C (nothing)
+    L0B(4);
+    // the image's border and A columns -> LDS (branch-free, see the lane constants above)
+    {
+      const int t = tinv[ccam];
+      const double* g = Gw + (t >= 0 ? t : 0) * kGStride;
+      double g0[6], g1[6], g2[6], av[9], gv9[9];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) { g0[rr] = g[rr * 16 + cidx0]; g1[rr] = g[rr * 16 + cidx1]; g2[rr] = g[rr * 16 + cidx2]; }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { av[i] = As[i * 9 + cjb]; gv9[i] = gs[i]; }
+      const double lj = ls[cjb];
+      double u[6];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) u[rr] = g0[rr] * cw0 + g1[rr] * cw1 + g2[rr] * cw2;
       double val[9];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) val[i] = 0.0;
-      const int jb = (e >= 0) ? e % 9 : 0;
-      const int cc = ci & 255, j = (ci >> 8) & 255;
-      const int t = (cc < kMaxCams) ? tinv[cc] : -1;
-      if (col < D && t >= 0) {
-        const int flags = s_cd[cc].flags, nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
-        const double* Rm = s_R + cc * 9;
-        const double* g = Gw + t * kGStride;
-        double u[6];
-        if (j < nrot) {
-#pragma unroll
-          for (int rr = 0; rr < 6; ++rr) u[rr] = -(g[rr * 16 + 3] * Rm[j] + g[rr * 16 + 4] * Rm[3 + j] + g[rr * 16 + 5] * Rm[6 + j]);
-        } else {
-          const int jj = (j < nrot + ntr) ? j - nrot : 6 + (j - nrot - ntr);
-#pragma unroll
-          for (int rr = 0; rr < 6; ++rr) u[rr] = g[rr * 16 + jj];
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          val[i] = -(Rm[i] * u[0] + Rm[3 + i] * u[1] + Rm[6 + i] * u[2]);
-          val[3 + i] = Rm[i] * u[3] + Rm[3 + i] * u[4] + Rm[6 + i] * u[5];
-        }
+      for (int i = 0; i < 3; ++i) {
+        val[i] = -(cR[i] * u[0] + cR[3 + i] * u[1] + cR[6 + i] * u[2]);
+        val[3 + i] = cR[i] * u[3] + cR[3 + i] * u[4] + cR[6 + i] * u[5];
+        val[6 + i] = 0.0;
       }
-      if (col == D) {
+      const bool cam_live = ckind == 1 && t >= 0;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) val[i] = gs[i];
+      for (int i = 0; i < 9; ++i) {
+        const double x = cam_live ? val[i] : (ckind == 2 ? gv9[i] : (ckind == 3 ? av[i] + ((i == cjb) ? lj : 0.0) : 0.0));
+        if (ckind != 0) im[i * kL0Ld + cic] = x;
       }
-      if (e >= 9 && e < 18) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) val[i] = As[i * 9 + jb] + ((i == jb) ? ls[i] : 0.0);
-      }
-      const int ic = col < nW ? col : nW + jb;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) im[i * kL0Ld + ic] = val[i];
     }
+    L0B(5);
     set_ready(slot);
+    L0B(6);
+    if (wv == 2) L0STAMP();                 // builder 2: frame handed over
   }
   // ---- chunk sums (chunk = group): builder 3 hands its sums over through LDS, builder 2 adds its own in front and writes the record
   __syncthreads();                       // (the sweeps' hand-over barrier: counts all four wavefronts)
