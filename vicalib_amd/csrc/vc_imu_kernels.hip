@@ -1606,9 +1606,8 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
   __shared__ int READY[10];              // [slot]: the frame's image is in IMG; [8]: builder 3's chunk sums are in SUM3
   __shared__ double BW[2][CMAX * kGStride + kInitPad];
   __shared__ double SUM3[CMAX * kGStride + kGStride + 16];
-  __shared__ CamDesc s_cd[kMaxCams];
-  __shared__ double s_R[kMaxCams * 9];
-  __shared__ int s_ci[128];
+  __shared__ CamDesc s_cd2[2][kMaxCams];      // every builder keeps its own small tables: no workgroup barrier between the builders' start and
+  __shared__ double s_R2[2][kMaxCams * 9];    // their first frame (the one barrier ahead of everything only publishes READY = 0)
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, group = blockIdx.x;
 #ifdef VC_L0_STAMPS
   const long long l0t0_ = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1627,15 +1626,23 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
   const bool has_r = q == 7 && r < N;
   const int nl = q > 0 ? (q - 1) / 2 : 0, mid = nl + 1, nr = q > 0 ? q - 1 - nl : 0;
   const size_t isz = (size_t)9 * ldx;
+  // Hand-over through LDS only.  A workgroup-scope fence would also wait for the wavefront's outstanding GLOBAL loads and stores -- the
+  // builder's requests for its next frames, the sweep's stores of the image it has just solved (1.7 us per frame, measured): here the
+  // producer waits for its own LDS stores (lgkmcnt(0), nothing else) before it raises the word, the consumer's LDS reads follow its poll
+  // in the wavefront's LDS queue, and wavefront-scope fences keep the compiler from moving LDS accesses across either.
   auto wait_ready = [&](int slot) {
     while (__hip_atomic_load(&READY[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   };
   auto set_ready = [&](int slot) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wavefront's LDS stores have been performed
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) __hip_atomic_store(&READY[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
+  if (tid < 10) READY[tid] = 0;
+  __syncthreads();
   // ---- the builders' first requests go out before anything else: the tile list of their first frame ahead of the control record, the
   // frame's records as soon as that record says which linearisation buffer is current -- under the tables and the barrier below
   const int b = wv - 2;                                            // (builders: 0 / 1)
@@ -1646,8 +1653,9 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
 #pragma unroll
   for (int a2 = 0; a2 < 15; ++a2) sp_col = (lane == a2) ? v.imu_param_col[a2] : sp_col;
   auto load_fct = [&](int f) { return (lane < C && f < N) ? v.frame_cam_tile[(size_t)f * C + lane] : -1; };
-  int fct = -1, fct_next = -1;
-  if (nmine > 0) fct = load_fct(a + slot_of(0));
+  int fctA = -1, fctB = -1;                                      // tile lists of the builder's first two frames
+  if (nmine > 0) fctA = load_fct(a + slot_of(0));
+  if (nmine > 1) fctB = load_fct(a + slot_of(1));
   if (ct->done) return;                                          // (uniform over the workgroup)
   const int cur = ct->cur;
   const double* segc = v.segb[cur];
@@ -1703,15 +1711,18 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) R.isum_in[qq] = ((lane + 64 * qq) < 240 && has_c) ? xi[qq] : 0.0;
   };
-  InitLoads<CMAX> R;
-  if (nmine > 0) { issue(a + slot_of(0), fct, R); if (nmine > 1) fct_next = load_fct(a + slot_of(1)); }
-  if (tid < 10) READY[tid] = 0;
-  if (wv >= 2) {       // the builders prepare the tables both of them use
-    const int t2 = tid - 128;
-    if (t2 < kMaxCams) s_cd[t2] = v.cd[t2];
-    if (t2 < C) { double Rm[9]; quat_to_R(v.cams[cur] + (size_t)t2 * kCamStride, Rm); for (int k = 0; k < 9; ++k) s_R[t2 * 9 + k] = Rm[k]; }
-    if (t2 < ncol) {
-      const int col = t2, e = col - nW;
+  // two frames' records in flight (two register sets): a frame's loads are requested BEHIND the hand-over of the frame two before it --
+  // issuing them (1.3 us of instructions) no longer sits between a frame's arrival and its hand-over
+  InitLoads<CMAX> RA, RB;
+  if (nmine > 0) issue(a + slot_of(0), fctA, RA);
+  if (nmine > 1) issue(a + slot_of(1), fctB, RB);
+  // the builder's own tables (camera descriptors, rotations R_ck) and what its lane's column is -- under its first frame's loads
+  int col_ci = 0;
+  if (wv >= 2) {
+    if (lane < kMaxCams) s_cd2[b][lane] = v.cd[lane];
+    if (lane < C) { double Rm[9]; quat_to_R(v.cams[cur] + (size_t)lane * kCamStride, Rm); for (int k2 = 0; k2 < 9; ++k2) s_R2[b][lane * 9 + k2] = Rm[k2]; }
+    if (lane < ncol) {
+      const int col = lane, e = col - nW;
       int cam = 255, loc = 0, skip = (e >= 18 && e < 27) ? 1 : 0;
       if (col < D) {
         const int cc = v.col_cam[col];
@@ -1719,10 +1730,10 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
 #pragma unroll
         for (int a2 = 0; a2 < 15; ++a2) skip |= (v.imu_param_col[a2] == col) ? 1 : 0;
       }
-      s_ci[col] = cam | (loc << 8) | (skip << 16);
+      col_ci = cam | (loc << 8) | (skip << 16);
     }
+    wave_lds_sync_local();
   }
-  __syncthreads();
 #ifdef VC_L0_STAMPS
   if (blockIdx.x == gridDim.x / 2 && lane == 0 && (wv == 0 || wv == 2)) v.dbg[wv == 0 ? 0 : 16] = l0t0_;
   if (wv == 0 || wv == 2) L0STAMP();      // 1: behind the first barrier
@@ -1982,7 +1993,7 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
 #pragma unroll
   for (int i = 0; i < 9; ++i) cR[i] = 0.0;
   if (wv >= 2 && lane < ncol) {
-    const int col = lane, ci = s_ci[col], e = col - nW;
+    const int col = lane, ci = col_ci, e = col - nW;
     const int cc = ci & 255, j = (ci >> 8) & 255;
     cic = col < nW ? col : nW + (e >= 0 ? e % 9 : 0);
     cjb = (e >= 0) ? e % 9 : 0;
@@ -1991,17 +2002,18 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
     else if (e >= 9 && e < 18) ckind = 3;
     else if (col < D && cc < kMaxCams) {
       ckind = 1; ccam = cc;
-      const int flags = s_cd[cc].flags, nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
-      const double* Rm = s_R + cc * 9;
+      const int flags = s_cd2[b][cc].flags, nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
+      const double* Rm = s_R2[b] + cc * 9;
 #pragma unroll
       for (int i = 0; i < 9; ++i) cR[i] = Rm[i];
       if (j < nrot) { cidx0 = 3; cidx1 = 4; cidx2 = 5; cw0 = -Rm[j]; cw1 = -Rm[3 + j]; cw2 = -Rm[6 + j]; }
       else { const int jj = (j < nrot + ntr) ? j - nrot : 6 + (j - nrot - ntr); cidx0 = jj; cidx1 = jj; cidx2 = jj; cw0 = 1.0; }
     } else if (col < nW) ckind = 4;                                // a border column nobody owns: zeros
   }
-  for (int it = 0; it < nmine; ++it) {
+  auto build = [&](int it, InitLoads<CMAX>& R, int& fct) {
     const int slot = slot_of(it), f = a + slot;
     double* im = IMG[slot];
+    const int fct2 = (it + 2 < nmine) ? load_fct(a + slot_of(it + 2)) : -1;      // the tile list of the frame that takes this register set next
     L0B(0);
     const unsigned long long present = __ballot(lane < C && fct >= 0);
     const int nt = __popcll(present);
@@ -2036,14 +2048,12 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
     const double g_imu = R.g_imu, sc2_in = R.sc2_in, dg_in = R.dg_in;
     wave_lds_sync_local();
     L0B(1);
-    fct = fct_next;
-    if (it + 1 < nmine) { issue(a + slot_of(it + 1), fct, R); if (it + 2 < nmine) fct_next = load_fct(a + slot_of(it + 2)); }
     L0B(2);
     if (lane < 42) {
       double hval = 0.0;
       for (int t = 0; t < nt; ++t) {
         const int cc = tcam[t];
-        const double* Rm = s_R + cc * 9;
+        const double* Rm = s_R2[b] + cc * 9;
         const double* g = Gw + t * kGStride;
         if (lane < 36) {
           const int i = lane / 6, j = lane % 6, a2 = i / 3, ii = i % 3, b2 = j / 3, jj = j % 3;
@@ -2055,7 +2065,7 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
           hval += (a2 == b2) ? sacc : -sacc;
         } else {
           const int i = lane - 36, a2 = i / 3, ii = i % 3;
-          const int nk = model_nk(s_cd[cc].model);
+          const int nk = model_nk(s_cd2[b][cc].model);
           double sacc = 0.0;
 #pragma unroll
           for (int pp = 0; pp < 3; ++pp) sacc += Rm[3 * pp + ii] * gram_grad(g, 3 * a2 + pp, nk);
@@ -2123,6 +2133,12 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
     set_ready(slot);
     L0B(6);
     if (wv == 2) L0STAMP();                 // builder 2: frame handed over
+    fct = fct2;
+    if (it + 2 < nmine) issue(a + slot_of(it + 2), fct, R);
+  };
+  for (int it = 0; it < nmine; it += 2) {
+    build(it, RA, fctA);
+    if (it + 1 < nmine) build(it + 1, RB, fctB);
   }
   // ---- chunk sums (chunk = group): builder 3 hands its sums over through LDS, builder 2 adds its own in front and writes the record
   __syncthreads();                       // (the sweeps' hand-over barrier: counts all four wavefronts)
