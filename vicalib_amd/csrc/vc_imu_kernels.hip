@@ -1603,11 +1603,11 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
   __shared__ double An2[2][81], Ls2[2][81];
   __shared__ double MID[9 * W], SEPR[9 * W];
   __shared__ double IMG[8][9 * kL0Ld];
-  __shared__ int READY[10];              // [slot]: the frame's image is in IMG; [8]: builder 3's chunk sums are in SUM3
-  __shared__ double BW[2][CMAX * kGStride + kInitPad];
-  __shared__ double SUM3[CMAX * kGStride + kGStride + 16];
-  __shared__ CamDesc s_cd2[2][kMaxCams];      // every builder keeps its own small tables: no workgroup barrier between the builders' start and
-  __shared__ double s_R2[2][kMaxCams * 9];    // their first frame (the one barrier ahead of everything only publishes READY = 0)
+  __shared__ int READY[12];              // [slot]: the frame's image is in IMG; [8 + w], w = 0, 1, 3: wavefront w's chunk sums are in SUMW
+  __shared__ double BW[4][CMAX * kGStride + kInitPad];
+  __shared__ double SUMW[4][CMAX * kGStride + kGStride + 16];
+  __shared__ CamDesc s_cd2[4][kMaxCams];      // every wavefront keeps its own small tables: no workgroup barrier between the start and the
+  __shared__ double s_R2[4][kMaxCams * 9];    // first frames (the one barrier ahead of everything only publishes READY = 0)
   const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, group = blockIdx.x;
 #ifdef VC_L0_STAMPS
   const long long l0t0_ = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1641,14 +1641,20 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) __hip_atomic_store(&READY[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
-  if (tid < 10) READY[tid] = 0;
+  if (tid < 12) READY[tid] = 0;
   __syncthreads();
   // ---- the builders' first requests go out before anything else: the tile list of their first frame ahead of the control record, the
   // frame's records as soon as that record says which linearisation buffer is current -- under the tables and the barrier below
-  const int b = wv - 2;                                            // (builders: 0 / 1)
-  // frames of this builder, in the order they are needed: slots 1 .. nl, mid  |  q .. mid + 1, 0
-  const int nmine = wv < 2 ? 0 : (q == 0 ? (b == 1 ? 1 : 0) : (b == 0 ? nl + 1 : nr + 1));
-  auto slot_of = [&](int i) { return q == 0 ? 0 : (b == 0 ? (i < nl ? 1 + i : mid) : (i < nr ? q - i : 0)); };
+  // Who builds what (round 5, second cut): the SWEEPS build their own first frame -- they would only wait for it -- while the builders
+  // already work on the second ones: wavefront 0 the first frame of the left sweep (the middle if there is none), wavefront 1 the first of
+  // the right sweep, builder 2 the rest of the left sweep's frames and then the middle, builder 3 the rest of the right sweep's and then
+  // the separator a.  (With the builders alone the sweeps ran at the builders' ~4 us per frame instead of their own 2.8.)
+  const int b = wv;                                                // (index of this wavefront's scratch and tables)
+  const int nmine = q == 0 ? (wv == 3 ? 1 : 0)
+                  : wv == 0 ? 1 : wv == 1 ? (nr > 0 ? 1 : 0) : wv == 2 ? (nl > 0 ? nl : 0) : (nr > 0 ? nr - 1 : 0) + 1;
+  auto slot_of = [&](int i) {
+    return q == 0 ? 0 : wv == 0 ? (nl > 0 ? 1 : mid) : wv == 1 ? q : wv == 2 ? (i < nl - 1 ? 2 + i : mid) : (i < nr - 1 ? q - 1 - i : 0);
+  };
   int sp_col = -1;
 #pragma unroll
   for (int a2 = 0; a2 < 15; ++a2) sp_col = (lane == a2) ? v.imu_param_col[a2] : sp_col;
@@ -1718,7 +1724,7 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
   if (nmine > 1) issue(a + slot_of(1), fctB, RB);
   // the builder's own tables (camera descriptors, rotations R_ck) and what its lane's column is -- under its first frame's loads
   int col_ci = 0;
-  if (wv >= 2) {
+  if (nmine > 0) {                                                 // (wave-uniform)
     if (lane < kMaxCams) s_cd2[b][lane] = v.cd[lane];
     if (lane < C) { double Rm[9]; quat_to_R(v.cams[cur] + (size_t)lane * kCamStride, Rm); for (int k2 = 0; k2 < 9; ++k2) s_R2[b][lane * 9 + k2] = Rm[k2]; }
     if (lane < ncol) {
@@ -1734,12 +1740,213 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
     }
     wave_lds_sync_local();
   }
+  // ============================================================ building (k_chain_init's work, frame by frame; all four wavefronts) ====
+  double* Gw = BW[b];
+  double* Hs = Gw + C * kGStride;
+  double* As = Hs + 42;
+  double* gs = As + 81;
+  double* ls = gs + 9;
+  int* tcam = reinterpret_cast<int*>(ls + 9);
+  int* tinv = tcam + kMaxCams;
+  double gsum[CMAX][3];
+  double isum[4] = {0.0, 0.0, 0.0, 0.0};
+  double csum = 0.0;
+  int po[3], pm[3];
+#pragma unroll
+  for (int qq = 0; qq < 3; ++qq) {
+    const int e = qq * 64 + lane;
+    int rr = 0;
+#pragma unroll
+    for (int a2 = 1; a2 < 16; ++a2) rr += (e >= a2 * 16 - (a2 * (a2 - 1)) / 2) ? 1 : 0;
+    const int cidx = rr + (e - (rr * 16 - (rr * (rr - 1)) / 2));
+    po[qq] = e < kGPackGrad ? rr * 16 + cidx : (e < kGPack ? kGGrad + (e - kGPackGrad) : -1);
+    pm[qq] = (e < kGPackGrad && cidx != rr) ? cidx * 16 + rr : -1;
+  }
+#pragma unroll
+  for (int cc = 0; cc < CMAX; ++cc)
+#pragma unroll
+    for (int qq = 0; qq < 3; ++qq) gsum[cc][qq] = 0.0;
+  // what this lane's image column is (one column per lane: D + 28 <= 64), once for all frames -- the column phase then runs without a
+  // divergent branch: a camera's column is three weighted entries per row of its tile's Gram block (a rotation column: -R's column over
+  // entries 3..5; a unit column: one entry with weight 1), A's and g's columns come from the frame's own block; everybody loads from valid
+  // addresses and keeps what is his by selects.  (As `if (camera column) { if (rotation) .. else .. } if (g) .. if (A) ..` the phase took
+  // 2.2 of the ~4 us a builder needs per frame: five serialised branch regions, each with its own LDS round trips.)
+  int ckind = 0, ccam = 0, cjb = 0, cidx0 = 0, cidx1 = 0, cidx2 = 0, cic = 0;
+  double cw0 = 0.0, cw1 = 0.0, cw2 = 0.0, cR[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) cR[i] = 0.0;
+  if (nmine > 0 && lane < ncol) {
+    const int col = lane, ci = col_ci, e = col - nW;
+    const int cc = ci & 255, j = (ci >> 8) & 255;
+    cic = col < nW ? col : nW + (e >= 0 ? e % 9 : 0);
+    cjb = (e >= 0) ? e % 9 : 0;
+    if ((ci >> 16) || (e >= 0 && e < 9)) ckind = 0;             // IMU-record columns (written with the records' values), C, B
+    else if (col == D) ckind = 2;
+    else if (e >= 9 && e < 18) ckind = 3;
+    else if (col < D && cc < kMaxCams) {
+      ckind = 1; ccam = cc;
+      const int flags = s_cd2[b][cc].flags, nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
+      const double* Rm = s_R2[b] + cc * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) cR[i] = Rm[i];
+      if (j < nrot) { cidx0 = 3; cidx1 = 4; cidx2 = 5; cw0 = -Rm[j]; cw1 = -Rm[3 + j]; cw2 = -Rm[6 + j]; }
+      else { const int jj = (j < nrot + ntr) ? j - nrot : 6 + (j - nrot - ntr); cidx0 = jj; cidx1 = jj; cidx2 = jj; cw0 = 1.0; }
+    } else if (col < nW) ckind = 4;                                // a border column nobody owns: zeros
+  }
+  auto build = [&](int it, InitLoads<CMAX>& R, int& fct) {
+    const int slot = slot_of(it), f = a + slot;
+    double* im = IMG[slot];
+    const int fct2 = (it + 2 < nmine) ? load_fct(a + slot_of(it + 2)) : -1;      // the tile list of the frame that takes this register set next
+    L0B(0);
+    const unsigned long long present = __ballot(lane < C && fct >= 0);
+    const int nt = __popcll(present);
+    if (lane < kMaxCams) {
+      const bool have = lane < C && fct >= 0;
+      tinv[lane] = have ? __popcll(present & ((1ull << lane) - 1ull)) : -1;
+    }
+    wave_lds_sync_local();
+    if (lane < C && fct >= 0) tcam[tinv[lane]] = lane;
+    csum += R.cost_in;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) isum[qq] += R.isum_in[qq];
+    int slot_c = 0;
+#pragma unroll
+    for (int cc = 0; cc < CMAX; ++cc) {
+      const bool have = cc < C && ((present >> cc) & 1ull);
+      if (have) {
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) {
+          if (po[qq] >= 0) Gw[slot_c * kGStride + po[qq]] = R.gv[cc][qq];
+          if (pm[qq] >= 0) Gw[slot_c * kGStride + pm[qq]] = R.gv[cc][qq];
+          gsum[cc][qq] += R.gv[cc][qq];
+        }
+        ++slot_c;
+      }
+    }
+    if (sp_col >= 0) {          // the IMU-parameter columns of the border, straight from the records
+#pragma unroll
+      for (int i = 0; i < 9; ++i) im[i * kL0Ld + sp_col] = R.pre[i];
+    }
+    const double a_imu[2] = {R.a_imu[0], R.a_imu[1]};
+    const double g_imu = R.g_imu, sc2_in = R.sc2_in, dg_in = R.dg_in;
+    wave_lds_sync_local();
+    L0B(1);
+    L0B(2);
+    if (lane < 42) {
+      double hval = 0.0;
+      for (int t = 0; t < nt; ++t) {
+        const int cc = tcam[t];
+        const double* Rm = s_R2[b] + cc * 9;
+        const double* g = Gw + t * kGStride;
+        if (lane < 36) {
+          const int i = lane / 6, j = lane % 6, a2 = i / 3, ii = i % 3, b2 = j / 3, jj = j % 3;
+          double sacc = 0.0;
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq) sacc += Rm[3 * pp + ii] * g[(3 * a2 + pp) * 16 + 3 * b2 + qq] * Rm[3 * qq + jj];
+          hval += (a2 == b2) ? sacc : -sacc;
+        } else {
+          const int i = lane - 36, a2 = i / 3, ii = i % 3;
+          const int nk = model_nk(s_cd2[b][cc].model);
+          double sacc = 0.0;
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) sacc += Rm[3 * pp + ii] * gram_grad(g, 3 * a2 + pp, nk);
+          hval += (a2 == 0) ? -sacc : sacc;
+        }
+      }
+      Hs[lane] = hval;
+    }
+    wave_lds_sync_local();
+    L0B(3);
+    double aval[2];
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int e = lane + 64 * qq, i = e / 9, j = e % 9;
+      aval[qq] = a_imu[qq] + ((e < 81 && i < 6 && j < 6) ? Hs[i * 6 + j] : 0.0);
+      if (e < 81) As[e] = aval[qq];
+    }
+    const double gval = g_imu + ((lane < 6) ? Hs[36 + lane] : 0.0);
+    double hd = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int e = i * 10;
+      const double d = readlane_f64(aval[e >> 6], e & 63);
+      if (lane == i) hd = d;
+    }
+    if (lane < 9) {
+      double sc2 = sc2_in, dg = dg_in;
+      if (init_scale) { sc2 = jacobi_scale2(hd); v.cscale2[(size_t)f * 9 + lane] = sc2; }
+      if (!reuse) { dg = lm_clamped_diag(hd, sc2); v.cdiag[(size_t)f * 9 + lane] = dg; }
+      const double lam = dg / (radius * sc2);
+      v.clam[(size_t)f * 9 + lane] = lam;
+      v.cg[(size_t)f * 9 + lane] = gval;
+      gs[lane] = gval; ls[lane] = lam;
+    }
+    wave_lds_sync_local();
+    L0B(4);
+    // the image's border and A columns -> LDS (branch-free, see the lane constants above)
+    {
+      const int t = tinv[ccam];
+      const double* g = Gw + (t >= 0 ? t : 0) * kGStride;
+      double g0[6], g1[6], g2[6], av[9], gv9[9];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) { g0[rr] = g[rr * 16 + cidx0]; g1[rr] = g[rr * 16 + cidx1]; g2[rr] = g[rr * 16 + cidx2]; }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { av[i] = As[i * 9 + cjb]; gv9[i] = gs[i]; }
+      const double lj = ls[cjb];
+      double u[6];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) u[rr] = g0[rr] * cw0 + g1[rr] * cw1 + g2[rr] * cw2;
+      double val[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        val[i] = -(cR[i] * u[0] + cR[3 + i] * u[1] + cR[6 + i] * u[2]);
+        val[3 + i] = cR[i] * u[3] + cR[3 + i] * u[4] + cR[6 + i] * u[5];
+        val[6 + i] = 0.0;
+      }
+      const bool cam_live = ckind == 1 && t >= 0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const double x = cam_live ? val[i] : (ckind == 2 ? gv9[i] : (ckind == 3 ? av[i] + ((i == cjb) ? lj : 0.0) : 0.0));
+        if (ckind != 0) im[i * kL0Ld + cic] = x;
+      }
+    }
+    L0B(5);
+    set_ready(slot);
+    L0B(6);
+    if (wv == 2) L0STAMP();                 // builder 2: frame handed over
+    fct = fct2;
+    if (it + 2 < nmine) issue(a + slot_of(it + 2), fct, R);
+  };
+  for (int it = 0; it < nmine; it += 2) {
+    build(it, RA, fctA);
+    if (it + 1 < nmine) build(it + 1, RB, fctB);
+  }
 #ifdef VC_L0_STAMPS
   if (blockIdx.x == gridDim.x / 2 && lane == 0 && (wv == 0 || wv == 2)) v.dbg[wv == 0 ? 0 : 16] = l0t0_;
   if (wv == 0 || wv == 2) L0STAMP();      // 1: behind the first barrier
 #endif
   if (wv < 2) {
     // ======================================================= the two sweeps (k_chain_fwd2<1> at s = 1, level 0) =======================
+    // this sweep's own frame's contribution to the chunk sums: to LDS for builder 2, which needs it at the very end -- published where the
+    // sweep has time (at the hand-over barrier), not between its frame's build and its first elimination
+    auto publish_sums = [&]() {
+      const int nsum_ = C * kGStride + kGStride;
+#pragma unroll
+      for (int cc = 0; cc < CMAX; ++cc)
+        if (cc < C) {
+#pragma unroll
+          for (int qq = 0; qq < 3; ++qq) {
+            if (po[qq] >= 0) SUMW[wv][cc * kGStride + po[qq]] = gsum[cc][qq];
+            if (pm[qq] >= 0) SUMW[wv][cc * kGStride + pm[qq]] = gsum[cc][qq];
+          }
+        }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) SUMW[wv][C * kGStride + qq * 64 + lane] = isum[qq];
+      if (lane < 9) SUMW[wv][nsum_ + lane] = csum;
+      set_ready(8 + wv);
+    };
     const int wave = wv;
     auto gsync = [&]() { wave_lds_sync_local(); };
     const int c = lane, e0 = c - nW;
@@ -1889,6 +2096,7 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
 #pragma unroll
           for (int k = 0; k < 9; ++k) SEPR[k * W + c] = dacc[k];
         }
+        publish_sums();
         __syncthreads();                 // (all four wavefronts: the builders arrive when their frames are built)
         if (wave == 1) return;
 #pragma unroll
@@ -1957,209 +2165,28 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
 #endif
     return;
   }
-  // ============================================================ the two builders (k_chain_init's work, frame by frame) ===============
-  double* Gw = BW[b];
-  double* Hs = Gw + C * kGStride;
-  double* As = Hs + 42;
-  double* gs = As + 81;
-  double* ls = gs + 9;
-  int* tcam = reinterpret_cast<int*>(ls + 9);
-  int* tinv = tcam + kMaxCams;
-  double gsum[CMAX][3];
-  double isum[4] = {0.0, 0.0, 0.0, 0.0};
-  double csum = 0.0;
-  int po[3], pm[3];
-#pragma unroll
-  for (int qq = 0; qq < 3; ++qq) {
-    const int e = qq * 64 + lane;
-    int rr = 0;
-#pragma unroll
-    for (int a2 = 1; a2 < 16; ++a2) rr += (e >= a2 * 16 - (a2 * (a2 - 1)) / 2) ? 1 : 0;
-    const int cidx = rr + (e - (rr * 16 - (rr * (rr - 1)) / 2));
-    po[qq] = e < kGPackGrad ? rr * 16 + cidx : (e < kGPack ? kGGrad + (e - kGPackGrad) : -1);
-    pm[qq] = (e < kGPackGrad && cidx != rr) ? cidx * 16 + rr : -1;
-  }
-#pragma unroll
-  for (int cc = 0; cc < CMAX; ++cc)
-#pragma unroll
-    for (int qq = 0; qq < 3; ++qq) gsum[cc][qq] = 0.0;
-  // what this lane's image column is (one column per lane: D + 28 <= 64), once for all frames -- the column phase then runs without a
-  // divergent branch: a camera's column is three weighted entries per row of its tile's Gram block (a rotation column: -R's column over
-  // entries 3..5; a unit column: one entry with weight 1), A's and g's columns come from the frame's own block; everybody loads from valid
-  // addresses and keeps what is his by selects.  (As `if (camera column) { if (rotation) .. else .. } if (g) .. if (A) ..` the phase took
-  // 2.2 of the ~4 us a builder needs per frame: five serialised branch regions, each with its own LDS round trips.)
-  int ckind = 0, ccam = 0, cjb = 0, cidx0 = 0, cidx1 = 0, cidx2 = 0, cic = 0;
-  double cw0 = 0.0, cw1 = 0.0, cw2 = 0.0, cR[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) cR[i] = 0.0;
-  if (wv >= 2 && lane < ncol) {
-    const int col = lane, ci = col_ci, e = col - nW;
-    const int cc = ci & 255, j = (ci >> 8) & 255;
-    cic = col < nW ? col : nW + (e >= 0 ? e % 9 : 0);
-    cjb = (e >= 0) ? e % 9 : 0;
-    if ((ci >> 16) || (e >= 0 && e < 9)) ckind = 0;             // IMU-record columns (written with the records' values), C, B
-    else if (col == D) ckind = 2;
-    else if (e >= 9 && e < 18) ckind = 3;
-    else if (col < D && cc < kMaxCams) {
-      ckind = 1; ccam = cc;
-      const int flags = s_cd2[b][cc].flags, nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
-      const double* Rm = s_R2[b] + cc * 9;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) cR[i] = Rm[i];
-      if (j < nrot) { cidx0 = 3; cidx1 = 4; cidx2 = 5; cw0 = -Rm[j]; cw1 = -Rm[3 + j]; cw2 = -Rm[6 + j]; }
-      else { const int jj = (j < nrot + ntr) ? j - nrot : 6 + (j - nrot - ntr); cidx0 = jj; cidx1 = jj; cidx2 = jj; cw0 = 1.0; }
-    } else if (col < nW) ckind = 4;                                // a border column nobody owns: zeros
-  }
-  auto build = [&](int it, InitLoads<CMAX>& R, int& fct) {
-    const int slot = slot_of(it), f = a + slot;
-    double* im = IMG[slot];
-    const int fct2 = (it + 2 < nmine) ? load_fct(a + slot_of(it + 2)) : -1;      // the tile list of the frame that takes this register set next
-    L0B(0);
-    const unsigned long long present = __ballot(lane < C && fct >= 0);
-    const int nt = __popcll(present);
-    if (lane < kMaxCams) {
-      const bool have = lane < C && fct >= 0;
-      tinv[lane] = have ? __popcll(present & ((1ull << lane) - 1ull)) : -1;
-    }
-    wave_lds_sync_local();
-    if (lane < C && fct >= 0) tcam[tinv[lane]] = lane;
-    csum += R.cost_in;
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) isum[qq] += R.isum_in[qq];
-    int slot_c = 0;
-#pragma unroll
-    for (int cc = 0; cc < CMAX; ++cc) {
-      const bool have = cc < C && ((present >> cc) & 1ull);
-      if (have) {
-#pragma unroll
-        for (int qq = 0; qq < 3; ++qq) {
-          if (po[qq] >= 0) Gw[slot_c * kGStride + po[qq]] = R.gv[cc][qq];
-          if (pm[qq] >= 0) Gw[slot_c * kGStride + pm[qq]] = R.gv[cc][qq];
-          gsum[cc][qq] += R.gv[cc][qq];
-        }
-        ++slot_c;
-      }
-    }
-    if (sp_col >= 0) {          // the IMU-parameter columns of the border, straight from the records
-#pragma unroll
-      for (int i = 0; i < 9; ++i) im[i * kL0Ld + sp_col] = R.pre[i];
-    }
-    const double a_imu[2] = {R.a_imu[0], R.a_imu[1]};
-    const double g_imu = R.g_imu, sc2_in = R.sc2_in, dg_in = R.dg_in;
-    wave_lds_sync_local();
-    L0B(1);
-    L0B(2);
-    if (lane < 42) {
-      double hval = 0.0;
-      for (int t = 0; t < nt; ++t) {
-        const int cc = tcam[t];
-        const double* Rm = s_R2[b] + cc * 9;
-        const double* g = Gw + t * kGStride;
-        if (lane < 36) {
-          const int i = lane / 6, j = lane % 6, a2 = i / 3, ii = i % 3, b2 = j / 3, jj = j % 3;
-          double sacc = 0.0;
-#pragma unroll
-          for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-            for (int qq = 0; qq < 3; ++qq) sacc += Rm[3 * pp + ii] * g[(3 * a2 + pp) * 16 + 3 * b2 + qq] * Rm[3 * qq + jj];
-          hval += (a2 == b2) ? sacc : -sacc;
-        } else {
-          const int i = lane - 36, a2 = i / 3, ii = i % 3;
-          const int nk = model_nk(s_cd2[b][cc].model);
-          double sacc = 0.0;
-#pragma unroll
-          for (int pp = 0; pp < 3; ++pp) sacc += Rm[3 * pp + ii] * gram_grad(g, 3 * a2 + pp, nk);
-          hval += (a2 == 0) ? -sacc : sacc;
-        }
-      }
-      Hs[lane] = hval;
-    }
-    wave_lds_sync_local();
-    L0B(3);
-    double aval[2];
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-      const int e = lane + 64 * qq, i = e / 9, j = e % 9;
-      aval[qq] = a_imu[qq] + ((e < 81 && i < 6 && j < 6) ? Hs[i * 6 + j] : 0.0);
-      if (e < 81) As[e] = aval[qq];
-    }
-    const double gval = g_imu + ((lane < 6) ? Hs[36 + lane] : 0.0);
-    double hd = 0.0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const int e = i * 10;
-      const double d = readlane_f64(aval[e >> 6], e & 63);
-      if (lane == i) hd = d;
-    }
-    if (lane < 9) {
-      double sc2 = sc2_in, dg = dg_in;
-      if (init_scale) { sc2 = jacobi_scale2(hd); v.cscale2[(size_t)f * 9 + lane] = sc2; }
-      if (!reuse) { dg = lm_clamped_diag(hd, sc2); v.cdiag[(size_t)f * 9 + lane] = dg; }
-      const double lam = dg / (radius * sc2);
-      v.clam[(size_t)f * 9 + lane] = lam;
-      v.cg[(size_t)f * 9 + lane] = gval;
-      gs[lane] = gval; ls[lane] = lam;
-    }
-    wave_lds_sync_local();
-    L0B(4);
-    // the image's border and A columns -> LDS (branch-free, see the lane constants above)
-    {
-      const int t = tinv[ccam];
-      const double* g = Gw + (t >= 0 ? t : 0) * kGStride;
-      double g0[6], g1[6], g2[6], av[9], gv9[9];
-#pragma unroll
-      for (int rr = 0; rr < 6; ++rr) { g0[rr] = g[rr * 16 + cidx0]; g1[rr] = g[rr * 16 + cidx1]; g2[rr] = g[rr * 16 + cidx2]; }
-#pragma unroll
-      for (int i = 0; i < 9; ++i) { av[i] = As[i * 9 + cjb]; gv9[i] = gs[i]; }
-      const double lj = ls[cjb];
-      double u[6];
-#pragma unroll
-      for (int rr = 0; rr < 6; ++rr) u[rr] = g0[rr] * cw0 + g1[rr] * cw1 + g2[rr] * cw2;
-      double val[9];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        val[i] = -(cR[i] * u[0] + cR[3 + i] * u[1] + cR[6 + i] * u[2]);
-        val[3 + i] = cR[i] * u[3] + cR[3 + i] * u[4] + cR[6 + i] * u[5];
-        val[6 + i] = 0.0;
-      }
-      const bool cam_live = ckind == 1 && t >= 0;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        const double x = cam_live ? val[i] : (ckind == 2 ? gv9[i] : (ckind == 3 ? av[i] + ((i == cjb) ? lj : 0.0) : 0.0));
-        if (ckind != 0) im[i * kL0Ld + cic] = x;
-      }
-    }
-    L0B(5);
-    set_ready(slot);
-    L0B(6);
-    if (wv == 2) L0STAMP();                 // builder 2: frame handed over
-    fct = fct2;
-    if (it + 2 < nmine) issue(a + slot_of(it + 2), fct, R);
-  };
-  for (int it = 0; it < nmine; it += 2) {
-    build(it, RA, fctA);
-    if (it + 1 < nmine) build(it + 1, RB, fctB);
-  }
-  // ---- chunk sums (chunk = group): builder 3 hands its sums over through LDS, builder 2 adds its own in front and writes the record
+  // ============================================================ the two builders: chunk sums ==========================================
+  // ---- chunk sums (chunk = group): wavefronts 0, 1 (above) and builder 3 hand their sums over through LDS, builder 2 adds them to its own
+  // in fixed order (2, 3, 0, 1) and writes the record
   __syncthreads();                       // (the sweeps' hand-over barrier: counts all four wavefronts)
   const int nsum = C * kGStride + kGStride;
-  if (b == 1) {
+  if (wv == 3) {
 #pragma unroll
     for (int cc = 0; cc < CMAX; ++cc)
       if (cc < C) {
 #pragma unroll
         for (int qq = 0; qq < 3; ++qq) {
-          if (po[qq] >= 0) SUM3[cc * kGStride + po[qq]] = gsum[cc][qq];
-          if (pm[qq] >= 0) SUM3[cc * kGStride + pm[qq]] = gsum[cc][qq];
+          if (po[qq] >= 0) SUMW[3][cc * kGStride + po[qq]] = gsum[cc][qq];
+          if (pm[qq] >= 0) SUMW[3][cc * kGStride + pm[qq]] = gsum[cc][qq];
         }
       }
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) SUM3[C * kGStride + qq * 64 + lane] = isum[qq];
-    if (lane < 9) SUM3[nsum + lane] = csum;
-    set_ready(8);
+    for (int qq = 0; qq < 4; ++qq) SUMW[3][C * kGStride + qq * 64 + lane] = isum[qq];
+    if (lane < 9) SUMW[3][nsum + lane] = csum;
+    set_ready(8 + 3);
     return;
   }
-  // builder 2: its own sums through its (now free) Gram scratch, expanded like builder 3's
+  // builder 2: its own sums through its (now free) Gram scratch, expanded like the others'
 #pragma unroll
   for (int cc = 0; cc < CMAX; ++cc)
     if (cc < C) {
@@ -2170,19 +2197,25 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
       }
     }
   wave_lds_sync_local();
-  wait_ready(8);
+  wait_ready(8 + 3);
+  const bool sw = q > 0;                  // (a group without interior frames: the sweeps built nothing and published nothing)
+  if (sw) { wait_ready(8 + 0); wait_ready(8 + 1); }
   double* part = v.part + (size_t)group * v.part_stride;
-  for (int e = lane; e < C * kGStride; e += 64) part[D * D + D + e] = Gw[e] + SUM3[e];
+  for (int e = lane; e < C * kGStride; e += 64) part[D * D + D + e] = ((Gw[e] + SUMW[3][e]) + (sw ? SUMW[0][e] : 0.0)) + (sw ? SUMW[1][e] : 0.0);
 #pragma unroll
-  for (int qq = 0; qq < 4; ++qq) part[D * D + D + C * kGStride + qq * 64 + lane] = isum[qq] + SUM3[C * kGStride + qq * 64 + lane];
+  for (int qq = 0; qq < 4; ++qq) {
+    const int e = C * kGStride + qq * 64 + lane;
+    part[D * D + D + e] = ((isum[qq] + SUMW[3][e]) + (sw ? SUMW[0][e] : 0.0)) + (sw ? SUMW[1][e] : 0.0);
+  }
   for (int e = C * kGStride + 256 + lane; e < nsum; e += 64) part[D * D + D + e] = 0.0;
   {
-    double t0 = (lane < 9) ? csum : 0.0, t1 = (lane < 9) ? SUM3[nsum + lane] : 0.0;
-    // fixed order: builder 2's nine lanes, then builder 3's
-    double tw0 = 0.0, tw1 = 0.0;
+    // fixed order: the nine lanes of builder 2, of builder 3, of wavefront 0, of wavefront 1
+    const double t2 = (lane < 9) ? csum : 0.0, t3 = (lane < 9) ? SUMW[3][nsum + lane] : 0.0;
+    const double t0 = (lane < 9 && sw) ? SUMW[0][nsum + lane] : 0.0, t1 = (lane < 9 && sw) ? SUMW[1][nsum + lane] : 0.0;
+    double u2 = 0.0, u3 = 0.0, u0 = 0.0, u1 = 0.0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { tw0 += readlane_f64(t0, k); tw1 += readlane_f64(t1, k); }
-    if (lane == 0) part[v.part_stride - 1] = tw0 + tw1;
+    for (int kk = 0; kk < 9; ++kk) { u2 += readlane_f64(t2, kk); u3 += readlane_f64(t3, kk); u0 += readlane_f64(t0, kk); u1 += readlane_f64(t1, kk); }
+    if (lane == 0) part[v.part_stride - 1] = ((u2 + u3) + u0) + u1;
   }
 }
 
