@@ -291,6 +291,11 @@ def main():
     if vi and "k_chain_gram" not in kt and "k_chain_fwd" in kt:
         # early Gram: the Gram sums ride in the top level's launch -- the group k_chain_fwd carries their flops and bytes
         algo["k_chain_fwd"] = ("fp64-valu", flops_fwd + flops_gram, bytes_fwd + bytes_gram)
+    if vi and "k_chain_init" not in kt and "k_chain_fwd" in kt:
+        # the chain assembly folded into the bottom level (k_chain_l0): its flops and the bytes it reads ride in the group as well; the
+        # unsolved images no longer travel (9 (D + 28) doubles per frame written and read back)
+        _, fl, by = algo["k_chain_fwd"]
+        algo["k_chain_fwd"] = ("fp64-valu", fl + flops_init, by + bytes_init - N * 2.0 * 9 * (D + 28) * 8)
     # launch groups that run on the second stream next to the critical path (vc_pass.cpp: enqueue_pass)
     overlapped = {"k_imu_weights", "k_imu_block(trial)", "k_imu_block", "k_imu_jac"} if vi else set()
     if vi and os.environ.get("VICALIB_AMD_JAC_STREAM2", "1") != "0" and os.environ.get("VICALIB_AMD_OVERLAP_WEIGHTS", "1") != "0":
@@ -313,7 +318,8 @@ def main():
         t = PMC_TRAFFIC.get(wl, {})
         base = group.replace("(trial)", "")
         if base == "k_chain_fwd":
-            parts = [t.get("k_chain_fwd@pass"), t.get("k_chain_fwd2@pass"), t.get("k_chain_top_gram@pass", t.get("k_chain_top_gram"))]
+            parts = [t.get("k_chain_fwd@pass"), t.get("k_chain_fwd2@pass"), t.get("k_chain_top_gram@pass", t.get("k_chain_top_gram")),
+                     t.get("k_chain_l0@pass", t.get("k_chain_l0"))]
             return sum(x for x in parts if x) if any(parts) else t.get(base)
         if base == "k_chain_back":
             return t.get("k_chain_back@pass", t.get(base))

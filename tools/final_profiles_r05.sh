@@ -20,6 +20,9 @@ txt=open('$O/bench_default.json').read(); d=json.loads([l for l in txt.splitline
 # round 5 extras: phase stamps of the kernels this round changed (k_chain_init, k_final, k_reduced) and the multi-rank bench branch on one GPU
 cd $R
 for spec in "cfg3" "cfg4 2500" "cfg5 6250"; do echo "== k_chain_init, $spec"; VICALIB_AMD_LIB=$R/tools/probe/libvicalib_amd_istamps.so python tools/init_stamps.py $spec; done > $O/init_stamps.txt 2>&1
+( echo "== k_chain_l0 (chain assembly folded into the bottom level), cfg3"; VICALIB_AMD_LIB=$R/tools/probe/libvicalib_amd_l0stamps.so python tools/l0_stamps.py ) > $O/l0_stamps.txt 2>&1
 ( echo "== k_final, cfg3"; VICALIB_AMD_LIB=$R/tools/probe/libvicalib_amd_fstamps.so python tools/final_stamps.py; echo "== k_reduced, cfg3"; VICALIB_AMD_LIB=$R/tools/probe/libvicalib_amd_rstamps.so python tools/reduced_stamps.py cfg3 ) > $O/final_reduced_stamps.txt 2>&1
 python bench.py --gpus 2 --transport gloo --steps 20 --warmup 5 --repeats 3 --no-cpu-baseline > $O/bench_two_ranks_gloo_one_gpu.json 2> $O/bench_two_ranks_gloo_one_gpu.err
 tools/ab_bench.sh "VICALIB_AMD_EARLY_GRAM=1" "VICALIB_AMD_EARLY_GRAM=0" 2 > $O/ab_early_gram.txt 2>&1
+tools/ab_bench.sh "VICALIB_AMD_FOLD_L0=1" "VICALIB_AMD_FOLD_L0=0" 3 > $O/ab_fold_l0.txt 2>&1
+tools/diag_fold.sh > $O/fold_vs_apart.txt 2>&1

@@ -10,8 +10,8 @@ cal = ViCalibrator(0).load_problem(p)
 cal.SetStageLimit(3); cal.Solve(); cal.prepare()
 cal.run_iterations(5)
 st = cal.debug_stamps().astype(float)
-sw = ["barrier passed", "e1 taken", "e1 done", "e2 taken", "e2 done", "e3 taken", "e3 done", "mid taken", "mid done", "separator stored (waited)"]
-bu = ["barrier passed", "e1 handed over", "e2 handed over", "e3 handed over", "mid handed over"]
+sw = ["own frame e1 built", "e1 taken", "e1 done", "e2 taken", "e2 done", "e3 taken", "e3 done", "mid taken", "mid done", "separator stored (waited)"]
+bu = ["e2 handed over", "e3 handed over", "mid handed over", "build loop left"]
 for title, off, names in (("sweep 0", 0, sw), ("builder 2", 16, bu)):
     print(title); prev = st[off]
     for i, n in enumerate(names):
