@@ -105,6 +105,53 @@ def test_gpu_detector_handles_extra_blobs_and_empty_images():
 
 
 @pytest.mark.gpu
+def test_gpu_detector_on_ragged_sizes_and_components_across_tiles():
+    """Labelling runs per 32 x 32 tile in LDS, pieces are joined across tile edges afterwards: an image whose sides are no multiples of
+    the tile, dots on tile edges and corners, components that wander through many tiles (a ring, a staircase, a comb) -- same dots, same
+    order, same boxes as the restatement (components named by their smallest pixel index on both sides)."""
+    from vicalib_amd.lib import ConicDetector
+    base, _ = dot_images.render(seed=2, tilt=(0.2, -0.1, 0.3))
+    img = np.ascontiguousarray(base[:457, :601])
+    yy, xx = np.mgrid[0:img.shape[0], 0:img.shape[1]]
+    img[(xx - 300) ** 2 + (yy - 230) ** 2 < 47 ** 2] = 25                       # large disc: its rim is a ring through ~12 tiles
+    for k in range(12):                                                          # staircase crossing tile corners
+        img[330 + 6 * k:330 + 6 * k + 7, 60 + 8 * k:60 + 8 * k + 9] = 20
+    img[20:24, 40:400] = 20                                                      # comb: a spine through 12 tiles ...
+    for k in range(20):
+        img[24:60, 44 + 18 * k:47 + 18 * k] = 20                                 # ... with teeth through two rows of tiles
+    for (cx, cy) in ((32.0, 128.0), (64.0, 96.0), (95.5, 159.5), (511.5, 63.5)):  # dots on tile edges / corners
+        img[(xx - cx) ** 2 + (yy - cy) ** 2 < 6.5 ** 2] = 25
+    cen, Cs, boxes = vco_detect.find_conics(img, full=True)
+    det = ConicDetector(img.shape[1], img.shape[0])
+    g_cen, g_C, g_box = det.find_conics(img)
+    assert len(cen) > 20 and g_cen.shape == cen.shape
+    np.testing.assert_allclose(g_cen, cen, rtol=0, atol=1e-7)
+    np.testing.assert_array_equal(g_box, boxes)
+    # twice on the same detector: no state left behind
+    np.testing.assert_array_equal(det.find(img), g_cen)
+
+
+@pytest.mark.gpu
+def test_gpu_detector_with_more_dots_than_travel_in_the_first_copy():
+    """The count and the first 512 records come back in one copy, the rest in a second one: 30 x 24 = 720 small dots."""
+    from vicalib_amd.lib import ConicDetector
+    w, h = 960, 768
+    img = np.full((h, w), 225, dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for j in range(24):
+        for i in range(30):
+            cx, cy = 20.3 + 31.0 * i, 18.7 + 31.0 * j
+            sl = (slice(int(cy) - 8, int(cy) + 9), slice(int(cx) - 8, int(cx) + 9))
+            img[sl] = np.where((xx[sl] - cx) ** 2 + (yy[sl] - cy) ** 2 < 5.2 ** 2, 30, img[sl])
+    ref = vco_detect.find_conics(img)
+    det = ConicDetector(w, h)
+    got = det.find(img)
+    assert len(ref) == 720 and got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-7)
+    assert len(det.find(img, max_conics=100)) == 100
+
+
+@pytest.mark.gpu
 def test_gpu_detector_returns_the_conics_and_boxes():
     """vc_detector_find_conics: the ellipse matrices and bounding boxes of calibu::Conic, equal to the restatement's (the 3 x 3
     inverse and the normalisation in a different order of operations: 1e-9 on unit-norm matrices)."""

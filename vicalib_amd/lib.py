@@ -442,7 +442,7 @@ class ConicDetector:
     def find(self, image, max_conics=4096):
         image = np.ascontiguousarray(image, dtype=np.uint8)
         assert image.shape == (self.hh, self.w)
-        out = np.zeros((max_conics, 2)); n = C.c_int(0)
+        out = np.empty((max_conics, 2)); n = C.c_int(0)
         _check(self.L.vc_detector_find(self.h, image.ctypes.data_as(C.c_void_p), int(image.strides[0]), _d(out), int(max_conics), C.byref(n)), "detector_find")
         return out[:min(n.value, max_conics)]
 
