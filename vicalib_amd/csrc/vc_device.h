@@ -197,6 +197,7 @@ struct DevView {
   //  more than a kernel boundary)
   int gram_top_stride;
   int fold_l0;                     // 1: k_chain_init's work rides in the bottom level's launch (k_chain_l0; chunk = group of 8 frames)
+  int back_path;                   // 1: the whole back-substitution in one launch, upper levels recomputed per bottom group (k_chain_back_path)
   int rank, world;                 // frame sharding: this process's rank, number of ranks
   // Merged decision (vision-only, single process): the accept/reject decision on pass k's trial point is taken at the head
   // of pass k+1's k_frame_schur -- by every workgroup, redundantly and identically -- instead of a k_final launch per pass.

@@ -2485,6 +2485,237 @@ __global__ __launch_bounds__(64) void k_chain_back_levels(DevView v, BackLevels 
   chain_back_group<true>(v, L.stride[li], L.m[li], 0, lvl, L.two[li], (int)blockIdx.x - L.start[li], ds, dl);
 }
 
+// PATH (round 5): the whole back-substitution in ONE launch without any hand-over between workgroups.  A workgroup per bottom-level
+// group; wavefront w works the group of level w that the bottom group hangs under (the last wavefront: the top level) -- the upper
+// levels are recomputed by every workgroup below them (8 / 64 / 250 times at cfg3: a few hundred KB more of L2 reads) instead of being
+// handed down through device-coherent stores and ready words (~5.5 us per level) or kernel boundaries.  All wavefronts request their
+// group's data at once; t0 = z + Y delta_s of the group's frames is formed in the kernel (rows staged through LDS: coalesced loads,
+// then one row per lane) -- the extra workgroups of the top level's launch and the ct0 round trip are gone with the launch; the steps
+// travel top-down through LDS (positions of a group: 0 = left separator, 1 .. q = interior frames, q + 1 = right separator; the top
+// level: its frames from position 0).  The dependent chain is chain_back_group's, instruction for instruction.
+struct BackPath { int n; int stride[6]; int m[6]; int two[6]; int top_stride; int ldr; };
+constexpr int kPathRowLoads = 37;      // 63 rows x (D + 1 <= 37) entries over 64 lanes
+constexpr int kPathDl = 96;            // doubles per level's step record (10 positions x 9)
+template <int NWMAX>      // wavefronts per workgroup at most (levels + 1): up to four leave a whole SIMD's registers to each
+__global__ __launch_bounds__(64 * NWMAX) void k_chain_back_path(DevView v, BackPath P) {
+  extern __shared__ __attribute__((aligned(16))) double bp_lds[];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int nw = P.n + 1;
+  double* DLall = bp_lds;                              // [nw][kPathDl]
+  double* DSW = DLall + nw * kPathDl + (size_t)wv * 64;      // this wavefront's copy of delta_s
+  int* READY = reinterpret_cast<int*>(DLall + nw * kPathDl + nw * 64);      // [8]
+  double* RW = DLall + nw * kPathDl + nw * 64 + 4 + (size_t)wv * 63 * P.ldr;      // this wavefront's rows [63][ldr]
+  double* DL = DLall + (size_t)wv * kPathDl;
+  if (threadIdx.x < 8) READY[threadIdx.x] = 0;
+  __syncthreads();
+  auto wait_ready = [&](int slot) {
+    while (__hip_atomic_load(&READY[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto set_ready = [&](int slot) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wavefront's LDS stores have been performed
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_store(&READY[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  const int done = v.ctrl->done;
+  const int N = v.n_frames, D = v.D, ldw = v.ldw, ldx = v.ldx;
+  const size_t isz = (size_t)9 * ldx;
+  const bool top = wv == P.n;
+  const int lvl = top ? P.n : wv;
+  const int s = top ? P.top_stride : P.stride[lvl], m = top ? kChainM : P.m[lvl], two = top ? 0 : P.two[lvl];
+  const long gs = (long)m * s;
+  const long a0 = (long)blockIdx.x * P.m[0] * P.stride[0];        // the bottom group's left separator
+  const int a = top ? -1 : (int)((a0 / gs) * gs);
+  const int first = top ? 0 : a + s;
+  const int q = first < N ? (top ? (N - 1) / s + 1 : min(m - 1, (N - 1 - first) / s + 1)) : 0;
+  const int r = first + q * s;
+  const bool has_a = a >= 0 && a < N, has_r = !top && q > 0 && r < N;
+  const int fi = lane / 9, k = lane % 9;
+  const bool mine = fi < q;
+  const int e = first + (mine ? fi : 0) * s;
+  const bool two_sided = two && !top && q >= 1;
+  const int fmid = (q - 1) / 2;
+  // ---- requests: the rows [Y | z] of the group's frames (lane-strided, coalesced), then this lane's blocks
+  const int ncolr = D + 1, nel = q * 9 * ncolr;
+  double rv[kPathRowLoads];
+  {
+    const int step_r = 64 / ncolr, step_c = 64 - step_r * ncolr;
+    int row = lane / ncolr, col = lane - row * ncolr;
+#pragma unroll
+    for (int u = 0; u < kPathRowLoads; ++u) {
+      const int idx = lane + 64 * u;
+      const int f2 = (row * 57) >> 9, k2 = row - 9 * f2;          // (row / 9 for rows below 64)
+      const bool in = idx < nel;          // (a lane without an entry reads frame 0 and drops the value)
+      const double* src = v.cW + (size_t)(in ? first + f2 * s : 0) * isz + (size_t)(in ? k2 : 0) * ldx + (in ? col : 0);
+      const double x = *src;
+      rv[u] = in ? x : 0.0;
+      row += step_r; col += step_c;
+      if (col >= ncolr) { col -= ncolr; ++row; }
+    }
+  }
+  if (lane < D) DSW[lane] = v.delta_s[lane];
+  double dinv = 1.0, Qrow[9], Lcol[9], Xs[9];
+  {
+    const double* img = v.cW + (size_t)(mine ? e : 0) * isz;
+    const double* Wr = img + (size_t)k * ldx;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const double qv = Wr[ldw + 18 + c], lv = img[c * ldx + ldw + 9 + k], xv = Wr[ldw + c];
+      Qrow[c] = mine ? qv : 0.0; Lcol[c] = (mine && c > k) ? lv : 0.0; Xs[c] = (mine && a >= 0) ? xv : 0.0;
+    }
+    const double dg = Wr[ldw + 9 + k];
+    dinv = mine ? 1.0 / dg : 1.0;
+  }
+  const int base = a, cnt = (a < N) ? q + 1 : 0;
+  if (done) return;                      // (uniform over the workgroup)
+  {
+    int row = lane / ncolr, col = lane - row * ncolr;
+    const int step_r = 64 / ncolr, step_c = 64 - step_r * ncolr;
+#pragma unroll
+    for (int u = 0; u < kPathRowLoads; ++u) {
+      const int idx = lane + 64 * u;
+      if (idx < nel) RW[row * P.ldr + col] = rv[u];
+      row += step_r; col += step_c;
+      if (col >= ncolr) { col -= ncolr; ++row; }
+    }
+  }
+  wave_lds_sync_local();
+  double t = 0.0;
+  if (mine) {
+    const double* Rr = RW + (size_t)(fi * 9 + k) * P.ldr;
+    double acc = Rr[D];
+    for (int j = 0; j < D; ++j) acc += Rr[j] * DSW[j];
+    t = acc;
+  }
+  // ---- the separators' steps from the level above
+  double da[9], dn[9], dr_in[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) { da[c] = 0.0; dn[c] = 0.0; }
+  if (!top) {
+    wait_ready(lvl + 1);
+    const double* DLp = DLall + (size_t)(lvl + 1) * kPathDl;
+    int pos;
+    if (lvl + 1 == P.n) pos = a / P.top_stride;                               // the top level keeps its frames from position 0
+    else { const long gp = (long)P.m[lvl + 1] * P.stride[lvl + 1]; const int ap = (int)((a0 / gp) * gp); pos = (a - ap) / P.stride[lvl + 1]; }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const double x0 = DLp[pos * 9 + c], x1 = DLp[(pos + 1) * 9 + c];
+      da[c] = has_a ? x0 : 0.0; dn[c] = has_r ? x1 : 0.0;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) dr_in[c] = dn[c];
+  if (mine && a >= 0) {
+    const bool right = two_sided && fi > fmid;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) t += Xs[c] * (right ? dn[c] : da[c]);       // (dn: still the right separator's step here)
+  }
+  double my = 0.0;
+  if (two_sided) {
+    {
+      double y = t;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) y += Qrow[c] * dn[c];
+#pragma unroll
+      for (int j = 8; j >= 0; --j) {
+        const double xj = readlane_f64(y * dinv, fmid * 9 + j);
+        dn[j] = -xj;
+        y -= Lcol[j] * xj;
+      }
+      if (fi == fmid) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) my = (j == k) ? dn[j] : my;
+      }
+    }
+    double dl_[9], dr_[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { dl_[j] = dn[j]; dr_[j] = dn[j]; }
+    const int nleft = fmid, nright = q - 1 - fmid;
+    for (int st = 1; st <= max(nleft, nright); ++st) {
+      const bool hl = st <= nleft, hr = st <= nright;              // wave-uniform
+      const int il = hl ? fmid - st : 0, ir = hr ? fmid + st : 0;
+      double yl = t, yr = t;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) { yl += Qrow[c] * dl_[c]; yr += Qrow[c] * dr_[c]; }
+#pragma unroll
+      for (int j = 8; j >= 0; --j) {
+        const double xl = readlane_f64(yl * dinv, il * 9 + j), xr = readlane_f64(yr * dinv, ir * 9 + j);
+        if (hl) { dl_[j] = -xl; yl -= Lcol[j] * xl; }
+        if (hr) { dr_[j] = -xr; yr -= Lcol[j] * xr; }
+      }
+      if (hl && fi == il) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) my = (j == k) ? dl_[j] : my;
+      }
+      if (hr && fi == ir) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) my = (j == k) ? dr_[j] : my;
+      }
+    }
+  } else
+  for (int i = q - 1; i >= 0; --i) {
+    double y = t;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) y += Qrow[c] * dn[c];
+#pragma unroll
+    for (int j = 8; j >= 0; --j) {
+      const double xj = readlane_f64(y * dinv, i * 9 + j);
+      dn[j] = -xj;
+      y -= Lcol[j] * xj;
+    }
+    if (fi == i) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) my = (j == k) ? dn[j] : my;
+    }
+  }
+  // ---- this level's steps for the level below (the bottom level: for its own epilogue)
+  if (mine) DL[(fi + (top ? 0 : 1)) * 9 + k] = my;
+  if (!top && lane < 9) { DL[lane] = da[lane]; DL[(q + 1) * 9 + lane] = dr_in[lane]; }
+  if (lvl != 0 || top) { set_ready(lvl); return; }
+  wave_lds_sync_local();
+  // ---- level 0: trial poses / velocities of the group's frames and their step terms (chain_back_group's epilogue)
+  double gd = 0, dld = 0, step2 = 0, x2 = 0, g2 = 0, gmax = 0;
+  if (lane < cnt) {
+    const int f = base + lane;
+    const int cur = v.ctrl->cur;
+    double d[9], Tin[7], vin[3], gi9[9], lam9[9];
+    {
+      const double* pin = v.poses[cur] + (size_t)f * kPoseStride;
+      const double* vi = v.vel[cur] + (size_t)f * 4;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) Tin[i] = pin[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) vin[i] = vi[i];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { gi9[i] = v.cg[(size_t)f * 9 + i]; lam9[i] = v.clam[(size_t)f * 9 + i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[i] = DL[lane * 9 + i];
+    double* pout = v.poses[1 - cur] + (size_t)f * kPoseStride;
+    double Tout[7], dd[6];
+    for (int i = 0; i < 6; ++i) dd[i] = d[i];
+    se3_plus(Tin, dd, Tout);
+    for (int i = 0; i < 7; ++i) { pout[i] = Tout[i]; const double ee = Tout[i] - Tin[i]; step2 += ee * ee; x2 += Tin[i] * Tin[i]; }
+    pout[7] = 0.0;
+    double* vout = v.vel[1 - cur] + (size_t)f * 4;
+    for (int i = 0; i < 3; ++i) { const double dv = d[6 + i]; vout[i] = vin[i] + dv; step2 += dv * dv; x2 += vin[i] * vin[i]; }
+    vout[3] = 0.0;
+    for (int i = 0; i < 9; ++i) {
+      const double gi = gi9[i];
+      gd += gi * d[i]; dld += lam9[i] * d[i] * d[i]; g2 += gi * gi; gmax = fmax(gmax, fabs(gi));
+    }
+  }
+  gd = wave_sum(gd); dld = wave_sum(dld); step2 = wave_sum(step2); x2 = wave_sum(x2); g2 = wave_sum(g2);
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) gmax = fmax(gmax, __shfl_down(gmax, o2, 64));
+  if (lane == 0) {
+    double* o = v.grp_part + (size_t)blockIdx.x * kNumScal;
+    o[kScGd] = gd; o[kScDld] = dld; o[kScStep2] = step2; o[kScX2] = x2; o[kScG2] = g2; o[kScCost] = 0.0; o[kScGmax] = gmax; o[kScSq] = 0.0;
+  }
+}
+
 // sum over all frames of [Y | z]^T [Y | z]: part[chunk] = [ D x D | D ]  (same layout as the vision path)
 constexpr int kMaxPairsPerWaveI = 9;
 // phase stamps of one workgroup of k_chain_gram (profiling builds only: -DVC_GRAM_STAMPS, tools/gram_stamps.py)
@@ -2722,6 +2953,24 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
       if (v.gram_top_stride > 0) launch_chain_gram(v, s);      // (A/B hook VICALIB_AMD_CHAIN_WAVES=0: the same masked sums, a launch of their own)
     }
   } else {
+    // single process, narrow border: the whole back-substitution as one launch without hand-overs (k_chain_back_path)
+    if (v.back_path && nl >= 1 && nl <= 5 && v.D + 1 <= kPathRowLoads && !v.pin_first && !v.pin_last) {
+      BackPath P; P.n = nl;
+      for (int l = 0; l < 6; ++l) { P.stride[l] = l < nl ? strides[l] : 1; P.m[l] = l < nl ? ms[l] : 2; P.two[l] = (l < nl && two_at(l)) ? 1 : 0; }
+      P.top_stride = top_stride; P.ldr = (v.D + 1) | 1;
+      const int groups0 = (int)(((long)N - 1) / ((long)strides[0] * ms[0]) + 1), nw = nl + 1;
+      const size_t lds = ((size_t)nw * kPathDl + (size_t)nw * 64 + 4 + (size_t)nw * 63 * P.ldr) * sizeof(double);
+      if (nw <= 4) {
+        static size_t lds_set = 0;
+        if (lds > 60000 && lds > lds_set) { (void)hipFuncSetAttribute((const void*)k_chain_back_path<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
+        hipLaunchKernelGGL(k_chain_back_path<4>, dim3(groups0), dim3(64 * nw), lds, s, v, P);
+      } else {
+        static size_t lds_set = 0;
+        if (lds > 60000 && lds > lds_set) { (void)hipFuncSetAttribute((const void*)k_chain_back_path<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
+        hipLaunchKernelGGL(k_chain_back_path<6>, dim3(groups0), dim3(64 * nw), lds, s, v, P);
+      }
+      return;
+    }
     hipLaunchKernelGGL(k_chain_back, dim3(1 + (nl > 0 ? (N + kBackT0Frames - 1) / kBackT0Frames : 0)), dim3(64), 0, s, v, top_stride, m_top, 1, nl, 0);
     // the levels below: one launch (k_chain_back_levels: ready words instead of kernel boundaries); VICALIB_AMD_BACK_FUSED=0: one launch per level
     static const bool fused = [] { const char* e = std::getenv("VICALIB_AMD_BACK_FUSED"); return !(e && std::atoi(e) == 0); }();
