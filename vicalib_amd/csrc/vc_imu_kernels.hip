@@ -18,7 +18,13 @@
 //  k_chain_fwd     one level of the partitioned chain elimination: a wavefront eliminates the interior frames of a group
 //                  of 8 (L, X_s = L^-1 C, X_n = L^-1 B, Y = L^-1 [W | g]); the group's first frame survives to the next level
 //  k_chain_gram    sum over all frames of [Y | z]^T [Y | z] on the matrix pipe (v_mfma_f64_16x16x4_f64)
+//  k_chain_l0      (round 5) k_chain_init's work and the bottom level of the elimination in one launch: the frames' images stay in LDS
+//                  (narrow borders, at most two cameras, single process)
+//  k_chain_top_gram  the top level of the elimination and, beside it in the same launch, k_chain_gram's sums of the frames below it
 //  k_chain_back    back-substitution, one level per launch; the bottom level also writes the trial poses / velocities
+//  k_chain_back_levels  ... all levels below the top in one launch (ready words between the workgroups)
+//  k_chain_back_path    (round 5) the whole back-substitution in one launch without hand-overs: a workgroup per bottom-level group
+//                  recomputes the levels above it (narrow borders, single process)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
