@@ -28,6 +28,9 @@ CASES = {
     "cfg3_full": (dict(models=("kb4",), grid="small", n_frames=2000, imu=True), dict(calibrate_imu=True)),
     # BASELINE cfg4's rig and grid (4 x poly3 + IMU, 900-dot grid) at 400 frames, D = 67
     "cfg4_rig_400": (dict(models=("poly3",) * 4, grid="large", n_frames=400, imu=True, seed=21), dict(calibrate_imu=True)),
+    # BASELINE cfg5's rig (8 cameras fov / kb4 alternating + IMU, small grid, extrinsics prior) at 160 frames, D = 115: three image columns
+    # per lane's worth of border in the chain elimination, the blocked reduced solve
+    "cfg5_rig_160": (dict(models=("fov", "kb4") * 4, grid="small", n_frames=160, imu=True, seed=33, extrinsics_prior=True), dict(calibrate_imu=True)),
 }
 
 

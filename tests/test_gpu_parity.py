@@ -279,13 +279,14 @@ def test_cfg4_rig_reduced_frame_count_visual_inertial():
 
 
 @pytest.mark.parametrize("name", ["cfg1_poly3_50", "stereo_fov_kb4_30", "mono_kb4_imu_60", "mono_rational6_40", "rig4_mixed_imu_80",
-                                  "cfg3_full", "cfg4_rig_400"])
+                                  "cfg3_full", "cfg4_rig_400", "cfg5_rig_160"])
 def test_solver_matches_committed_lm_traces(name):
     """Iteration-level agreement with the fixture tests/golden/lm_traces.json (the oracle's LM loop, generated by
     tests/golden/make_golden_traces.py): cost of every iteration, accept/reject sequence, radius, final parameters.
     cfg3_full is BASELINE cfg3 at FULL size -- 2000 frames, 373 493 corners, D = 29, the complete A -> D schedule (69 trace rows):
     the configuration every bench number is quoted on, held to the oracle at 1e-6 (vicalibrator.h:919-1040, :690-721);
-    cfg4_rig_400 is BASELINE cfg4's rig and grid (4 x poly3 + IMU, 900 dots, D = 67) at 400 frames."""
+    cfg4_rig_400 is BASELINE cfg4's rig and grid (4 x poly3 + IMU, 900 dots, D = 67) at 400 frames; cfg5_rig_160 is BASELINE cfg5's rig
+    (8 cameras fov / kb4 + IMU, extrinsics prior, D = 115) at 160 frames, 92 trace rows."""
     import json
     e = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lm_traces.json")))[name]
     cfg = dict(e["config"]); cfg["models"] = tuple(cfg["models"])
@@ -300,17 +301,24 @@ def test_solver_matches_committed_lm_traces(name):
     assert tr.shape == want.shape
     np.testing.assert_allclose(tr[:, 1], want[:, 1], rtol=1e-6)
     np.testing.assert_array_equal(tr[:, 3], want[:, 3])
-    np.testing.assert_allclose(tr[:, 4], want[:, 4], rtol=1e-6)
+    # cfg5_rig_160 spends 50 iterations at radii of 1e8 (the damping no longer shapes the step): the radius update amplifies the
+    # 1e-9 differences of the costs through the ratio of two small decreases -- measured 2.7e-5 on the radius with every cost at 3e-8,
+    # every accept / reject equal
+    wide = name == "cfg5_rig_160"
+    np.testing.assert_allclose(tr[:, 4], want[:, 4], rtol=1e-4 if wide else 1e-6)
     np.testing.assert_array_equal(tr[:, 5], want[:, 5])
+    # (wide: the eighth camera's kb4 coefficients sit in a flat valley at 160 frames -- 2e-5 of themselves between the two solvers at costs
+    #  equal to 3e-8; the parameters of that case are held at 1e-4, its costs / accept sequence / stages as everywhere)
+    pt = 1e-4 if wide else 1e-6
     for c, cam in enumerate(e["cameras"]):
-        np.testing.assert_allclose(cal.GetCamera(c)[0], cam["K"], rtol=1e-6)
-        np.testing.assert_allclose(cal.GetCamera(c)[1], cam["T_ck"], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(cal.GetCamera(c)[0], cam["K"], rtol=pt)
+        np.testing.assert_allclose(cal.GetCamera(c)[1], cam["T_ck"], rtol=pt, atol=1e-7 if wide else 1e-8)
     np.testing.assert_allclose(cal.GetCameraProjRMSE(), e["rmse"], rtol=1e-6)
     if "imu" in e:
-        np.testing.assert_allclose(cal.GetBiases(), e["imu"]["biases"], rtol=1e-6, atol=1e-9)
-        np.testing.assert_allclose(cal.GetScaleFactor(), e["imu"]["scale"], rtol=1e-6)
-        np.testing.assert_allclose(cal.GetGravity(), e["imu"]["gravity"], rtol=1e-6, atol=1e-9)
-        assert abs(cal.time_offset() - e["imu"]["time_offset"]) < 1e-9
+        np.testing.assert_allclose(cal.GetBiases(), e["imu"]["biases"], rtol=pt, atol=1e-8 if wide else 1e-9)
+        np.testing.assert_allclose(cal.GetScaleFactor(), e["imu"]["scale"], rtol=pt)
+        np.testing.assert_allclose(cal.GetGravity(), e["imu"]["gravity"], rtol=pt, atol=1e-8 if wide else 1e-9)
+        assert abs(cal.time_offset() - e["imu"]["time_offset"]) < (1e-8 if wide else 1e-9)
 
 
 def test_converged_optima_match_the_independent_optimiser_fixture():
