@@ -1,3 +1,5 @@
+"""GPU solve of the committed cfg5_rig_160 fixture (tests/golden/lm_traces.json) with the differences to the oracle's record printed per
+quantity -- what the tolerances of test_solver_matches_committed_lm_traces[cfg5_rig_160] were set from.  Run from the repo root on a GPU box."""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())
