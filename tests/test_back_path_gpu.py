@@ -25,7 +25,7 @@ def _run(tmp_path, name, n_frames, **env):
     return np.load(out)
 
 
-@pytest.mark.parametrize("n_frames", [9, 17, 57, 60, 64, 65, 130, 513, 577, 600])
+@pytest.mark.parametrize("n_frames", [9, 57, 60, 64, 65, 130, 513, 600])
 def test_one_launch_back_substitution_matches_the_levels(tmp_path, n_frames):
     a = _run(tmp_path, "path", n_frames, VICALIB_AMD_BACK_PATH=1)
     b = _run(tmp_path, "levels", n_frames, VICALIB_AMD_BACK_PATH=0)
