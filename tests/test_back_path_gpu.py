@@ -1,8 +1,8 @@
 """The back-substitution as one launch (k_chain_back_path, DESIGN 4.2: every bottom group recomputes the levels above it, no hand-over
 between workgroups) against the level-by-level form (VICALIB_AMD_BACK_PATH=0: k_chain_back + k_chain_back_levels): the same dependent
 chain per group; z + Y delta_s is summed in another (fixed) order -- every iteration's cost, the accept / reject sequence and the final
-state at rounding level.  Frame counts: short last groups of every length at the bottom level (57 .. 65), one, two and three levels
-below the top (9, 60, 130, 520, 600), counts where upper-level groups are short or empty (65, 513, 577), and a count without a level
+state at rounding level.  Frame counts: short, full and empty last groups at the bottom level (57, 60, 64, 65), one, two and three levels
+below the top (9, 60, 130, 600), counts where upper-level groups are short or empty (65, 513), and a count without a level
 below the top (7: both runs take the classic kernel and must agree bit for bit)."""
 import os
 import subprocess
