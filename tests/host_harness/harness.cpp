@@ -131,4 +131,13 @@ void hh_se3_log_dual_jacobian(const double* T, double* J42) {
   }
 }
 int hh_chol6(double* M) { return chol_small<6>(M) ? 1 : 0; }
+// exp of a rotation vector with the left Jacobian's coefficients (vc_imu.hpp: so3_exp_jl, what the closed-form partials of the IMU
+// block deltas use) and exp's derivative along `dir` under a dual number (tso3_exp<D1>): large angles go through halving + squaring
+void hh_so3_exp_jl(const double* w, const double* dir, double* q, double* AB, double* dq) {
+  so3_exp_jl(w, q, AB, AB + 1);
+  D1 W[3], Q[4];
+  for (int k = 0; k < 3; ++k) W[k] = mk(w[k], dir[k]);
+  tso3_exp(W, Q);
+  for (int k = 0; k < 4; ++k) dq[k] = Q[k].v;
+}
 }

@@ -3,6 +3,7 @@ for the host by tests/host_harness) against the oracle: closed-form projection J
 duals, and the unique-column tile Gram block + post-reduction rotations vs the oracle's normal equations
 (which come from AutoDiff x local-parameterisation Jacobians, as in the reference)."""
 import ctypes as C
+import math
 import os
 import subprocess
 import numpy as np
@@ -345,3 +346,31 @@ def test_imu_block_forms_match_oracle_on_irregular_sample_times():
                        d(W[j - 1]), 0, d(T2), d(T1), d(v2), d(v1), d(g), d(b), d(sfac), C.c_double(toff), d(r), d(J))
                     np.testing.assert_allclose(r, r0, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(r0).max()))
                     np.testing.assert_allclose(J, J0, rtol=1e-8, atol=1e-8 * max(np.abs(J0).max(), 1e-300))
+
+
+def test_so3_exp_large_angles_and_left_jacobian_coefficients():
+    """exp of a rotation vector beyond the polynomial's range (halving + quaternion squaring, vc_imu.hpp: tso3_exp_factors) against
+    sin / cos, the left Jacobian's coefficients A = (1 - cos th) / th^2, B = (th - sin th) / th^3 that the closed-form IMU partials
+    take from exp's own factors, and the quaternion's derivative along a direction: dual number == 1/2 (Jl d, 0) q."""
+    H = hh()
+    rng = np.random.default_rng(5)
+    for th in [0.0, 1e-9, 1e-4, 9.9e-4, 1.1e-3, 0.01, 0.3, 1.5, 1.56, 3.0, 3.14159, 6.0, 12.5, 40.0]:
+        for _ in range(4):
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            w = ax * th; dr = rng.normal(size=3)
+            q = np.zeros(4); AB = np.zeros(2); dq = np.zeros(4)
+            H.hh_so3_exp_jl(d(w), d(dr), d(q), d(AB), d(dq))
+            s = np.sin(th / 2) / th if th > 0 else 0.5
+            np.testing.assert_allclose(q, np.concatenate([s * w, [np.cos(th / 2)]]), rtol=0, atol=4e-15 * max(1.0, th))
+            # references without cancellation: A = 2 (sin(th/2) / th)^2; B by its series below 0.5 rad
+            A = 2.0 * s * s
+            B = (th - np.sin(th)) / th ** 3 if th > 0.5 else sum((-1) ** k * th ** (2 * k) / math.factorial(2 * k + 3) for k in range(10))
+            assert abs(AB[0] - A) <= 1e-14 * max(1.0, th), (th, AB[0], A)
+            # B multiplies [w]x^2 (size th^2) in Jl: its error counts against th^2
+            assert abs(AB[1] - B) * min(th * th, 1.0) <= 2e-15 * max(1.0, th), (th, AB[1], B)
+            # d exp(w) along dr = 1/2 (Jl dr, 0) (x) q
+            c1 = np.cross(w, dr); c2 = np.cross(w, c1)
+            dth = dr + AB[0] * c1 + AB[1] * c2
+            hq = np.concatenate([0.5 * dth, [0.0]])
+            v = hq[3] * q[:3] + q[3] * hq[:3] + np.cross(hq[:3], q[:3]); sc = hq[3] * q[3] - hq[:3] @ q[:3]
+            np.testing.assert_allclose(dq, np.concatenate([v, [sc]]), rtol=0, atol=2e-13 * max(1.0, th * th))

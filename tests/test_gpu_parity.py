@@ -502,8 +502,12 @@ def test_reduced_system_for_every_combination_of_optimisation_flags(flags):
     gravity, time offset, velocities and camera extrinsics get columns.  For all 16 combinations: the reduced system the GPU pass
     leaves (two cameras) against the dense Schur complement of
     the oracle's normal equations, and the same column layout (weights: the initial 500 I on both sides)."""
+    _check_reduced_system(("fov", "kb4"), 21, flags)
+
+
+def _check_reduced_system(models, n_frames, flags, want_D=None):
     bias_active, inertial_active, rot_only, toff_free = flags
-    p = synth.generate(synth.Config(models=("fov", "kb4"), n_frames=21, imu=True, seed=11))
+    p = synth.generate(synth.Config(models=models, n_frames=n_frames, imu=True, seed=11))
     gt = p.imu_gt
     cal = ViCalibrator(0).load_problem(p, init=False)
     orc = ol.Oracle().load(p, init=False); orc.set_options(calibrate_imu=True)
@@ -514,8 +518,9 @@ def test_reduced_system_for_every_combination_of_optimisation_flags(flags):
     orc.prepare(vis_mult=1, imu_mult=1)
     lin = orc.linearize()
     g = cal.linearize()
-    n, D = 21, lin["Hss"].shape[0]
+    n, D = n_frames, lin["Hss"].shape[0]
     assert cal.shared_dim() == D
+    assert want_D is None or D == want_D
     M = np.zeros((9 * n, 9 * n))
     for f in range(n):
         M[9 * f:9 * f + 9, 9 * f:9 * f + 9] = lin["A"][f]
@@ -530,6 +535,16 @@ def test_reduced_system_for_every_combination_of_optimisation_flags(flags):
     assert abs(g["cost"] - lin["cost"]) <= 1e-10 * abs(lin["cost"]) + 1e-12
     np.testing.assert_allclose(g["S"], S, rtol=1e-6, atol=1e-8 * np.abs(lin["Hss"]).max())
     np.testing.assert_allclose(g["g_red"], gr, rtol=1e-6, atol=1e-8 * np.abs(lin["gs"]).max())
+
+
+@pytest.mark.parametrize("models,flags,n_frames", [(("poly3", "rational6"), (False, True, False, True), 21), (("poly3", "rational6"), (False, True, False, True), 70),
+                                                   (("linear", "linear", "linear"), (False, True, False, False), 21), (("fov", "fov"), (True, True, True, True), 70)])
+def test_reduced_system_at_width_32_with_imu(models, flags, n_frames):
+    """D = 32 with inertial terms: the widest one-wavefront reduced solve, where the [Y | z] rows of the chain's top-level frames have 33
+    columns -- one more than the three 16 x 16 column tiles of the early Gram inside k_reduced cover (kEarlyTopD, vc_device.h; advice round 5:
+    the gradient's Y^T z term of up to 7 frames was dropped there).  Reduced system against the dense Schur complement of the oracle's normal
+    equations, below and above one chain group per level."""
+    _check_reduced_system(models, n_frames, flags, want_D=32)
 
 
 def test_imu_weight_update_matches_oracle():

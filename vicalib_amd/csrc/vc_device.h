@@ -24,6 +24,7 @@ constexpr int kNumScal = 8;
 enum { kScGd = 0, kScDld = 1, kScStep2 = 2, kScX2 = 3, kScG2 = 4, kScCost = 5, kScGmax = 6, kScSq = 7 };
 constexpr int kTraceCols = 10;     // iteration cost cost_change gmax gnorm step_norm rho radius accepted stage
 constexpr int kSmallD = 32;        // reduced systems up to this width are solved by one wavefront; above it the workgroup-wide LDS factorisation is faster
+constexpr int kEarlyTopD = kSmallD - 1;   // early Gram inside k_reduced: its three 16 x 16 column tiles cover the D + 1 <= 32 columns of [Y | z] (D = 32: the z column would fall outside)
 constexpr int kSyncWords = 16;     // DevView::sync_flags
 
 // termination codes in Ctrl::done (0 = keep running)
@@ -190,7 +191,7 @@ struct DevView {
   int pin_first, pin_last, sep_col0, sep_col1;
   // Early Gram (visual-inertial passes): sum [Y | z]^T [Y | z] of every frame below the chain's top level is formed by extra workgroups of
   // the top level's launch (beside its one group); the top level's own frames (index = 0 mod gram_top_stride, at most 7) are added by
-  // k_reduced itself from their images (single process, D <= kSmallD) or summed by a one-workgroup launch into partial record n_chunks
+  // k_reduced itself from their images (single process, D <= kEarlyTopD) or summed by a one-workgroup launch into partial record n_chunks
   // (n_part = n_chunks + 1).  0: k_chain_gram is a launch of its own and covers every frame.
   // (Tried: the partial sums as extra workgroups of k_reduced's launch, delivered with device-coherent stores and a count the first
   //  workgroup waits for -- 36 us against 7.4 + 23 for the two launches: coherent stores, the count and the coherent loads behind it cost

@@ -78,24 +78,32 @@ template <class T> VC_HD void tq_matvec(const T* q, const T* v, T* o) {   // toR
 // SO3::exp as a unit quaternion [sin(th/2) w/th, cos(th/2)].  Within th/2 <= pi/4 -- the RK4 increments are
 // gyro rate x a few milliseconds -- both factors are polynomials in z = th^2/4 (the fdlibm kernel forms, < 1 ulp; Sophus'
 // own small-angle series is their leading part): no square root, no division, no sin / cos call, and under dual numbers
-// the derivative comes from the same polynomial.  Larger angles take the closed form.
+// the derivative comes from the same polynomial.  Larger angles (round 6; a sin / cos call before -- ~600 instructions inlined at every
+// call site for a branch a gyro stream never takes): the vector is halved until it is in range and the quaternion squared back,
+// on the two factors alone -- with q(u) = [i u, r]:  q(2u) = q(u)^2 = [(r i) 2u, r^2 - i^2 |u|^2].
+template <class T> VC_HD void tso3_exp_factors(const T& th2, T* imag_out, T* real_out) {
+  T t2 = th2;
+  int halvings = 0;
+  while (val(t2) > 2.4 && halvings < 60) { t2 = t2 * 0.25; ++halvings; }      // (not taken by any lane of a sane stream)
+  const T z = 0.25 * t2;
+  const T S = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+              z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  const T Cc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+               z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  T imag = 0.5 + 0.5 * (z * S);                  // sin(th/2) / th
+  T real = (1.0 - 0.5 * z) + (z * z) * Cc;
+  for (; halvings > 0; --halvings) {
+    const T i2 = real * imag;
+    real = real * real - (imag * imag) * t2;
+    imag = i2;
+    t2 = t2 * 4.0;
+  }
+  *imag_out = imag; *real_out = real;
+}
 template <class T> VC_HD void tso3_exp(const T* w, T* q) {
   const T th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
   T imag, real;
-  if (val(th2) <= 2.4) {
-    const T z = 0.25 * th2;
-    const T S = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
-                z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
-    const T Cc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
-                 z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
-    imag = 0.5 + 0.5 * (z * S);                  // sin(th/2) / th
-    real = (1.0 - 0.5 * z) + (z * z) * Cc;
-  } else {
-    const T th = sqrt(th2);
-    const T half = 0.5 * th;
-    imag = sin(half) / th;
-    real = cos(half);
-  }
+  tso3_exp_factors(th2, &imag, &real);
   q[0] = imag * w[0]; q[1] = imag * w[1]; q[2] = imag * w[2]; q[3] = real;
 }
 // log of the SE3 element [q, t] -> [upsilon, omega]  (Sophus SE3::log / SO3::logAndTheta)
@@ -460,27 +468,70 @@ constexpr int kBlockDeltaStride = kDeltaCols * 11;     // one block: [column][Q 
 // frame times, those in between stored sample pairs).  Its RK4 step from the identity state without gravity, written out
 // (the stage states of imu_rk4_step_p from s = identity: the products with the identity quaternion are exact):
 //     w1 = ug(t0)                                 q1 = exp(w1 h/2)
-//     w2 = R(q1) ug(tm),  a2 = q1 * ua(tm)        q2 = exp(w2 h/2)
-//     w3 = R(q2) ug(tm),  a3 = q2 * ua(tm)        q3 = exp(w3 h)
-//     w4 = R(q3) ug(t1),  a4 = q3 * ua(t1)
+//     w2 = R(q1) ug(tm),  a2 = R(q1) ua(tm)       q2 = exp(w2 h/2)
+//     w3 = R(q2) ug(tm),  a3 = R(q2) ua(tm)       q3 = exp(w3 h)
+//     w4 = R(q3) ug(t1),  a4 = R(q3) ua(t1)
 //     dq = exp((w1 + 2 w2 + 2 w3 + w4) h/6),  dv = (ua(t0) + 2 a2 + 2 a3 + a4) h/6,  dp = (2 ua(t0) h/2 + 2 a2 h/2 + a3 h) h/6
 // with ug = gyro sample * scale factor + bias, ua likewise (ceres-cost-functions.h:93-100), the samples interpolated at t0, the
 // midpoint and t1 (weights 1, 1/2, 0: the interpolation weight of :89 does not depend on anything that is optimised).
-// One dual direction rides along (D1): gyro bias / scale factor `gsel` (0..2 / 3..5), or -- gsel >= 6 with off.v = 1 -- the time
-// offset, which moves the interpolated end samples and the interval's length.  The ACCELEROMETER parameters need no dual
-// number: dq does not depend on them and dv, dp are linear in ua, so the partials along accelerometer bias / scale factor
-// gsel are sums of the stage rotations' columns (ap, av: values only, ~100 flop instead of a second dual pass).
-struct IntervalDeltaGA { DeltaAcc<D1> d; double ap[3], av[3]; };
-VC_HD void imu_interval_delta_ga(const ImuView& buf, const ImuRange& rg, D1 off, double t_start, double t_end, int m, int n_int,
-                                 const double* b, const double* sf, int gsel, IntervalDeltaGA* X) {
+//
+// PARTIALS IN CLOSED FORM (round 6; rounds 2-5 pushed a dual number through every operation above -- exp's polynomial, the
+// quaternion -> matrix products, the sums: ~2.1 k fp64 instructions per interval and direction).  One direction of the parameter space
+// -- gyro bias / scale factor `gsel` (0..2 / 3..5), or (gsel >= 6 with off.v = 1) the time offset, which moves the interpolated end
+// samples and the interval's length -- enters through the tangents of the inputs (d ug(t0), d ug(t1), d ua(t0), d ua(t1), d h) and is
+// carried as ROTATION TANGENTS, not as quaternion partials: a stage rotation moves as R -> exp(dth) R with
+//     dth = Jl(phi) d phi,    Jl(phi) = I + A [phi]x + B [phi]x^2,   A = (1 - cos th) / th^2,  B = (th - sin th) / th^3
+// (the left Jacobian of SO3; A and B fall out of exp's own two factors, so3_exp_jl), and a rotated vector as
+//     d (R u) = dth x (R u) + R du .
+// Per stage: one 3 x 3 matrix from the quaternion (shared by the gyro rate, the accelerometer input, both tangents and the
+// accelerometer columns), two cross products, one Jl product.  The ACCELEROMETER parameters need no tangent at all: dq does not
+// depend on them and dv, dp are linear in ua, so their partials are sums of the stage rotations' columns (ap, av).
+// The same derivative as the dual numbers' up to rounding (tests/test_device_math_cpu.py: against the integrated dual form at
+// 1e-10 and the oracle's Dual<35> at 1e-8).
+VC_HD void so3_exp_jl(const double* w, double* q, double* A, double* B) {
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double imag, real;
+  tso3_exp_factors(th2, &imag, &real);
+  q[0] = imag * w[0]; q[1] = imag * w[1]; q[2] = imag * w[2]; q[3] = real;
+  // 1 - cos th = 2 sin^2(th/2);  sin th = 2 sin(th/2) cos(th/2).  The difference 1 - 2 imag real cancels to ~1e-16 / th^2 relative,
+  // against a term of relative size th^2 / 6 in Jl: 1e-16 absolute; below th^2 = 1e-6 the series' first two terms are exact to rounding
+  const bool tiny = th2 < 1e-6;
+  *A = 2.0 * imag * imag;
+  *B = tiny ? 1.0 / 6.0 - th2 * (1.0 / 120.0) : (1.0 - 2.0 * imag * real) * fast_rcp(tiny ? 1.0 : th2);
+}
+VC_HD void cross3(const double* a, const double* b, double* o) {
+  const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+VC_HD void so3_jl_apply(const double* w, double A, double B, const double* d, double* o) {
+  double c1[3], c2[3];
+  cross3(w, d, c1);
+  cross3(w, c1, c2);
+  for (int i = 0; i < 3; ++i) o[i] = d[i] + A * c1[i] + B * c2[i];
+}
+VC_HD void mat3_vec(const double* R, const double* v, double* o) {
+  const double a = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+  const double b = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+  const double c = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+// An interval's (or a run of intervals') delta with one parameter direction beside it: the values (Q, P, V, T), the direction's
+// tangents -- rotation as exp(dth) Q, the rest plain partials -- and the partials along the group's accelerometer parameter.
+struct IntervalDeltaT { DeltaAcc<double> d; double dth[3], dp[3], dv[3], dt; double ap[3], av[3]; };
+constexpr int kDtDoubles = 27;                     // as doubles: values 11 | tangent 10 | ap 3 | av 3
+VC_HD void imu_delta_t_identity(IntervalDeltaT* X) {
   imu_delta_identity(&X->d);
-  for (int i = 0; i < 3; ++i) { X->ap[i] = 0.0; X->av[i] = 0.0; }
+  for (int i = 0; i < 3; ++i) { X->dth[i] = 0.0; X->dp[i] = 0.0; X->dv[i] = 0.0; X->ap[i] = 0.0; X->av[i] = 0.0; }
+  X->dt = 0.0;
+}
+VC_HD void imu_interval_delta_t(const ImuView& buf, const ImuRange& rg, D1 off, double t_start, double t_end, int m, int n_int,
+                                const double* b, const double* sf, int gsel, IntervalDeltaT* X) {
+  imu_delta_t_identity(X);
   const int kk = gsel < 3 ? gsel : (gsel < 6 ? gsel - 3 : 0);
   const bool seeded = gsel < 6, scale = gsel >= 3;
-  // the model inputs at t0 (they become the running sums' first terms) and t1, formed as soon as the samples are there: the
-  // samples themselves -- 28 doubles under the dual direction -- are not kept.  The midpoint's inputs are the mean of the two (the
-  // model is affine in the sample; the mean of the seeds is the midpoint sample's seed).
-  D1 ws[3], vs[3], ug1[3], ua1[3], h;
+  // the model inputs at t0 and t1 with their tangents, formed as soon as the samples are there (the samples themselves are not kept).
+  // The midpoint's inputs are the mean of the two (the model is affine in the sample).
+  double u0[3], u1[3], a0[3], a1[3], du0[3], du1[3], da0[3], da1[3], h, dh;
   double c0, c1;                                   // component kk of the accelerometer samples at t0, t1 (scale factor) or 1 (bias)
   {
     Meas<D1> z0, z1;
@@ -488,93 +539,111 @@ VC_HD void imu_interval_delta_ga(const ImuView& buf, const ImuRange& rg, D1 off,
     z0.time = z1.time = mk(0.0);
     if (m <= n_int) { imu_range_get_flat(buf, rg, off, t_start, t_end, m - 1, &z0); imu_range_get_flat(buf, rg, off, t_start, t_end, m, &z1); }
     if (z1.time.a == z0.time.a) return;            // a zero-length interval is skipped (:150-152), and so is m > n_int
-    h = z1.time - z0.time;
+    h = z1.time.a - z0.time.a; dh = z1.time.v - z0.time.v;
     for (int i = 0; i < 3; ++i) {
       const double s0 = (seeded && i == kk) ? (scale ? z0.w[i].a : 1.0) : 0.0, s1 = (seeded && i == kk) ? (scale ? z1.w[i].a : 1.0) : 0.0;
-      ws[i] = mk(z0.w[i].a * sf[i] + b[i], z0.w[i].v * sf[i] + s0);
-      ug1[i] = mk(z1.w[i].a * sf[i] + b[i], z1.w[i].v * sf[i] + s1);
-      vs[i] = mk(z0.a[i].a * sf[3 + i] + b[3 + i], z0.a[i].v * sf[3 + i]);
-      ua1[i] = mk(z1.a[i].a * sf[3 + i] + b[3 + i], z1.a[i].v * sf[3 + i]);
+      u0[i] = z0.w[i].a * sf[i] + b[i]; du0[i] = z0.w[i].v * sf[i] + s0;
+      u1[i] = z1.w[i].a * sf[i] + b[i]; du1[i] = z1.w[i].v * sf[i] + s1;
+      a0[i] = z0.a[i].a * sf[3 + i] + b[3 + i]; da0[i] = z0.a[i].v * sf[3 + i];
+      a1[i] = z1.a[i].a * sf[3 + i] + b[3 + i]; da1[i] = z1.a[i].v * sf[3 + i];
     }
     // (selected, not indexed: a run-time index would put the arrays into scratch memory on the device)
     c0 = scale ? (kk == 0 ? z0.a[0].a : kk == 1 ? z0.a[1].a : z0.a[2].a) : 1.0;
     c1 = scale ? (kk == 0 ? z1.a[0].a : kk == 1 ? z1.a[1].a : z1.a[2].a) : 1.0;
   }
-  const D1 hh = h * 0.5, h6 = h / 6.0;
+  const double hh = h * 0.5, h6 = h / 6.0, dhh = dh * 0.5, dh6 = dh / 6.0;
   const double cm = 0.5 * c0 + 0.5 * c1;
-  const double e[3] = {kk == 0 ? 1.0 : 0.0, kk == 1 ? 1.0 : 0.0, kk == 2 ? 1.0 : 0.0};
-  // running sums k1 + 2 k2 + 2 k3 + k4 in that order (ws, vs start as k1); sv, sp: the same sums for
-  // d ua / d (accelerometer parameter kk) = c(t) e_kk -- the stage rotations' columns, values only
-  D1 ugm[3], uam[3], ps[3], wk[3], ak[3], t[3], q[4];
-  double sv[3], sp[3], r[3], qa[4];
-  for (int i = 0; i < 3; ++i) {                    // stage 1: w1 = ug(t0), a1 = ua(t0)
-    ugm[i] = ws[i] * 0.5 + ug1[i] * 0.5;
-    uam[i] = vs[i] * 0.5 + ua1[i] * 0.5;
-    ps[i] = 2.0 * (vs[i] * hh);
-    sv[i] = c0 * e[i]; sp[i] = 2.0 * (c0 * e[i] * hh.a);
-    t[i] = ws[i] * hh;
-  }
-  tso3_exp(t, q);
-  tq_matvec(q, ugm, wk);                           // stage 2
-  tq_rotate(q, uam, ak);
-  for (int i = 0; i < 4; ++i) qa[i] = q[i].a;
-  tq_rotate(qa, e, r);
+  // running sums k1 + 2 k2 + 2 k3 + k4 in that order (they start as k1) with their tangents; sp = ua(t0) + a2 + a3 (dp = sp h^2 / 6);
+  // cv, cp: the same sums for d ua / d (accelerometer parameter kk) = c(t) e_kk -- column kk of the stage rotations, values only
+  double sw[3], sv[3], sp[3], dsw[3], dsv[3], dsp[3], cv[3], cp[3], phi[3], dphi[3];
   for (int i = 0; i < 3; ++i) {
-    ws[i] = ws[i] + 2.0 * wk[i]; vs[i] = vs[i] + 2.0 * ak[i]; ps[i] = ps[i] + 2.0 * (ak[i] * hh);
-    sv[i] = sv[i] + 2.0 * (cm * r[i]); sp[i] = sp[i] + 2.0 * (cm * r[i] * hh.a);
-    t[i] = wk[i] * hh;
+    sw[i] = u0[i]; dsw[i] = du0[i]; sv[i] = a0[i]; dsv[i] = da0[i]; sp[i] = a0[i]; dsp[i] = da0[i];
+    cv[i] = (i == kk) ? c0 : 0.0; cp[i] = cv[i];
+    phi[i] = u0[i] * hh; dphi[i] = du0[i] * hh + u0[i] * dhh;
   }
-  tso3_exp(t, q);
-  tq_matvec(q, ugm, wk);                           // stage 3
-  tq_rotate(q, uam, ak);
-  for (int i = 0; i < 4; ++i) qa[i] = q[i].a;
-  tq_rotate(qa, e, r);
-  for (int i = 0; i < 3; ++i) {
-    ws[i] = ws[i] + 2.0 * wk[i]; vs[i] = vs[i] + 2.0 * ak[i]; ps[i] = ps[i] + ak[i] * h;
-    sv[i] = sv[i] + 2.0 * (cm * r[i]); sp[i] = sp[i] + cm * r[i] * h.a;
-    t[i] = wk[i] * h;
+  // stages 2, 3, 4 (statically unrolled: `stage` folds)
+  for (int stage = 2; stage <= 4; ++stage) {
+    double q[4], A, B, R[9], dth[3], ug[3], ua[3], dug[3], dua[3], wk[3], ak[3], dwk[3], dak[3], t1[3], t2[3];
+    so3_exp_jl(phi, q, &A, &B);
+    quat_to_R(q, R);
+    so3_jl_apply(phi, A, B, dphi, dth);
+    for (int i = 0; i < 3; ++i) {
+      if (stage < 4) { ug[i] = u0[i] * 0.5 + u1[i] * 0.5; ua[i] = a0[i] * 0.5 + a1[i] * 0.5; dug[i] = du0[i] * 0.5 + du1[i] * 0.5; dua[i] = da0[i] * 0.5 + da1[i] * 0.5; }
+      else { ug[i] = u1[i]; ua[i] = a1[i]; dug[i] = du1[i]; dua[i] = da1[i]; }
+    }
+    mat3_vec(R, ug, wk); mat3_vec(R, ua, ak);
+    cross3(dth, wk, t1); mat3_vec(R, dug, t2);
+    for (int i = 0; i < 3; ++i) dwk[i] = t1[i] + t2[i];
+    cross3(dth, ak, t1); mat3_vec(R, dua, t2);
+    for (int i = 0; i < 3; ++i) dak[i] = t1[i] + t2[i];
+    const double r[3] = {kk == 0 ? R[0] : kk == 1 ? R[1] : R[2], kk == 0 ? R[3] : kk == 1 ? R[4] : R[5], kk == 0 ? R[6] : kk == 1 ? R[7] : R[8]};
+    const double wgt = stage < 4 ? 2.0 : 1.0, cc = stage < 4 ? cm : c1;
+    for (int i = 0; i < 3; ++i) {
+      sw[i] = sw[i] + wgt * wk[i]; dsw[i] = dsw[i] + wgt * dwk[i];
+      sv[i] = sv[i] + wgt * ak[i]; dsv[i] = dsv[i] + wgt * dak[i];
+      cv[i] = cv[i] + wgt * (cc * r[i]);
+      if (stage < 4) { sp[i] = sp[i] + ak[i]; dsp[i] = dsp[i] + dak[i]; cp[i] = cp[i] + cc * r[i]; }
+      const double hs = stage == 2 ? hh : h, dhs = stage == 2 ? dhh : dh;
+      if (stage < 4) { phi[i] = wk[i] * hs; dphi[i] = dwk[i] * hs + wk[i] * dhs; }
+    }
   }
-  tso3_exp(t, q);
-  tq_matvec(q, ug1, wk);                           // stage 4
-  tq_rotate(q, ua1, ak);
-  for (int i = 0; i < 4; ++i) qa[i] = q[i].a;
-  tq_rotate(qa, e, r);
-  for (int i = 0; i < 3; ++i) {
-    ws[i] = ws[i] + wk[i]; vs[i] = vs[i] + ak[i];
-    sv[i] = sv[i] + c1 * r[i];
-    t[i] = ws[i] * h6;
-    X->d.v[i] = vs[i] * h6;
-    X->d.p[i] = ps[i] * h6;
-    X->av[i] = sv[i] * h6.a;
-    X->ap[i] = sp[i] * h6.a;
+  {
+    double A, B;
+    for (int i = 0; i < 3; ++i) { phi[i] = sw[i] * h6; dphi[i] = dsw[i] * h6 + sw[i] * dh6; }
+    so3_exp_jl(phi, X->d.q, &A, &B);
+    so3_jl_apply(phi, A, B, dphi, X->dth);
+    const double hh6 = h * h6, dhh6 = 2.0 * h * dh6;          // d (h^2 / 6) = h dh / 3
+    for (int i = 0; i < 3; ++i) {
+      X->d.v[i] = sv[i] * h6; X->dv[i] = dsv[i] * h6 + sv[i] * dh6;
+      X->d.p[i] = sp[i] * hh6; X->dp[i] = dsp[i] * hh6 + sp[i] * dhh6;
+      X->av[i] = cv[i] * h6; X->ap[i] = cp[i] * hh6;
+    }
+    X->d.t = h; X->dt = dh;
   }
-  tso3_exp(t, X->d.q);
-  X->d.t = h;
 }
-// a <- a followed by x, with the accelerometer partials (Q carries none: dP' = dP + dV dt + R(Q) dp, dV' = dV + R(Q) dv)
-VC_HD void imu_delta_ga_then(IntervalDeltaGA* A, const IntervalDeltaGA& X) {
-  const double qa[4] = {A->d.q[0].a, A->d.q[1].a, A->d.q[2].a, A->d.q[3].a};
-  double rp[3], rv[3];
-  tq_rotate(qa, X.ap, rp);
-  tq_rotate(qa, X.av, rv);
+// a <- a followed by x.  Values: P <- P + V t + R(Q) p, V <- V + R(Q) v, Q <- Q q, T <- T + t.  Tangents: with Q -> exp(dth_a) Q and
+// q -> exp(dth_x) q the product moves as exp(dth_a) exp(R(Q) dth_x) Q q; a rotated vector as d (R u) = dth_a x (R u) + R du.
+// The accelerometer partials (Q carries none): ap <- ap + av t + R(Q) ap_x, av <- av + R(Q) av_x.
+VC_HD void imu_delta_t_then(IntervalDeltaT* A, const IntervalDeltaT& X) {
+  double R[9], rp[3], rv[3], t1[3], t2[3], t3[3], q[4];
+  quat_to_R(A->d.q, R);
+  mat3_vec(R, X.d.p, rp); mat3_vec(R, X.d.v, rv);
+  cross3(A->dth, rp, t1); mat3_vec(R, X.dp, t2);
+  for (int i = 0; i < 3; ++i) A->dp[i] = ((A->dp[i] + A->dv[i] * X.d.t) + A->d.v[i] * X.dt) + (t1[i] + t2[i]);
+  cross3(A->dth, rv, t1); mat3_vec(R, X.dv, t2);
+  for (int i = 0; i < 3; ++i) A->dv[i] = A->dv[i] + (t1[i] + t2[i]);
+  mat3_vec(R, X.dth, t3);
+  for (int i = 0; i < 3; ++i) A->dth[i] = A->dth[i] + t3[i];
+  A->dt = A->dt + X.dt;
+  mat3_vec(R, X.ap, t1); mat3_vec(R, X.av, t2);
   for (int i = 0; i < 3; ++i) {
-    A->ap[i] = (A->ap[i] + A->av[i] * X.d.t.a) + rp[i];
-    A->av[i] = A->av[i] + rv[i];
+    A->ap[i] = (A->ap[i] + A->av[i] * X.d.t) + t1[i];
+    A->av[i] = A->av[i] + t2[i];
   }
-  imu_delta_then(&A->d, X.d);
+  for (int i = 0; i < 3; ++i) {
+    A->d.p[i] = (A->d.p[i] + A->d.v[i] * X.d.t) + rp[i];
+    A->d.v[i] = A->d.v[i] + rv[i];
+  }
+  quat_mul(A->d.q, X.d.q, q);
+  for (int i = 0; i < 4; ++i) A->d.q[i] = q[i];
+  A->d.t = A->d.t + X.d.t;
 }
 // Record columns (k_imu_jac's dcol): 0 values | 1..3 gyro bias | 4..6 accelerometer bias | 7..9 gyro scale | 10..12 accelerometer
-// scale | 13 time offset.  Group g of the kernel (8 lanes) carries dual direction g (0..5: gyro parameter g, 6: time offset) and the
+// scale | 13 time offset.  Group g of the kernel (8 lanes) carries direction g (0..5: gyro parameter g, 6: time offset) and the
 // accelerometer parameter g beside it.
 VC_HD int imu_group_dual_col(int g) { return g < 3 ? 1 + g : (g < 6 ? 4 + g : 13); }
 VC_HD int imu_group_accel_col(int g) { return g < 3 ? 4 + g : 7 + g; }
-// what lane 7 of group g stores once the block's delta has been composed
-VC_HD void imu_block_record_store(const IntervalDeltaGA& X, int g, double* rec) {
+// what lane 7 of group g stores once the block's delta has been composed.  The record keeps quaternion partials (what k_imu_jac's
+// dual numbers start from): d Q = 1/2 (dth, 0) Q.
+VC_HD void imu_block_record_store(const IntervalDeltaT& X, int g, double* rec) {
   if (g > 6) return;
   double* cd = rec + imu_group_dual_col(g) * 11;
-  for (int k = 0; k < 4; ++k) cd[k] = X.d.q[k].v;
-  for (int k = 0; k < 3; ++k) { cd[4 + k] = X.d.p[k].v; cd[7 + k] = X.d.v[k].v; }
-  cd[10] = X.d.t.v;
+  const double hq[4] = {0.5 * X.dth[0], 0.5 * X.dth[1], 0.5 * X.dth[2], 0.0};
+  double dq[4];
+  quat_mul(hq, X.d.q, dq);
+  for (int k = 0; k < 4; ++k) cd[k] = dq[k];
+  for (int k = 0; k < 3; ++k) { cd[4 + k] = X.dp[k]; cd[7 + k] = X.dv[k]; }
+  cd[10] = X.dt;
   if (g < 6) {
     double* ca = rec + imu_group_accel_col(g) * 11;
     for (int k = 0; k < 4; ++k) ca[k] = 0.0;
@@ -582,9 +651,9 @@ VC_HD void imu_block_record_store(const IntervalDeltaGA& X, int g, double* rec) 
     ca[10] = 0.0;
   }
   if (g == 0) {
-    for (int k = 0; k < 4; ++k) rec[k] = X.d.q[k].a;
-    for (int k = 0; k < 3; ++k) { rec[4 + k] = X.d.p[k].a; rec[7 + k] = X.d.v[k].a; }
-    rec[10] = X.d.t.a;
+    for (int k = 0; k < 4; ++k) rec[k] = X.d.q[k];
+    for (int k = 0; k < 3; ++k) { rec[4 + k] = X.d.p[k]; rec[7 + k] = X.d.v[k]; }
+    rec[10] = X.d.t;
   }
 }
 // Host form of k_imu_block, for tests/host_harness: the same bracketing -- rounds of 16 intervals, lane l of a group takes
@@ -597,20 +666,20 @@ inline int imu_block_delta_record(const ImuView& buf, double t_start, double t_e
   const int n_int = (rg.k1 - rg.k0 + 1) + 1;
   for (int g = 0; g < 7; ++g) {
     const D1 offD = mk(toff, g == 6 ? 1.0 : 0.0);
-    IntervalDeltaGA carry;
+    IntervalDeltaT carry;
     for (int base = 0; base < n_int; base += 16) {
-      IntervalDeltaGA X[8], Y[8];
+      IntervalDeltaT X[8], Y[8];
       for (int l = 0; l < 8; ++l) {
-        IntervalDeltaGA second;
-        imu_interval_delta_ga(buf, rg, offD, t_start, t_end, base + 2 * l + 1, n_int, b, sf, g, &X[l]);
-        imu_interval_delta_ga(buf, rg, offD, t_start, t_end, base + 2 * l + 2, n_int, b, sf, g, &second);
-        imu_delta_ga_then(&X[l], second);
+        IntervalDeltaT second;
+        imu_interval_delta_t(buf, rg, offD, t_start, t_end, base + 2 * l + 1, n_int, b, sf, g, &X[l]);
+        imu_interval_delta_t(buf, rg, offD, t_start, t_end, base + 2 * l + 2, n_int, b, sf, g, &second);
+        imu_delta_t_then(&X[l], second);
       }
       for (int n = 1; n < 8; n <<= 1) {
-        for (int l = 0; l < 8; ++l) { Y[l] = X[l]; if (l >= n) { Y[l] = X[l - n]; imu_delta_ga_then(&Y[l], X[l]); } }
+        for (int l = 0; l < 8; ++l) { Y[l] = X[l]; if (l >= n) { Y[l] = X[l - n]; imu_delta_t_then(&Y[l], X[l]); } }
         for (int l = 0; l < 8; ++l) X[l] = Y[l];
       }
-      if (base == 0) carry = X[7]; else imu_delta_ga_then(&carry, X[7]);
+      if (base == 0) carry = X[7]; else imu_delta_t_then(&carry, X[7]);
     }
     imu_block_record_store(carry, g, rec);
   }

@@ -279,24 +279,37 @@ __device__ __forceinline__ ImuRange imu_range_lanes(const ImuView& b, double t0,
 // costing as much as the steps: 57 us at cfg3 against 53 for the two kernels it replaced; this form runs a quarter of the wavefronts.
 // Depends on the shared IMU parameters only: in a solve it runs behind the reduced solve, next to the chain's back-substitution.
 // An empty sample range is flagged by T = -1 in the record.
-template <int N> __device__ __forceinline__ void delta_ga_scan_level(IntervalDeltaGA* X, int l) {
-  IntervalDeltaGA A;
+// an IntervalDeltaT (vc_imu.hpp) as kDtDoubles doubles: values Q P V T | tangent dth dp dv dt | ap | av
+__device__ __forceinline__ void delta_t_pack(const IntervalDeltaT& X, double* f) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { A.d.q[k].a = row_shr<N>(X->d.q[k].a, X->d.q[k].a); A.d.q[k].v = row_shr<N>(X->d.q[k].v, X->d.q[k].v); }
+  for (int k = 0; k < 4; ++k) f[k] = X.d.q[k];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    A.d.p[k].a = row_shr<N>(X->d.p[k].a, X->d.p[k].a); A.d.p[k].v = row_shr<N>(X->d.p[k].v, X->d.p[k].v);
-    A.d.v[k].a = row_shr<N>(X->d.v[k].a, X->d.v[k].a); A.d.v[k].v = row_shr<N>(X->d.v[k].v, X->d.v[k].v);
-    A.ap[k] = row_shr<N>(X->ap[k], X->ap[k]); A.av[k] = row_shr<N>(X->av[k], X->av[k]);
-  }
-  A.d.t.a = row_shr<N>(X->d.t.a, X->d.t.a); A.d.t.v = row_shr<N>(X->d.t.v, X->d.t.v);
-  imu_delta_ga_then(&A, *X);
+  for (int k = 0; k < 3; ++k) { f[4 + k] = X.d.p[k]; f[7 + k] = X.d.v[k]; f[11 + k] = X.dth[k]; f[14 + k] = X.dp[k]; f[17 + k] = X.dv[k]; f[21 + k] = X.ap[k]; f[24 + k] = X.av[k]; }
+  f[10] = X.d.t; f[20] = X.dt;
+}
+__device__ __forceinline__ void delta_t_unpack(const double* f, IntervalDeltaT* X) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) X->d.q[k] = f[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { X->d.p[k] = f[4 + k]; X->d.v[k] = f[7 + k]; X->dth[k] = f[11 + k]; X->dp[k] = f[14 + k]; X->dv[k] = f[17 + k]; X->ap[k] = f[21 + k]; X->av[k] = f[24 + k]; }
+  X->d.t = f[10]; X->dt = f[20];
+}
+template <int N> __device__ __forceinline__ void delta_t_scan_level(IntervalDeltaT* X, int l) {
+  double f[kDtDoubles];
+  delta_t_pack(*X, f);
+#pragma unroll
+  for (int k = 0; k < kDtDoubles; ++k) f[k] = row_shr<N>(f[k], f[k]);
+  IntervalDeltaT A;
+  delta_t_unpack(f, &A);
+  imu_delta_t_then(&A, *X);
   if (l >= N) *X = A;                            // (the first N lanes of a group have no partner: what the shift brought them belongs to the group below)
 }
-constexpr int kGaDoubles = 28;                   // an IntervalDeltaGA as doubles: D1 delta 22 | ap 3 | av 3
-__global__ __launch_bounds__(256, 2) void k_imu_block(DevView v, int trial) {
-  __shared__ double s_carry[32 * kGaDoubles];
-  __shared__ double s_park[256 * kGaDoubles];
+#ifndef VC_IMU_BLOCK_WAVES
+#define VC_IMU_BLOCK_WAVES 2
+#endif
+__global__ __launch_bounds__(256, VC_IMU_BLOCK_WAVES) void k_imu_block(DevView v, int trial) {
+  __shared__ double s_carry[32 * kDtDoubles];
+  __shared__ double s_park[256 * kDtDoubles];
   const Ctrl* ct = v.ctrl;
   if (ct->done || (!trial && !ct->need_lin)) return;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: everything per block stays out of the vector registers)
@@ -317,62 +330,52 @@ __global__ __launch_bounds__(256, 2) void k_imu_block(DevView v, int trial) {
   if (rg.valid) {                                                      // (wave-uniform)
     const int n_int = (rg.k1 - rg.k0 + 1) + 1;                         // intervals between the n_int + 1 range elements
     const int gsel = g < 7 ? g : 6;
-    double* cr = s_carry + (threadIdx.x >> 3) * kGaDoubles;
-    IntervalDeltaGA X;
+    double* cr = s_carry + (threadIdx.x >> 3) * kDtDoubles;
+    IntervalDeltaT X;
 #pragma unroll 1
     for (int base = 0; base < n_int; base += 16) {
       {
-        // the first interval's delta waits in LDS while the second is formed (28 doubles that would otherwise sit -- or spill --
+        // the first interval's delta waits in LDS while the second is formed (27 doubles that would otherwise sit -- or spill --
         // under the second RK4 step); a loop that is not unrolled: one copy of the step, nothing of the second interval scheduled
         // into the first
         double* pk = s_park + threadIdx.x;
-        IntervalDeltaGA Y;
+        IntervalDeltaT Y;
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
           // (the group index made opaque per iteration: otherwise everything the step derives from it -- seed masks, unit vector,
-          //  selects -- is hoisted out of the loops and sits in ~90 registers across both steps and the scan)
+          //  selects -- is hoisted out of the loops and sits in registers across both steps and the scan)
           int gs = gsel;
           asm volatile("" : "+v"(gs));
-          imu_interval_delta_ga(buf, rg, mk(toff, gs == 6 ? 1.0 : 0.0), t_start, t_end, base + 2 * l + 1 + half, n_int, im + 2, im + 8, gs, &Y);
+          imu_interval_delta_t(buf, rg, mk(toff, gs == 6 ? 1.0 : 0.0), t_start, t_end, base + 2 * l + 1 + half, n_int, im + 2, im + 8, gs, &Y);
           if (half == 0) {
+            double f[kDtDoubles];
+            delta_t_pack(Y, f);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { pk[k * 256] = Y.d.q[k].a; pk[(11 + k) * 256] = Y.d.q[k].v; }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              pk[(4 + k) * 256] = Y.d.p[k].a; pk[(15 + k) * 256] = Y.d.p[k].v; pk[(7 + k) * 256] = Y.d.v[k].a; pk[(18 + k) * 256] = Y.d.v[k].v;
-              pk[(22 + k) * 256] = Y.ap[k]; pk[(25 + k) * 256] = Y.av[k];
-            }
-            pk[10 * 256] = Y.d.t.a; pk[21 * 256] = Y.d.t.v;
+            for (int k = 0; k < kDtDoubles; ++k) pk[k * 256] = f[k];
           }
         }
+        double f[kDtDoubles];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) X.d.q[k] = mk(pk[k * 256], pk[(11 + k) * 256]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          X.d.p[k] = mk(pk[(4 + k) * 256], pk[(15 + k) * 256]); X.d.v[k] = mk(pk[(7 + k) * 256], pk[(18 + k) * 256]);
-          X.ap[k] = pk[(22 + k) * 256]; X.av[k] = pk[(25 + k) * 256];
-        }
-        X.d.t = mk(pk[10 * 256], pk[21 * 256]);
-        imu_delta_ga_then(&X, Y);
+        for (int k = 0; k < kDtDoubles; ++k) f[k] = pk[k * 256];
+        delta_t_unpack(f, &X);
+        imu_delta_t_then(&X, Y);
       }
-      delta_ga_scan_level<1>(&X, l); delta_ga_scan_level<2>(&X, l); delta_ga_scan_level<4>(&X, l);
+      delta_t_scan_level<1>(&X, l); delta_t_scan_level<2>(&X, l); delta_t_scan_level<4>(&X, l);
       if (l == 7) {                                                    // the round's total; the rounds before it rest in LDS
         if (base > 0) {
-          IntervalDeltaGA A;
+          IntervalDeltaT A;
+          double f[kDtDoubles];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) A.d.q[k] = mk(cr[k], cr[11 + k]);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) { A.d.p[k] = mk(cr[4 + k], cr[15 + k]); A.d.v[k] = mk(cr[7 + k], cr[18 + k]); A.ap[k] = cr[22 + k]; A.av[k] = cr[25 + k]; }
-          A.d.t = mk(cr[10], cr[21]);
-          imu_delta_ga_then(&A, X);
+          for (int k = 0; k < kDtDoubles; ++k) f[k] = cr[k];
+          delta_t_unpack(f, &A);
+          imu_delta_t_then(&A, X);
           X = A;
         }
         if (base + 16 < n_int) {
+          double f[kDtDoubles];
+          delta_t_pack(X, f);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { cr[k] = X.d.q[k].a; cr[11 + k] = X.d.q[k].v; }
-#pragma unroll
-          for (int k = 0; k < 3; ++k) { cr[4 + k] = X.d.p[k].a; cr[15 + k] = X.d.p[k].v; cr[7 + k] = X.d.v[k].a; cr[18 + k] = X.d.v[k].v; cr[22 + k] = X.ap[k]; cr[25 + k] = X.av[k]; }
-          cr[10] = X.d.t.a; cr[21] = X.d.t.v;
+          for (int k = 0; k < kDtDoubles; ++k) cr[k] = f[k];
         }
       }
     }
@@ -3065,7 +3068,7 @@ static void chain_gram_go(const DevView& v, hipStream_t s, int gather) {
   else go(k_chain_gram<9, 30>);
 }
 void launch_chain_gram(const DevView& v, hipStream_t s) { chain_gram_go(v, s, 0); }
-// early Gram where k_reduced does not add the top level's frames itself (D > kSmallD, sharded passes): their sums as one more partial record
+// early Gram where k_reduced does not add the top level's frames itself (D > kEarlyTopD, sharded passes): their sums as one more partial record
 void launch_chain_gram_top(const DevView& v, hipStream_t s) { chain_gram_go(v, s, 1); }
 void launch_chain_solve_a(const DevView& v, hipStream_t s) { launch_chain_init(v, s); launch_chain_fwd(v, s); launch_chain_gram(v, s); }
 void launch_chain_solve_b(const DevView& v, hipStream_t s) { chain_levels(v, s, false); }

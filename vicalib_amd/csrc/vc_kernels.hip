@@ -714,7 +714,7 @@ __device__ __forceinline__ void schur_final_phase(const DevView& v, int cur, Fin
     for (int q = 0; q < kSIter; ++q) { const int e = tid + 256 * q; if (e < D * D + D) S[e] = s_in[q]; }
     if (top) {
       // S -= sum over the top-level frames of Y^T Y, g_red -= Y^T z, on the matrix pipe: the (at most 64, zero-padded) rows are the k
-      // dimension, the column tiles (0,0), (0,1), (1,1) of the D + 1 <= 33 columns one wavefront each (v_mfma_f64_16x16x4; entries (i, j)
+      // dimension, the column tiles (0,0), (0,1), (1,1) of the D + 1 <= 32 columns (kEarlyTopD) one wavefront each (v_mfma_f64_16x16x4; entries (i, j)
       // and (j, i) are the same products in the same order: S stays symmetric to the bit).  (As a scalar loop -- thread per entry, two LDS
       // reads per row and entry -- this took 6 us: 0.7 MB through the LDS pipe.)
       __syncthreads();
@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   // early Gram: [Y | z] rows of the chain's top-level frames, behind phase A's record in the dynamic region (static LDS is at its limit
   // where the packed matrix of a D = 178 system takes 137 KB of the dynamic one)
   double* s_top = dyn + (sizeof(FinalLds) + 7) / 8;
-  const bool early = v.gram_top_stride > 0 && mode == 0 && v.D <= kSmallD;
+  const bool early = v.gram_top_stride > 0 && mode == 0 && v.D <= kEarlyTopD;
   const int top_rows = early ? 9 * min(7, (v.n_frames - 1) / v.gram_top_stride + 1) : 0;
   if (early) {
     // the top-level frames' rows (final since the launch before the partial sums): requested first, their latency under everything below
@@ -2040,7 +2040,7 @@ void launch_frame_schur(const DevView& v, hipStream_t s) {
 static inline size_t reduced_lds(const DevView& v) {
   const size_t solve = v.D <= kSmallD ? ((size_t)(kSmallD + 1) * (kSmallD + 2) + 3 * (kSmallD + 1)) * sizeof(double)
                                       : ((size_t)(v.D + 1) * (v.D + 2) / 2 + 3 * (v.D + 1) + 256 + 16 + 256) * sizeof(double);
-  const size_t top = (v.gram_top_stride > 0 && v.D <= kSmallD) ? (size_t)64 * kTopLd * sizeof(double) : 0;      // (k_reduced: s_top)
+  const size_t top = (v.gram_top_stride > 0 && v.D <= kEarlyTopD) ? (size_t)64 * kTopLd * sizeof(double) : 0;      // (k_reduced: s_top)
   return std::max(solve, (sizeof(FinalLds) + 7) / 8 * 8 + top);
 }
 void launch_reduced(const DevView& v, int mode, hipStream_t s) {

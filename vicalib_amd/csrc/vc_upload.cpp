@@ -294,7 +294,7 @@ int vc_calibrator::upload() {
     static const bool path_env = [] { const char* e = std::getenv("VICALIB_AMD_BACK_PATH"); return !(e && e[0] == '0'); }();
     dv.back_path = (path_env && dv.imu_on && !sharded() && !shard_imu && D + 1 <= 37) ? 1 : 0;
     // the top level's own frames: added by k_reduced (single process, narrow system) or a partial record of their own
-    top_gram_launch = dv.gram_top_stride > 0 && !(D <= kSmallD && !sharded());
+    top_gram_launch = dv.gram_top_stride > 0 && !(D <= kEarlyTopD && !sharded());
     dv.n_part = dv.n_chunks + (top_gram_launch ? 1 : 0);
   }
   dv.pin_first = (shard_imu && rank > 0) ? 1 : 0; dv.pin_last = ghost ? 1 : 0;
