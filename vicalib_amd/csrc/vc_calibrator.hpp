@@ -20,7 +20,7 @@ struct vc_calibrator {
   bool flag_sync = false;               // hand-overs to the second stream through device flags instead of event records (set at creation)
   bool weights_behind_l0 = !(std::getenv("VICALIB_AMD_WEIGHTS_BEHIND_L0") && std::getenv("VICALIB_AMD_WEIGHTS_BEHIND_L0")[0] == '0');
   bool shard_flag_sync = std::getenv("VICALIB_AMD_SHARD_FLAG_SYNC") && std::getenv("VICALIB_AMD_SHARD_FLAG_SYNC")[0] == '1';
-  long long sync_bound = 400000;        // polls before a flag wait gives up (~0.2 s); VICALIB_AMD_SYNC_BOUND (test hook: a tiny bound forces the time-out path)
+  long long sync_bound = 800000;        // polls before a flag wait gives up (~0.2 s); VICALIB_AMD_SYNC_BOUND (test hook: a tiny bound forces the time-out path)
   int sync_bound_from_pass = 0;         // VICALIB_AMD_SYNC_BOUND_FROM_PASS (test hook): the tiny bound only from this pass of the calibrator on -- a time-out in the middle of a solve
   int wr_ring[16] = {0};                // weight buffer read by pass (pass_seq & 15)
   int sync_timeouts = 0;                // flag hand-overs that ran into their bound (each one reported on stderr, the solve resumed with events)

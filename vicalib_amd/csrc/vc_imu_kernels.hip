@@ -304,14 +304,31 @@ template <int N> __device__ __forceinline__ void delta_t_scan_level(IntervalDelt
   imu_delta_t_then(&A, *X);
   if (l >= N) *X = A;                            // (the first N lanes of a group have no partner: what the shift brought them belongs to the group below)
 }
+// phase stamps of one wavefront in the middle of the grid (profiling builds only, -DVC_IB_STAMPS): 100 MHz s_memrealtime ticks in dbg[0..9]
+#ifdef VC_IB_STAMPS
+#define IBSTAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) v.dbg[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define IBSTAMP(i) do { } while (0)
+#endif
 #ifndef VC_IMU_BLOCK_WAVES
 #define VC_IMU_BLOCK_WAVES 2
 #endif
+#ifndef VC_IMU_BLOCK_PARK
+#define VC_IMU_BLOCK_PARK 1
+#endif
 __global__ __launch_bounds__(256, VC_IMU_BLOCK_WAVES) void k_imu_block(DevView v, int trial) {
   __shared__ double s_carry[32 * kDtDoubles];
-  __shared__ double s_park[256 * kDtDoubles];
+#if VC_IMU_BLOCK_PARK
+  // the first interval's delta while the second is formed: tangent and accelerometer partials per lane (16 doubles), the VALUES once per
+  // interval -- they are the same numbers in all eight groups, group 0 writes them: 42 KB per workgroup with the carry, not 62, so that
+  // two workgroups fit a CU beside a workgroup of the back-substitution (70 KB at BASELINE cfg3) and the grid is resident in one round
+  __shared__ double s_park[256 * (kDtDoubles - 11)];
+  __shared__ double s_parkv[4 * 8 * 11];
+#endif
+  IBSTAMP(0);
   const Ctrl* ct = v.ctrl;
   if (ct->done || (!trial && !ct->need_lin)) return;
+  IBSTAMP(1);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: everything per block stays out of the vector registers)
   const int g = lane >> 3, l = lane & 7;
   const int n_blocks = v.n_frames - 1;
@@ -327,6 +344,7 @@ __global__ __launch_bounds__(256, VC_IMU_BLOCK_WAVES) void k_imu_block(DevView v
   rg.k0 = __builtin_amdgcn_readfirstlane(rg.k0); rg.k1 = __builtin_amdgcn_readfirstlane(rg.k1);
   rg.first_end = __builtin_amdgcn_readfirstlane(rg.first_end); rg.last_end = __builtin_amdgcn_readfirstlane(rg.last_end);
   double* rec = v.imu_delta_blk + (size_t)s * kBlockDeltaStride;
+  IBSTAMP(2);
   if (rg.valid) {                                                      // (wave-uniform)
     const int n_int = (rg.k1 - rg.k0 + 1) + 1;                         // intervals between the n_int + 1 range elements
     const int gsel = g < 7 ? g : 6;
@@ -338,8 +356,11 @@ __global__ __launch_bounds__(256, VC_IMU_BLOCK_WAVES) void k_imu_block(DevView v
         // the first interval's delta waits in LDS while the second is formed (27 doubles that would otherwise sit -- or spill --
         // under the second RK4 step); a loop that is not unrolled: one copy of the step, nothing of the second interval scheduled
         // into the first
-        double* pk = s_park + threadIdx.x;
         IntervalDeltaT Y;
+#if VC_IMU_BLOCK_PARK
+        double* pk = s_park + threadIdx.x;
+        double* pv = s_parkv + (wave * 8 + l) * 11;
+#endif
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
           // (the group index made opaque per iteration: otherwise everything the step derives from it -- seed masks, unit vector,
@@ -347,20 +368,37 @@ __global__ __launch_bounds__(256, VC_IMU_BLOCK_WAVES) void k_imu_block(DevView v
           int gs = gsel;
           asm volatile("" : "+v"(gs));
           imu_interval_delta_t(buf, rg, mk(toff, gs == 6 ? 1.0 : 0.0), t_start, t_end, base + 2 * l + 1 + half, n_int, im + 2, im + 8, gs, &Y);
+          IBSTAMP(3 + half);
           if (half == 0) {
+#if VC_IMU_BLOCK_PARK
             double f[kDtDoubles];
             delta_t_pack(Y, f);
 #pragma unroll
-            for (int k = 0; k < kDtDoubles; ++k) pk[k * 256] = f[k];
+            for (int k = 11; k < kDtDoubles; ++k) pk[(k - 11) * 256] = f[k];
+            if (g == 0) {
+#pragma unroll
+              for (int k = 0; k < 11; ++k) pv[k] = f[k];
+            }
+#else
+            X = Y;
+#endif
           }
         }
+#if VC_IMU_BLOCK_PARK
+        wave_lds_sync_local();               // (group 0's values are read by the other groups' lanes)
         double f[kDtDoubles];
 #pragma unroll
-        for (int k = 0; k < kDtDoubles; ++k) f[k] = pk[k * 256];
+        for (int k = 0; k < 11; ++k) f[k] = pv[k];
+#pragma unroll
+        for (int k = 11; k < kDtDoubles; ++k) f[k] = pk[(k - 11) * 256];
         delta_t_unpack(f, &X);
+        wave_lds_sync_local();               // (... before the next round's first interval overwrites them)
+#endif
         imu_delta_t_then(&X, Y);
       }
+      IBSTAMP(5);
       delta_t_scan_level<1>(&X, l); delta_t_scan_level<2>(&X, l); delta_t_scan_level<4>(&X, l);
+      IBSTAMP(6);
       if (l == 7) {                                                    // the round's total; the rounds before it rest in LDS
         if (base > 0) {
           IntervalDeltaT A;
@@ -380,13 +418,14 @@ __global__ __launch_bounds__(256, VC_IMU_BLOCK_WAVES) void k_imu_block(DevView v
       }
     }
     if (l == 7 && s_raw < n_blocks) imu_block_record_store(X, g, rec);
+    IBSTAMP(7);
   } else if (lane == 0 && s_raw < n_blocks) rec[10] = -1.0;
   // the gravity record of this state for k_imu_jac (one lane of the spare group)
   if (blockIdx.x == 0 && threadIdx.x == 63) imu_gravity_record(im, v.imu_grav + cur * 16);
   // flag hand-overs, trial point: k_imu_jac behind this kernel needs the main stream's trial poses.  One thread of this kernel
   // waits for their flag before the kernel ends -- the kernel boundary then orders k_imu_jac behind it like any other kernel,
   // without a waiting kernel of its own (5 us on this stream's queue, which is the critical one at the end of a small pass)
-  if (trial && v.block_wait > 0 && blockIdx.x == 0 && threadIdx.x == 0) spin_until_flag(v, 2, v.block_wait);
+  if (trial && v.block_wait > 0 && blockIdx.x == 0 && threadIdx.x == 0) spin_until_flag<false>(v, 2, v.block_wait);
 }
 
 // phase stamps of the first wavefront (profiling builds only, -DVC_W_STAMPS): 100 MHz s_memrealtime ticks in dbg[0..15]
@@ -1071,7 +1110,7 @@ __device__ __forceinline__ void chain_fwd_group(const DevView& v, int s, int m, 
   // the control record is requested here and looked at after the first frame's image has been requested as well: a finished
   // solve costs a few wasted loads, a running one saves the record's round trip at the head of every level
   const int done = v.ctrl->done;
-  if (lvl == 1 && blockIdx.x == 0 && threadIdx.x == 0) signal_flag(v, 7);      // the bottom level is complete: this launch runs (the weight update waits for it)
+  if (lvl == 1 && blockIdx.x == 0 && threadIdx.x == 0) signal_started(v, 7);      // the bottom level is complete: this launch runs (the weight update waits for it)
   const int lane = threadIdx.x & 63;
   const int N = v.n_frames, D = v.D, ldw = v.ldw, ldx = v.ldx, nW = D + 1, ncol = nW + 27;
   const long gs = (long)m * s;
@@ -1359,7 +1398,7 @@ __global__ __launch_bounds__(128 * NW) void k_chain_fwd2(DevView v, int s, int m
   const long gs = (long)m * s;
   const int a = (int)((long)group * gs), first = a + s;
   const int done = v.ctrl->done;
-  if (lvl == 1 && blockIdx.x == 0 && threadIdx.x == 0) signal_flag(v, 7);      // the bottom level is complete: this launch runs (the weight update waits for it)
+  if (lvl == 1 && blockIdx.x == 0 && threadIdx.x == 0) signal_started(v, 7);      // the bottom level is complete: this launch runs (the weight update waits for it)
   const bool pend = lvl > 0;
   const double* rp = v.rX[(lvl + 1) & 1];
   double* rw = v.rX[lvl & 1];

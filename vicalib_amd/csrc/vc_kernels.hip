@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_reproj_jac(DevView v, int trial) {
   __shared__ double s_cost[4];
   // the trial sweep follows the back-substitution on the main stream: that this kernel has started says the trial poses are complete
   // and written back -- published for the second stream's k_imu_jac (no event record between the two kernels of the critical path)
-  if (trial && blockIdx.x == 0 && threadIdx.x == 0) signal_flag(v, 2);
+  if (trial && blockIdx.x == 0 && threadIdx.x == 0) signal_started(v, 2);
   if (ct->done || (!trial && !ct->need_lin)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;

@@ -81,6 +81,12 @@ __device__ __forceinline__ void signal_flag(const DevView& v, int idx) {
     __hip_atomic_store(v.sync_flags + idx, v.sync_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+// ... for a kernel that only announces that it has STARTED (what it publishes are its predecessor's results, which that kernel's end
+// has written back already): no fence -- the device-scope fence of signal_flag writes back the XCD's L2, 3-6 us right behind a
+// kernel that has just dirtied it, on the signalling thread and on everybody waiting for the flag
+__device__ __forceinline__ void signal_started(const DevView& v, int idx) {
+  if (v.sync_seq > 0) __hip_atomic_store(v.sync_flags + idx, v.sync_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // The waiting side.  Bounded: a flag that never comes (the two streams sharing one hardware queue would do it: the producer
 // queued behind the waiting kernel; a tool that serialises the kernels of all queues; several processes time-sliced on one
@@ -100,14 +106,21 @@ __device__ __forceinline__ void mark_sync_timeout(const DevView& v, long long se
   if (!__hip_atomic_compare_exchange_strong(v.sync_flags + 6, &expect, seq, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     __hip_atomic_fetch_min(v.sync_flags + 6, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// (relaxed polls, ONE acquire at the end: an acquire load per poll invalidates the CU's L1 every time round -- 2-3x slower per hop; the
+//  flag and the sticky word are requested together: one memory round trip per poll.)  ACQ = false: the waiting thread reads nothing of
+//  what the flag publishes itself (k_imu_block's thread, which only holds its kernel's end back: the next kernel's start acquires).
+template <bool ACQ = true>
 __device__ __forceinline__ void spin_until_flag(const DevView& v, int idx, long long seq) {      // one thread
   long long n = 0;
-  while (__hip_atomic_load(v.sync_flags + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
-    __builtin_amdgcn_s_sleep(16);
+  for (;;) {
+    const long long f = __hip_atomic_load(v.sync_flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const long long m = sync_marked(v);
+    if (f >= seq) break;
     if (m != 0 && m <= v.sync_seq) return;             // this pass is void already
     if (++n > v.sync_bound) { mark_sync_timeout(v, v.sync_seq); return; }
+    __builtin_amdgcn_s_sleep(8);
   }
+  if (ACQ) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 // ... and for a whole workgroup at its entry: thread 0 waits, then every wavefront drops what it may hold of the other stream's
 // results (device-scope acquire).  For single-workgroup kernels: a grid of workgroups doing this invalidates the L2 under whatever

@@ -49,7 +49,7 @@ int vc_calibrator::enqueue_pass(bool first_pass, bool events_only) {
     ++pass_seq;
     dv.pass_id = pass_seq;
     wr_ring[pass_seq & 15] = wcur;              // (what a resume after a flag time-out restores: the weight buffer this pass reads)
-    dv.sync_flags = d_sync.p; dv.sync_seq = fs ? pass_seq : 0; dv.final_wait = 0; dv.block_wait = 0; dv.sync_bound = (pass_seq >= sync_bound_from_pass) ? sync_bound : 400000;
+    dv.sync_flags = d_sync.p; dv.sync_seq = fs ? pass_seq : 0; dv.final_wait = 0; dv.block_wait = 0; dv.sync_bound = (pass_seq >= sync_bound_from_pass) ? sync_bound : 800000;
     const bool fs_trial = fs && jac_on_stream2 && dv.n_tiles > 0;      // (no tiles: no trial sweep to publish the back-substitution's end)
     dv.final_wait = fs_trial ? pass_seq : 0;      // (k_imu_jac(trial) and k_final both look at it)
     dv.block_wait = fs_trial ? pass_seq : 0;      // (k_imu_block(trial))
