@@ -238,6 +238,22 @@ def main():
     else:
         n_obs_total = n_obs_local
     allreduce_calls = cal.allreduce_calls() if comm_kind == "rccl" else None
+    # what the transport itself says about its size: RCCL's ncclCommCount / ncclCommUserRank (vc_shard_info) or torch.distributed's group
+    shard_info = cal.shard_info()
+    if comm_kind == "rccl":
+        ranks_seen, rank_seen = shard_info["rccl_ranks"], shard_info["rccl_rank"]
+    elif world > 1:
+        ranks_seen, rank_seen = dist.get_world_size(), dist.get_rank()
+    else:
+        ranks_seen, rank_seen = (1, 0) if comm_kind != "none" else (None, None)
+    if world > 1:
+        seen = torch.tensor([float(ranks_seen), float(rank_seen == rank)], device=coll_dev, dtype=torch.float64)
+        lo_hi = [seen.clone(), seen.clone()]
+        dist.all_reduce(lo_hi[0], op=dist.ReduceOp.MIN); dist.all_reduce(lo_hi[1], op=dist.ReduceOp.MAX)
+        ranks_seen_min, ranks_seen_max, ranks_agree = int(lo_hi[0][0].item()), int(lo_hi[1][0].item()), bool(lo_hi[0][1].item() == 1.0)
+    else:
+        ranks_seen_min = ranks_seen_max = ranks_seen
+        ranks_agree = rank_seen == rank if rank_seen is not None else None
 
     # ---- in-loop kernel durations (HIP events on the calibrator's stream around every launch group of the same loop) ----
     cal.set_kernel_timing(True)
@@ -371,7 +387,12 @@ def main():
     comm = None
     if world > 1 or force_shard:
         ar = {k: kernels[k] for k in kernels if k.startswith("allreduce")}
-        comm = {"transport": comm_kind, "communicator_size": world, "allreduce_calls": allreduce_calls, "per_rank_ms_per_step": per_rank_ms,
+        # communicator_size: the smallest size any rank's transport reports for itself (== WORLD_SIZE when every rank is in ONE
+        # communicator of all ranks); rccl_ranks_seen: [min, max] over the ranks of ncclCommCount; ranks_agree: every rank sits at the
+        # rank it was launched as
+        comm = {"transport": comm_kind, "communicator_size": ranks_seen_min, "world_size_env": world,
+                "rccl_ranks_seen": [ranks_seen_min, ranks_seen_max] if comm_kind == "rccl" else None, "ranks_agree": ranks_agree,
+                "allreduce_calls": allreduce_calls, "per_rank_ms_per_step": per_rank_ms,
                 "allreduce_ms_per_step": {k: v["ms_per_step"] for k, v in ar.items()},
                 "payload_doubles": {"allreduce(S)": D * D + 3 * D + 2, "allreduce(step scalars)": world * 8},
                 "rccl_error": rccl_errors[0] if rccl_errors else None}

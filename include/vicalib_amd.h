@@ -175,6 +175,14 @@ int vc_shard_comm_create(int device, int rank, int world_size, const void* uniqu
 int vc_set_shard_comm(vc_calibrator* h, vc_shard_comm* comm);
 void vc_shard_comm_destroy(vc_shard_comm* comm);
 long long vc_allreduce_calls(vc_calibrator* h);    /* all-reduces issued through the library's own communicator */
+/* The sharding a calibrator runs with: rank / world_size as set by vc_set_shard*, and -- for the library's own communicator -- what
+ * RCCL itself reports (ncclCommCount, ncclCommUserRank; -1: no RCCL communicator attached): a launcher can check that RCCL saw the
+ * ranks it was started with.  Any of the pointers may be NULL.  (The reference is single-process: vicalibrator.h:263-274.) */
+int vc_shard_info(vc_calibrator* h, int* rank, int* world_size, int* rccl_ranks, int* rccl_rank);
+/* Which forms of the visual-inertial pass the uploaded problem runs (after vc_prepare / a solve; a parity hook: the tests assert that the
+ * kernels they mean to check are the ones that ran): out4 = { chain assembly folded into the bottom level (k_chain_l0), back-substitution as
+ * one launch (k_chain_back_path), Gram sums in the top level's launch, top-level frames as a partial record of their own }. */
+int vc_pass_paths(vc_calibrator* h, int* out4);
 /* Text behind the last failing status of vc_set_shard_rccl on this thread (which library call failed, RCCL's error string and
  * last-error text): what a launcher prints before it falls back to another transport.  Empty if nothing failed. */
 const char* vc_last_error(void);

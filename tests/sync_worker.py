@@ -12,7 +12,8 @@ from vicalib_amd.lib import ViCalibrator          # noqa: E402
 
 out = sys.argv[1]
 n_frames = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-p = synth.generate(synth.Config(models=("kb4",), n_frames=n_frames, imu=True, seed=5))
+models = tuple(os.environ.get("VICALIB_TEST_MODELS", "kb4").split(","))      # (the rig: one model name per camera)
+p = synth.generate(synth.Config(models=models, n_frames=n_frames, imu=True, seed=5, extrinsics_prior=len(models) > 1))
 cal = ViCalibrator(0).load_problem(p)
 cal.SetMaxIters(100)
 cal.Solve()

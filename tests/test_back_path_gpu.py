@@ -3,7 +3,10 @@ between workgroups) against the level-by-level form (VICALIB_AMD_BACK_PATH=0: k_
 chain per group; z + Y delta_s is summed in another (fixed) order -- every iteration's cost, the accept / reject sequence and the final
 state at rounding level.  Frame counts: short, full and empty last groups at the bottom level (57, 60, 64, 65), one, two and three levels
 below the top (9, 60, 130, 600), counts where upper-level groups are short or empty (65, 513), and a count without a level
-below the top (7: both runs take the classic kernel and must agree bit for bit)."""
+below the top (7: both runs take the classic kernel and must agree bit for bit).  Round 6: wide borders -- cfg4's rig (4 x poly3, D = 67: the
+rows [Y] staged in two rounds of columns) and cfg5's (8 cameras, D = 115: four rounds); sharded passes with their pinned separator / ghost
+frames are held to the single-process solve and to the oracle by tests/test_sharding.py (which also keeps one run on the level-by-level
+form)."""
 import os
 import subprocess
 import sys
@@ -25,10 +28,11 @@ def _run(tmp_path, name, n_frames, **env):
     return np.load(out)
 
 
-@pytest.mark.parametrize("n_frames", [9, 57, 60, 64, 65, 130, 513, 600])
-def test_one_launch_back_substitution_matches_the_levels(tmp_path, n_frames):
-    a = _run(tmp_path, "path", n_frames, VICALIB_AMD_BACK_PATH=1)
-    b = _run(tmp_path, "levels", n_frames, VICALIB_AMD_BACK_PATH=0)
+@pytest.mark.parametrize("n_frames,rig", [(n, "kb4") for n in (9, 57, 60, 64, 65, 130, 513, 600)] +
+                         [(66, "poly3,poly3,poly3,poly3"), (130, "poly3,poly3,poly3,poly3"), (66, "fov,kb4,fov,kb4,fov,kb4,fov,kb4")])
+def test_one_launch_back_substitution_matches_the_levels(tmp_path, n_frames, rig):
+    a = _run(tmp_path, "path", n_frames, VICALIB_AMD_BACK_PATH=1, VICALIB_TEST_MODELS=rig)
+    b = _run(tmp_path, "levels", n_frames, VICALIB_AMD_BACK_PATH=0, VICALIB_TEST_MODELS=rig)
     assert int(a["timeouts"]) == 0 and int(b["timeouts"]) == 0
     ta, tb = a["trace"], b["trace"]
     if n_frames < 20:

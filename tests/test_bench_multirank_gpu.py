@@ -31,7 +31,8 @@ def test_two_ranks_through_gloo_on_one_gpu():
     assert out["config"]["frames_total"] == 2000 and out["config"]["corners_total"] == 373493      # BASELINE cfg3, both shards together
     assert out["config"]["reduced_dim"] == 29 + 9                                                    # + one separator frame
     comm = out["comm"]
-    assert comm["transport"] == "gloo" and comm["communicator_size"] == 2
+    assert comm["transport"] == "gloo" and comm["communicator_size"] == 2 and comm["world_size_env"] == 2
+    assert comm["ranks_agree"] is True and comm["rccl_ranks_seen"] is None      # (torch.distributed's group: every rank at its own rank)
     assert len(comm["per_rank_ms_per_step"]) == 2 and all(x > 0 for x in comm["per_rank_ms_per_step"])
     assert set(comm["allreduce_ms_per_step"]) == {"allreduce(S)", "allreduce(step scalars)"}
     assert all(v > 0 for v in comm["allreduce_ms_per_step"].values())
@@ -44,3 +45,21 @@ def test_single_rank_line_is_unchanged_by_the_transport_switch():
     out, _ = _bench("--steps", "4", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline", "--no-secondary")
     assert out["n_gpus"] == 1 and out["comm"] is None and out["config"]["reduced_dim"] == 29
     assert out["roofline"]["kernel"] and 0 < out["roofline"]["frac"] < 1
+
+
+def test_one_rank_through_the_library_rccl_communicator_reports_what_rccl_saw():
+    """VICALIB_AMD_FORCE_SHARD_PATH=1: one rank through the sharded code path with the library's own RCCL communicator -- the
+    `comm` object carries what RCCL itself reports (ncclCommCount / ncclCommUserRank through vc_shard_info), not WORLD_SIZE."""
+    env_keep = os.environ.get("VICALIB_AMD_FORCE_SHARD_PATH")
+    os.environ["VICALIB_AMD_FORCE_SHARD_PATH"] = "1"
+    try:
+        out, _ = _bench("--steps", "4", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline", "--no-secondary", "--workload", "cfg3", "--frames", "200")
+    finally:
+        if env_keep is None:
+            os.environ.pop("VICALIB_AMD_FORCE_SHARD_PATH", None)
+        else:
+            os.environ["VICALIB_AMD_FORCE_SHARD_PATH"] = env_keep
+    comm = out["comm"]
+    assert comm["transport"] == "rccl" and comm["rccl_error"] is None
+    assert comm["communicator_size"] == 1 and comm["rccl_ranks_seen"] == [1, 1] and comm["ranks_agree"] is True
+    assert comm["allreduce_calls"] > 0

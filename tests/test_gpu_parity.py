@@ -286,7 +286,8 @@ def test_solver_matches_committed_lm_traces(name):
     cfg3_full is BASELINE cfg3 at FULL size -- 2000 frames, 373 493 corners, D = 29, the complete A -> D schedule (69 trace rows):
     the configuration every bench number is quoted on, held to the oracle at 1e-6 (vicalibrator.h:919-1040, :690-721);
     cfg4_rig_400 is BASELINE cfg4's rig and grid (4 x poly3 + IMU, 900 dots, D = 67) at 400 frames; cfg5_rig_160 is BASELINE cfg5's rig
-    (8 cameras fov / kb4 + IMU, extrinsics prior, D = 115) at 160 frames, 92 trace rows."""
+    (8 cameras fov / kb4 + IMU, extrinsics prior, D = 115) at 160 frames, 92 trace rows -- the same tolerances as every other case (round 6;
+    its linearisation is pinned separately: test_chain_elimination_matches_dense_schur_complement at D = 115, 1e-6)."""
     import json
     e = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lm_traces.json")))[name]
     cfg = dict(e["config"]); cfg["models"] = tuple(cfg["models"])
@@ -296,29 +297,38 @@ def test_solver_matches_committed_lm_traces(name):
     if "max_iters" in e["options"]:
         cal.SetMaxIters(e["options"]["max_iters"])
     cal.Solve()
+    if name in ("mono_kb4_imu_60", "cfg3_full"):
+        # narrow border, single process: the round-5 forms of the chain are the ones this comparison with the oracle's record covers
+        assert cal.pass_paths() == dict(fold_l0=1, back_path=1, early_gram=1, top_gram_launch=0)
     tr = cal.trace()[:, [0, 1, 3, 8, 7, 9]]
     want = np.array(e["trace"])
     assert tr.shape == want.shape
     np.testing.assert_allclose(tr[:, 1], want[:, 1], rtol=1e-6)
     np.testing.assert_array_equal(tr[:, 3], want[:, 3])
-    # cfg5_rig_160 spends 50 iterations at radii of 1e8 (the damping no longer shapes the step): the radius update amplifies the
-    # 1e-9 differences of the costs through the ratio of two small decreases -- measured 2.7e-5 on the radius with every cost at 3e-8,
-    # every accept / reject equal
-    wide = name == "cfg5_rig_160"
-    np.testing.assert_allclose(tr[:, 4], want[:, 4], rtol=1e-4 if wide else 1e-6)
+    # The radius enters a pass as the damping diag / radius on a Jacobi-scaled system (diagonal <= 1): it is compared as what it does --
+    # the INVERSE radius at 1e-6 relative + 1e-12 absolute.  (Where the damping shapes the step, radius <= 1e6, that is 1e-6 on the radius
+    # itself; at radii of 1e8, where cfg5_rig_160 spends 50 iterations, the ratio of two tiny cost decreases amplifies the 1e-9 agreement
+    # of the costs to 3e-5 on a radius that no longer matters: 4e-13 on its inverse.)
+    np.testing.assert_allclose(1.0 / tr[:, 4], 1.0 / want[:, 4], rtol=1e-6, atol=1e-12)
     np.testing.assert_array_equal(tr[:, 5], want[:, 5])
-    # (wide: the eighth camera's kb4 coefficients sit in a flat valley at 160 frames -- 2e-5 of themselves between the two solvers at costs
-    #  equal to 3e-8; the parameters of that case are held at 1e-4, its costs / accept sequence / stages as everywhere)
-    pt = 1e-4 if wide else 1e-6
+    # Intrinsics: focal lengths and principal point at 1e-6; the full parameter vector through what it means -- the projection over the
+    # image at 1e-6 of a focal length (the pattern of test_rational6_calibration_matches_oracle).  Distortion coefficients are only
+    # determined up to the valley the data leave them (cfg5_rig_160's outermost camera: its four kb4 terms agree to 2e-5 of themselves
+    # while its projection agrees to 1e-7 f and every other quantity of the rig to 1e-8); extrinsics, IMU parameters, RMSE at 1e-6.
+    rays = np.stack(np.meshgrid(np.linspace(-0.6, 0.6, 9), np.linspace(-0.45, 0.45, 7), [1.0]), -1).reshape(-1, 3)
     for c, cam in enumerate(e["cameras"]):
-        np.testing.assert_allclose(cal.GetCamera(c)[0], cam["K"], rtol=pt)
-        np.testing.assert_allclose(cal.GetCamera(c)[1], cam["T_ck"], rtol=pt, atol=1e-7 if wide else 1e-8)
+        Kg, Tg = cal.GetCamera(c); Ko = np.array(cam["K"])
+        np.testing.assert_allclose(Kg[:4], Ko[:4], rtol=1e-6)
+        pg = synth.project(p.cam_model[c], Kg, rays); po = synth.project(p.cam_model[c], Ko, rays)
+        assert np.abs(pg - po).max() < 1e-6 * Ko[0], (c, np.abs(pg - po).max() / Ko[0])
+        np.testing.assert_allclose(Kg, Ko, rtol=1e-4)          # (coarse guard on the coefficients themselves)
+        np.testing.assert_allclose(Tg, cam["T_ck"], rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(cal.GetCameraProjRMSE(), e["rmse"], rtol=1e-6)
     if "imu" in e:
-        np.testing.assert_allclose(cal.GetBiases(), e["imu"]["biases"], rtol=pt, atol=1e-8 if wide else 1e-9)
-        np.testing.assert_allclose(cal.GetScaleFactor(), e["imu"]["scale"], rtol=pt)
-        np.testing.assert_allclose(cal.GetGravity(), e["imu"]["gravity"], rtol=pt, atol=1e-8 if wide else 1e-9)
-        assert abs(cal.time_offset() - e["imu"]["time_offset"]) < (1e-8 if wide else 1e-9)
+        np.testing.assert_allclose(cal.GetBiases(), e["imu"]["biases"], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(cal.GetScaleFactor(), e["imu"]["scale"], rtol=1e-6)
+        np.testing.assert_allclose(cal.GetGravity(), e["imu"]["gravity"], rtol=1e-6, atol=1e-9)
+        assert abs(cal.time_offset() - e["imu"]["time_offset"]) < 1e-9
 
 
 def test_converged_optima_match_the_independent_optimiser_fixture():
@@ -482,6 +492,8 @@ def test_chain_elimination_matches_dense_schur_complement(n_frames, models):
     g = cal.linearize()
     n, D = n_frames, lin["Hss"].shape[0]
     assert cal.shared_dim() == D
+    if D + 28 <= 64 and n_frames >= 9:
+        assert cal.pass_paths()["fold_l0"] == 1          # mono kb4: the folded bottom level (k_chain_l0) is what this system came through
     M = np.zeros((9 * n, 9 * n))
     for f in range(n):
         M[9 * f:9 * f + 9, 9 * f:9 * f + 9] = lin["A"][f]

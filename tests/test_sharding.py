@@ -59,6 +59,13 @@ def test_two_rank_sharded_visual_inertial_solve_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_two_rank_sharded_visual_inertial_solve_with_the_level_by_level_back_substitution():
+    """The same with VICALIB_AMD_BACK_PATH=0: since round 6 sharded passes take the one-launch back-substitution (k_chain_back_path with
+    pinned frames); the level-by-level kernels remain as the fall-back for chains of more than five levels and stay covered here."""
+    _run("gpu_imu", 900, extra_env={"VICALIB_AMD_BACK_PATH": "0"})
+
+
+@pytest.mark.gpu
 def test_two_processes_on_one_gpu_with_flag_handovers():
     """The same two-rank solve with the device-flag hand-overs left on in the workers' single-process reference solves: two
     processes' waiting kernels time-sliced on one device (advice r3).  Parity must hold whether or not a wait starves."""
@@ -125,6 +132,9 @@ comm = FrameShardComm(device="cuda:0", stream_ptr=cal.stream()); cal.set_shard(0
 cal.Solve()
 assert comm.calls > 10, comm.calls
 nat = ViCalibrator(0).load_problem(p); nat.SetCalibrateImu(False); nat.set_shard_rccl(0, 1)     # the library's own communicator
+info = nat.shard_info()
+assert info == dict(rank=0, world=1, rccl_ranks=1, rccl_rank=0), info          # what RCCL itself reports (ncclCommCount / ncclCommUserRank)
+assert cal.shard_info()["rccl_ranks"] == -1                                    # the callback transport has no RCCL communicator of the library's
 nat.Solve()
 assert nat.allreduce_calls() > 10
 np.testing.assert_allclose(nat.trace()[:, 1], cal.trace()[:, 1], rtol=1e-12)

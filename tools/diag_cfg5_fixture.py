@@ -22,3 +22,14 @@ print("rmse rel %.2e" % np.max(np.abs(cal.GetCameraProjRMSE() - np.array(e["rmse
 print("biases abs %.2e" % np.max(np.abs(cal.GetBiases() - np.array(e["imu"]["biases"]))), "toff %.2e" % abs(cal.time_offset() - e["imu"]["time_offset"]))
 for i in np.nonzero(rr > 1e-6)[0][:6]:
     print(" row", i, "stage", want[i, 5], "radius", tr[i, 4], want[i, 4], "cost", tr[i, 1], want[i, 1], "acc", tr[i, 3])
+# round 6: what is well determined -- the projection of every camera over the image (rays on a grid), in pixels per focal length
+rays = np.stack(np.meshgrid(np.linspace(-0.6, 0.6, 9), np.linspace(-0.45, 0.45, 7), [1.0]), -1).reshape(-1, 3)
+for c, cam in enumerate(e["cameras"]):
+    K, T = cal.GetCamera(c); Ko = np.array(cam["K"]); To = np.array(cam["T_ck"])
+    pg = synth.project(p.cam_model[c], K, rays); po = synth.project(p.cam_model[c], Ko, rays)
+    print(c, "model", p.cam_model[c], "projection max |diff| / f = %.2e" % (np.abs(pg - po).max() / K[0]), "K rel per entry", np.array2string(np.abs(K - Ko) / np.abs(Ko), precision=1),
+          "T_ck q abs %.1e t abs %.1e (|t| %.2f)" % (np.abs(T[:4] - To[:4]).max(), np.abs(T[4:] - To[4:]).max(), np.linalg.norm(To[4:])))
+print("scale rel %.2e" % np.max(np.abs(cal.GetScaleFactor() - np.array(e["imu"]["scale"])) / np.abs(np.array(e["imu"]["scale"]))),
+      "gravity abs %.2e" % np.max(np.abs(cal.GetGravity() - np.array(e["imu"]["gravity"]))), "biases", np.array2string(np.abs(cal.GetBiases() - np.array(e["imu"]["biases"])), precision=1), np.array2string(np.array(e["imu"]["biases"]), precision=3))
+inv = np.abs(1.0 / tr[:k, 4] - 1.0 / want[:k, 4])
+print("inverse radius: max abs diff %.2e; max (abs diff / (1e-12 + 1e-6 / radius)) = %.3f" % (inv.max(), (inv / (1e-12 + 1e-6 / want[:k, 4])).max()))

@@ -2,9 +2,11 @@
 # per-rank passes of the multi-GPU configurations on one GPU (no separators / all-reduces): tools/perrank_round.sh TAG
 set -u
 TAG=$1; ROOT=$PWD; OUT=$ROOT/gpurun_out/pr_$TAG; mkdir -p $OUT
-for spec in "cfg4 2500" "cfg5 6250"; do
+# (cfg3 / 2: 1000 frames through the SHARDED code path -- split k_reduced / k_final around the two all-reduces, which go through the
+#  library's RCCL communicator with its one rank; without a peer there is no separator frame: D = 29, not the 38 of a real two-rank run)
+for spec in "cfg3 1000 1" "cfg4 2500 0" "cfg5 6250 0"; do
   set -- $spec
-  python bench.py --workload $1 --frames $2 --steps 20 --warmup 5 --repeats 3 --no-cpu-baseline --no-secondary > $OUT/bench_$1_$2.json 2> $OUT/bench_$1_$2.err
+  VICALIB_AMD_FORCE_SHARD_PATH=$3 python bench.py --workload $1 --frames $2 --steps 20 --warmup 5 --repeats 3 --no-cpu-baseline --no-secondary > $OUT/bench_$1_$2.json 2> $OUT/bench_$1_$2.err
   python - <<PY
 import json
 d = json.load(open("$OUT/bench_$1_$2.json"))

@@ -466,6 +466,14 @@ static int rccl_comm_init(int device, int rank, int world_size, const void* uniq
     if (g_rccl.GetLastError) { const char* le = g_rccl.GetLastError(nullptr); if (le && le[0]) g_last_error += std::string(": ") + le; }
     *comm = nullptr; return VC_ERR_NO_DEVICE;
   }
+  // what RCCL itself says it built: a communicator of another size or with this process at another rank (a launcher that mixed up its
+  // environment) would reduce over the wrong set of shards without any error
+  int cnt = -1, ur = -1;
+  if (g_rccl.CommCount && g_rccl.CommCount(*comm, &cnt) == 0 && g_rccl.CommUserRank && g_rccl.CommUserRank(*comm, &ur) == 0 && (cnt != world_size || ur != rank)) {
+    g_last_error = "ncclCommInitRank built a communicator of " + std::to_string(cnt) + " ranks with this process at rank " + std::to_string(ur) + "; asked for rank " +
+                   std::to_string(rank) + " of " + std::to_string(world_size);
+    (void)g_rccl.CommDestroy(*comm); *comm = nullptr; return VC_ERR_BAD_ARG;
+  }
   return VC_OK;
 }
 static void attach_rccl(vc_calibrator* h, int rank, int world_size, void* comm, bool owned) {
@@ -514,7 +522,26 @@ void vc_shard_comm_destroy(vc_shard_comm* c) {
   delete c;
 }
 long long vc_allreduce_calls(vc_calibrator* h) { return h ? h->rccl_calls : 0; }
+int vc_shard_info(vc_calibrator* h, int* rank, int* world_size, int* rccl_ranks, int* rccl_rank) {
+  if (!h) return VC_ERR_BAD_ARG;
+  if (rank) *rank = h->rank;
+  if (world_size) *world_size = h->world;
+  int cnt = -1, ur = -1;
+  if (h->rccl_comm && g_rccl.CommCount && g_rccl.CommUserRank) {
+    if (g_rccl.CommCount(h->rccl_comm, &cnt) != 0) cnt = -1;
+    if (g_rccl.CommUserRank(h->rccl_comm, &ur) != 0) ur = -1;
+  }
+  if (rccl_ranks) *rccl_ranks = cnt;
+  if (rccl_rank) *rccl_rank = ur;
+  return VC_OK;
+}
 const char* vc_last_error(void) { return g_last_error.c_str(); }
+int vc_pass_paths(vc_calibrator* h, int* out4) {
+  if (!h || !out4) return VC_ERR_BAD_ARG;
+  out4[0] = h->dv.imu_on ? h->dv.fold_l0 : 0; out4[1] = h->dv.imu_on ? h->dv.back_path : 0;
+  out4[2] = (h->dv.imu_on && h->dv.gram_top_stride > 0) ? 1 : 0; out4[3] = h->top_gram_launch ? 1 : 0;
+  return VC_OK;
+}
 void* vc_get_stream(vc_calibrator* h) { return h ? (void*)h->stream : nullptr; }
 int vc_prepare(vc_calibrator* h) {
   NOT_RUNNING(h);

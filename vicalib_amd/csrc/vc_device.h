@@ -242,7 +242,6 @@ int chain_group_size();          // frames per group of the partitioned chain el
 void launch_imu_delta(const DevView& v, hipStream_t s, int trial = 0);         // block deltas under the IMU parameters of the accepted (0) / trial (1) state (k_imu_block)
 void launch_imu_jac(const DevView& v, int wr, hipStream_t s, int trial = 0);   // wr: weight buffer to read; trial as for launch_reproj_jac; needs launch_imu_delta
 void launch_imu_weights(const DevView& v, int wr, hipStream_t s);          // reads wsqrtb[wr], writes wsqrtb[1 - wr];                   // weight_sqrt_ from the accepted state
-void launch_chain_solve_a(const DevView& v, hipStream_t s);                 // the three below in a row: assemble + partitioned elimination + Gram partials
 void launch_chain_init(const DevView& v, hipStream_t s);                    // frame images from the tile Gram records and the IMU blocks
 void launch_chain_fwd(const DevView& v, hipStream_t s);                     // forward elimination, one launch per level
 void launch_chain_gram(const DevView& v, hipStream_t s);                    // sum of [Y | z]^T [Y | z] per chunk

@@ -196,6 +196,8 @@ struct RcclApi {
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;      // optional: diagnostics only
   const char* (*GetLastError)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;           // optional: what the communicator itself says about its size and this rank
+  int (*CommUserRank)(void*, int*) = nullptr;        // (checked against the caller's numbers at creation; reported by vc_shard_info)
   bool load() {
     if (AllReduce) return true;
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
@@ -208,6 +210,8 @@ struct RcclApi {
     CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
     GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
     GetLastError = (const char* (*)(void*))dlsym(lib, "ncclGetLastError");
+    CommCount = (int (*)(void*, int*))dlsym(lib, "ncclCommCount");
+    CommUserRank = (int (*)(void*, int*))dlsym(lib, "ncclCommUserRank");
     if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) { AllReduce = nullptr; return false; }
     return true;
   }

@@ -2523,6 +2523,36 @@ __global__ __launch_bounds__(64) void k_chain_back(DevView v, int s, int m, int 
   }
   chain_back_group<false>(v, s, m, top, lvl, two, (int)blockIdx.x, ds, dl);
 }
+// ... the same sums as a launch of their own, one frame per wavefront: what the one-launch back-substitution reads at wide borders
+// (k_chain_back_path below recomputes the upper levels in every bottom group -- with their rows [Y | z] that is 58 KB per wavefront at
+// D = 115, 230 MB through the L2 at 6250 frames: the one-launch form then took 218 us against 71 for the level-by-level kernels; with t0
+// formed once per frame here it reads nine values per frame)
+__global__ __launch_bounds__(256) void k_chain_t0(DevView v) {
+  if (v.ctrl->done) return;
+  const int lane = threadIdx.x & 63, f = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (f >= v.n_frames) return;
+  const int D = v.D, ldx = v.ldx;
+  double dsl[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) { const int j = lane + 64 * u; dsl[u] = j < D ? v.delta_s[j] : (j == D ? 1.0 : 0.0); }      // (column D: z itself)
+  double p[9];
+#pragma unroll
+  for (int kk = 0; kk < 9; ++kk) {
+    const double* Wr = v.cW + ((size_t)f * 9 + kk) * ldx;
+    double x[3];
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { const int j = lane + 64 * w; x[w] = Wr[j <= D ? j : 0]; }
+    double acc = 0.0;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { const int j = lane + 64 * w; acc += (j <= D) ? x[w] * dsl[w] : 0.0; }
+    p[kk] = acc;
+  }
+#pragma unroll
+  for (int kk = 0; kk < 9; ++kk) {
+    const double t0 = wave_sum(p[kk]);
+    if (lane == 0) v.ct0[(size_t)f * 9 + kk] = t0;
+  }
+}
 __global__ __launch_bounds__(64) void k_chain_back_levels(DevView v, BackLevels L) {
   __shared__ double ds[192 + 8];
   __shared__ double dl[kChainM * 9];
@@ -2541,8 +2571,13 @@ __global__ __launch_bounds__(64) void k_chain_back_levels(DevView v, BackLevels 
 // then one row per lane) -- the extra workgroups of the top level's launch and the ct0 round trip are gone with the launch; the steps
 // travel top-down through LDS (positions of a group: 0 = left separator, 1 .. q = interior frames, q + 1 = right separator; the top
 // level: its frames from position 0).  The dependent chain is chain_back_group's, instruction for instruction.
-struct BackPath { int n; int stride[6]; int m[6]; int two[6]; int top_stride; int ldr; };
-constexpr int kPathRowLoads = 37;      // 63 rows x (D + 1 <= 37) entries over 64 lanes
+// Round 6: any border width and sharded passes.  Borders of more than kPathChunk columns take t0 from k_chain_t0 (BackPath::ct0; the
+// staging below also runs in rounds of kPathChunk columns -- correct at any width, but the redundancy of the recomputed levels then costs
+// more than a launch); z comes with the lane's own blocks; a pinned frame (separator / ghost of a sharded chain, DevView::pin_first /
+// pin_last) steps with the reduced system's solution in the epilogue.
+struct BackPath { int n; int stride[6]; int m[6]; int two[6]; int top_stride; int ldr; int dsw; int ct0; };
+constexpr int kPathChunk = 36;         // columns of Y per staging round
+constexpr int kPathRowLoads = 37;      // 63 rows x kPathChunk entries over 64 lanes
 constexpr int kPathDl = 96;            // doubles per level's step record (10 positions x 9)
 template <int NWMAX>      // wavefronts per workgroup at most (levels + 1): up to four leave a whole SIMD's registers to each
 __global__ __launch_bounds__(64 * NWMAX) void k_chain_back_path(DevView v, BackPath P) {
@@ -2550,9 +2585,9 @@ __global__ __launch_bounds__(64 * NWMAX) void k_chain_back_path(DevView v, BackP
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int nw = P.n + 1;
   double* DLall = bp_lds;                              // [nw][kPathDl]
-  double* DSW = DLall + nw * kPathDl + (size_t)wv * 64;      // this wavefront's copy of delta_s
-  int* READY = reinterpret_cast<int*>(DLall + nw * kPathDl + nw * 64);      // [8]
-  double* RW = DLall + nw * kPathDl + nw * 64 + 4 + (size_t)wv * 63 * P.ldr;      // this wavefront's rows [63][ldr]
+  double* DSW = DLall + nw * kPathDl + (size_t)wv * P.dsw;      // this wavefront's copy of delta_s
+  int* READY = reinterpret_cast<int*>(DLall + nw * kPathDl + nw * P.dsw);      // [8]
+  double* RW = DLall + nw * kPathDl + nw * P.dsw + 4 + (size_t)wv * 63 * P.ldr;      // this wavefront's rows [63][ldr]
   double* DL = DLall + (size_t)wv * kPathDl;
   if (threadIdx.x < 8) READY[threadIdx.x] = 0;
   __syncthreads();
@@ -2585,26 +2620,28 @@ __global__ __launch_bounds__(64 * NWMAX) void k_chain_back_path(DevView v, BackP
   const int e = first + (mine ? fi : 0) * s;
   const bool two_sided = two && !top && q >= 1;
   const int fmid = (q - 1) / 2;
-  // ---- requests: the rows [Y | z] of the group's frames (lane-strided, coalesced), then this lane's blocks
-  const int ncolr = D + 1, nel = q * 9 * ncolr;
+  // ---- requests: the rows [Y] of the group's frames in rounds of kPathChunk columns (lane-strided, coalesced), then this lane's blocks
+  const int nchunks = P.ct0 ? 0 : (D + kPathChunk - 1) / kPathChunk;
   double rv[kPathRowLoads];
-  {
-    const int step_r = 64 / ncolr, step_c = 64 - step_r * ncolr;
-    int row = lane / ncolr, col = lane - row * ncolr;
+  auto request = [&](int c0) {
+    const int ncc = min(kPathChunk, D - c0), nel = q * 9 * ncc;      // (wave-uniform)
+    const int step_r = 64 / ncc, step_c = 64 - step_r * ncc;
+    int row = lane / ncc, col = lane - row * ncc;
 #pragma unroll
     for (int u = 0; u < kPathRowLoads; ++u) {
       const int idx = lane + 64 * u;
       const int f2 = (row * 57) >> 9, k2 = row - 9 * f2;          // (row / 9 for rows below 64)
       const bool in = idx < nel;          // (a lane without an entry reads frame 0 and drops the value)
-      const double* src = v.cW + (size_t)(in ? first + f2 * s : 0) * isz + (size_t)(in ? k2 : 0) * ldx + (in ? col : 0);
+      const double* src = v.cW + (size_t)(in ? first + f2 * s : 0) * isz + (size_t)(in ? k2 : 0) * ldx + (in ? c0 + col : 0);
       const double x = *src;
       rv[u] = in ? x : 0.0;
       row += step_r; col += step_c;
-      if (col >= ncolr) { col -= ncolr; ++row; }
+      if (col >= ncc) { col -= ncc; ++row; }
     }
-  }
-  if (lane < D) DSW[lane] = v.delta_s[lane];
-  double dinv = 1.0, Qrow[9], Lcol[9], Xs[9];
+  };
+  if (nchunks > 0) request(0);
+  for (int j = lane; j < D; j += 64) DSW[j] = v.delta_s[j];
+  double dinv = 1.0, Qrow[9], Lcol[9], Xs[9], zrow;
   {
     const double* img = v.cW + (size_t)(mine ? e : 0) * isz;
     const double* Wr = img + (size_t)k * ldx;
@@ -2613,29 +2650,36 @@ __global__ __launch_bounds__(64 * NWMAX) void k_chain_back_path(DevView v, BackP
       const double qv = Wr[ldw + 18 + c], lv = img[c * ldx + ldw + 9 + k], xv = Wr[ldw + c];
       Qrow[c] = mine ? qv : 0.0; Lcol[c] = (mine && c > k) ? lv : 0.0; Xs[c] = (mine && a >= 0) ? xv : 0.0;
     }
-    const double dg = Wr[ldw + 9 + k];
+    const double dg = Wr[ldw + 9 + k], zv = P.ct0 ? v.ct0[(size_t)(mine ? e : 0) * 9 + k] : Wr[D];      // (ct0: the finished sum z + Y delta_s)
     dinv = mine ? 1.0 / dg : 1.0;
+    zrow = mine ? zv : 0.0;
   }
   const int base = a, cnt = (a < N) ? q + 1 : 0;
   if (done) return;                      // (uniform over the workgroup)
-  {
-    int row = lane / ncolr, col = lane - row * ncolr;
-    const int step_r = 64 / ncolr, step_c = 64 - step_r * ncolr;
+  double t = zrow;                       // t0 = z + Y delta_s, summed left to right
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int c0 = ch * kPathChunk, ncc = min(kPathChunk, D - c0), nel = q * 9 * ncc;
+    {
+      int row = lane / ncc, col = lane - row * ncc;
+      const int step_r = 64 / ncc, step_c = 64 - step_r * ncc;
 #pragma unroll
-    for (int u = 0; u < kPathRowLoads; ++u) {
-      const int idx = lane + 64 * u;
-      if (idx < nel) RW[row * P.ldr + col] = rv[u];
-      row += step_r; col += step_c;
-      if (col >= ncolr) { col -= ncolr; ++row; }
+      for (int u = 0; u < kPathRowLoads; ++u) {
+        const int idx = lane + 64 * u;
+        if (idx < nel) RW[row * P.ldr + col] = rv[u];
+        row += step_r; col += step_c;
+        if (col >= ncc) { col -= ncc; ++row; }
+      }
     }
-  }
-  wave_lds_sync_local();
-  double t = 0.0;
-  if (mine) {
-    const double* Rr = RW + (size_t)(fi * 9 + k) * P.ldr;
-    double acc = Rr[D];
-    for (int j = 0; j < D; ++j) acc += Rr[j] * DSW[j];
-    t = acc;
+    if (ch + 1 < nchunks) request(c0 + kPathChunk);      // the next round's loads under this round's sums
+    wave_lds_sync_local();
+    if (mine) {
+      const double* Rr = RW + (size_t)(fi * 9 + k) * P.ldr;
+      const double* dsc = DSW + c0;
+      double acc = t;
+      for (int j = 0; j < ncc; ++j) acc += Rr[j] * dsc[j];
+      t = acc;
+    }
+    if (ch + 1 < nchunks) wave_lds_sync_local();         // (the rows are overwritten by the next round)
   }
   // ---- the separators' steps from the level above
   double da[9], dn[9], dr_in[9];
@@ -2739,8 +2783,12 @@ __global__ __launch_bounds__(64 * NWMAX) void k_chain_back_path(DevView v, BackP
 #pragma unroll
       for (int i = 0; i < 9; ++i) { gi9[i] = v.cg[(size_t)f * 9 + i]; lam9[i] = v.clam[(size_t)f * 9 + i]; }
     }
+    // pinned frames (sharded chain) step with the reduced system's solution; their gradient / damping terms are counted there, and only
+    // the owner (not the rank that holds the ghost copy) counts the step and parameter norms -- chain_back_group's rule
+    const bool pin_f = (f == 0 && v.pin_first), pin_l = (f == N - 1 && v.pin_last);
+    const int sc = pin_f ? v.sep_col0 : (pin_l ? v.sep_col1 : 0);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) d[i] = DL[lane * 9 + i];
+    for (int i = 0; i < 9; ++i) { const double dch = DL[lane * 9 + i], dsp = DSW[sc + i]; d[i] = (pin_f || pin_l) ? dsp : dch; }
     double* pout = v.poses[1 - cur] + (size_t)f * kPoseStride;
     double Tout[7], dd[6];
     for (int i = 0; i < 6; ++i) dd[i] = d[i];
@@ -2754,6 +2802,8 @@ __global__ __launch_bounds__(64 * NWMAX) void k_chain_back_path(DevView v, BackP
       const double gi = gi9[i];
       gd += gi * d[i]; dld += lam9[i] * d[i] * d[i]; g2 += gi * gi; gmax = fmax(gmax, fabs(gi));
     }
+    if (pin_f || pin_l) { gd = 0; dld = 0; g2 = 0; gmax = 0; }
+    if (pin_l) { step2 = 0; x2 = 0; }
   }
   gd = wave_sum(gd); dld = wave_sum(dld); step2 = wave_sum(step2); x2 = wave_sum(x2); g2 = wave_sum(g2);
 #pragma unroll
@@ -3001,20 +3051,22 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
       if (v.gram_top_stride > 0) launch_chain_gram(v, s);      // (A/B hook VICALIB_AMD_CHAIN_WAVES=0: the same masked sums, a launch of their own)
     }
   } else {
-    // single process, narrow border: the whole back-substitution as one launch without hand-overs (k_chain_back_path)
-    if (v.back_path && nl >= 1 && nl <= 5 && v.D + 1 <= kPathRowLoads && !v.pin_first && !v.pin_last) {
+    // the whole back-substitution as one launch without hand-overs (k_chain_back_path): any border width, sharded passes included
+    if (v.back_path && nl >= 1 && nl <= 5) {
       BackPath P; P.n = nl;
       for (int l = 0; l < 6; ++l) { P.stride[l] = l < nl ? strides[l] : 1; P.m[l] = l < nl ? ms[l] : 2; P.two[l] = (l < nl && two_at(l)) ? 1 : 0; }
-      P.top_stride = top_stride; P.ldr = (v.D + 1) | 1;
+      P.top_stride = top_stride; P.ldr = std::min(v.D, kPathChunk) | 1; P.dsw = ((v.D + 63) / 64) * 64;
+      P.ct0 = v.D > kPathChunk ? 1 : 0;
+      if (P.ct0) hipLaunchKernelGGL(k_chain_t0, dim3((N + 3) / 4), dim3(256), 0, s, v);
       const int groups0 = (int)(((long)N - 1) / ((long)strides[0] * ms[0]) + 1), nw = nl + 1;
-      const size_t lds = ((size_t)nw * kPathDl + (size_t)nw * 64 + 4 + (size_t)nw * 63 * P.ldr) * sizeof(double);
+      const size_t lds = ((size_t)nw * kPathDl + (size_t)nw * P.dsw + 4 + (P.ct0 ? 0 : (size_t)nw * 63 * P.ldr)) * sizeof(double);
+      // (the attribute is a property of the function on ONE device: the cache is per device -- advice r5)
+      static LdsGrant g4, g6;
       if (nw <= 4) {
-        static size_t lds_set = 0;
-        if (lds > 60000 && lds > lds_set) { (void)hipFuncSetAttribute((const void*)k_chain_back_path<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
+        if (lds > 60000 && g4.need(lds)) (void)hipFuncSetAttribute((const void*)k_chain_back_path<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_chain_back_path<4>, dim3(groups0), dim3(64 * nw), lds, s, v, P);
       } else {
-        static size_t lds_set = 0;
-        if (lds > 60000 && lds > lds_set) { (void)hipFuncSetAttribute((const void*)k_chain_back_path<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
+        if (lds > 60000 && g6.need(lds)) (void)hipFuncSetAttribute((const void*)k_chain_back_path<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_chain_back_path<6>, dim3(groups0), dim3(64 * nw), lds, s, v, P);
       }
       return;
@@ -3109,7 +3161,6 @@ static void chain_gram_go(const DevView& v, hipStream_t s, int gather) {
 void launch_chain_gram(const DevView& v, hipStream_t s) { chain_gram_go(v, s, 0); }
 // early Gram where k_reduced does not add the top level's frames itself (D > kEarlyTopD, sharded passes): their sums as one more partial record
 void launch_chain_gram_top(const DevView& v, hipStream_t s) { chain_gram_go(v, s, 1); }
-void launch_chain_solve_a(const DevView& v, hipStream_t s) { launch_chain_init(v, s); launch_chain_fwd(v, s); launch_chain_gram(v, s); }
 void launch_chain_solve_b(const DevView& v, hipStream_t s) { chain_levels(v, s, false); }
 
 }  // namespace vc

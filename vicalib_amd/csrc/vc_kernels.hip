@@ -255,7 +255,10 @@ __device__ __forceinline__ double jac_tile_dispatch(const DevView& v, int model,
 // trial = 0: linearisation at the accepted state (only when the control record asks for one); trial = 1: the sweep runs at the
 // trial state and fills buffer 1 - cur -- its cost is the trial cost, its Gram blocks are the next linearisation if the step is
 // accepted (the decision flips `cur`), and a rejected step leaves buffer cur untouched.
-__global__ __launch_bounds__(256) void k_reproj_jac(DevView v, int trial) {
+#ifndef VC_JAC_WAVES
+#define VC_JAC_WAVES 2
+#endif
+__global__ __launch_bounds__(256, VC_JAC_WAVES) void k_reproj_jac(DevView v, int trial) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const Ctrl* ct = v.ctrl;
 #ifdef VC_JAC_STAMPS
@@ -2015,8 +2018,8 @@ void launch_reproj_jac(const DevView& v, hipStream_t s, int trial) {
   static const bool one_wg = [] { const char* e = std::getenv("VICALIB_AMD_TRIAL_ONE_WG"); return e && e[0] == '1'; }();
   if (trial && v.imu_on && one_wg && tiles_grid(v) <= 1024) {
     lds = 88 * 1024;
-    static bool granted = false;
-    if (!granted) { (void)hipFuncSetAttribute((const void*)k_reproj_jac, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = true; }
+    static LdsGrant granted;
+    if (granted.need(lds)) (void)hipFuncSetAttribute((const void*)k_reproj_jac, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   hipLaunchKernelGGL(k_reproj_jac, dim3(tiles_grid(v)), dim3(256), lds, s, v, trial);
 }
@@ -2045,16 +2048,16 @@ static inline size_t reduced_lds(const DevView& v) {
 }
 void launch_reduced(const DevView& v, int mode, hipStream_t s) {
   const size_t lds = reduced_lds(v);
-  static size_t granted = 0;
-  if (lds > 30000 && lds > granted) { (void)hipFuncSetAttribute((const void*)k_reduced, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
+  static LdsGrant granted;
+  if (lds > 30000 && granted.need(lds)) (void)hipFuncSetAttribute((const void*)k_reduced, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_reduced, dim3(1), dim3(256), lds, s, v, mode);
 }
 void launch_trial(const DevView& v, hipStream_t s) {
   if (v.n_tiles == 0) return;
   if (v.pre_backsub) hipLaunchKernelGGL(k_backsub, dim3((v.n_frames + 3) / 4), dim3(256), 0, s, v);
   const size_t lds = 4 * 64 * kDotStride * sizeof(double);
-  static bool granted = false;
-  if (lds > 0 && !granted) { (void)hipFuncSetAttribute((const void*)k_trial<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 4096)); granted = true; }
+  static LdsGrant granted;
+  if (lds > 0 && granted.need(lds + 4096)) (void)hipFuncSetAttribute((const void*)k_trial<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 4096));
   hipLaunchKernelGGL(k_trial<true>, dim3(tiles_grid(v)), dim3(256), lds, s, v);      // vision-only passes are always fused
 }
 void launch_final_merged(const DevView& v, hipStream_t s) { hipLaunchKernelGGL(k_final_merged, dim3(1), dim3(256), 0, s, v); }

@@ -70,6 +70,17 @@ __device__ __forceinline__ double wave_allsum(double x) {   // result in every l
 }
 
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a function ON ONE DEVICE: what has been granted is remembered per device
+// (a process-wide flag skipped the attribute on a second device and the > 64 KB launch there failed silently -- advice r5).
+struct LdsGrant {
+  size_t got[16] = {};
+  bool need(size_t lds) {
+    int dev = 0; (void)hipGetDevice(&dev); dev = (dev >= 0 && dev < 16) ? dev : 0;
+    if (lds <= got[dev]) return false;
+    got[dev] = lds; return true;
+  }
+};
+
 // ---- cross-stream hand-overs through device flags (DevView::sync_flags) --------------------------------------------------
 // Publishing "this kernel of pass sync_seq is done" to the other stream (one thread of a single-workgroup kernel, behind a
 // workgroup barrier: everybody's stores have reached the L2, the device-scope fence writes them back before the flag moves).

@@ -290,9 +290,11 @@ int vc_calibrator::upload() {
     const bool narrow = D + 1 + 27 <= 128;      // at most two image columns per lane
     dv.gram_top_stride = (early_env && dv.imu_on && N >= 1 && N <= 4096 && narrow) ? chain_top_stride(N) : 0;
     dv.fold_l0 = fold ? 1 : 0;
-    // the back-substitution as one launch (k_chain_back_path): single process (no pinned frames), border rows of at most 37 entries
+    // the back-substitution as one launch (k_chain_back_path): round 6 -- any border width, sharded passes (pinned frames) included
     static const bool path_env = [] { const char* e = std::getenv("VICALIB_AMD_BACK_PATH"); return !(e && e[0] == '0'); }();
-    dv.back_path = (path_env && dv.imu_on && !sharded() && !shard_imu && D + 1 <= 37) ? 1 : 0;
+    // (every bottom group recomputes the levels above it: (levels + 1) x the level-by-level form's work -- free while the bottom groups
+    //  fit the chip in one round, 120 us against 71 at 6250 frames x D = 115 (profiles/r06_per_rank_passes.txt): up to 4096 frames)
+    dv.back_path = (path_env && dv.imu_on && N <= 4096) ? 1 : 0;
     // the top level's own frames: added by k_reduced (single process, narrow system) or a partial record of their own
     top_gram_launch = dv.gram_top_stride > 0 && !(D <= kEarlyTopD && !sharded());
     dv.n_part = dv.n_chunks + (top_gram_launch ? 1 : 0);

@@ -29,7 +29,7 @@ SYMBOLS = [
     "vc_get_biases", "vc_get_scale_factor", "vc_get_gravity", "vc_time_offset", "vc_mean_squared_error", "vc_get_camera_proj_rmse",
     "vc_get_num_iterations", "vc_num_imu_measurements", "vc_get_imu_measurements", "vc_get_integration_poses", "vc_print_results", "vc_write_camera_models", "vc_trace_len", "vc_get_trace", "vc_set_shard", "vc_get_stream", "vc_prepare",
     "vc_linearize", "vc_shared_dim", "vc_run_iterations", "vc_evaluate", "vc_time_kernels", "vc_time_stages", "vc_get_imu_blocks", "vc_get_debug_stamps", "vc_num_observations", "vc_num_tiles",
-    "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_pnp_planar_ransac", "vc_set_pnp_ransac", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_shard_comm_create", "vc_set_shard_comm", "vc_shard_comm_destroy", "vc_allreduce_calls", "vc_last_error", "vc_get_imu_weights",
+    "vc_init_frame_poses_pnp", "vc_pnp_planar", "vc_pnp_planar_ransac", "vc_set_pnp_ransac", "vc_rccl_unique_id", "vc_set_shard_rccl", "vc_shard_comm_create", "vc_set_shard_comm", "vc_shard_comm_destroy", "vc_allreduce_calls", "vc_shard_info", "vc_pass_paths", "vc_last_error", "vc_get_imu_weights",
     "vc_solution_covariance_dim", "vc_get_solution_covariance", "vc_get_solution_covariance_names",
     "vc_target_make_pattern", "vc_target_find",
     "vc_detector_create", "vc_detector_destroy", "vc_detector_set_params", "vc_detector_find", "vc_detector_find_conics",
@@ -340,6 +340,18 @@ class ViCalibrator:
             raise VicalibError("set_shard_comm: status %d: %s" % (rc, (self.L.vc_last_error() or b"").decode(errors="replace")))
 
     def allreduce_calls(self): return int(self.L.vc_allreduce_calls(self.h))
+
+    def pass_paths(self):
+        """Which forms of the visual-inertial pass the uploaded problem runs (vc_pass_paths)."""
+        out = (C.c_int * 4)()
+        _check(self.L.vc_pass_paths(self.h, out), "pass_paths")
+        return dict(fold_l0=out[0], back_path=out[1], early_gram=out[2], top_gram_launch=out[3])
+
+    def shard_info(self):
+        """rank / world size the calibrator shards with and, for the library's own communicator, what RCCL reports (-1: none attached)."""
+        v = [C.c_int(-1) for _ in range(4)]
+        _check(self.L.vc_shard_info(self.h, *[C.byref(x) for x in v]), "shard_info")
+        return dict(rank=v[0].value, world=v[1].value, rccl_ranks=v[2].value, rccl_rank=v[3].value)
 
     def stream(self): return self.L.vc_get_stream(self.h)
     def prepare(self): _check(self.L.vc_prepare(self.h), "prepare")
