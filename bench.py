@@ -270,15 +270,17 @@ def main():
     flops_jac = 1050.0 * n_obs_local
     bytes_res = 18.0 * n_obs_local + n_tiles * (64 + 8)
     imu_samples = len(prob.imu_t) if vi else 0
-    # IMU sweep in delta form, counted as the kernels run it (dual number = value + one partial, ~2.5 flop per operation):
-    #   k_imu_block: per block 7 dual directions (6 gyro parameters + the time offset; the accelerometer partials are analytic, ~100 flop) x one
-    #                RK4 step from the identity state per sample interval (~4 x 400 flop as dual numbers) + the ordered product of the interval
-    #                deltas (pairwise append, then a three-level scan over eight lanes: ~4 appends of ~265 flop per lane); in 56 B per sample + the
-    #                IMU parameters, out one 154-double record per block (round 3 wrote and re-read a 140-double record per interval)
+    # IMU sweep in delta form, counted as the kernels run it:
+    #   k_imu_block: per block 7 parameter directions (6 gyro parameters + the time offset; the accelerometer partials are sums of the stage
+    #                rotations' columns) x one RK4 step from the identity state per sample interval with CLOSED-FORM partials (round 6:
+    #                values + one rotation tangent, 612 fp64 instructions per interval in the kernel's ISA, ~1100 flop with FMA = 2; rounds
+    #                2-5 ran dual numbers, ~1700 flop) + the ordered product of the interval deltas (pairwise append, then a three-level scan
+    #                over eight lanes: ~4 appends of ~280 flop per lane); in 56 B per sample + the IMU parameters, out one 154-double
+    #                record per block
     #   k_imu_jac:   per block 30 lanes put the delta on the start state and run the residual's tail (~900 flop each), then the 33 x 33
     #                weighted J^T J (9 x 33 x 33 x 2 flop); in the record, two states, the 9 x 9 weight; out 33 x 33 + 33 + 1 doubles
     n_meas = imu_samples / max(n_imu_blocks, 1) + 2
-    flops_delta = n_imu_blocks * 7 * ((n_meas - 1) * 1700.0 + 8 * 4 * 265.0)
+    flops_delta = n_imu_blocks * 7 * ((n_meas - 1) * 1100.0 + 8 * 4 * 280.0)
     bytes_delta = imu_samples * 56.0 + n_imu_blocks * (2 * 56 + 15 * 8 + 154 * 8)
     flops_imu = n_imu_blocks * (30 * 900.0 + 9 * 33 * 33 * 2.0)
     bytes_imu = n_imu_blocks * (154 * 8 + 2 * 12 * 8 + 81 * 8 + (33 * 33 + 34) * 8.0)

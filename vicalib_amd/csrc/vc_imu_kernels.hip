@@ -61,6 +61,7 @@ constexpr int kSegIters = (kSegLen + 31) / 32;      // entries of the record per
 #endif
 __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   __shared__ double sh[8 * kImuJacLds];
+  __shared__ double s_wq[8 * 84];                  // the block's 9 x 9 weight, staged once (round 6: every lane loaded all 81 entries itself)
   IJSTAMP(0);
   const Ctrl* ct = v.ctrl;
   if (ct->done || (!trial && !ct->need_lin)) {
@@ -81,7 +82,15 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   const double* T1 = v.poses[cur] + (size_t)(j - 1) * kPoseStride;
   const double* v2 = v.vel[cur] + (size_t)j * 4;
   const double* v1 = v.vel[cur] + (size_t)(j - 1) * 4;
-  const double* wq = v.wsqrtb[wr] + (size_t)s * 81;
+  const double* wq_g = v.wsqrtb[wr] + (size_t)s * 81;
+  double* wq = s_wq + (wave * 2 + half) * 84;
+  {
+    double t3[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { const int idx = l + 32 * t; t3[t] = wq_g[idx < 81 ? idx : 0]; }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { const int idx = l + 32 * t; if (idx < 81) wq[idx] = t3[t]; }
+  }
   const double* brec = v.imu_delta_blk + (size_t)s * kBlockDeltaStride;
   double r[9], dr[9];
   const int col = (l < 6) ? l : (l < 30 ? l + 3 : -1);         // lanes 30, 31 carry the values only
@@ -89,6 +98,7 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   int seg_ab[kSegIters];
 #pragma unroll
   for (int it = 0; it < kSegIters; ++it) { const int e = l + 32 * it; seg_ab[it] = d_seg_tab.v[e < kSegLen ? e : 0]; }
+  wave_lds_sync();
   IJSTAMP(1);
   imu_block_final_direction(valid, brec, wq, v.rotation_only, T2, T1, v2, v1, v.imu_grav + cur * 16, col, r, dr);
   IJSTAMP(2);
@@ -123,6 +133,8 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
       if (v.final_wait > 0) {
         // flag hand-overs: k_final (main stream) takes the trial cost as soon as every workgroup has delivered its share -- a
         // device-coherent store and a count, no cache write-back -- and decides while this kernel still writes its records
+        // (round 6 tried moving the count behind this thread's record stores -- the store's acknowledgement holds wavefront 0 back by
+        //  ~2 us here: the kernel ended 1.2 us earlier and k_final 3.2 us later behind it; reverted)
         __hip_atomic_store(v.wg_imu_trial + blockIdx.x, wc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_waitcnt(0);          // the store has been performed before the count moves
         __hip_atomic_fetch_add(v.sync_flags + 4, 1LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1382,7 +1394,10 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(DevView v, int s, int m, 
 // sweeps then meet in lockstep (a sweep with one frame less runs an empty round).  ~370 registers: one wavefront per SIMD, so NW = 2 fills
 // a CU -- used on levels whose groups the chip holds at once (chain_levels).
 template <int NW>
-__global__ __launch_bounds__(128 * NW) void k_chain_fwd2(DevView v, int s, int m, int lvl) {
+#ifndef VC_FWD2_WAVES
+#define VC_FWD2_WAVES 1
+#endif
+__global__ __launch_bounds__(128 * NW, VC_FWD2_WAVES) void k_chain_fwd2(DevView v, int s, int m, int lvl) {
   constexpr int W = 64 * NW;
   __shared__ __attribute__((aligned(16))) double XS2[2][9 * kXsLd];
   __shared__ double An2[2][81], Ls2[2][81];
