@@ -238,7 +238,9 @@ int vc_detector_create(int device, int width, int height, vc_detector** out);
 void vc_detector_destroy(vc_detector* d);
 int vc_detector_set_params(vc_detector* d, int black_on_white, double at_threshold, double at_window_ratio, double conic_min_area,
                            double conic_min_density, double conic_min_aspect);
-/* centres: 2 x max_conics doubles; *n_found is the number of dots found (may exceed max_conics: the first max_conics are written) */
+/* centres: 2 x max_conics doubles; *n_found is the number of dots found (may exceed max_conics: the first max_conics are written).
+ * A detector handle is single-threaded: one image at a time (its staging buffers and stream belong to the call in progress); use one
+ * handle per thread. */
 int vc_detector_find(vc_detector* d, const unsigned char* image, int pitch, double* centres, int max_conics, int* n_found);
 /* The same with the rest of what calibu::Conic carries (vicalib-task.cc:270-277 hands the conics to TargetGridDot::FindTarget):
  * conics (nullable): 9 doubles per dot, the ellipse as a symmetric 3 x 3 matrix C with x^T C x = 0 on its edge, image coordinates

@@ -323,6 +323,7 @@ struct vc_detector {
   unsigned char* h_out = nullptr;      // pinned mirror of d_out
   unsigned char* h_img = nullptr;      // pinned staging of the image (rows packed): one asynchronous copy instead of the runtime's pageable path
   int max_cand = kMaxCand;
+  bool in_flight = false;              // a call is in progress or left through an error path: the stream may still read the staging buffers
   // calibu::ImageProcessing / ConicFinder parameters as VicalibTask sets them (vicalib-task.cc:116-122)
   int black_on_white = 1;
   double at_threshold = 0.9, at_window_ratio = 30.0, conic_min_area = 4.0, conic_min_density = 0.6, conic_min_aspect = 0.2;
@@ -370,7 +371,12 @@ int vc_detector_find_conics(vc_detector* d, const unsigned char* image, int pitc
   if (!d || !image || pitch < d->w || !n_found || max_conics < 0 || (max_conics > 0 && !centres)) return VC_ERR_BAD_ARG;
   if (hipSetDevice(d->device) != hipSuccess) return VC_ERR_NO_DEVICE;
   const int w = d->w, h = d->h, np = w * h;
-  // (the previous call has synchronised on its download: the staging buffer is free)
+  // A detector is SINGLE-THREADED: one image at a time per handle (the staging buffers and the stream belong to the call in progress) --
+  // one handle per thread.  A clean call has synchronised on its download, the staging buffers are free; a call that left through an
+  // error path may have copies in flight that still read them: it leaves the handle marked and this call drains the stream first
+  // (advice round 5).
+  if (d->in_flight) (void)hipStreamSynchronize(d->stream);
+  d->in_flight = true;
   if (pitch == w) std::memcpy(d->h_img, image, (size_t)np);
   else for (int y = 0; y < h; ++y) std::memcpy(d->h_img + (size_t)y * w, image + (size_t)y * pitch, (size_t)w);
   // (one copy: bands of 256 KB, each sent while the host packs the next, measured slower -- 8.7 k against 9.6 k images/s at 640 x 480)
@@ -395,13 +401,14 @@ int vc_detector_find_conics(vc_detector* d, const unsigned char* image, int pitc
   const size_t fast_bytes = kHeadBytes + (size_t)std::min(kFastRecs, d->max_cand) * sizeof(DetRec);
   if (hipMemcpyAsync(d->h_out, d->d_out, fast_bytes, hipMemcpyDeviceToHost, d->stream) != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess) return VC_ERR_NO_DEVICE;
   const int n = *reinterpret_cast<const int*>(d->h_out);
-  if (n > d->max_cand) return VC_ERR_UNSUPPORTED;
+  if (n > d->max_cand) { d->in_flight = false; return VC_ERR_UNSUPPORTED; }      // (synchronised: nothing pending)
   *n_found = n;
   const int nout = std::min(n, max_conics);
   if (nout > kFastRecs) {
     if (hipMemcpyAsync(d->h_out + fast_bytes, d->d_out + fast_bytes, (size_t)(nout - kFastRecs) * sizeof(DetRec), hipMemcpyDeviceToHost, d->stream) != hipSuccess ||
         hipStreamSynchronize(d->stream) != hipSuccess) return VC_ERR_NO_DEVICE;
   }
+  d->in_flight = false;                          // (everything this call queued has completed)
   const DetRec* recs = reinterpret_cast<const DetRec*>(d->h_out + kHeadBytes);
   for (int i = 0; i < nout; ++i) {
     centres[2 * i] = recs[i].cx; centres[2 * i + 1] = recs[i].cy;

@@ -1375,6 +1375,117 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(DevView v, int s, int m, 
   chain_fwd_group<CPL, NW>(v, s, m, top, lvl, (int)blockIdx.x, (int)(threadIdx.x >> 6), XS, An, Ls_all);
 }
 
+// ---- one elimination of a two-sided sweep (k_chain_fwd2, k_chain_l0) --------------------------------------------------------------------
+// The frame's block A is in An (LDS, complete behind the first synchronisation); lane = image column, x = the lane's column of the
+// frame's image (role: 0 border (W | g), 1 C, 2 A, 3 B, 4 none; sub = column inside the 9 x 9 block; pc = the column's position in an
+// image row).  A = L L^T in EVERY lane, from registers (round 4; before: nine lanes, one row each, pivots and pivot columns through
+// v_readlane -- ~240 cycles per pivot, 0.9 us per frame, and the factor went through LDS to the lanes that solve with it): all lanes
+// read the lower triangle (broadcast LDS reads) and run the same scalar factorisation -- per pivot one v_rsq_f64 chain, then independent
+// multiplies / FMAs; the triangular solve that follows takes L from registers.  The solved column goes to the frame's image
+// [Y | z | X_s | L | X_n] in HBM, [X_s | X_n] to XS (LDS) for everybody, out = [X_s | X_n]^T (column).
+// WG_SYNC: the sweep is several wavefronts side by side (k_chain_fwd2<NW > 1>): workgroup barriers instead of wavefront-local ones.
+struct ElimLds { double* XS; double* An; double* Ls; };
+template <bool WG_SYNC>
+__device__ __forceinline__ void chain_eliminate(const DevView& v, double* img /* the frame's image */, int ldx, int role, int pc, int sub, bool flag_lane,
+                                                const ElimLds& M, double* x, double* out, long long* stamp = nullptr /* profiling builds: phase stamps of this call */) {
+  auto gsync = [&]() { if (WG_SYNC) __syncthreads(); else wave_lds_sync_local(); };
+#ifdef VC_F2_STAMPS
+#define ELSTAMP(i) do { if (stamp) stamp[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ELSTAMP(i) do { } while (0)
+#endif
+  double* XS = M.XS; double* An = M.An; double* Ls = M.Ls;
+  ELSTAMP(0);
+  gsync();
+  ELSTAMP(1);
+  double Lr[45], dinv[9];
+  {
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) Lr[i * (i + 1) / 2 + j] = An[i * 9 + j];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      double d = Lr[j * (j + 1) / 2 + j];
+      const bool ok = d > 0.0;
+      bad |= !ok;
+      d = ok ? d : 1.0;
+      const double ip = fast_rsqrt(d);
+      dinv[j] = ip;
+      Lr[j * (j + 1) / 2 + j] = d * ip;
+#pragma unroll
+      for (int i = j + 1; i < 9; ++i) Lr[i * (i + 1) / 2 + j] *= ip;
+#pragma unroll
+      for (int i = j + 1; i < 9; ++i)
+#pragma unroll
+        for (int k = j + 1; k <= i; ++k) Lr[i * (i + 1) / 2 + k] -= Lr[i * (i + 1) / 2 + j] * Lr[k * (k + 1) / 2 + j];
+    }
+    if (bad) {               // wave-uniform (every lane holds the same numbers): the frame gets an identity block, the pass is flagged
+      if (flag_lane) atomicAdd(&v.flags[4 + 2 * v.par], 1);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        dinv[i] = 1.0;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Lr[i * (i + 1) / 2 + j] = (i == j) ? 1.0 : 0.0;
+      }
+    }
+  }
+  ELSTAMP(2);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    x[k] *= dinv[k];
+#pragma unroll
+    for (int rr = k + 1; rr < 9; ++rr) x[rr] -= Lr[rr * (rr + 1) / 2 + k] * x[k];
+  }
+  ELSTAMP(3);
+  // Hand-over through LDS, WITHOUT a divergent branch per role (round 6: the five `if (role == ..)` regions of this function were ~40 exec-mask
+  // and branch instructions per elimination of a wavefront that is alone on its SIMD and pays ~4 cycles for every instruction it issues):
+  // every lane stores its nine values through ONE address pattern chosen by its role --
+  //   A lanes: row `sub` of L (x = L^T e_sub) as column `sub` of Ls (the image wants the column: the nine lanes transpose here),
+  //   C / B lanes: their solved column into [X_s | X_n],   everybody else: the padding column 18 of XS (never read).
+  {
+    double* dst = role == 2 ? Ls + sub : XS + (role == 1 ? sub : role == 3 ? 9 + sub : 18);
+    const int st = role == 2 ? 9 : kXsLd;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dst[k * st] = (role == 2 && k > sub) ? 0.0 : x[k];
+  }
+  ELSTAMP(4);
+  gsync();
+  ELSTAMP(5);
+  // the frame's solved image [Y | z | X_s | L | X_n]: one store region for all lanes that own a column; the A lanes store L's column and
+  // carry on with X_n's column `sub` (the A columns of the next frame are driven by X_n's)
+  {
+    const double* rl = Ls + (role == 2 ? sub * 9 : 0);
+    const double* rx = XS + (role == 2 ? 9 + sub : 18);
+    double lv[9], xv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { lv[k] = rl[k]; xv[k] = rx[k * kXsLd]; }
+    if (role < 4) {
+      double* ic = img + pc;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) ic[k * ldx] = role == 2 ? lv[k] : x[k];       // (A: L[k][sub], zero above the diagonal)
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) x[k] = role == 2 ? xv[k] : x[k];
+  }
+  ELSTAMP(6);
+  // out = [X_s | X_n]^T x in two halves: rows 9..17 (the next frame's update, which the critical path waits for) first
+#pragma unroll
+  for (int h = 1; h >= 0; --h) {
+#pragma unroll
+    for (int rr = 0; rr < 9; ++rr) out[9 * h + rr] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double xk = x[k];
+#pragma unroll
+      for (int rr = 0; rr < 9; ++rr) out[9 * h + rr] += XS[k * kXsLd + 9 * h + rr] * xk;
+    }
+    if (h == 1) __builtin_amdgcn_sched_barrier(0);
+  }
+  ELSTAMP(7);
+}
+
 // ---- two-sided elimination of a group (narrow borders: one column per lane) ------------------------------------------------
 // A full group [a | e_1 .. e_{m-1} | r] is eliminated from both ends at once: wavefront 0 sweeps e_1, e_2, .. left to right
 // against the left separator a (exactly the one-sided scheme), wavefront 1 sweeps e_{m-1}, e_{m-2}, .. right to left against the
@@ -1385,7 +1496,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(DevView v, int s, int m, 
 // Images of the right sweep's frames hold [Y | z | X_s (coupling to r) | L | X_n (coupling to the frame on the LEFT)]; the
 // back-substitution (k_chain_back, two = 1) mirrors the order.  The short group at the chain's end works the same way without r.
 #ifdef VC_F2_STAMPS
-#define F2STAMP(i) do { if (NW == 1 && blockIdx.x == 0 && lvl == 1 && (threadIdx.x & 63) == 0 && (i) < 16) v.dbg[(i) + 16 * (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define F2STAMP(i) do { if (NW == 1 && blockIdx.x == 0 && lvl == 1 && threadIdx.x == 0 && (i) < 16) v.dbg[(i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)      // (sweep 0; dbg[16..23]: the phases of its second elimination, chain_eliminate)
 #else
 #define F2STAMP(i) do { } while (0)
 #endif
@@ -1483,9 +1594,11 @@ __global__ __launch_bounds__(128 * NW, VC_FWD2_WAVES) void k_chain_fwd2(DevView 
   }
   // (a side without frames of its own: wavefront 0 starts with the middle frame, wavefront 1 has nothing to load)
   load_cols(a + (cnt > 0 ? i0 : mid) * s, true, cnt > 0 || wave == 0, xin);
+  // (round 6 tried requesting a frame's columns TWO eliminations ahead -- they come from HBM, the level below wrote them from other XCDs --:
+  //  21.9 / 21.1 us per level against 20.2 / 19.6: nine more doubles per lane through the accumulation registers cost more than the wait)
   if (done) return;
 #ifdef VC_F2_STAMPS
-  if (NW == 1 && blockIdx.x == 0 && lvl == 1 && (threadIdx.x & 63) == 0) v.dbg[16 * (threadIdx.x >> 6)] = f2_t0;
+  if (NW == 1 && blockIdx.x == 0 && lvl == 1 && threadIdx.x == 0) v.dbg[0] = f2_t0;
 #endif
   F2STAMP(1);
   if (role == 2) {
@@ -1493,84 +1606,17 @@ __global__ __launch_bounds__(128 * NW, VC_FWD2_WAVES) void k_chain_fwd2(DevView 
     for (int k = 0; k < 9; ++k) An[k * 9 + sub] = xin[k];
   }
   // one elimination: A (in An) = L L^T, all columns solved, image stored, [X_s | X_n] to XS, out = [X_s | X_n]^T (column)
+  const ElimLds elds = {XS, An, Ls};
+#ifdef VC_F2_STAMPS
+  int el_n_ = 0;
   auto eliminate = [&](int e, double* x, double* out) {
-    gsync();
-    // A = L L^T in EVERY lane, from registers (round 4; before: nine lanes, one row each, pivots and pivot columns through
-    // v_readlane -- ~240 cycles per pivot, 0.9 us per frame, and the factor went through LDS to the lanes that solve with it).  All
-    // lanes read the lower triangle (broadcast LDS reads) and run the same scalar factorisation: per pivot one v_rsq_f64 chain,
-    // then independent multiplies / FMAs; the triangular solve that follows takes L from registers.
-    double Lr[45], dinv[9];
-    {
-#pragma unroll
-      for (int i = 0; i < 9; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) Lr[i * (i + 1) / 2 + j] = An[i * 9 + j];
-      bool bad = false;
-#pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        double d = Lr[j * (j + 1) / 2 + j];
-        const bool ok = d > 0.0;
-        bad |= !ok;
-        d = ok ? d : 1.0;
-        const double ip = fast_rsqrt(d);
-        dinv[j] = ip;
-        Lr[j * (j + 1) / 2 + j] = d * ip;
-#pragma unroll
-        for (int i = j + 1; i < 9; ++i) Lr[i * (i + 1) / 2 + j] *= ip;
-#pragma unroll
-        for (int i = j + 1; i < 9; ++i)
-#pragma unroll
-          for (int k = j + 1; k <= i; ++k) Lr[i * (i + 1) / 2 + k] -= Lr[i * (i + 1) / 2 + j] * Lr[k * (k + 1) / 2 + j];
-      }
-      if (bad) {               // wave-uniform (every lane holds the same numbers): the frame gets an identity block, the pass is flagged
-        if (c == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-          dinv[i] = 1.0;
-#pragma unroll
-          for (int j = 0; j <= i; ++j) Lr[i * (i + 1) / 2 + j] = (i == j) ? 1.0 : 0.0;
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      x[k] *= dinv[k];
-#pragma unroll
-      for (int rr = k + 1; rr < 9; ++rr) x[rr] -= Lr[rr * (rr + 1) / 2 + k] * x[k];
-    }
-    // an A lane has solved L x = A e_sub: x = L^T e_sub, row `sub` of L.  The image wants column `sub`: the nine lanes transpose
-    // through LDS, behind the barrier the [X_s | X_n] exchange needs anyway
-    if (role == 2) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) Ls[k * 9 + sub] = (k <= sub) ? x[k] : 0.0;
-    }
-    if (role == 0 || role == 1 || role == 3) {
-      double* img = v.cW + (size_t)e * isz + pc;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) img[k * ldx] = x[k];
-    }
-    if (role == 1 || role == 3) {
-      const int xc = sub + (role == 3 ? 9 : 0);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) XS[k * kXsLd + xc] = x[k];
-    }
-    gsync();
-    if (role == 2) {
-      double* img = v.cW + (size_t)e * isz + pc;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) img[k * ldx] = Ls[sub * 9 + k];       // L[k][sub] (zero above the diagonal)
-#pragma unroll
-      for (int k = 0; k < 9; ++k) x[k] = XS[k * kXsLd + 9 + sub];
-    }
-#pragma unroll
-    for (int rr = 0; rr < 18; ++rr) out[rr] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const double xk = x[k];
-#pragma unroll
-      for (int rr = 0; rr < 18; ++rr) out[rr] += XS[k * kXsLd + rr] * xk;
-    }
+    long long* st = (NW == 1 && blockIdx.x == 0 && lvl == 1 && threadIdx.x == 0 && el_n_ == 1) ? v.dbg + 16 : nullptr;      // (the second elimination of sweep 0)
+    ++el_n_;
+    chain_eliminate<(NW > 1)>(v, v.cW + (size_t)e * isz, ldx, role, pc, sub, c == 0, elds, x, out, st);
   };
+#else
+  auto eliminate = [&](int e, double* x, double* out) { chain_eliminate<(NW > 1)>(v, v.cW + (size_t)e * isz, ldx, role, pc, sub, c == 0, elds, x, out); };
+#endif
   // The sweep's frames, then -- wavefront 0 only, behind the barrier that hands it the right sweep's results -- the middle frame:
   // a on its left (C), r on its right (B: the right sweep's fill-in, or -- no right sweep -- its own B block, already loaded).
   // One loop, one copy of the elimination: wavefront 1 leaves at the barrier.
@@ -2076,78 +2122,8 @@ __global__ __launch_bounds__(256) void k_chain_l0(DevView v) {
       for (int k = 0; k < 9; ++k) An[k * 9 + sub] = xin[k];
     }
     // one elimination: A (in An) = L L^T, all columns solved, image stored, [X_s | X_n] to XS, out = [X_s | X_n]^T (column)
-    auto eliminate = [&](int e, double* x, double* out) {
-      gsync();
-      double Lr[45], dinv[9];
-      {
-#pragma unroll
-        for (int i = 0; i < 9; ++i)
-#pragma unroll
-          for (int j = 0; j <= i; ++j) Lr[i * (i + 1) / 2 + j] = An[i * 9 + j];
-        bool bad = false;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-          double d = Lr[j * (j + 1) / 2 + j];
-          const bool ok = d > 0.0;
-          bad |= !ok;
-          d = ok ? d : 1.0;
-          const double ip = fast_rsqrt(d);
-          dinv[j] = ip;
-          Lr[j * (j + 1) / 2 + j] = d * ip;
-#pragma unroll
-          for (int i = j + 1; i < 9; ++i) Lr[i * (i + 1) / 2 + j] *= ip;
-#pragma unroll
-          for (int i = j + 1; i < 9; ++i)
-#pragma unroll
-            for (int k = j + 1; k <= i; ++k) Lr[i * (i + 1) / 2 + k] -= Lr[i * (i + 1) / 2 + j] * Lr[k * (k + 1) / 2 + j];
-        }
-        if (bad) {
-          if (c == 0) atomicAdd(&v.flags[4 + 2 * v.par], 1);
-#pragma unroll
-          for (int i = 0; i < 9; ++i) {
-            dinv[i] = 1.0;
-#pragma unroll
-            for (int j = 0; j <= i; ++j) Lr[i * (i + 1) / 2 + j] = (i == j) ? 1.0 : 0.0;
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        x[k] *= dinv[k];
-#pragma unroll
-        for (int rr = k + 1; rr < 9; ++rr) x[rr] -= Lr[rr * (rr + 1) / 2 + k] * x[k];
-      }
-      if (role == 2) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Ls[k * 9 + sub] = (k <= sub) ? x[k] : 0.0;
-      }
-      if (role == 0 || role == 1 || role == 3) {
-        double* img = v.cW + (size_t)e * isz + pc;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) img[k * ldx] = x[k];
-      }
-      if (role == 1 || role == 3) {
-        const int xc = sub + (role == 3 ? 9 : 0);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) XS[k * kXsLd + xc] = x[k];
-      }
-      gsync();
-      if (role == 2) {
-        double* img = v.cW + (size_t)e * isz + pc;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) img[k * ldx] = Ls[sub * 9 + k];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) x[k] = XS[k * kXsLd + 9 + sub];
-      }
-#pragma unroll
-      for (int rr = 0; rr < 18; ++rr) out[rr] = 0.0;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const double xk = x[k];
-#pragma unroll
-        for (int rr = 0; rr < 18; ++rr) out[rr] += XS[k * kXsLd + rr] * xk;
-      }
-    };
+    const ElimLds elds = {XS, An, Ls};
+    auto eliminate = [&](int e, double* x, double* out) { chain_eliminate<false>(v, v.cW + (size_t)e * isz, ldx, role, pc, sub, c == 0, elds, x, out); };
     for (int j = 0; ; ++j) {
       const bool at_mid = j == cnt;
       if (at_mid) {
@@ -2586,15 +2562,15 @@ __global__ __launch_bounds__(64) void k_chain_back_levels(DevView v, BackLevels 
 // then one row per lane) -- the extra workgroups of the top level's launch and the ct0 round trip are gone with the launch; the steps
 // travel top-down through LDS (positions of a group: 0 = left separator, 1 .. q = interior frames, q + 1 = right separator; the top
 // level: its frames from position 0).  The dependent chain is chain_back_group's, instruction for instruction.
-// Round 6: any border width and sharded passes.  Borders of more than kPathChunk columns take t0 from k_chain_t0 (BackPath::ct0; the
-// staging below also runs in rounds of kPathChunk columns -- correct at any width, but the redundancy of the recomputed levels then costs
-// more than a launch); z comes with the lane's own blocks; a pinned frame (separator / ghost of a sharded chain, DevView::pin_first /
-// pin_last) steps with the reduced system's solution in the epilogue.
-struct BackPath { int n; int stride[6]; int m[6]; int two[6]; int top_stride; int ldr; int dsw; int ct0; };
-constexpr int kPathChunk = 36;         // columns of Y per staging round
-constexpr int kPathRowLoads = 37;      // 63 rows x kPathChunk entries over 64 lanes
+// Round 6: any border width and sharded passes.  Borders of more than kPathRowCols columns take t0 from k_chain_t0 (instance CT0: staging
+// the rows of the recomputed levels in every bottom group then costs more than a launch -- measured 218 us against 71 for the level-by-level
+// kernels at 6250 frames x D = 115, 120 us with t0 from its own launch); a pinned frame (separator / ghost of a sharded chain,
+// DevView::pin_first / pin_last) steps with the reduced system's solution in the epilogue.
+struct BackPath { int n; int stride[6]; int m[6]; int two[6]; int top_stride; int ldr; int dsw; };
+constexpr int kPathRowCols = 37;       // widest row [Y | z] the in-kernel staging serves (D + 1 entries)
+constexpr int kPathRowLoads = 37;      // 63 rows x kPathRowCols entries over 64 lanes
 constexpr int kPathDl = 96;            // doubles per level's step record (10 positions x 9)
-template <int NWMAX>      // wavefronts per workgroup at most (levels + 1): up to four leave a whole SIMD's registers to each
+template <int NWMAX, bool CT0>      // wavefronts per workgroup at most (levels + 1): up to four leave a whole SIMD's registers to each; CT0: t0 from k_chain_t0
 __global__ __launch_bounds__(64 * NWMAX) void k_chain_back_path(DevView v, BackPath P) {
   extern __shared__ __attribute__((aligned(16))) double bp_lds[];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -2635,28 +2611,29 @@ __global__ __launch_bounds__(64 * NWMAX) void k_chain_back_path(DevView v, BackP
   const int e = first + (mine ? fi : 0) * s;
   const bool two_sided = two && !top && q >= 1;
   const int fmid = (q - 1) / 2;
-  // ---- requests: the rows [Y] of the group's frames in rounds of kPathChunk columns (lane-strided, coalesced), then this lane's blocks
-  const int nchunks = P.ct0 ? 0 : (D + kPathChunk - 1) / kPathChunk;
-  double rv[kPathRowLoads];
-  auto request = [&](int c0) {
-    const int ncc = min(kPathChunk, D - c0), nel = q * 9 * ncc;      // (wave-uniform)
-    const int step_r = 64 / ncc, step_c = 64 - step_r * ncc;
-    int row = lane / ncc, col = lane - row * ncc;
+  // ---- requests: the rows [Y | z] of the group's frames (lane-strided, coalesced; narrow borders only -- CT0: t0 comes finished from
+  // k_chain_t0), then this lane's blocks
+  const int ncolr = D + 1, nel = q * 9 * ncolr;
+  double rv[CT0 ? 1 : kPathRowLoads];
+  if (!CT0) {
+    const int step_r = 64 / ncolr, step_c = 64 - step_r * ncolr;
+    int row = lane / ncolr, col = lane - row * ncolr;
 #pragma unroll
     for (int u = 0; u < kPathRowLoads; ++u) {
       const int idx = lane + 64 * u;
       const int f2 = (row * 57) >> 9, k2 = row - 9 * f2;          // (row / 9 for rows below 64)
       const bool in = idx < nel;          // (a lane without an entry reads frame 0 and drops the value)
-      const double* src = v.cW + (size_t)(in ? first + f2 * s : 0) * isz + (size_t)(in ? k2 : 0) * ldx + (in ? c0 + col : 0);
+      const double* src = v.cW + (size_t)(in ? first + f2 * s : 0) * isz + (size_t)(in ? k2 : 0) * ldx + (in ? col : 0);
       const double x = *src;
       rv[u] = in ? x : 0.0;
       row += step_r; col += step_c;
-      if (col >= ncc) { col -= ncc; ++row; }
+      if (col >= ncolr) { col -= ncolr; ++row; }
     }
-  };
-  if (nchunks > 0) request(0);
-  for (int j = lane; j < D; j += 64) DSW[j] = v.delta_s[j];
-  double dinv = 1.0, Qrow[9], Lcol[9], Xs[9], zrow;
+  }
+  double dsv[3];
+#pragma unroll
+  for (int u = 0; u < (CT0 ? 3 : 1); ++u) { const int j = lane + 64 * u; dsv[u] = v.delta_s[j < D ? j : 0]; }
+  double dinv = 1.0, Qrow[9], Lcol[9], Xs[9], t0_in = 0.0;
   {
     const double* img = v.cW + (size_t)(mine ? e : 0) * isz;
     const double* Wr = img + (size_t)k * ldx;
@@ -2665,36 +2642,32 @@ __global__ __launch_bounds__(64 * NWMAX) void k_chain_back_path(DevView v, BackP
       const double qv = Wr[ldw + 18 + c], lv = img[c * ldx + ldw + 9 + k], xv = Wr[ldw + c];
       Qrow[c] = mine ? qv : 0.0; Lcol[c] = (mine && c > k) ? lv : 0.0; Xs[c] = (mine && a >= 0) ? xv : 0.0;
     }
-    const double dg = Wr[ldw + 9 + k], zv = P.ct0 ? v.ct0[(size_t)(mine ? e : 0) * 9 + k] : Wr[D];      // (ct0: the finished sum z + Y delta_s)
+    const double dg = Wr[ldw + 9 + k];
     dinv = mine ? 1.0 / dg : 1.0;
-    zrow = mine ? zv : 0.0;
+    if (CT0) { const double tv = v.ct0[(size_t)(mine ? e : 0) * 9 + k]; t0_in = mine ? tv : 0.0; }      // (the finished sum z + Y delta_s)
   }
   const int base = a, cnt = (a < N) ? q + 1 : 0;
   if (done) return;                      // (uniform over the workgroup)
-  double t = zrow;                       // t0 = z + Y delta_s, summed left to right
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int c0 = ch * kPathChunk, ncc = min(kPathChunk, D - c0), nel = q * 9 * ncc;
-    {
-      int row = lane / ncc, col = lane - row * ncc;
-      const int step_r = 64 / ncc, step_c = 64 - step_r * ncc;
 #pragma unroll
-      for (int u = 0; u < kPathRowLoads; ++u) {
-        const int idx = lane + 64 * u;
-        if (idx < nel) RW[row * P.ldr + col] = rv[u];
-        row += step_r; col += step_c;
-        if (col >= ncc) { col -= ncc; ++row; }
-      }
+  for (int u = 0; u < (CT0 ? 3 : 1); ++u) { const int j = lane + 64 * u; if (j < D) DSW[j] = dsv[u]; }
+  double t = t0_in;
+  if (!CT0) {
+    int row = lane / ncolr, col = lane - row * ncolr;
+    const int step_r = 64 / ncolr, step_c = 64 - step_r * ncolr;
+#pragma unroll
+    for (int u = 0; u < kPathRowLoads; ++u) {
+      const int idx = lane + 64 * u;
+      if (idx < nel) RW[row * P.ldr + col] = rv[u];
+      row += step_r; col += step_c;
+      if (col >= ncolr) { col -= ncolr; ++row; }
     }
-    if (ch + 1 < nchunks) request(c0 + kPathChunk);      // the next round's loads under this round's sums
     wave_lds_sync_local();
     if (mine) {
       const double* Rr = RW + (size_t)(fi * 9 + k) * P.ldr;
-      const double* dsc = DSW + c0;
-      double acc = t;
-      for (int j = 0; j < ncc; ++j) acc += Rr[j] * dsc[j];
+      double acc = Rr[D];
+      for (int j = 0; j < D; ++j) acc += Rr[j] * DSW[j];
       t = acc;
     }
-    if (ch + 1 < nchunks) wave_lds_sync_local();         // (the rows are overwritten by the next round)
   }
   // ---- the separators' steps from the level above
   double da[9], dn[9], dr_in[9];
@@ -3070,20 +3043,18 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
     if (v.back_path && nl >= 1 && nl <= 5) {
       BackPath P; P.n = nl;
       for (int l = 0; l < 6; ++l) { P.stride[l] = l < nl ? strides[l] : 1; P.m[l] = l < nl ? ms[l] : 2; P.two[l] = (l < nl && two_at(l)) ? 1 : 0; }
-      P.top_stride = top_stride; P.ldr = std::min(v.D, kPathChunk) | 1; P.dsw = ((v.D + 63) / 64) * 64;
-      P.ct0 = v.D > kPathChunk ? 1 : 0;
-      if (P.ct0) hipLaunchKernelGGL(k_chain_t0, dim3((N + 3) / 4), dim3(256), 0, s, v);
+      const bool ct0 = v.D + 1 > kPathRowCols;
+      P.top_stride = top_stride; P.ldr = ct0 ? 1 : ((v.D + 1) | 1); P.dsw = ((v.D + 63) / 64) * 64;
+      if (ct0) hipLaunchKernelGGL(k_chain_t0, dim3((N + 3) / 4), dim3(256), 0, s, v);
       const int groups0 = (int)(((long)N - 1) / ((long)strides[0] * ms[0]) + 1), nw = nl + 1;
-      const size_t lds = ((size_t)nw * kPathDl + (size_t)nw * P.dsw + 4 + (P.ct0 ? 0 : (size_t)nw * 63 * P.ldr)) * sizeof(double);
-      // (the attribute is a property of the function on ONE device: the cache is per device -- advice r5)
+      const size_t lds = ((size_t)nw * kPathDl + (size_t)nw * P.dsw + 4 + (ct0 ? 0 : (size_t)nw * 63 * P.ldr)) * sizeof(double);
       static LdsGrant g4, g6;
-      if (nw <= 4) {
-        if (lds > 60000 && g4.need(lds)) (void)hipFuncSetAttribute((const void*)k_chain_back_path<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_chain_back_path<4>, dim3(groups0), dim3(64 * nw), lds, s, v, P);
-      } else {
-        if (lds > 60000 && g6.need(lds)) (void)hipFuncSetAttribute((const void*)k_chain_back_path<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_chain_back_path<6>, dim3(groups0), dim3(64 * nw), lds, s, v, P);
-      }
+      auto go = [&](auto kern, LdsGrant& g) {
+        if (lds > 60000 && g.need(lds)) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(groups0), dim3(64 * nw), lds, s, v, P);
+      };
+      if (nw <= 4) { if (ct0) go(k_chain_back_path<4, true>, g4); else go(k_chain_back_path<4, false>, g4); }
+      else { if (ct0) go(k_chain_back_path<6, true>, g6); else go(k_chain_back_path<6, false>, g6); }
       return;
     }
     hipLaunchKernelGGL(k_chain_back, dim3(1 + (nl > 0 ? (N + kBackT0Frames - 1) / kBackT0Frames : 0)), dim3(64), 0, s, v, top_stride, m_top, 1, nl, 0);
