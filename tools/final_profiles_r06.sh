@@ -21,6 +21,7 @@ done
 cd $R
 ( echo "== k_imu_block, cfg3"; VICALIB_AMD_LIB=$R/tools/probe/libvicalib_amd_ibstamps.so python tools/ib_stamps.py cfg3; echo "== k_imu_jac, cfg3"; VICALIB_AMD_LIB=$R/tools/probe/libvicalib_amd_ijstamps.so python tools/ij_stamps.py cfg3 ) > $O/imu_stamps.txt 2>&1
 python bench.py --gpus 2 --transport gloo --steps 20 --warmup 5 --repeats 3 --no-cpu-baseline > $O/bench_two_ranks_gloo_one_gpu.json 2> $O/bench_two_ranks_gloo_one_gpu.err
+( echo "== k_chain_fwd2, cfg3"; VICALIB_AMD_LIB=$R/tools/probe/libvicalib_amd_f2stamps.so python tools/f2_stamps.py ) > $O/f2_stamps.txt 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -3 $O/prof_cfg3.log; grep "frames:" $O/perrank.txt; python -c "
 import json

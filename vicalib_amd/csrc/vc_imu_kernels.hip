@@ -62,6 +62,8 @@ constexpr int kSegIters = (kSegLen + 31) / 32;      // entries of the record per
 __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   __shared__ double sh[8 * kImuJacLds];
   __shared__ double s_wq[8 * 84];                  // the block's 9 x 9 weight, staged once (round 6: every lane loaded all 81 entries itself)
+  // (round 6 also tried requesting everything ahead of the control record -- the two frames' states and the gravity record of BOTH state
+  //  buffers, one value per lane, the buffer in use to LDS --: 23.1 us against 21.4 on the same box, reverted)
   IJSTAMP(0);
   const Ctrl* ct = v.ctrl;
   if (ct->done || (!trial && !ct->need_lin)) {
@@ -332,25 +334,30 @@ __global__ __launch_bounds__(256, VC_IMU_BLOCK_WAVES) void k_imu_block(DevView v
   __shared__ double s_carry[32 * kDtDoubles];
 #if VC_IMU_BLOCK_PARK
   // the first interval's delta while the second is formed: tangent and accelerometer partials per lane (16 doubles), the VALUES once per
-  // interval -- they are the same numbers in all eight groups, group 0 writes them: 42 KB per workgroup with the carry, not 62, so that
-  // two workgroups fit a CU beside a workgroup of the back-substitution (70 KB at BASELINE cfg3) and the grid is resident in one round
+  // interval -- they are the same numbers in all eight groups, group 0 writes them: 42 KB per workgroup with the carry, not 62: two
+  // workgroups fit a CU's LDS beside a workgroup of the back-substitution (68 KB at BASELINE cfg3).  (Its registers then hold the grid to
+  // one workgroup per CU there -- 252 + 216 of a SIMD's 512 -- and two rounds; a step under ~144 registers spills: HISTORY round 6)
   __shared__ double s_park[256 * (kDtDoubles - 11)];
   __shared__ double s_parkv[4 * 8 * 11];
 #endif
   IBSTAMP(0);
-  const Ctrl* ct = v.ctrl;
-  if (ct->done || (!trial && !ct->need_lin)) return;
-  IBSTAMP(1);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: everything per block stays out of the vector registers)
   const int g = lane >> 3, l = lane & 7;
   const int n_blocks = v.n_frames - 1;
   const int s_raw = blockIdx.x * 4 + wave;                             // block s couples frames s -> s + 1
   const int s = s_raw < n_blocks ? s_raw : n_blocks - 1;               // (a wavefront past the end shadows the last block and stores nothing)
-  const int cur = trial ? 1 - ct->cur : ct->cur;
-  const double* im = v.imus[cur];
-  const double toff = im[14];
-  const ImuView buf = imu_view(v);
+  // requested together with the control record, not behind it (a wavefront's life is a chain of dependent memory round trips -- control
+  // record, time offset, sample range, samples: ~7 of its 14 us; this is one of them): the frame times and the time offset of BOTH buffers
+  const double toff0 = v.imus[0][14], toff1 = v.imus[1][14];
   const double t_start = v.frame_time[s], t_end = v.frame_time[s + 1];
+  const Ctrl* ct = v.ctrl;
+  const int c_done = ct->done, c_need = ct->need_lin, c_cur = ct->cur;
+  if (c_done || (!trial && !c_need)) return;
+  IBSTAMP(1);
+  const int cur = trial ? 1 - c_cur : c_cur;
+  const double* im = v.imus[cur];
+  const double toff = cur ? toff1 : toff0;
+  const ImuView buf = imu_view(v);
   ImuRange rg = imu_range_lanes(buf, t_start, t_end, toff, lane);
   rg.valid = __builtin_amdgcn_readfirstlane(rg.valid); rg.i0 = __builtin_amdgcn_readfirstlane(rg.i0); rg.i1 = __builtin_amdgcn_readfirstlane(rg.i1);
   rg.k0 = __builtin_amdgcn_readfirstlane(rg.k0); rg.k1 = __builtin_amdgcn_readfirstlane(rg.k1);

@@ -42,6 +42,9 @@ __device__ void merged_control(const DevView& v, Ctrl* out, double* red, bool wr
 //   <= 12 used columns (fov, linear; 3 block columns): 2 instructions -- diagonal (0,0)(1,1)(2,2)(3,3) and, with
 //                A = (0,0,1,3), B = (1,2,2,3): (0,1)(0,2)(1,2)(3,3)           [3 LDS reads per group]
 //   otherwise  : 3 instructions -- B = A rotated by 0, 1, 2 blocks: diagonal, (0,1)(1,2)(2,3)(3,0), (0,2)(1,3)(2,0)(3,1)
+#ifndef VC_JAC_SPLIT_ROWS
+#define VC_JAC_SPLIT_ROWS 1      // poly2 / poly3: the two row types' Gram blocks apart (jac_tile_body_split below; 0: the four-block-column form for A/B runs)
+#endif
 template <int MODEL>
 __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* pose, const double* cam, double mult, int tile, int lane,
                                                 double* wl, double* G, int off_in, int cnt_in /* corner range if known (cnt_in >= 0) */) {
@@ -240,12 +243,167 @@ __device__ __forceinline__ double jac_tile_body(const DevView& v, const double* 
   JSTAMP(5);
   return wave_sum(cost);          // valid in lane 0
 }
+// ---- fov / linear / poly2 / poly3 (round 6): the two residual rows of a corner have DIFFERENT structural zeros ------------------------------
+// Row u of a radial model has no entry in the columns of fy and cy, row v none in fx and cx: of the 11 .. 14 used columns of
+// [A | A x q | B | r] each row type fills 9 .. 12 -- THREE block columns of four (poly2 / poly3: instead of four; fov / linear: three
+// before as well, but with both row types in every k-step: 16 sub-block slots per four corners for 12 products).  The Gram block is the sum of the two row
+// types' Gram blocks, G = sum u_row^T u_row + sum v_row^T v_row, each over its own compact columns (6 sub-blocks of 4 x 4 instead of 10):
+// a group of four corners costs THREE v_mfma_f64_4x4x4 (12 sub-block slots, all used: u-type rows of the four corners as the k dimension
+// for six of them, v-type rows for the other six) where the four-block-column form needs five for the same four corners (two k-steps of two
+// corners x two rows).  The matrix instructions are this kernel's time: -40 % of them for these models.  The two compact
+// 12 x 12 blocks are added into the packed 16 x 16 record once per tile.
+//   compact column j of row type t:  0..5 -> A, A x q;  6 -> fx | fy;  7 -> cx | cy;  8.. -> the nk - 4 distortion terms;  then r
+template <int MODEL>
+__device__ __forceinline__ double jac_tile_body_split(const DevView& v, const double* pose, const double* cam, double mult, int tile, int lane,
+                                                      double* wl, double* G, int off_in, int cnt_in) {
+  static_assert(MODEL == kPoly2 || MODEL == kPoly3 || MODEL == kFov || MODEL == kLinear, "split rows: the radial models with at most seven intrinsics");
+  constexpr int nk = MODEL == kFov ? 5 : MODEL == kPoly2 ? 6 : MODEL == kPoly3 ? 7 : 4;
+  constexpr int nd = nk - 4;                       // distortion terms
+  constexpr int ncomp = 9 + nd;                    // compact columns in use (11 / 12)
+  const int off = cnt_in >= 0 ? off_in : __builtin_amdgcn_readfirstlane(v.tile_off[tile]);
+  const int cnt = cnt_in >= 0 ? cnt_in : __builtin_amdgcn_readfirstlane(v.tile_off[tile + 1]) - off;
+  const int b = (lane >> 2) & 3, i4 = lane & 3, kq = lane >> 4;
+  // (row type, block column of A, of B) of block b in the three instructions of a group
+  const int t0 = b == 3 ? 1 : 0, xa0 = b == 3 ? 0 : b, xb0 = xa0;                                   // (0;0,0) (0;1,1) (0;2,2) (1;0,0)
+  const int t1 = b == 3 ? 1 : 0, xa1 = b == 0 ? 0 : b == 1 ? 0 : 1, xb1 = b == 0 ? 1 : b == 1 ? 2 : b == 2 ? 2 : 1;      // (0;0,1) (0;0,2) (0;1,2) (1;1,1)
+  const int xa2 = b == 0 ? 2 : b == 1 ? 0 : b == 2 ? 0 : 1, xb2 = b == 0 ? 2 : b == 1 ? 1 : 2;      // (1;2,2) (1;0,1) (1;0,2) (1;1,2)
+  double acc[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  double cost = 0.0;
+  if (cnt > 0) {
+    TileXf x;
+    make_tile_xf(pose, cam, &x);
+    double K[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) K[i] = cam[kCamK + i];
+    ModelPre pre;
+    model_precompute(MODEL, K, &pre);
+    double* mine = wl + lane * kDotStride;
+    const double* rowp = wl + kq * kDotStride + i4;                    // row kq of a group of four corners
+    const double* pa0 = rowp + t0 * 16 + 4 * xa0; const double* pb0 = rowp + t0 * 16 + 4 * xb0;
+    const double* pa1 = rowp + t1 * 16 + 4 * xa1; const double* pb1 = rowp + t1 * 16 + 4 * xb1;
+    const double* pa2 = rowp + 16 + 4 * xa2;      const double* pb2 = rowp + 16 + 4 * xb2;
+    double2 uv_n = make_double2(0.0, 0.0);
+    double pw_n[3] = {0.0, 0.0, 0.0};
+    int id_n = 0;
+    if (lane < cnt) {
+      uv_n = v.obs_uv[off + lane];
+      id_n = v.obs_pt[off + lane];
+      const double* pp = v.points + 3 * (size_t)(id_n & kObsPointMask);
+      pw_n[0] = pp[0]; pw_n[1] = pp[1]; pw_n[2] = pp[2];
+    }
+    for (int base = 0; base < cnt; base += 64) {
+      const int d = base + lane;
+      const double2 uv = uv_n;
+      const double pw[3] = {pw_n[0], pw_n[1], pw_n[2]};
+      const double mult_d = (id_n & kObsOneLess) ? mult - 1.0 : mult;
+      if (d + 64 < cnt) {
+        uv_n = v.obs_uv[off + d + 64];
+        id_n = v.obs_pt[off + d + 64];
+        const double* pp = v.points + 3 * (size_t)(id_n & kObsPointMask);
+        pw_n[0] = pp[0]; pw_n[1] = pp[1]; pw_n[2] = pp[2];
+      }
+      if (d < cnt) {
+        double r0[16], r1[16];
+        cost += corner_rows<MODEL>(x, K, pre, pw, uv.x, uv.y, mult_d, r0, r1);
+        // compact rows: u drops fy (7), cy (9); v drops fx (6), cx (8)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { mine[j] = r0[j]; mine[16 + j] = r1[j]; }
+        mine[6] = r0[6]; mine[7] = r0[8]; mine[16 + 6] = r1[7]; mine[16 + 7] = r1[9];
+#pragma unroll
+        for (int j = 0; j < nd + 1; ++j) { mine[8 + j] = r0[10 + j]; mine[16 + 8 + j] = r1[10 + j]; }      // distortion terms, then the residual (column 6 + nk)
+#pragma unroll
+        for (int j = ncomp; j < 12; ++j) { mine[j] = 0.0; mine[16 + j] = 0.0; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { mine[i] = 0.0; mine[16 + i] = 0.0; }
+      }
+      wave_lds_sync();
+      const int ngroups = (min(64, cnt - base) + 3) >> 2;      // groups of four corners that hold data; rows past the data are zero
+      auto fetch = [&](int g, double* a3, double* b3) {
+        const int o = g * 4 * kDotStride;
+        a3[0] = pa0[o]; b3[0] = pb0[o]; a3[1] = pa1[o]; b3[1] = pb1[o]; a3[2] = pa2[o]; b3[2] = pb2[o];
+      };
+      if (ngroups == 16) {
+        // full pass, straight-line: operands of four groups at a time, the next chunk's LDS reads in flight under the current chunk's MFMAs
+        double ua[2][4][3], ub[2][4][3];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fetch(g, ua[0][g], ub[0][g]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (c < 3) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) fetch((c + 1) * 4 + g, ua[(c + 1) & 1][g], ub[(c + 1) & 1][g]);
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[g & 1][n] = __builtin_amdgcn_mfma_f64_4x4x4f64(ua[c & 1][g][n], ub[c & 1][g][n], acc[g & 1][n], 0, 0, 0);
+        }
+      } else {
+        for (int g0 = 0; g0 < ngroups; g0 += 4) {              // ragged last pass: chunks of four groups (a chunk may run over the end into zero rows)
+          double ua[4][3], ub[4][3];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) fetch(g0 + g, ua[g], ub[g]);
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[g & 1][n] = __builtin_amdgcn_mfma_f64_4x4x4f64(ua[g][n], ub[g][n], acc[g & 1][n], 0, 0, 0);
+        }
+      }
+      wave_lds_sync();
+    }
+  }
+  // ---- the two compact blocks -> the packed record.  D lane = 16 i + 4 b + j holds entry (4 XA + i, 4 XB + j) of row type t's block.
+  {
+    double* GC = wl;                                // [2][12 x 12], upper block triangle written (this wavefront's corner rows are done with)
+    const int i = lane >> 4, j = lane & 3;
+    const double d0 = acc[0][0] + acc[1][0], d1 = acc[0][1] + acc[1][1], d2 = acc[0][2] + acc[1][2];
+    GC[t0 * 144 + (4 * xa0 + i) * 12 + 4 * xb0 + j] = d0;
+    GC[t1 * 144 + (4 * xa1 + i) * 12 + 4 * xb1 + j] = d1;
+    GC[144 + (4 * xa2 + i) * 12 + 4 * xb2 + j] = d2;
+    wave_lds_sync();
+    // compact column of full column fc in row type t (-1: structurally zero there / unused)
+    auto comp = [&](int fc, int t) {
+      return fc < 6 ? fc : fc == 6 ? (t == 0 ? 6 : -1) : fc == 7 ? (t == 1 ? 6 : -1) : fc == 8 ? (t == 0 ? 7 : -1) : fc == 9 ? (t == 1 ? 7 : -1)
+           : fc <= 6 + nk ? 8 + (fc - 10) : -1;
+    };
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int e = lane + 64 * q;
+      if (e < kGPackGrad) {
+        int r = 0;
+#pragma unroll
+        for (int a2 = 1; a2 < 16; ++a2) r += (e >= a2 * 16 - (a2 * (a2 - 1)) / 2) ? 1 : 0;      // row of packed entry e
+        const int c = r + (e - (r * 16 - (r * (r - 1)) / 2));
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int jr = comp(r, t), jc = comp(c, t);
+          // (the upper block triangle is what was written: entry (jr, jc), jr <= jc, lies in block (jr / 4, jc / 4); inside a diagonal
+          //  block both triangles are there)
+          const double g = GC[t * 144 + (jr >= 0 ? jr : 0) * 12 + (jc >= 0 ? jc : 0)];
+          s += (jr >= 0 && jc >= 0) ? g : 0.0;
+        }
+        G[e] = s;
+      }
+    }
+  }
+  return wave_sum(cost);          // valid in lane 0
+}
 __device__ __forceinline__ double jac_tile_dispatch(const DevView& v, int model, const double* pose, const double* cam, double mult, int tile,
                                                     int lane, double* wl, double* G, int off = 0, int cnt = -1) {
   switch (model) {   // wave-uniform
     case kFov: return jac_tile_body<kFov>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
+    // (fov / linear through the split form as well -- 48 instead of 64 matrix instructions per pass -- measured SLOWER: 237 against 233.5 us
+    //  at cfg5 / 6250 frames, k_trial 16.8 against 15.6 us at cfg2: their tiles are three passes long and the per-tile assembly of the
+    //  two compact blocks costs more than the instructions saved; poly3 at cfg4's nine passes per tile: 150 against 161 us)
+#if VC_JAC_SPLIT_ROWS
+    case kPoly2: return jac_tile_body_split<kPoly2>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
+    case kPoly3: return jac_tile_body_split<kPoly3>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
+#else
     case kPoly2: return jac_tile_body<kPoly2>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
     case kPoly3: return jac_tile_body<kPoly3>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
+#endif
     case kKb4: return jac_tile_body<kKb4>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
     case kRational6: return jac_tile_body<kRational6>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
     default: return jac_tile_body<kLinear>(v, pose, cam, mult, tile, lane, wl, G, off, cnt);
@@ -268,16 +426,22 @@ __global__ __launch_bounds__(256, VC_JAC_WAVES) void k_reproj_jac(DevView v, int
   // the trial sweep follows the back-substitution on the main stream: that this kernel has started says the trial poses are complete
   // and written back -- published for the second stream's k_imu_jac (no event record between the two kernels of the critical path)
   if (trial && blockIdx.x == 0 && threadIdx.x == 0) signal_started(v, 2);
-  if (ct->done || (!trial && !ct->need_lin)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
+  // the tile's header (frame, camera, model, corner range: one 48-byte record) is requested together with the control record, not behind
+  // it (round 6: control record -> tile_frame / tile_cam -> model -> tile_off -> corners -> target points were five dependent round
+  // trips at the head of a 17 us kernel; now three)
+  const TileHdr h = v.tile_hdr[tile < v.n_tiles ? tile : 0];
+  const int c_done = ct->done, c_need = ct->need_lin, c_cur = ct->cur;
+  const double c_mult = ct->mult;
+  if (c_done || (!trial && !c_need)) return;
   double cost = 0.0;
   if (tile < v.n_tiles) {
     double* wl = lds + wave * 64 * kDotStride;
-    const int cur = trial ? 1 - ct->cur : ct->cur;
-    const int f = v.tile_frame[tile], c = v.tile_cam[tile];
-    cost = jac_tile_dispatch(v, v.cd[c].model, v.poses[cur] + (size_t)f * kPoseStride, v.cams[cur] + (size_t)c * kCamStride, ct->mult,
-                             tile, lane, wl, v.Gb[cur] + (size_t)tile * kGPack);
+    const int cur = trial ? 1 - c_cur : c_cur;
+    const int f = __builtin_amdgcn_readfirstlane(h.frame), c = __builtin_amdgcn_readfirstlane(h.cam);
+    cost = jac_tile_dispatch(v, __builtin_amdgcn_readfirstlane(h.model), v.poses[cur] + (size_t)f * kPoseStride, v.cams[cur] + (size_t)c * kCamStride, c_mult,
+                             tile, lane, wl, v.Gb[cur] + (size_t)tile * kGPack, __builtin_amdgcn_readfirstlane(h.off), __builtin_amdgcn_readfirstlane(h.cnt));
     if (lane == 0) v.tile_costb[cur][tile] = cost;
   }
   if (trial) {               // the workgroup's share of the trial cost, in fixed order
@@ -1283,22 +1447,26 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   __shared__ double s_x2;
   __shared__ CamDesc s_cd[kMaxCams];     // the kernel-argument table costs a scalar memory round trip per (dynamically indexed) access
   const Ctrl* ct = v.ctrl;
-  if (ct->done) { if (threadIdx.x == 0 && mode != 1) signal_flag(v, 1); return; }
-  if (threadIdx.x < kMaxCams) s_cd[threadIdx.x] = v.cd[threadIdx.x];
   __shared__ double s_S[kSmallD * kSmallD + 3 * kSmallD + 2];      // single process, D <= kSmallD: the reduced system stays in LDS between the phases
   // early Gram: [Y | z] rows of the chain's top-level frames, behind phase A's record in the dynamic region (static LDS is at its limit
   // where the packed matrix of a D = 178 system takes 137 KB of the dynamic one)
   double* s_top = dyn + (sizeof(FinalLds) + 7) / 8;
   const bool early = v.gram_top_stride > 0 && mode == 0 && v.D <= kEarlyTopD;
   const int top_rows = early ? 9 * min(7, (v.n_frames - 1) / v.gram_top_stride + 1) : 0;
-  if (early) {
-    // the top-level frames' rows (final since the launch before the partial sums): requested first, their latency under everything below
-    double tin[9];
+  // the top-level frames' rows (final since the launch before the partial sums): requested first -- together with the control record,
+  // not behind it --, their latency under everything below
+  double tin[9];
+  const double* top_src = early ? v.cW : v.Sbuf;      // (no chain: every lane reads the always-present first entry of Sbuf and drops it)
 #pragma unroll
-    for (int u = 0; u < 9; ++u) {
-      const int idx = threadIdx.x + 256 * u, r = idx / kTopLd, c = idx - r * kTopLd;
-      tin[u] = (idx < 64 * kTopLd && r < top_rows && c <= v.D) ? v.cW[((size_t)(r / 9) * v.gram_top_stride * 9 + (r % 9)) * v.ldx + c] : 0.0;
-    }
+  for (int u = 0; u < 9; ++u) {
+    const int idx = threadIdx.x + 256 * u, r = idx / kTopLd, c = idx - r * kTopLd;
+    const bool in = early && idx < 64 * kTopLd && r < top_rows && c <= v.D;
+    const double x = top_src[in ? ((size_t)(r / 9) * v.gram_top_stride * 9 + (r % 9)) * v.ldx + c : 0];
+    tin[u] = in ? x : 0.0;
+  }
+  if (ct->done) { if (threadIdx.x == 0 && mode != 1) signal_flag(v, 1); return; }
+  if (threadIdx.x < kMaxCams) s_cd[threadIdx.x] = v.cd[threadIdx.x];
+  if (early) {
 #pragma unroll
     for (int u = 0; u < 9; ++u) { const int idx = threadIdx.x + 256 * u; if (idx < 64 * kTopLd) s_top[idx] = tin[u]; }
   }
