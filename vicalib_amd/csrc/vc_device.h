@@ -210,6 +210,10 @@ struct DevView {
   double* wgpart;                  // k_trial: per-workgroup sums of the step scalars [n_workgroups][kNumScal]
   double* gath;                    // world x kNumScal: every rank's step scalars (one all-reduce(SUM) of disjoint slots = all-gather)
   double* sep_strip;               // 2 x 9 x ldw: rows of the reduced system contributed directly by the pinned frames
+  // (round 6) 1: k_reduced ends with the step and the trial IMU parameters stored; the trial cameras and the shared parameters' terms of the
+  // step scalars (vc_reduced_tail.hpp) are formed by one extra workgroup of the back-substitution's launch (k_chain_back_path).  Set per pass
+  // by enqueue_pass (chain_back_is_path)
+  int tail_deferred;
 };
 
 // launchers (vc_kernels.hip); all asynchronous on `s`
@@ -223,6 +227,7 @@ void launch_final(const DevView& v, int mode, hipStream_t s);
 int chain_forward_launches(const DevView& v);      // launches of the chain's forward elimination (levels + top)
 int chain_top_stride(int n_frames);                // stride of the frames the chain's top level eliminates
 bool chain_fold_supported(int n_frames, int D, int n_cams);      // k_chain_l0 can serve this problem (vc_imu_kernels.hip)
+bool chain_back_is_path(const DevView& v);         // the back-substitution of this problem is one launch of k_chain_back_path with >= 256 threads per workgroup (it can carry the reduced solve's tail)
 // a segment of a packed upload: `bytes` (a multiple of 4) from offset src_off of the staging image to dst; src_off = ~0: zero-fill
 struct UnpackSeg { unsigned long long dst, src_off, bytes; };
 void launch_unpack(const UnpackSeg* segs, int n, const void* image, size_t total_bytes, hipStream_t s);

@@ -33,6 +33,7 @@
 #include "vc_imu_weights.hpp"
 #include "vc_device.h"
 #include "vc_kutil.hpp"
+#include "vc_reduced_tail.hpp"
 
 namespace vc {
 
@@ -47,6 +48,24 @@ struct SegTab {
 };
 __constant__ SegTab d_seg_tab = SegTab();
 constexpr int kSegIters = (kSegLen + 31) / 32;      // entries of the record per lane (32 lanes per block)
+// ... and the other way round for the matrix-pipe form of the block's J^T J (round 6): the 34 columns (33 local columns + the residual) are
+// three column tiles of 16; tile pair (I, J) of v_mfma_f64_16x16x4 leaves entry (a, b) = (16 I + 4 g + lane / 16, 16 J + lane % 16) in
+// accumulator register g of `lane` -- v[I * 3 + J][lane][g] is that entry's place in the compact record (0xffff: the record has no such entry)
+#ifndef VC_IJ_MFMA
+#define VC_IJ_MFMA 1      // (0: the block's J^T J as 25 nine-term dot products per lane out of LDS, the form of rounds 1-5 -- A/B builds)
+#endif
+struct SegInv {
+  unsigned short v[9][64][4];
+  constexpr SegInv() : v() {
+    for (int t = 0; t < 9; ++t) for (int l = 0; l < 64; ++l) for (int g = 0; g < 4; ++g) v[t][l][g] = 0xffff;
+    for (int e = 0; e < kSegLen; ++e) {
+      int a = 0, b = 0; seg_entry(e, &a, &b);
+      const int I = a / 16, J = b / 16, rt = a % 16;
+      v[I * 3 + J][(rt % 4) * 16 + b % 16][rt / 4] = (unsigned short)e;
+    }
+  }
+};
+__constant__ SegInv d_seg_inv = SegInv();
 // The sweep proper.  Two IMU blocks per wavefront, lane = local column of the block: frame j's pose (6), frame j-1's pose (6) and
 // velocity (3), gravity (2), biases (6), scale factors (6), time offset -- 30 lanes put the block's delta on the start state and
 // run the residual's tail under one dual direction each (vc_imu.hpp: imu_block_final_direction); the three columns of frame j's
@@ -97,9 +116,15 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   double r[9], dr[9];
   const int col = (l < 6) ? l : (l < 30 ? l + 3 : -1);         // lanes 30, 31 carry the values only
   const bool valid = brec[10] >= 0.0;
+#if VC_IJ_MFMA
+  unsigned long long seg_at[9];      // where the lane's four accumulator entries of every tile pair go in the record (tile pair (2, 0) has none)
+#pragma unroll
+  for (int t = 0; t < 9; ++t) seg_at[t] = t == 6 ? ~0ull : *reinterpret_cast<const unsigned long long*>(&d_seg_inv.v[t][lane][0]);
+#else
   int seg_ab[kSegIters];
 #pragma unroll
   for (int it = 0; it < kSegIters; ++it) { const int e = l + 32 * it; seg_ab[it] = d_seg_tab.v[e < kSegLen ? e : 0]; }
+#endif
   wave_lds_sync();
   IJSTAMP(1);
   imu_block_final_direction(valid, brec, wq, v.rotation_only, T2, T1, v2, v1, v.imu_grav + cur * 16, col, r, dr);
@@ -148,6 +173,51 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   // have been performed -- k_final ends on that count (round 4: on a flag a one-thread kernel raised behind this one, 6 us after this
   // kernel's end, which since round 5's leaner k_final was what the pass ended on)
   const bool counted2 = trial && v.final_wait > 0;
+#if VC_IJ_MFMA
+  // J^T J and J^T r of the block in the compact record, entry e = w * <column a, column b> with the residual as column 33 -- on the matrix
+  // pipe (round 6).  As 25 nine-term dot products per lane the phase was 450 LDS reads per lane, 6.2 of the kernel's ~20 us; here the whole
+  // wavefront takes its two blocks one after the other: the block's [34][9] image read ONCE as nine operand registers (column tile T, rows
+  // 4 ks .. 4 ks + 3: the same register is the A operand of tile pairs (T, .) and the B operand of (., T)), 8 tile pairs x 3 k-steps of
+  // v_mfma_f64_16x16x4, and every accumulator entry goes to the place the inverse table names.  (a, b) and (b, a) are the same products in
+  // the same order: the record's symmetric blocks stay symmetric to the bit.
+  {
+    const int i16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (!__builtin_amdgcn_readlane((int)exists, 32 * h)) continue;               // (wave-uniform)
+      const double wh = readlane_f64(w, 32 * h);
+      const int sb = __builtin_amdgcn_readlane(s, 32 * h);
+      const double* Jb = sh + (wave * 2 + h) * kImuJacLds;
+      double op[3][3];
+#pragma unroll
+      for (int T = 0; T < 3; ++T)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const int c = 16 * T + i16, rr = 4 * ks + kq;
+          const bool in = c < 34 && rr < 9;
+          const double x = Jb[in ? c * 9 + rr : 0];
+          op[T][ks] = in ? x : 0.0;
+        }
+      double* rec = v.segb[cur] + (size_t)sb * kSegStride;
+#pragma unroll
+      for (int I = 0; I < 3; ++I)
+#pragma unroll
+        for (int J = 0; J < 3; ++J) {
+          if (I == 2 && J == 0) continue;
+          v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(op[I][ks], op[J][ks], acc, 0, 0, 0);
+          const unsigned long long at = seg_at[I * 3 + J];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const unsigned e = (unsigned)(at >> (16 * g)) & 0xffffu;
+            if (e != 0xffffu) { if (counted2) __hip_atomic_store(rec + e, wh * acc[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else rec[e] = wh * acc[g]; }
+          }
+        }
+    }
+    if (exists && l == 0) { if (counted2) __hip_atomic_store(v.seg_costb[cur] + s, ct->imu_mult * rho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else v.seg_costb[cur][s] = ct->imu_mult * rho; }
+  }
+#else
   if (exists) {
   // J^T J and J^T r of the block in the compact record: entry e = w * <column a, column b> with the residual as column 33
   // (statically unrolled, the (row, column) pairs of the lane's 25 entries requested at the kernel's entry: as a loop every entry
@@ -164,6 +234,7 @@ __global__ __launch_bounds__(256) void k_imu_jac(DevView v, int wr, int trial) {
   }
   if (l == 0) { if (counted2) __hip_atomic_store(v.seg_costb[cur] + s, ct->imu_mult * rho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else v.seg_costb[cur][s] = ct->imu_mult * rho; }
   }
+#endif
   if (counted2) {
     __builtin_amdgcn_s_waitcnt(0);          // this wavefront's stores have been performed
     __syncthreads();
@@ -1391,6 +1462,12 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(DevView v, int s, int m, 
 // multiplies / FMAs; the triangular solve that follows takes L from registers.  The solved column goes to the frame's image
 // [Y | z | X_s | L | X_n] in HBM, [X_s | X_n] to XS (LDS) for everybody, out = [X_s | X_n]^T (column).
 // WG_SYNC: the sweep is several wavefronts side by side (k_chain_fwd2<NW > 1>): workgroup barriers instead of wavefront-local ones.
+// a double at a BYTE offset from a wave-uniform base: scalar base + 32-bit lane offset (global_load / global_store with an SGPR pair as the
+// address and one VGPR as the offset) instead of a 64-bit address per lane and access.  A lone wavefront pays ~4 cycles for EVERY instruction
+// it issues, address arithmetic included: per frame of a two-sided sweep the columns' addresses were ~340 instructions, the frame's
+// elimination itself ~850 (round 6, tools/isa_classes.py with markers).  Images stay below 4 GB (n_frames x 9 x ldx x 8: 0.9 GB at 50 000 frames).
+__device__ __forceinline__ double ld_boff(const double* base, unsigned boff) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff); }
+__device__ __forceinline__ void st_boff(double* base, unsigned boff, double x) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = x; }
 struct ElimLds { double* XS; double* An; double* Ls; };
 template <bool WG_SYNC>
 __device__ __forceinline__ void chain_eliminate(const DevView& v, double* img /* the frame's image */, int ldx, int role, int pc, int sub, bool flag_lane,
@@ -1469,9 +1546,9 @@ __device__ __forceinline__ void chain_eliminate(const DevView& v, double* img /*
 #pragma unroll
     for (int k = 0; k < 9; ++k) { lv[k] = rl[k]; xv[k] = rx[k * kXsLd]; }
     if (role < 4) {
-      double* ic = img + pc;
+      const unsigned pcb = 8u * (unsigned)pc, ldxb = 8u * (unsigned)ldx;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) ic[k * ldx] = role == 2 ? lv[k] : x[k];       // (A: L[k][sub], zero above the diagonal)
+      for (int k = 0; k < 9; ++k) st_boff(img, pcb + k * ldxb, role == 2 ? lv[k] : x[k]);       // (A: L[k][sub], zero above the diagonal)
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) x[k] = role == 2 ? xv[k] : x[k];
@@ -1564,25 +1641,35 @@ __global__ __launch_bounds__(128 * NW, VC_FWD2_WAVES) void k_chain_fwd2(DevView 
   // next frame of the sweep
   // (branch-free: every lane reads nine values from ONE address pattern -- base + k stride -- chosen by its role, idle lanes read
   // column 0 of the image and scale it by zero; the pending contribution likewise)
-  auto load_cols = [&](int e, bool first_of_sweep, bool with_image, double* x) {
-    const double* img = v.cW + (size_t)e * isz;
-    const double* rpe = rp + (size_t)(e / s) * isz;
-    const double* p = img; long st = ldx; double sc = 0.0, psc = 0.0;
-    if (role == 0 || role == 2) { p = img + pc; sc = 1.0; psc = pend ? 1.0 : 0.0; }
-    else if (role == 1 && first_of_sweep) {
-      if (dir > 0) { p = v.cW + (size_t)a * isz + (size_t)sub * ldx + ldw + 18; st = 1; } else p = img + ldw + 18 + sub;
-      sc = 1.0;
-    } else if (role == 3) {
-      if (dir > 0) p = img + pc; else { p = v.cW + (size_t)(e - s) * isz + (size_t)sub * ldx + ldw + 18; st = 1; }
-      sc = 1.0;
-    }
-    if (!with_image) { sc = 0.0; psc = 0.0; p = img; st = ldx; }
-    const double* p2 = rpe + ((role == 0 || role == 2) ? pc : 0);
+  // (round 6: ONE byte offset pattern per lane -- first column entry c0b, step stb -- relative to the image of the frame the lane reads
+  //  from (fsel: the sweep's frame e, the left separator a, or the frame e - s whose B block row is this frame's coupling), wave-uniform
+  //  bases: 18 offset additions and 18 loads per frame where the 64-bit addresses per lane and load were ~340 instructions)
+  const unsigned ldxb = 8u * (unsigned)ldx, iszb = 9u * ldxb;
+  unsigned c0b = 0, stb = ldxb; int fsel = 0;
+  if (role == 0 || role == 2) c0b = 8u * (unsigned)pc;
+  else if (role == 1) { if (dir > 0) { c0b = 8u * (unsigned)(sub * ldx + ldw + 18); stb = 8; fsel = 1; } else c0b = 8u * (unsigned)(ldw + 18 + sub); }
+  else if (role == 3) { if (dir > 0) c0b = 8u * (unsigned)pc; else { c0b = 8u * (unsigned)(sub * ldx + ldw + 18); stb = 8; fsel = 2; } }
+  const unsigned ab = (unsigned)a * iszb;
+  const int qa = group * m;             // e / s of frame e = a + i s is qa + i (a = group m s)
+  auto load_cols = [&](int idx /* frame e = a + idx s, idx >= 1 */, bool first_of_sweep, bool with_image, double* x) {
+    const int e = a + idx * s;
+    const unsigned eb = (unsigned)e * iszb, emb = (unsigned)(e - s) * iszb;
+    const unsigned fb = fsel == 1 ? ab : (fsel == 2 ? emb : eb);
+    const unsigned pb = (unsigned)(qa + idx) * iszb;      // (the pending image of frame e in rp: one base for the whole kernel, the frame in the offset)
+    const bool live0 = with_image && (role == 0 || role == 2 || role == 3 || (role == 1 && first_of_sweep));
+    const bool live1 = with_image && pend && (role == 0 || role == 2);
     double y0[9], y1[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { y0[k] = p[k * st]; y1[k] = pend ? p2[k * ldx] : 0.0; }
+    for (int k = 0; k < 9; ++k) y0[k] = ld_boff(v.cW, fb + c0b + k * stb);
+    if (pend) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) x[k] = (sc != 0.0 ? y0[k] : 0.0) + (psc != 0.0 ? y1[k] : 0.0);
+      for (int k = 0; k < 9; ++k) y1[k] = ld_boff(rp, pb + c0b + k * stb);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) y1[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) x[k] = (live0 ? y0[k] : 0.0) + (live1 ? y1[k] : 0.0);
   };
   double xin[9], o[9], dacc[9];
 #pragma unroll
@@ -1600,7 +1687,7 @@ __global__ __launch_bounds__(128 * NW, VC_FWD2_WAVES) void k_chain_fwd2(DevView 
     for (int k = 0; k < 9; ++k) sep0[k] = mine ? img[k * ldx] + (pa ? rpa[k * ldx] : 0.0) : 0.0;
   }
   // (a side without frames of its own: wavefront 0 starts with the middle frame, wavefront 1 has nothing to load)
-  load_cols(a + (cnt > 0 ? i0 : mid) * s, true, cnt > 0 || wave == 0, xin);
+  load_cols(cnt > 0 ? i0 : mid, true, cnt > 0 || wave == 0, xin);
   // (round 6 tried requesting a frame's columns TWO eliminations ahead -- they come from HBM, the level below wrote them from other XCDs --:
   //  21.9 / 21.1 us per level against 20.2 / 19.6: nine more doubles per lane through the accumulation registers cost more than the wait)
   if (done) return;
@@ -1655,8 +1742,12 @@ __global__ __launch_bounds__(128 * NW, VC_FWD2_WAVES) void k_chain_fwd2(DevView 
       }
     }
     const int e = a + (at_mid ? mid : i0 + dir * j) * s;
+#ifdef VC_EXP_NO_O_LOADS      // (timing experiment only -- wrong numbers: what the level costs when the next frame's columns need no memory round trip)
+    if (!at_mid) { for (int k = 0; k < 9; ++k) o[k] = xin[k] * 0.999; }
+#else
     if (!at_mid)                        // the columns of the frame after this one: requested now, used after the elimination
-      load_cols(a + (j + 1 < cnt ? i0 + dir * (j + 1) : mid) * s, false, j + 1 < cnt || wave == 0, o);
+      load_cols(j + 1 < cnt ? i0 + dir * (j + 1) : mid, false, j + 1 < cnt || wave == 0, o);
+#endif
     double x[9], out[18];
 #pragma unroll
     for (int k = 0; k < 9; ++k) x[k] = xin[k];
@@ -2573,13 +2664,36 @@ __global__ __launch_bounds__(64) void k_chain_back_levels(DevView v, BackLevels 
 // the rows of the recomputed levels in every bottom group then costs more than a launch -- measured 218 us against 71 for the level-by-level
 // kernels at 6250 frames x D = 115, 120 us with t0 from its own launch); a pinned frame (separator / ghost of a sharded chain,
 // DevView::pin_first / pin_last) steps with the reduced system's solution in the epilogue.
-struct BackPath { int n; int stride[6]; int m[6]; int two[6]; int top_stride; int ldr; int dsw; };
+struct BackPath { int n; int stride[6]; int m[6]; int two[6]; int top_stride; int ldr; int dsw; int tail; };
+// (round 6) the launch's LAST workgroup, when BackPath::tail is set, is not a bottom group: it forms what k_reduced left out
+// (DevView::tail_deferred) -- the trial cameras and the shared parameters' terms of the step scalars -- beside the back-substitution
+// instead of at the end of a one-workgroup kernel the whole chip waits for.  The first 256 threads; LDS: kTailLds doubles.
+constexpr int kTailLds = kMaxCams * kCamStride + 16 + 8 + 6 * 256;
+__device__ __forceinline__ void reduced_tail_workgroup(const DevView& v, double* lds) {
+  const int tid = threadIdx.x, D = v.D;
+  if (tid >= 256) return;
+  const Ctrl* ct = v.ctrl;
+  const int cur = ct->cur, done = ct->done;
+  if (done) return;
+  double* s_cam = lds;
+  CamDesc* s_cd = reinterpret_cast<CamDesc*>(lds + kMaxCams * kCamStride);
+  int* s_ipc = reinterpret_cast<int*>(lds + kMaxCams * kCamStride + 16);
+  double* red = lds + kMaxCams * kCamStride + 16 + 8;
+  for (int i = tid; i < v.n_cams * kCamStride; i += 256) s_cam[i] = v.cams[cur][i];
+  if (tid < kMaxCams) s_cd[tid] = v.cd[tid];
+  if (tid >= 64 && tid < 64 + 15) s_ipc[tid - 64] = v.imu_param_col[tid - 64];
+  double pre_imu = 0.0;
+  if (v.imu_on && (tid >> 6) == (D <= 64 ? 0 : 1) && (tid & 63) < 16) pre_imu = v.imus[cur][tid & 63];
+  __syncthreads();
+  reduced_tail(v, cur, v.delta_s, v.Sbuf + (size_t)D * D + 2 * D, v.slam, s_cam, s_cd, s_ipc, pre_imu, nullptr, red, false, false);
+}
 constexpr int kPathRowCols = 37;       // widest row [Y | z] the in-kernel staging serves (D + 1 entries)
 constexpr int kPathRowLoads = 37;      // 63 rows x kPathRowCols entries over 64 lanes
 constexpr int kPathDl = 96;            // doubles per level's step record (10 positions x 9)
 template <int NWMAX, bool CT0>      // wavefronts per workgroup at most (levels + 1): up to four leave a whole SIMD's registers to each; CT0: t0 from k_chain_t0
 __global__ __launch_bounds__(64 * NWMAX) void k_chain_back_path(DevView v, BackPath P) {
   extern __shared__ __attribute__((aligned(16))) double bp_lds[];
+  if (P.tail && blockIdx.x == gridDim.x - 1) { reduced_tail_workgroup(v, bp_lds); return; }
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int nw = P.n + 1;
   double* DLall = bp_lds;                              // [nw][kPathDl]
@@ -3054,11 +3168,12 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
       P.top_stride = top_stride; P.ldr = ct0 ? 1 : ((v.D + 1) | 1); P.dsw = ((v.D + 63) / 64) * 64;
       if (ct0) hipLaunchKernelGGL(k_chain_t0, dim3((N + 3) / 4), dim3(256), 0, s, v);
       const int groups0 = (int)(((long)N - 1) / ((long)strides[0] * ms[0]) + 1), nw = nl + 1;
-      const size_t lds = ((size_t)nw * kPathDl + (size_t)nw * P.dsw + 4 + (ct0 ? 0 : (size_t)nw * 63 * P.ldr)) * sizeof(double);
+      P.tail = (v.tail_deferred && nw >= 4) ? 1 : 0;
+      const size_t lds = std::max(((size_t)nw * kPathDl + (size_t)nw * P.dsw + 4 + (ct0 ? 0 : (size_t)nw * 63 * P.ldr)), (size_t)(P.tail ? kTailLds : 0)) * sizeof(double);
       static LdsGrant g4, g6;
       auto go = [&](auto kern, LdsGrant& g) {
         if (lds > 60000 && g.need(lds)) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(groups0), dim3(64 * nw), lds, s, v, P);
+        hipLaunchKernelGGL(kern, dim3(groups0 + P.tail), dim3(64 * nw), lds, s, v, P);
       };
       if (nw <= 4) { if (ct0) go(k_chain_back_path<4, true>, g4); else go(k_chain_back_path<4, false>, g4); }
       else { if (ct0) go(k_chain_back_path<6, true>, g6); else go(k_chain_back_path<6, false>, g6); }
@@ -3101,6 +3216,17 @@ bool chain_fold_supported(int n_frames, int D, int n_cams) {
   static const bool two_env = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO"); return !(e && std::atoi(e) == 0); }();
   static const bool two_bottom = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO_BOTTOM"); return !(e && std::atoi(e) == 0); }();
   return two_env && two_bottom && chain_group_size() == kChainM && D + 1 + 27 <= 64 && n_cams <= 2 && (n_frames - 1) + 1 > kChainM - 1;
+}
+// the back-substitution is one launch of k_chain_back_path (chain_levels, backward) whose workgroups have at least 256 threads
+bool chain_back_is_path(const DevView& v) {
+  if (!v.back_path || v.n_frames < 1) return false;
+  int nl = 0; long st = 1;
+  while (true) {
+    const int m = nl == 0 ? chain_group_size() : chain_group_size_upper();
+    if (!((v.n_frames - 1) / st + 1 > m - 1)) break;
+    ++nl; st *= m;
+  }
+  return nl >= 3 && nl <= 5;
 }
 // stride of the frames the top level eliminates (1: no level below it)
 int chain_top_stride(int n_frames) {

@@ -835,10 +835,15 @@ struct FinalLds { double gsum[(kMaxCams + 1) * kGStride]; double P[kMaxCams * 25
 // shader-clock stamps of k_reduced's phases (tools/dbg_stamps.py): profiling builds only (-DVC_REDUCED_STAMPS) -- each stamp is
 // a global store whose acknowledgement the next barrier waits for (~1.5k cycles apiece)
 #ifdef VC_REDUCED_STAMPS
-#define VC_STAMP(i) do { if (threadIdx.x == 0) v.dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+// (round 6: the stamps are kept in LDS and copied out at the kernel's end -- as global stores every stamp cost ~1.5k cycles at the next barrier)
+__shared__ long long s_rst[32];
+#define VC_STAMP(i) do { if (threadIdx.x == 0) s_rst[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define VC_STAMP(i) do { } while (0)
 #endif
+}  // namespace vc
+#include "vc_reduced_tail.hpp"
+namespace vc {
 // S: v.Sbuf, or (single process, D <= kSmallD) an LDS image of it that this phase fills first -- every read-modify-write of the
 // phase and the solve's row loads then stay on chip (three L2 round trips less on the critical path); the kernel writes it back.
 // top / top_rows (early Gram, DevView::gram_top_stride): the [Y | z] rows of the chain's top-level frames (LDS, 64 rows x kTopLd, zero
@@ -1036,14 +1041,18 @@ __device__ __forceinline__ void schur_final_phase(const DevView& v, int cur, Fin
 // (the arguments by value: a function that is not inlined and takes the DevView by reference makes its caller keep a copy of the
 //  whole record in scratch memory -- 1 KB per lane and a slower launch)
 struct SmallSolveArgs { int D; double* sscale2; double* sdiag; double* slam; int* bad_flag; long long* dbg; };
+#ifndef VC_SMALL_SOLVE_BCAST
+#define VC_SMALL_SOLVE_BCAST 1      // (0: pivot columns through v_readlane, the form of rounds 2-5 -- A/B builds)
+#endif
 template <int DMAX>
-__device__ __forceinline__ void solve_small_wave(const SmallSolveArgs v, const Ctrl* ct, int lane, double* Lt, double* x, double pre_sc2, double pre_dg, const double* S /* v.Sbuf or its LDS image */) {
+__device__ __forceinline__ void solve_small_wave(const SmallSolveArgs v, const Ctrl* ct, int lane, double* Lt, double* x, double pre_sc2, double pre_dg, const double* S /* v.Sbuf or its LDS image */,
+                                                 double* bc /* LDS, 2 x 64: the pivot column's broadcast image */) {
   const int D = v.D;
   constexpr int ldt = DMAX + 2;
   const double* gred = S + D * D;
   const double* hd = gred + D;
 #ifdef VC_REDUCED_STAMPS
-  if (lane == 0) v.dbg[8] = (long long)__builtin_readcyclecounter();
+  if (lane == 0) s_rst[8] = (long long)__builtin_readcyclecounter();
 #endif
   double row[DMAX];
   {
@@ -1052,6 +1061,9 @@ __device__ __forceinline__ void solve_small_wave(const SmallSolveArgs v, const C
 #pragma unroll
     for (int k = 0; k < DMAX; ++k) { double t = 0.0; if (k < D) t = rp[k]; row[k] = lane <= D ? t : 0.0; }
   }
+#if VC_SMALL_SOLVE_BCAST
+  double diag = lane < D ? S[lane * D + lane] : 0.0;      // row `lane`'s diagonal entry, kept apart (see the factorisation below)
+#endif
   double lam = 0.0;
   if (lane < D) {
     double sc2, dg;
@@ -1066,8 +1078,11 @@ __device__ __forceinline__ void solve_small_wave(const SmallSolveArgs v, const C
   }
 #pragma unroll
   for (int k = 0; k < DMAX; ++k) row[k] += (k == lane) ? lam : 0.0;
+#if VC_SMALL_SOLVE_BCAST
+  diag += lam;
+#endif
 #ifdef VC_REDUCED_STAMPS
-#define VC_SS(i) do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); if (lane == 0) v.dbg[8 + (i)] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define VC_SS(i) do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); if (lane == 0) s_rst[8 + (i)] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define VC_SS(i) do { } while (0)
 #endif
@@ -1078,6 +1093,60 @@ __device__ __forceinline__ void solve_small_wave(const SmallSolveArgs v, const C
   // j + 1's reciprocal square root.  Columns >= D only ever hold zeros (or, for column D, unused values): their steps run
   // on harmless operands (pivot forced to 1) and are not checked, so the loop needs no bound on j or k.
   bool bad = false;
+#if VC_SMALL_SOLVE_BCAST
+  // Round 6.  What a pivot costs is its DEPENDENT chain, and on a lone wavefront every link is ~10 cycles (a trip through LDS ~130): the
+  // v_readlane form paid 2 v_readlane + SGPR hazard + FMA per entry of the trailing update (~460 cycles per pivot at D = 29), and a first
+  // LDS-broadcast form put the LDS round trip of column j + 1 between pivot j and pivot j + 1 (~350).  Now:
+  //   * the DIAGONAL entry of row i lives in a register of its own (`diag`): it only ever needs the lane's own l_ij, so the next pivot is
+  //     one FMA and one v_readlane behind l_ij, and its reciprocal square root (v_rsq_f64 + two Newton steps; the pivot's sign is tested
+  //     beside it, not ahead of it) starts at once;
+  //   * column j + 1 -- the only one pivot j + 1 waits for -- takes l_(j+1)j through v_readlane;
+  //   * every other column takes the pivot column from an LDS broadcast image (one ds_write_b64 per lane, two entries per wave-uniform read)
+  //     and applies it ONE PIVOT LATE, behind the next pivot's chain: the LDS latency is never waited for.
+  // A row's updates arrive in another order than in the v_readlane form (column j + 1: pivot j ahead of pivot j - 1); no lane select for the
+  // pivot's own row: row j's entry j is the pivot itself (same FMAs as `diag`).
+  double ipiv;
+  {
+    const double d0 = readlane_f64(diag, 0);
+    const bool ok = d0 > 0.0;
+    bad |= (0 < D) & !ok;
+    const double y = fast_rsqrt(d0);
+    ipiv = ok ? y : 1.0;
+  }
+  double lprev = 0.0, bprev[DMAX];
+#pragma unroll
+  for (int k = 0; k < DMAX; ++k) bprev[k] = 0.0;
+#pragma unroll
+  for (int j = 0; j < DMAX; ++j) {
+    const double lij = row[j] * ipiv;
+    row[j] = lij * ipiv;      // what the back-substitution wants: column j of L over its diagonal entry (off the dependent chain)
+    if (j + 1 < DMAX) {
+      diag -= lij * lij;
+      const double dn = readlane_f64(diag, j + 1);
+      double bnew[DMAX];
+      if (j + 2 < DMAX) {
+        double* col = bc + (j & 1) * 64;
+        col[lane] = lij;
+        wave_lds_sync_local();
+#pragma unroll
+        for (int k = j + 2; k < DMAX; ++k) bnew[k] = col[k];
+      }
+      __builtin_amdgcn_sched_barrier(0);      // (the reads are ISSUED here -- the scheduler otherwise sinks them, and the store, to their uses one pivot later)
+      const bool ok = dn > 0.0;
+      bad |= (j + 1 < D) & !ok;
+      const double y = fast_rsqrt(dn);      // (of a pivot <= 0: inf / NaN, dropped by the select)
+      const double ipn = ok ? y : 1.0;
+      row[j + 1] -= lij * readlane_f64(lij, j + 1);
+      // pivot j - 1's column, read one pivot ago: columns j + 1 ..
+#pragma unroll
+      for (int k = j + 1; k < DMAX; ++k) row[k] -= lprev * bprev[k];
+      lprev = lij;
+#pragma unroll
+      for (int k = j + 2; k < DMAX; ++k) bprev[k] = bnew[k];
+      ipiv = ipn;
+    }
+  }
+#else
 #pragma unroll
   for (int j = 0; j < DMAX; ++j) {
     const double mine = row[j];
@@ -1091,6 +1160,7 @@ __device__ __forceinline__ void solve_small_wave(const SmallSolveArgs v, const C
 #pragma unroll
     for (int k = j + 1; k < DMAX; ++k) row[k] -= lij * readlane_f64(lij, k);
   }
+#endif
   VC_SS(2);
   if (bad && lane == 0) *v.bad_flag = 1;
   // column j of L / L_jj, contiguous over the rows (entries above the diagonal / beyond row D are never read; lanes past the
@@ -1187,6 +1257,52 @@ __device__ __forceinline__ void solve_large_blocked(const DevView& v, const Ctrl
       for (int k = 0; k < 16; ++k) row[k] = (lane < nb && k <= lane) ? M[tri(p0 + lane) + p0 + k] : ((k == lane) ? 1.0 : 0.0);
       bool bad = false;
       double my_dinv = 1.0;
+#if VC_SMALL_SOLVE_BCAST
+      // (round 6, as solve_small_wave: the diagonal entry in a register of its own, column j + 1 through v_readlane, the others through an
+      //  LDS broadcast image applied one pivot late; ~7.5k cycles per panel in the v_readlane form)
+      double diag = lane < nb ? M[tri(p0 + lane) + p0 + lane] : 1.0;
+      double ipiv;
+      {
+        const double d0 = readlane_f64(diag, 0);
+        const bool ok = d0 > 0.0;
+        bad |= !ok;
+        const double y = fast_rsqrt(d0);
+        ipiv = ok ? y : 1.0;
+      }
+      double lprev = 0.0, bprev[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) bprev[k] = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double lij = row[j] * ipiv;
+        row[j] = lij;
+        if (lane == j) my_dinv = ipiv;
+        if (j + 1 < 16) {
+          diag -= lij * lij;
+          const double dn = readlane_f64(diag, j + 1);
+          double bnew[16];
+          if (j + 2 < 16) {
+            double* col = red + (j & 1) * 64;
+            col[lane] = lij;
+            wave_lds_sync_local();
+#pragma unroll
+            for (int k = j + 2; k < 16; ++k) bnew[k] = col[k];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const bool ok = dn > 0.0;
+          bad |= !ok;
+          const double y = fast_rsqrt(dn);
+          const double ipn = ok ? y : 1.0;
+          row[j + 1] -= lij * readlane_f64(lij, j + 1);
+#pragma unroll
+          for (int k = j + 1; k < 16; ++k) row[k] -= lprev * bprev[k];
+          lprev = lij;
+#pragma unroll
+          for (int k = j + 2; k < 16; ++k) bprev[k] = bnew[k];
+          ipiv = ipn;
+        }
+      }
+#else
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         double d = readlane_f64(row[j], j);
@@ -1198,6 +1314,7 @@ __device__ __forceinline__ void solve_large_blocked(const DevView& v, const Ctrl
 #pragma unroll
         for (int k = j + 1; k < 16; ++k) row[k] -= lij * readlane_f64(lij, k);
       }
+#endif
       if (lane < 16) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) Lp[lane * 16 + k] = (k <= lane) ? row[k] : 0.0;
@@ -1310,13 +1427,13 @@ __device__ __forceinline__ void solve_large_blocked(const DevView& v, const Ctrl
     VC_PH(5);
   }
 #ifdef VC_REDUCED_STAMPS
-  if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) v.dbg[8 + i] = ph_[i];
+  if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) s_rst[8 + i] = ph_[i];
 #endif
 }
 
 __device__ __forceinline__ void reduced_solve_phase(const DevView& v, const Ctrl* ct, double* dyn, double* red /* 6 x 256 */, const double* s_cam,
                                     double pre_sc2, double pre_dg, const double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */,
-                                    const double* Sb /* v.Sbuf or its LDS image */, double pre_imu) {
+                                    const double* Sb /* v.Sbuf or its LDS image */, double pre_imu, const int* ipc /* LDS copy of v.imu_param_col */) {
   const int tid = threadIdx.x, D = v.D, cur = ct->cur;
   double* x;
   VC_STAMP(4);
@@ -1325,11 +1442,11 @@ __device__ __forceinline__ void reduced_solve_phase(const DevView& v, const Ctrl
     if (tid < 64 && D > 0) {
       // (every column up to DMAX is eliminated whether the matrix has it or not: instances close to the common widths)
       const SmallSolveArgs a = {D, v.sscale2, v.sdiag, v.slam, v.flags + 5 + 2 * v.par, v.dbg};
-      if (D <= 16) solve_small_wave<16>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb);
-      else if (D <= 24) solve_small_wave<24>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb);
-      else if (D <= 28) solve_small_wave<28>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb);
-      else if (D <= 30) solve_small_wave<30>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb);
-      else solve_small_wave<32>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb);
+      if (D <= 16) solve_small_wave<16>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb, red);
+      else if (D <= 24) solve_small_wave<24>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb, red);
+      else if (D <= 28) solve_small_wave<28>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb, red);
+      else if (D <= 30) solve_small_wave<30>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb, red);
+      else solve_small_wave<32>(a, ct, tid, dyn, x, pre_sc2, pre_dg, Sb, red);
     }
     __syncthreads();
   } else {
@@ -1340,102 +1457,17 @@ __device__ __forceinline__ void reduced_solve_phase(const DevView& v, const Ctrl
   const bool small = D <= kSmallD;      // the one-wavefront solve left damping and g_s in LDS behind x
   const double* gs = small ? x + 2 * (kSmallD + 1) : v.Sbuf + (size_t)D * D + 2 * D;
   const double* lamv = small ? x + (kSmallD + 1) : v.slam;
-  double gd = 0, dld = 0, step2 = 0, x2 = 0, g2 = 0, gmax = 0;
-  for (int i = tid; i < D; i += 256) {
-    const double d = x[i], g = gs[i];
-    v.delta_s[i] = d;
-    gd += g * d; dld += lamv[i] * d * d; g2 += g * g; gmax = fmax(gmax, fabs(g));
-  }
-  // D <= 64: every term lives in wavefront 0 (the IMU parameters move to its lane 63) -- no staging through LDS, no barriers
-  const bool one_wave = D <= 64;
-  if (one_wave) { if (tid < 64) for (int i = tid; i < v.n_cams * kCamStride; i += 64) v.cams[1 - cur][i] = s_cam[i]; }
-  else {
-    for (int i = tid; i < v.n_cams * kCamStride; i += 256) v.cams[1 - cur][i] = s_cam[i];
-    __syncthreads();
-  }
-  if (tid < v.n_cams) {
-    const int c = tid;
-    const double* cin = s_cam + (size_t)c * kCamStride;
-    double* cout = v.cams[1 - cur] + (size_t)c * kCamStride;
-    const int flags = cd[c].flags, nk = model_nk(cd[c].model);
-    int cc = cd[c].col0;
-    if (flags & kCamRotFree) {
-      double q[4], w[3] = {x[cc], x[cc + 1], x[cc + 2]}, qi[4] = {cin[0], cin[1], cin[2], cin[3]};
-      so3_plus(qi, w, q);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { const double e = q[i] - qi[i]; step2 += e * e; x2 += qi[i] * qi[i]; cout[i] = q[i]; }
-      cc += 3;
+  if (v.tail_deferred) {
+    // (round 6) the back-substitution's launch carries the rest (reduced_tail, one extra workgroup): this kernel -- one workgroup the whole
+    // chip waits for -- ends with the step and the trial IMU parameters (which the second stream's k_imu_block(trial) starts from)
+    for (int i = tid; i < D; i += 256) v.delta_s[i] = x[i];
+    if (v.imu_on && (tid >> 6) == (D <= 64 ? 0 : 1) && (tid & 63) < 16) {
+      const int a = tid & 63, col = a < 15 ? ipc[a] : -1;
+      v.imus[1 - cur][a] = pre_imu + (col >= 0 ? x[col] : 0.0);      // (g(2) b(6) sf(6) toff(1): plain additive parameters; entry 15: padding)
     }
-    if (flags & kCamTransFree) {
-      for (int i = 0; i < 3; ++i) { const double d = x[cc + i], o = cin[4 + i]; step2 += d * d; x2 += o * o; cout[4 + i] = o + d; }
-      cc += 3;
-    }
-    if (flags & kCamKFree) {
-      for (int i = 0; i < nk; ++i) { const double d = x[cc + i], o = cin[kCamK + i]; step2 += d * d; x2 += o * o; cout[kCamK + i] = o + d; }
-    }
+    return;
   }
-  double o[16];      // accepted IMU parameters: requested at kernel entry by lanes 0..15 of this thread's wavefront
-  if (v.imu_on && (tid >> 6) == (one_wave ? 0 : 1)) {
-#pragma unroll
-    for (int a = 0; a < 16; ++a) o[a] = readlane_f64(pre_imu, a);
-  }
-  if (v.imu_on && tid == (one_wave ? 63 : 64)) {     // g(2) b(6) sf(6) toff(1): plain additive parameters
-    double* iout = v.imus[1 - cur];
-    // all loads first, then the arithmetic, then the stores: interleaved, every store would hold back the next element's loads
-    // (the compiler cannot tell the two buffers apart) -- 15 dependent memory round trips in the tail of a critical-path kernel
-    double dlt[15];
-#pragma unroll
-    for (int a = 0; a < 15; ++a) { const int col = v.imu_param_col[a]; dlt[a] = (col >= 0) ? x[col >= 0 ? col : 0] : 0.0; }
-#pragma unroll
-    for (int a = 0; a < 15; ++a) {
-      if (v.imu_param_col[a] >= 0) { step2 += dlt[a] * dlt[a]; x2 += o[a] * o[a]; }
-      iout[a] = o[a] + dlt[a];
-    }
-    iout[15] = o[15];
-  }
-  double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;      // totals, valid in thread 0
-  if (one_wave) {
-    if (tid < 64) {
-      const double in6[6] = {gd, dld, step2, x2, g2, 0.0};
-      double out6[6];
-      wave_sum6(in6, out6, tid);
-      t0 = out6[0]; t1 = out6[1]; t2 = out6[2]; t3 = out6[3]; t4 = out6[4]; t5 = gmax;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) t5 = fmax(t5, __shfl_down(t5, o, 64));
-    }
-  } else {
-    // only threads < max(D, 65) hold terms: stage them, one wavefront adds them in fixed order
-    red[tid] = gd; red[256 + tid] = dld; red[512 + tid] = step2; red[768 + tid] = x2; red[1024 + tid] = g2; red[1280 + tid] = gmax;
-    __syncthreads();
-    if (tid < 64) {
-      double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = tid + 64 * q;
-        a0 += red[i]; a1 += red[256 + i]; a2 += red[512 + i]; a3 += red[768 + i]; a4 += red[1024 + i]; a5 = fmax(a5, red[1280 + i]);
-      }
-      t0 = wave_sum(a0); t1 = wave_sum(a1); t2 = wave_sum(a2); t3 = wave_sum(a3); t4 = wave_sum(a4); t5 = a5;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) t5 = fmax(t5, __shfl_down(t5, o, 64));
-    }
-  }
-  VC_STAMP(6);
-  if (tid == 0) {
-    double* h = v.scal + kNumScal;
-    h[kScGd] = t0; h[kScDld] = t1; h[kScStep2] = t2; h[kScX2] = t3; h[kScG2] = t4;
-    h[kScCost] = 0.0; h[kScGmax] = t5; h[kScSq] = 0.0;
-    if (v.merged) {
-      // frames without observations take no part in k_trial: their parameter norm (chunk sums in the Schur partials) is
-      // added here; then flag the record (a trial point is about to exist) and clear the failure flags of the next pass
-      // (x2_noobs: that sum, left in LDS by phase A when it ran in this launch)
-      double x2 = 0.0;
-      if (x2_noobs) x2 = *x2_noobs;
-      else x2 = v.part_total[v.part_stride - 2];
-      h[kScX2] += x2;
-      v.ctrl->needs_decision = 1;
-      v.flags[4 + 2 * (1 - v.par)] = 0; v.flags[5 + 2 * (1 - v.par)] = 0;
-    }
-  }
+  reduced_tail(v, cur, x, gs, lamv, s_cam, cd, ipc, pre_imu, x2_noobs, red, true, true);
 }
 
 // mode 0: phase A + phase B in one launch (single process); 1: phase A only (an all-reduce of Sbuf follows);
@@ -1446,6 +1478,7 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   __shared__ double s_cam[kMaxCams * kCamStride];     // accepted camera records: requested at kernel entry, used by the tail
   __shared__ double s_x2;
   __shared__ CamDesc s_cd[kMaxCams];     // the kernel-argument table costs a scalar memory round trip per (dynamically indexed) access
+  __shared__ int s_ipc[16];              // ... and so does DevView::imu_param_col (as 15 s_load_dword, one per use, it was 3.6k cycles of the tail)
   const Ctrl* ct = v.ctrl;
   __shared__ double s_S[kSmallD * kSmallD + 3 * kSmallD + 2];      // single process, D <= kSmallD: the reduced system stays in LDS between the phases
   // early Gram: [Y | z] rows of the chain's top-level frames, behind phase A's record in the dynamic region (static LDS is at its limit
@@ -1466,6 +1499,7 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   }
   if (ct->done) { if (threadIdx.x == 0 && mode != 1) signal_flag(v, 1); return; }
   if (threadIdx.x < kMaxCams) s_cd[threadIdx.x] = v.cd[threadIdx.x];
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + 15) s_ipc[threadIdx.x - 64] = v.imu_param_col[threadIdx.x - 64];
   if (early) {
 #pragma unroll
     for (int u = 0; u < 9; ++u) { const int idx = threadIdx.x + 256 * u; if (idx < 64 * kTopLd) s_top[idx] = tin[u]; }
@@ -1484,8 +1518,13 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
     // Sbuf keeps its meaning for k_final (cost slot) and the parity hooks: written back off the critical path
     for (int e = threadIdx.x; e < v.D * v.D + 3 * v.D + 2; e += 256) v.Sbuf[e] = s_S[e];
   } else if (mode != 2) { schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2, s_cd, v.Sbuf, false); __syncthreads(); }
-  if (mode != 1) reduced_solve_phase(v, ct, dyn, red, s_cam, pre_sc2, pre_dg, mode == 0 ? &s_x2 : nullptr, s_cd, s_in_lds ? s_S : v.Sbuf, pre_imu);
+  if (mode != 1) reduced_solve_phase(v, ct, dyn, red, s_cam, pre_sc2, pre_dg, mode == 0 ? &s_x2 : nullptr, s_cd, s_in_lds ? s_S : v.Sbuf, pre_imu, s_ipc);
   if (mode != 1) { __syncthreads(); if (threadIdx.x == 0) signal_flag(v, 1); }      // the trial IMU parameters exist (stream B's deltas wait for this)
+#ifdef VC_REDUCED_STAMPS
+  VC_STAMP(7);
+  __syncthreads();
+  if (threadIdx.x < 32) v.dbg[threadIdx.x] = s_rst[threadIdx.x];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ trial point

@@ -28,7 +28,7 @@ int vc_calibrator::launch_pass_graph() {
 int vc_calibrator::enqueue_pass(bool first_pass, bool events_only) {
   RoctxRange rr(first_pass ? "vicalib_amd: LM pass (first of a solve: + linearisation)" : "vicalib_amd: LM pass");
   const int D = dv.D;
-  dv.merged = 0; dv.par = 0; dv.ctrl = d_ctrl.p; dv.ctrl_prev = d_ctrl.p + 1;
+  dv.merged = 0; dv.par = 0; dv.ctrl = d_ctrl.p; dv.ctrl_prev = d_ctrl.p + 1; dv.tail_deferred = 0;
   if (dv.imu_on) {
     // UpdateImuWeights of the iteration callback (vicalibrator.h:691): linearise with the current weights, evaluate the
     // trial point with the updated ones.  The pass is a small graph over two streams: the weight update (which only needs the
@@ -97,6 +97,9 @@ int vc_calibrator::enqueue_pass(bool first_pass, bool events_only) {
     else if (top_gram_launch) KT("k_chain_gram(top)", launch_chain_gram_top(dv, stream));
     KT("k_part_sum", launch_part_sum(dv, stream));
     int rc = VC_OK;
+    // (round 6) the reduced solve's tail rides in the back-substitution's launch where that is one launch of k_chain_back_path
+    static const bool defer_env = [] { const char* e = std::getenv("VICALIB_AMD_DEFER_TAIL"); return !(e && e[0] == '0'); }();
+    dv.tail_deferred = (defer_env && chain_back_is_path(dv)) ? 1 : 0;
     if (sharded()) {
       KT("k_reduced(assemble)", launch_reduced(dv, 1, stream));
       KT("allreduce(S)", rc = do_allreduce(dv.Sbuf, D * D + 3 * D + 2, 0)); if (rc) return rc;
