@@ -95,7 +95,7 @@ struct vc_calibrator {
       d_col_cam, d_col_local, d_flags;
   DBuf<double> d_wgpart;
   int kpass = 0;                  // passes enqueued since init_ctrl (merged mode: selects the control record and flag parity)
-  DBuf<double> d_pose[2], d_cam[2], d_G[2], d_tile_cost[2], d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_sdiag,
+  DBuf<double> d_pose[2], d_cam[2], d_G[2], d_tile_cost[2], d_Y, d_fr, d_fdiag, d_fscale2, d_part, d_Sbuf, d_hadd, d_sdiag,
       d_sscale2, d_slam, d_delta_s, d_fpart, d_scal, d_tmp, d_pose_init, d_cam_init, d_tile_trial, d_trace, d_part_total;
   DBuf<Ctrl> d_ctrl;
   DBuf<double> d_vel[2], d_imus[2], d_imu_t, d_imu_w, d_imu_a, d_frame_time, d_wsqrt[2], d_seg[2], d_seg_cost[2],

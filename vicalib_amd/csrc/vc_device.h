@@ -214,6 +214,10 @@ struct DevView {
   // step scalars (vc_reduced_tail.hpp) are formed by one extra workgroup of the back-substitution's launch (k_chain_back_path).  Set per pass
   // by enqueue_pass (chain_back_is_path)
   int tail_deferred;
+  // (round 6) the camera blocks, the IMU-parameter block and the chunk costs of the reduced system, formed ahead of k_reduced by side jobs of
+  // the chain's upper-level launches (vc_shared_blocks.hpp): hadd has Sbuf's layout; hadd_early = 1: this pass's k_reduced starts from Sbuf + hadd
+  double* hadd;
+  int hadd_early;
 };
 
 // launchers (vc_kernels.hip); all asynchronous on `s`
@@ -227,6 +231,7 @@ void launch_final(const DevView& v, int mode, hipStream_t s);
 int chain_forward_launches(const DevView& v);      // launches of the chain's forward elimination (levels + top)
 int chain_top_stride(int n_frames);                // stride of the frames the chain's top level eliminates
 bool chain_fold_supported(int n_frames, int D, int n_cams);      // k_chain_l0 can serve this problem (vc_imu_kernels.hip)
+bool chain_hadd_early(const DevView& v);           // the forward elimination of this problem has the two launches above the bottom level that carry the side jobs of DevView::hadd
 bool chain_back_is_path(const DevView& v);         // the back-substitution of this problem is one launch of k_chain_back_path with >= 256 threads per workgroup (it can carry the reduced solve's tail)
 // a segment of a packed upload: `bytes` (a multiple of 4) from offset src_off of the staging image to dst; src_off = ~0: zero-fill
 struct UnpackSeg { unsigned long long dst, src_off, bytes; };

@@ -34,6 +34,7 @@
 #include "vc_device.h"
 #include "vc_kutil.hpp"
 #include "vc_reduced_tail.hpp"
+#include "vc_shared_blocks.hpp"
 
 namespace vc {
 
@@ -1469,6 +1470,9 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(DevView v, int s, int m, 
 __device__ __forceinline__ double ld_boff(const double* base, unsigned boff) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff); }
 __device__ __forceinline__ void st_boff(double* base, unsigned boff, double x) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = x; }
 struct ElimLds { double* XS; double* An; double* Ls; };
+#ifndef VC_ELIM_STORE_BOFF
+#define VC_ELIM_STORE_BOFF 0      // (1: the solved image stored through scalar base + byte offsets as well -- same-box A/B: the folded bottom level 28.0 -> 30.0 us, the upper levels unchanged)
+#endif
 template <bool WG_SYNC>
 __device__ __forceinline__ void chain_eliminate(const DevView& v, double* img /* the frame's image */, int ldx, int role, int pc, int sub, bool flag_lane,
                                                 const ElimLds& M, double* x, double* out, long long* stamp = nullptr /* profiling builds: phase stamps of this call */) {
@@ -1546,9 +1550,15 @@ __device__ __forceinline__ void chain_eliminate(const DevView& v, double* img /*
 #pragma unroll
     for (int k = 0; k < 9; ++k) { lv[k] = rl[k]; xv[k] = rx[k * kXsLd]; }
     if (role < 4) {
+#if VC_ELIM_STORE_BOFF
       const unsigned pcb = 8u * (unsigned)pc, ldxb = 8u * (unsigned)ldx;
 #pragma unroll
       for (int k = 0; k < 9; ++k) st_boff(img, pcb + k * ldxb, role == 2 ? lv[k] : x[k]);       // (A: L[k][sub], zero above the diagonal)
+#else
+      double* ic = img + pc;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) ic[k * ldx] = role == 2 ? lv[k] : x[k];       // (A: L[k][sub], zero above the diagonal)
+#endif
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) x[k] = role == 2 ? xv[k] : x[k];
@@ -1592,12 +1602,15 @@ template <int NW>
 #ifndef VC_FWD2_WAVES
 #define VC_FWD2_WAVES 1
 #endif
-__global__ __launch_bounds__(128 * NW, VC_FWD2_WAVES) void k_chain_fwd2(DevView v, int s, int m, int lvl) {
+__global__ __launch_bounds__(128 * NW, VC_FWD2_WAVES) void k_chain_fwd2(DevView v, int s, int m, int lvl, int n_groups) {
   constexpr int W = 64 * NW;
   __shared__ __attribute__((aligned(16))) double XS2[2][9 * kXsLd];
   __shared__ double An2[2][81], Ls2[2][81];
   __shared__ double MID[9 * W];      // right sweep -> wavefront 0: its update of the middle frame (W, A columns) and the middle's coupling to r
   __shared__ double SEPR[9 * W];     // the right sweep's accumulated update of r
+  // (round 6) workgroups behind the level's groups: a side job -- the chunk records' camera / IMU / cost entries summed into part_total while
+  // the level leaves most of the chip idle (vc_shared_blocks.hpp; DevView::hadd_early)
+  if ((int)blockIdx.x >= n_groups) { part_tail_sum_job(v, (int)blockIdx.x - n_groups, MID, 128 * NW); return; }
   // (the wavefront's index as a scalar: everything that depends on it -- sweep direction, frame count, addresses -- stays uniform)
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wave = wv / NW /* the sweep */, lane = threadIdx.x & 63, group = blockIdx.x;
   auto gsync = [&]() { if (NW > 1) __syncthreads(); else wave_lds_sync_local(); };
@@ -3049,6 +3062,9 @@ __global__ __launch_bounds__(256) void k_chain_top_gram(DevView v, int s, int m,
     chain_fwd_group<1, NW>(v, s, m, 1, lvl, 0, (int)(threadIdx.x >> 6), XS, An, Ls_all);
     return;
   }
+  // (round 6) the workgroup behind the chunks: the camera blocks, the IMU block and the chunk costs of the reduced system, formed here -- beside the
+  // top level's dependent eliminations -- instead of inside k_reduced (vc_shared_blocks.hpp; DevView::hadd_early)
+  if ((int)blockIdx.x == 1 + v.n_chunks) { hadd_side_job(v, R, 256); return; }
   chain_gram_chunk<NQ, NL>(v, (int)blockIdx.x - 1, R, s_pair, v.gram_top_stride);
 }
 
@@ -3119,8 +3135,10 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
   auto fwd = [&](int groups, int stride, int m, int top, int lvl) {
     const bool side_by_side = cpl > 1 && !columns_per_lane;
     if (!top && two_at(lvl)) {
-      if (cpl <= 1) hipLaunchKernelGGL(k_chain_fwd2<1>, dim3(groups), dim3(128), 0, s, v, stride, m, lvl);
-      else hipLaunchKernelGGL(k_chain_fwd2<2>, dim3(groups), dim3(256), 0, s, v, stride, m, lvl);
+      // (hadd_early: the first launch above the bottom level carries the sums of the chunk records' entries behind S and g_red)
+      const int extra = (v.hadd_early && lvl == 1) ? (v.part_stride - (v.D * v.D + v.D) + 15) / 16 : 0;
+      if (cpl <= 1) hipLaunchKernelGGL(k_chain_fwd2<1>, dim3(groups + extra), dim3(128), 0, s, v, stride, m, lvl, groups);
+      else hipLaunchKernelGGL(k_chain_fwd2<2>, dim3(groups + extra), dim3(256), 0, s, v, stride, m, lvl, groups);
     }
     else if (cpl <= 1) hipLaunchKernelGGL((k_chain_fwd<1, 1>), dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
     else if (side_by_side) {
@@ -3143,12 +3161,12 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
     const bool side_by_side_top = cpl <= 1 || !columns_per_lane;
     if (v.gram_top_stride > 0 && side_by_side_top) {
       // early Gram: the top level's one group and the Gram sums of all frames below it in one launch
-      const size_t lds = (size_t)36 * v.ldw * sizeof(double);
+      const size_t lds = std::max((size_t)36 * v.ldw, (size_t)(v.hadd_early ? kHaddLds : 0)) * sizeof(double);
       const int nT = (v.D + 1 + 15) / 16, nPairs = nT * (nT + 1) / 2, nq = std::min(kMaxPairsPerWaveI, (nPairs + 3) / 4);
       const int nlr = (36 * v.ldw + 255) / 256;
       auto go = [&](auto kern) {
         if (lds > 40000) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(1 + v.n_chunks), dim3(256), lds, s, v, top_stride, m_top, nl);
+        hipLaunchKernelGGL(kern, dim3(1 + v.n_chunks + (v.hadd_early ? 1 : 0)), dim3(256), lds, s, v, top_stride, m_top, nl);
       };
       // (wavefronts of the top group by the border's width, Gram instance by the row image's size: the pairs that occur)
       if (cpl <= 1) { if (nq <= 1) go(k_chain_top_gram<1, 1, 7>); else go(k_chain_top_gram<1, 2, 7>); }
@@ -3216,6 +3234,26 @@ bool chain_fold_supported(int n_frames, int D, int n_cams) {
   static const bool two_env = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO"); return !(e && std::atoi(e) == 0); }();
   static const bool two_bottom = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO_BOTTOM"); return !(e && std::atoi(e) == 0); }();
   return two_env && two_bottom && chain_group_size() == kChainM && D + 1 + 27 <= 64 && n_cams <= 2 && (n_frames - 1) + 1 > kChainM - 1;
+}
+// The forward elimination has the two launches above the bottom level that carry the side jobs of DevView::hadd (vc_shared_blocks.hpp): a
+// two-sided level 1 (k_chain_fwd2: the sums of the chunk records' entries behind S and g_red) and the top level with the early Gram sums
+// (k_chain_top_gram: the record itself).  Mirrors chain_levels.
+bool chain_hadd_early(const DevView& v) {
+  if (!v.imu_on || v.world > 1 || !v.hadd || v.gram_top_stride <= 0 || v.n_frames < 1) return false;
+  static const bool two_env = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO"); return !(e && std::atoi(e) == 0); }();
+  static const bool columns_per_lane = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_WAVES"); return e && std::atoi(e) == 0; }();
+  const int cpl = (v.D + 1 + 27 + 63) / 64;
+  if (!two_env || cpl > 2 || (cpl > 1 && columns_per_lane) || chain_group_size_upper() < 4) return false;
+  int nl = 0; long st = 1, st1 = 1;
+  while (true) {
+    const int m = nl == 0 ? chain_group_size() : chain_group_size_upper();
+    if (!((v.n_frames - 1) / st + 1 > m - 1)) break;
+    if (nl == 1) st1 = st;
+    ++nl; st *= m;
+  }
+  if (nl < 2) return false;
+  const long groups1 = ((long)v.n_frames - 1) / (st1 * chain_group_size_upper()) + 1;
+  return cpl <= 1 || groups1 <= 256;      // (two_at(1))
 }
 // the back-substitution is one launch of k_chain_back_path (chain_levels, backward) whose workgroups have at least 256 threads
 bool chain_back_is_path(const DevView& v) {

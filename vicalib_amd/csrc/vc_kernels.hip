@@ -843,16 +843,99 @@ __shared__ long long s_rst[32];
 #endif
 }  // namespace vc
 #include "vc_reduced_tail.hpp"
+#include "vc_shared_blocks.hpp"
 namespace vc {
 // S: v.Sbuf, or (single process, D <= kSmallD) an LDS image of it that this phase fills first -- every read-modify-write of the
 // phase and the solve's row loads then stay on chip (three L2 round trips less on the critical path); the kernel writes it back.
 // top / top_rows (early Gram, DevView::gram_top_stride): the [Y | z] rows of the chain's top-level frames (LDS, 64 rows x kTopLd, zero
 // beyond the rows and beyond column D) -- their Gram sums are subtracted here
 constexpr int kTopLd = 34;
-__device__ __forceinline__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */, double* S, bool s_in_lds,
-                                                  const double* top = nullptr, int top_rows = 0) {
+// the top-level frames' Gram sums (early Gram, D + 1 <= 32 columns): S -= Y^T Y, g_red -= Y^T z on the matrix pipe.  The (at most 64, zero-padded) rows are
+// the k dimension, the column tiles (0,0), (0,1), (1,1) one wavefront each (v_mfma_f64_16x16x4; entries (i, j) and (j, i) are the same products in the same
+// order: S stays symmetric to the bit).  (As a scalar loop -- thread per entry, two LDS reads per row and entry -- this took 6 us: 0.7 MB through the LDS pipe.)
+__device__ __forceinline__ void top_gram_subtract(double* S, int D, const double* top, int top_rows) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (wave < 3) {
+    const int I = wave == 2 ? 1 : 0, J = wave == 0 ? 0 : 1;
+    const double* pa = top + (lane >> 4) * kTopLd + I * 16 + (lane & 15);
+    const double* pb = top + (lane >> 4) * kTopLd + J * 16 + (lane & 15);
+    // (four accumulators over the 16 k-steps of the 64 padded rows: the instruction's ~300 cycles of latency four times, not sixteen)
+    v4d ac[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ac[u] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 4) {
+      if (4 * ks < top_rows) {      // (wave-uniform)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ac[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(ks + u) * 4 * kTopLd], pb[(ks + u) * 4 * kTopLd], ac[u], 0, 0, 0);
+      }
+    }
+    const v4d acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = I * 16 + (lane >> 4) + 4 * g, col = J * 16 + (lane & 15);
+      if (row < D) {
+        if (col < D) { S[row * D + col] -= acc[g]; if (I != J) S[col * D + row] -= acc[g]; }
+        else if (col == D) S[D * D + row] -= acc[g];
+      }
+    }
+  }
+}
+// rows of the pinned frames of a sharded chain (separator of this rank, ghost of the next rank's): straight into the reduced system
+__device__ __forceinline__ void pinned_rows_phase(const DevView& v, double* S, double* gred, double* hd, double* gs) {
+  const int tid = threadIdx.x, D = v.D;
+  for (int slot = 0; slot < 2; ++slot) {
+    if (!(slot ? v.pin_last : v.pin_first)) continue;
+    const int sc = slot ? v.sep_col1 : v.sep_col0;
+    const double* st = v.sep_strip + (size_t)slot * 9 * v.ldw;
+    for (int e = tid; e < 9 * (D + 1); e += 256) {
+      const int i = e / (D + 1), col = e % (D + 1);
+      const double val = st[i * v.ldw + col];
+      if (col == D) { gred[sc + i] += val; gs[sc + i] += val; }
+      else if (col < sc) { const double sn = S[col * D + sc + i] + val; S[col * D + sc + i] = sn; S[(sc + i) * D + col] = sn; }
+      else if (col >= sc + i) {            // each pair once, both triangles written
+        const double sn = S[(sc + i) * D + col] + val;
+        S[(sc + i) * D + col] = sn;
+        if (col == sc + i) hd[sc + i] += val; else S[col * D + sc + i] = sn;
+      }
+    }
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ void schur_final_phase(const DevView& v, int cur, FinalLds& L, double* x2_noobs, const CamDesc* cd /* LDS copy of v.cd */, const int* ipc /* ... of v.imu_param_col */,
+                                                  double* S, bool s_in_lds, const double* top = nullptr, int top_rows = 0) {
   VC_STAMP(0);
   const int tid = threadIdx.x, D = v.D, C = v.n_cams;
+  if (v.hadd_early) {
+    // (round 6) the camera blocks, the IMU block and the chunk costs were formed ahead of this launch (DevView::hadd, vc_shared_blocks.hpp): the
+    // reduced system is Sbuf (the frames' partial sums, k_part_sum) + that record, minus the top-level frames' Gram sums
+    const double* H = v.hadd;
+    const int nS = D * D + D, nAll = nS + 2 * D + 2;
+    if (s_in_lds) {
+      constexpr int kAIter = (kSmallD * kSmallD + 3 * kSmallD + 2 + 255) / 256;
+      double s_in[kAIter], h_in[kAIter];
+#pragma unroll
+      for (int q = 0; q < kAIter; ++q) { const int e = tid + 256 * q; s_in[q] = e < nS ? v.Sbuf[e] : 0.0; h_in[q] = e < nAll ? H[e] : 0.0; }
+#pragma unroll
+      for (int q = 0; q < kAIter; ++q) { const int e = tid + 256 * q; if (e < nAll) S[e] = s_in[q] + h_in[q]; }
+      if (top) { __syncthreads(); top_gram_subtract(S, D, top, top_rows); }
+    } else {
+      // (eight entries per thread and round: all loads out before the first store -- the compiler cannot tell S and H apart, a plain loop is one
+      //  memory round trip per entry: 14.7k cycles at D = 67)
+      for (int e0 = tid; e0 < nAll; e0 += 8 * 256) {
+        double a[8], h[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int e = e0 + 256 * q; a[q] = e < nS ? S[e] : 0.0; h[q] = e < nAll ? H[e] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int e = e0 + 256 * q; if (e < nAll) S[e] = a[q] + h[q]; }
+      }
+    }
+    VC_STAMP(1); VC_STAMP(2); VC_STAMP(3);
+    __syncthreads();
+    if (v.imu_on) pinned_rows_phase(v, S, S + D * D, S + nS, S + nS + D);
+    return;
+  }
   // (all of a thread's loads go out before the first is stored to LDS: a plain copy loop is one memory round trip per iteration)
   constexpr int kSIter = (kSmallD * kSmallD + kSmallD + 255) / 256;
   double s_in[kSIter];
@@ -884,149 +967,16 @@ __device__ __forceinline__ void schur_final_phase(const DevView& v, int cur, Fin
   if (s_in_lds) {
 #pragma unroll
     for (int q = 0; q < kSIter; ++q) { const int e = tid + 256 * q; if (e < D * D + D) S[e] = s_in[q]; }
-    if (top) {
-      // S -= sum over the top-level frames of Y^T Y, g_red -= Y^T z, on the matrix pipe: the (at most 64, zero-padded) rows are the k
-      // dimension, the column tiles (0,0), (0,1), (1,1) of the D + 1 <= 32 columns (kEarlyTopD) one wavefront each (v_mfma_f64_16x16x4; entries (i, j)
-      // and (j, i) are the same products in the same order: S stays symmetric to the bit).  (As a scalar loop -- thread per entry, two LDS
-      // reads per row and entry -- this took 6 us: 0.7 MB through the LDS pipe.)
-      __syncthreads();
-      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-      if (wave < 3) {
-        const int I = wave == 2 ? 1 : 0, J = wave == 0 ? 0 : 1;
-        const double* pa = top + (lane >> 4) * kTopLd + I * 16 + (lane & 15);
-        const double* pb = top + (lane >> 4) * kTopLd + J * 16 + (lane & 15);
-        // (four accumulators over the 16 k-steps of the 64 padded rows: the instruction's ~300 cycles of latency four times, not sixteen)
-        v4d ac[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ac[u] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 16; ks += 4) {
-          if (4 * ks < top_rows) {      // (wave-uniform)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ac[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(ks + u) * 4 * kTopLd], pb[(ks + u) * 4 * kTopLd], ac[u], 0, 0, 0);
-          }
-        }
-        const v4d acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = I * 16 + (lane >> 4) + 4 * g, col = J * 16 + (lane & 15);
-          if (row < D) {
-            if (col < D) { S[row * D + col] -= acc[g]; if (I != J) S[col * D + row] -= acc[g]; }
-            else if (col == D) S[D * D + row] -= acc[g];
-          }
-        }
-      }
-    }
+    if (top) { __syncthreads(); top_gram_subtract(S, D, top, top_rows); }
   }
   VC_STAMP(1);
   for (int i = tid; i < D; i += 256) { hd[i] = 0.0; gs[i] = 0.0; }
   if (tid == 0) { sc[0] = 0.5 * ptot[stride - 1]; sc[1] = 0.0; }      // chunk costs (the chain path's k_chain_init fills the same slot)
   __syncthreads();
   VC_STAMP(2);
-  // camera blocks H_cc = P^T G P, g_c = P^T G[:, r]   (P: u-columns -> shared columns of the camera).  A column of P is either a
-  // unit vector (translation and intrinsics columns) or -R's column a in rows 3..5 (rotation columns): at most three non-zeros, so
-  // thread (b, a) forms its entry directly from at most nine entries of G -- no intermediate product, no barrier between the
-  // cameras, every LDS read of the phase independent of the others (round 2's P / G P / P^T (G P) passes: 5.5k cycles per camera).
-  if (tid < C) { double R[9]; quat_to_R(L.camq + 4 * tid, R);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) L.P[tid * 256 + k] = R[k]; }
-  __syncthreads();
-  {
-    // the cameras' blocks are disjoint: every camera's old entries are requested before the first one is written back (one
-    // memory round trip for the phase instead of one per camera)
-    const int b = tid >> 4, a = tid & 15;
-    double so[kMaxCams], go[kMaxCams];
-#pragma unroll
-    for (int c = 0; c < kMaxCams; ++c) {
-      so[c] = 0.0; go[c] = 0.0;
-      if (c < C) {
-        const int nc = cam_ncols(cd[c].flags, model_nk(cd[c].model)), c0 = cd[c].col0;
-        if (a < nc && b < nc && a >= b) so[c] = S[(c0 + b) * D + c0 + a];
-        if (b == 15 && a < nc) go[c] = gred[c0 + a];
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < kMaxCams; ++c)
-      if (c < C) {
-        const int flags = cd[c].flags, nk = model_nk(cd[c].model);
-        const int nc = cam_ncols(flags, nk), c0 = cd[c].col0;
-        const int nrot = (flags & kCamRotFree) ? 3 : 0, ntr = (flags & kCamTransFree) ? 3 : 0;
-        const double* G = L.gsum + c * kGStride;
-        const double* R = L.P + c * 256;
-        // column q of P: rows r0 + {0, 1, 2} with coefficients cf[] (unit columns: one row, the other two coefficients zero and
-        // their rows kept in range)
-        int ra, rb; double ca[3], cb[3];
-        {
-          const bool rot = a < nrot;
-          const int col = a < nc ? a : 0;
-          ra = rot ? 3 : (col < nrot + ntr ? col - nrot : 6 + (col - nrot - ntr));
-          ca[0] = rot ? -R[col] : 1.0; ca[1] = rot ? -R[3 + col] : 0.0; ca[2] = rot ? -R[6 + col] : 0.0;
-        }
-        {
-          const bool rot = b < nrot;
-          const int col = b < nc ? b : 0;
-          rb = rot ? 3 : (col < nrot + ntr ? col - nrot : 6 + (col - nrot - ntr));
-          cb[0] = rot ? -R[col] : 1.0; cb[1] = rot ? -R[3 + col] : 0.0; cb[2] = rot ? -R[6 + col] : 0.0;
-        }
-        const int sa = (a < nrot) ? 1 : 0, sb = (b < nrot) ? 1 : 0;      // row step: 1 for rotation columns, 0 for unit columns
-        if (a < nc && b < nc && a >= b) {
-          double s = 0.0;
-#pragma unroll
-          for (int x = 0; x < 3; ++x) {
-            double t = 0.0;
-#pragma unroll
-            for (int y = 0; y < 3; ++y) t += ca[y] * G[(rb + sb * x) * 16 + ra + sa * y];
-            s += cb[x] * t;
-          }
-          S[(c0 + b) * D + c0 + a] = so[c] + s;
-          if (a == b) hd[c0 + a] = s; else S[(c0 + a) * D + c0 + b] = so[c] + s;      // (S is symmetric on entry and stays so)
-        }
-        if (b == 15 && a < nc) {
-          double gca = 0.0;
-#pragma unroll
-          for (int y = 0; y < 3; ++y) gca += ca[y] * gram_grad(G, ra + sa * y, nk);
-          gred[c0 + a] = go[c] + gca; gs[c0 + a] = gca;
-        }
-      }
-  }
-  __syncthreads();
+  shared_blocks_phase(v, 256, L.gsum, L.P, L.camq, cd, ipc, S, gred, hd, gs);
   VC_STAMP(3);
-  if (v.imu_on) {      // shared IMU parameters: sum over the blocks of their 15 x 15 Hessian and gradient
-    const double* Hi = L.gsum + C * kGStride;
-    const int a = tid >> 4, b = tid & 15;
-    if (a < 15) {
-      const int ca = v.imu_param_col[a];
-      if (ca >= 0) {
-        if (b < 15) {
-          const int cb = v.imu_param_col[b];
-          if (cb >= ca) {
-            const double sn = S[ca * D + cb] + Hi[a * 16 + b];
-            S[ca * D + cb] = sn;
-            if (a == b) hd[ca] = Hi[a * 16 + a]; else S[cb * D + ca] = sn;
-          }
-        } else { gred[ca] += Hi[a * 16 + 15]; gs[ca] = Hi[a * 16 + 15]; }
-      }
-    }
-    __syncthreads();
-    // rows of the pinned frames (separator of this rank, ghost of the next rank's): straight into the reduced system
-    for (int slot = 0; slot < 2; ++slot) {
-      if (!(slot ? v.pin_last : v.pin_first)) continue;
-      const int sc = slot ? v.sep_col1 : v.sep_col0;
-      const double* st = v.sep_strip + (size_t)slot * 9 * v.ldw;
-      for (int e = tid; e < 9 * (D + 1); e += 256) {
-        const int i = e / (D + 1), col = e % (D + 1);
-        const double val = st[i * v.ldw + col];
-        if (col == D) { gred[sc + i] += val; gs[sc + i] += val; }
-        else if (col < sc) { const double sn = S[col * D + sc + i] + val; S[col * D + sc + i] = sn; S[(sc + i) * D + col] = sn; }
-        else if (col >= sc + i) {            // each pair once, both triangles written
-          const double sn = S[(sc + i) * D + col] + val;
-          S[(sc + i) * D + col] = sn;
-          if (col == sc + i) hd[sc + i] += val; else S[col * D + sc + i] = sn;
-        }
-      }
-      __syncthreads();
-    }
-  }
+  if (v.imu_on) pinned_rows_phase(v, S, gred, hd, gs);
 }
 
 // ------------------------------------------------------------------------------------------ reduced solve
@@ -1513,11 +1463,11 @@ __global__ __launch_bounds__(256) void k_reduced(DevView v, int mode) {
   }
   const bool s_in_lds = mode == 0 && v.D <= kSmallD;
   if (s_in_lds) {
-    schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2, s_cd, s_S, true, early ? s_top : nullptr, top_rows);
+    schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2, s_cd, s_ipc, s_S, true, early ? s_top : nullptr, top_rows);
     __syncthreads();
     // Sbuf keeps its meaning for k_final (cost slot) and the parity hooks: written back off the critical path
     for (int e = threadIdx.x; e < v.D * v.D + 3 * v.D + 2; e += 256) v.Sbuf[e] = s_S[e];
-  } else if (mode != 2) { schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2, s_cd, v.Sbuf, false); __syncthreads(); }
+  } else if (mode != 2) { schur_final_phase(v, ct->cur, *reinterpret_cast<FinalLds*>(dyn), &s_x2, s_cd, s_ipc, v.Sbuf, false); __syncthreads(); }
   if (mode != 1) reduced_solve_phase(v, ct, dyn, red, s_cam, pre_sc2, pre_dg, mode == 0 ? &s_x2 : nullptr, s_cd, s_in_lds ? s_S : v.Sbuf, pre_imu, s_ipc);
   if (mode != 1) { __syncthreads(); if (threadIdx.x == 0) signal_flag(v, 1); }      // the trial IMU parameters exist (stream B's deltas wait for this)
 #ifdef VC_REDUCED_STAMPS
@@ -2231,7 +2181,9 @@ void launch_reproj_jac(const DevView& v, hipStream_t s, int trial) {
   hipLaunchKernelGGL(k_reproj_jac, dim3(tiles_grid(v)), dim3(256), lds, s, v, trial);
 }
 void launch_part_sum(const DevView& v, hipStream_t s) {
-  hipLaunchKernelGGL(k_part_sum, dim3((v.part_stride + kSumEntries - 1) / kSumEntries), dim3(kSumEntries * kSumSlices), 0, s, v);
+  // (hadd_early: the entries behind S and g_red were summed ahead of this launch, vc_shared_blocks.hpp -- only the frames' partial sums are left)
+  const int entries = v.hadd_early ? v.D * v.D + v.D : v.part_stride;
+  hipLaunchKernelGGL(k_part_sum, dim3((entries + kSumEntries - 1) / kSumEntries), dim3(kSumEntries * kSumSlices), 0, s, v);
 }
 void launch_frame_schur(const DevView& v, hipStream_t s) {
   const int D = v.D;
