@@ -3239,7 +3239,7 @@ bool chain_fold_supported(int n_frames, int D, int n_cams) {
 // two-sided level 1 (k_chain_fwd2: the sums of the chunk records' entries behind S and g_red) and the top level with the early Gram sums
 // (k_chain_top_gram: the record itself).  Mirrors chain_levels.
 bool chain_hadd_early(const DevView& v) {
-  if (!v.imu_on || v.world > 1 || !v.hadd || v.gram_top_stride <= 0 || v.n_frames < 1) return false;
+  if (!v.imu_on || !v.hadd || v.gram_top_stride <= 0 || v.n_frames < 1) return false;
   static const bool two_env = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO"); return !(e && std::atoi(e) == 0); }();
   static const bool columns_per_lane = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_WAVES"); return e && std::atoi(e) == 0; }();
   const int cpl = (v.D + 1 + 27 + 63) / 64;

@@ -93,7 +93,7 @@ int vc_calibrator::enqueue_pass(bool first_pass, bool events_only) {
     }
     // (round 6) camera blocks, IMU block and chunk costs of the reduced system as side jobs of the chain's upper-level launches
     static const bool hadd_env = [] { const char* e = std::getenv("VICALIB_AMD_HADD_EARLY"); return !(e && e[0] == '0'); }();
-    dv.hadd_early = (hadd_env && !sharded() && chain_hadd_early(dv)) ? 1 : 0;
+    dv.hadd_early = (hadd_env && chain_hadd_early(dv)) ? 1 : 0;      // (sharded passes too: every rank's record is its own frames' share, the all-reduce of Sbuf adds them)
     if (!dv.fold_l0) KT("k_chain_init", launch_chain_init(dv, stream));      // (fold: the bottom level's launch assembles its frames itself)
     KT("k_chain_fwd", launch_chain_fwd(dv, stream));
     if (dv.gram_top_stride == 0) KT("k_chain_gram", launch_chain_gram(dv, stream));      // (early Gram: the sums ride in the top level's launch)
