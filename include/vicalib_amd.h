@@ -181,8 +181,9 @@ long long vc_allreduce_calls(vc_calibrator* h);    /* all-reduces issued through
 int vc_shard_info(vc_calibrator* h, int* rank, int* world_size, int* rccl_ranks, int* rccl_rank);
 /* Which forms of the visual-inertial pass the uploaded problem runs (after vc_prepare / a solve; a parity hook: the tests assert that the
  * kernels they mean to check are the ones that ran): out4 = { chain assembly folded into the bottom level (k_chain_l0), back-substitution as
- * one launch (k_chain_back_path), Gram sums in the top level's launch, top-level frames as a partial record of their own }. */
-int vc_pass_paths(vc_calibrator* h, int* out4);
+ * one launch (k_chain_back_path), Gram sums in the top level's launch, top-level frames as a partial record of their own, the reduced
+ * solve's tail in the back-substitution's launch, the shared parameters' blocks formed ahead of the reduced solve }. */
+int vc_pass_paths(vc_calibrator* h, int* out6);
 /* Text behind the last failing status of vc_set_shard_rccl on this thread (which library call failed, RCCL's error string and
  * last-error text): what a launcher prints before it falls back to another transport.  Empty if nothing failed. */
 const char* vc_last_error(void);

@@ -298,8 +298,9 @@ def test_solver_matches_committed_lm_traces(name):
         cal.SetMaxIters(e["options"]["max_iters"])
     cal.Solve()
     if name in ("mono_kb4_imu_60", "cfg3_full"):
-        # narrow border, single process: the round-5 forms of the chain are the ones this comparison with the oracle's record covers
-        assert cal.pass_paths() == dict(fold_l0=1, back_path=1, early_gram=1, top_gram_launch=0)
+        # narrow border, single process: the round-5 / round-6 forms of the pass are the ones this comparison with the oracle's record covers
+        # (60 frames: two levels -- the back-substitution's workgroups are three wavefronts, the reduced solve keeps its tail)
+        assert cal.pass_paths() == dict(fold_l0=1, back_path=1, early_gram=1, top_gram_launch=0, tail_deferred=int(name == "cfg3_full"), shared_blocks_ahead=1)
     tr = cal.trace()[:, [0, 1, 3, 8, 7, 9]]
     want = np.array(e["trace"])
     assert tr.shape == want.shape

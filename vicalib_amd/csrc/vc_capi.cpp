@@ -536,10 +536,15 @@ int vc_shard_info(vc_calibrator* h, int* rank, int* world_size, int* rccl_ranks,
   return VC_OK;
 }
 const char* vc_last_error(void) { return g_last_error.c_str(); }
-int vc_pass_paths(vc_calibrator* h, int* out4) {
-  if (!h || !out4) return VC_ERR_BAD_ARG;
-  out4[0] = h->dv.imu_on ? h->dv.fold_l0 : 0; out4[1] = h->dv.imu_on ? h->dv.back_path : 0;
-  out4[2] = (h->dv.imu_on && h->dv.gram_top_stride > 0) ? 1 : 0; out4[3] = h->top_gram_launch ? 1 : 0;
+int vc_pass_paths(vc_calibrator* h, int* out6) {
+  if (!h || !out6) return VC_ERR_BAD_ARG;
+  out6[0] = h->dv.imu_on ? h->dv.fold_l0 : 0; out6[1] = h->dv.imu_on ? h->dv.back_path : 0;
+  out6[2] = (h->dv.imu_on && h->dv.gram_top_stride > 0) ? 1 : 0; out6[3] = h->top_gram_launch ? 1 : 0;
+  // (decided per pass by enqueue_pass from the same predicates and switches)
+  static const bool defer_env = [] { const char* e = std::getenv("VICALIB_AMD_DEFER_TAIL"); return !(e && e[0] == '0'); }();
+  static const bool hadd_env = [] { const char* e = std::getenv("VICALIB_AMD_HADD_EARLY"); return !(e && e[0] == '0'); }();
+  out6[4] = (h->dv.imu_on && defer_env && chain_back_is_path(h->dv)) ? 1 : 0;
+  out6[5] = (h->dv.imu_on && hadd_env && chain_hadd_early(h->dv)) ? 1 : 0;
   return VC_OK;
 }
 void* vc_get_stream(vc_calibrator* h) { return h ? (void*)h->stream : nullptr; }

@@ -402,7 +402,11 @@ template <int N> __device__ __forceinline__ void delta_t_scan_level(IntervalDelt
 #ifndef VC_IMU_BLOCK_PARK
 #define VC_IMU_BLOCK_PARK 1
 #endif
+#ifdef VC_IMU_BLOCK_EU      // (A/B builds: a register budget of 512 / n per wavefront -- n = 3: 168 registers, 268 B of scratch)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VC_IMU_BLOCK_EU, VC_IMU_BLOCK_EU))) void k_imu_block(DevView v, int trial) {
+#else
 __global__ __launch_bounds__(256, VC_IMU_BLOCK_WAVES) void k_imu_block(DevView v, int trial) {
+#endif
   __shared__ double s_carry[32 * kDtDoubles];
 #if VC_IMU_BLOCK_PARK
   // the first interval's delta while the second is formed: tangent and accelerometer partials per lane (16 doubles), the VALUES once per
@@ -2704,7 +2708,11 @@ constexpr int kPathRowCols = 37;       // widest row [Y | z] the in-kernel stagi
 constexpr int kPathRowLoads = 37;      // 63 rows x kPathRowCols entries over 64 lanes
 constexpr int kPathDl = 96;            // doubles per level's step record (10 positions x 9)
 template <int NWMAX, bool CT0>      // wavefronts per workgroup at most (levels + 1): up to four leave a whole SIMD's registers to each; CT0: t0 from k_chain_t0
+#ifdef VC_BACK_PATH_EU      // (A/B builds, as VC_IMU_BLOCK_EU: n = 3: 168 registers, 212 B of scratch)
+__global__ __launch_bounds__(64 * NWMAX) __attribute__((amdgpu_waves_per_eu(VC_BACK_PATH_EU, VC_BACK_PATH_EU))) void k_chain_back_path(DevView v, BackPath P) {
+#else
 __global__ __launch_bounds__(64 * NWMAX) void k_chain_back_path(DevView v, BackPath P) {
+#endif
   extern __shared__ __attribute__((aligned(16))) double bp_lds[];
   if (P.tail && blockIdx.x == gridDim.x - 1) { reduced_tail_workgroup(v, bp_lds); return; }
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;

@@ -1178,13 +1178,26 @@ __device__ __forceinline__ void solve_large_blocked(const DevView& v, const Ctrl
   const double* S = v.Sbuf;
   const double* gred = S + D * D;
   const double* hd = gred + D;
-  for (int i = tid >> 4; i < D; i += 16) {            // 16 x 16 thread grid over (row, column); a row's loads go out together
-    const int ri = tri(i);
-    double tmp[12];                                   // D <= 191: at most 12 column steps
+  // 16 x 16 thread grid over (row, column); FOUR rows' loads go out together (round 6: one row per round was one memory round trip per 16 rows
+  // of the matrix -- 9.4k cycles at D = 67, 15.7k at D = 115)
+  for (int i0 = tid >> 4; i0 < D; i0 += 64) {
+    double tmp[4][12];                                // D <= 191: at most 12 column steps
 #pragma unroll
-    for (int u = 0; u < 12; ++u) { const int k = (tid & 15) + 16 * u; tmp[u] = (k <= i) ? S[i * D + k] : 0.0; }
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 16 * r;
 #pragma unroll
-    for (int u = 0; u < 12; ++u) { const int k = (tid & 15) + 16 * u; if (k <= i) M[ri + k] = tmp[u]; }
+      for (int u = 0; u < 12; ++u) {      // (every lane loads from a valid address and keeps the value or a zero: no exec-mask region per load)
+        const int k = (tid & 15) + 16 * u; const bool in = i < D && k <= i;
+        const double t = S[in ? i * D + k : 0];
+        tmp[r][u] = in ? t : 0.0;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 16 * r, ri = tri(i);
+#pragma unroll
+      for (int u = 0; u < 12; ++u) { const int k = (tid & 15) + 16 * u; if (i < D && k <= i) M[ri + k] = tmp[r][u]; }
+    }
   }
   for (int i = tid; i < D; i += 256) M[tri(D) + i] = gred[i];
   __syncthreads();
@@ -1204,13 +1217,18 @@ __device__ __forceinline__ void solve_large_blocked(const DevView& v, const Ctrl
     if (tid < 64) {
       double row[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) row[k] = (lane < nb && k <= lane) ? M[tri(p0 + lane) + p0 + k] : ((k == lane) ? 1.0 : 0.0);
+      for (int k = 0; k < 16; ++k) {      // (unconditional loads from a clamped row, then a select)
+        const bool in = lane < nb && k <= lane;
+        const double t = M[tri(p0 + (lane < nb ? lane : 0)) + p0 + (k <= lane ? k : 0)];
+        row[k] = in ? t : ((k == lane) ? 1.0 : 0.0);
+      }
       bool bad = false;
       double my_dinv = 1.0;
 #if VC_SMALL_SOLVE_BCAST
       // (round 6, as solve_small_wave: the diagonal entry in a register of its own, column j + 1 through v_readlane, the others through an
       //  LDS broadcast image applied one pivot late; ~7.5k cycles per panel in the v_readlane form)
-      double diag = lane < nb ? M[tri(p0 + lane) + p0 + lane] : 1.0;
+      const double dg0 = M[tri(p0 + (lane < nb ? lane : 0)) + p0 + (lane < nb ? lane : 0)];
+      double diag = lane < nb ? dg0 : 1.0;
       double ipiv;
       {
         const double d0 = readlane_f64(diag, 0);
@@ -1312,11 +1330,12 @@ __device__ __forceinline__ void solve_large_blocked(const DevView& v, const Ctrl
       for (int p = 0; p < nP; ++p) {
         if ((p & 3) == wave) {
           const int rowA = r0 + 16 * I + lr, rowB = r0 + 16 * J + lr;
-          const double* pa = M + tri(rowA) + p0 + lq;
-          const double* pb = M + tri(rowB) + p0 + lq;
+          // (operands from clamped rows, kept or dropped by a select: as exec-masked loads every one of them was an LDS round trip of its own)
+          const double* pa = M + tri(min(rowA, D)) + p0 + lq;
+          const double* pb = M + tri(min(rowB, D)) + p0 + lq;
           double a[4], b[4];
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) { a[ks] = (rowA <= D) ? -pa[4 * ks] : 0.0; b[ks] = (rowB <= D) ? pb[4 * ks] : 0.0; }
+          for (int ks = 0; ks < 4; ++ks) { const double ta = pa[4 * ks], tb = pb[4 * ks]; a[ks] = (rowA <= D) ? -ta : 0.0; b[ks] = (rowB <= D) ? tb : 0.0; }
           const int col = r0 + 16 * J + lr;
           v4d c4;
           bool ok[4];
@@ -1324,7 +1343,8 @@ __device__ __forceinline__ void solve_large_blocked(const DevView& v, const Ctrl
           for (int g = 0; g < 4; ++g) {
             const int rC = r0 + 16 * I + lq + 4 * g;
             ok[g] = rC <= D && col < D && col <= rC;
-            c4[g] = ok[g] ? M[tri(rC) + col] : 0.0;
+            const double tc = M[ok[g] ? tri(rC) + col : 0];
+            c4[g] = ok[g] ? tc : 0.0;
           }
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], c4, 0, 0, 0);
@@ -1362,13 +1382,19 @@ __device__ __forceinline__ void solve_large_blocked(const DevView& v, const Ctrl
         for (int q = 0; q < 16; ++q) t -= red[q * 16 + lane];
       }
       const double di = (lane < nb) ? dinv[p0 + lane] : 1.0;
+      // the lane's column of the diagonal block, requested before the dependent chain (round 6: as a read inside every step the chain was an
+      // LDS round trip per unknown -- 3.7k cycles per panel; now a multiply, two v_readlane and an FMA)
+      double Lc[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { const bool in = j < nb && lane < j; const double t = M[in ? tri(p0 + j) + p0 + lane : 0]; Lc[j] = in ? t : 0.0; }
+      __builtin_amdgcn_sched_barrier(0);      // (the reads are issued here, not sunk to their uses)
       double z = 0.0;
 #pragma unroll
       for (int j = 15; j >= 0; --j) {
         if (j < nb) {                                  // wave-uniform
           const double zj = readlane_f64(t * di, j);
           if (lane == j) z = zj;
-          if (lane < j) t -= M[tri(p0 + j) + p0 + lane] * zj;
+          t -= Lc[j] * zj;
         }
       }
       if (lane < nb) x[p0 + lane] = z;

@@ -343,9 +343,9 @@ class ViCalibrator:
 
     def pass_paths(self):
         """Which forms of the visual-inertial pass the uploaded problem runs (vc_pass_paths)."""
-        out = (C.c_int * 4)()
+        out = (C.c_int * 6)()
         _check(self.L.vc_pass_paths(self.h, out), "pass_paths")
-        return dict(fold_l0=out[0], back_path=out[1], early_gram=out[2], top_gram_launch=out[3])
+        return dict(fold_l0=out[0], back_path=out[1], early_gram=out[2], top_gram_launch=out[3], tail_deferred=out[4], shared_blocks_ahead=out[5])
 
     def shard_info(self):
         """rank / world size the calibrator shards with and, for the library's own communicator, what RCCL reports (-1: none attached)."""
