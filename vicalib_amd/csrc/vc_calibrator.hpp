@@ -26,7 +26,7 @@ struct vc_calibrator {
   int sync_timeouts = 0;                // flag hand-overs that ran into their bound (each one reported on stderr, the solve resumed with events)
   long long pass_seq = 0;               // passes enqueued (the value the flags carry)
   bool prev_pass_signals = false;       // the previous pass of this solve was enqueued with signalling kernels
-  DBuf<long long> d_sync;
+  DBuf<long long> d_sync, d_part_ready;
   bool jac_on_stream2 = true;           // the trial point's k_imu_jac beside the vision sweep (VICALIB_AMD_JAC_STREAM2=0: after it, main stream)
   bool serial_weights = false;          // false: IMU Jacobians + weight update on the second stream (VICALIB_AMD_OVERLAP_WEIGHTS=0: in line); was: VICALIB_AMD_OVERLAP_WEIGHTS=1 moves it to a second
                                         // stream under the Jacobian sweeps / chain solve (measured: the two latency-bound kernels then

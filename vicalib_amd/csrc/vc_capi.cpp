@@ -669,7 +669,7 @@ int vc_time_stages(vc_calibrator* h, int reps, double* out) {
   h->merged_enabled = was_merged;
   if (rc_pass) return VC_ERR_NO_DEVICE;
   h->dv.sync_seq = 0; h->dv.final_wait = 0; h->dv.block_wait = 0;      // the stand-alone launches below neither signal nor wait for the other stream
-  h->dv.tail_deferred = 0; h->dv.hadd_early = 0;                         // ... and k_reduced runs its own tail and forms the shared parameters' blocks itself
+  h->dv.tail_deferred = 0; h->dv.hadd_early = 0; h->dv.part_ride = 0;                         // ... and k_reduced runs its own tail and forms the shared parameters' blocks itself
   EventSet<7> evs;
   if (!evs.create()) return VC_ERR_NO_DEVICE;
   hipEvent_t* ev = evs.e;

@@ -218,6 +218,11 @@ struct DevView {
   // the chain's upper-level launches (vc_shared_blocks.hpp): hadd has Sbuf's layout; hadd_early = 1: this pass's k_reduced starts from Sbuf + hadd
   double* hadd;
   int hadd_early;
+  // (round 6) flag hand-overs, narrow single-process systems: the fixed-order sum of the chunk records (k_part_sum's work) rides in the top level's
+  // launch -- extra workgroups behind the Gram chunks that wait for the chunks' ready words (part_ready[chunk] = pass number, published behind
+  // device-coherent stores of the record) instead of for a kernel boundary.  Same slices, same order: Sbuf is identical to k_part_sum's to the bit.
+  long long* part_ready;           // n_chunks + 1
+  int part_ride;
 };
 
 // launchers (vc_kernels.hip); all asynchronous on `s`

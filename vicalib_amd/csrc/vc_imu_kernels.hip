@@ -2962,7 +2962,8 @@ constexpr int kMaxPairsPerWaveI = 9;
 // gather_stride > 0: the chunk is the top level itself -- frames 0, gather_stride, 2 gather_stride, ... (at most 7), summed into the partial
 // record behind the dense chunks' (a launch of its own after the top level, where k_reduced does not add these frames itself)
 template <int NQ, int NL>
-__device__ __forceinline__ void chain_gram_chunk(const DevView& v, int chunk, double* R /* 36 x ld */, unsigned short* s_pair /* 128 */, int mask_stride, int gather_stride = 0) {
+// publish: the record goes out as device-coherent stores and the chunk's ready word follows them (DevView::part_ride: the partial sums ride in the same launch)
+__device__ __forceinline__ void chain_gram_chunk(const DevView& v, int chunk, double* R /* 36 x ld */, unsigned short* s_pair /* 128 */, int mask_stride, int gather_stride = 0, bool publish = false) {
   const Ctrl* ct = v.ctrl;
   if (ct->done) return;
   GSTAMP(0);
@@ -3036,10 +3037,18 @@ __device__ __forceinline__ void chain_gram_chunk(const DevView& v, int chunk, do
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int row = I * 16 + (lane >> 4) + 4 * g, col = J * 16 + (lane & 15);
-          if (row < D) { if (col < D) part[row * D + col] = acc[q][g]; else if (col == D) part[D * D + row] = acc[q][g]; }
+          if (row < D && col <= D) {
+            double* dst = col < D ? part + row * D + col : part + D * D + row;
+            if (publish) __hip_atomic_store(dst, acc[q][g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = acc[q][g];
+          }
         }
       }
     }
+  }
+  if (publish) {
+    __builtin_amdgcn_s_waitcnt(0);          // this wavefront's stores have been performed
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(v.part_ready + chunk, v.pass_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #ifdef VC_GRAM_STAMPS
   __builtin_amdgcn_s_waitcnt(0);
@@ -3073,7 +3082,9 @@ __global__ __launch_bounds__(256) void k_chain_top_gram(DevView v, int s, int m,
   // (round 6) the workgroup behind the chunks: the camera blocks, the IMU block and the chunk costs of the reduced system, formed here -- beside the
   // top level's dependent eliminations -- instead of inside k_reduced (vc_shared_blocks.hpp; DevView::hadd_early)
   if ((int)blockIdx.x == 1 + v.n_chunks) { hadd_side_job(v, R, 256); return; }
-  chain_gram_chunk<NQ, NL>(v, (int)blockIdx.x - 1, R, s_pair, v.gram_top_stride);
+  // ... and behind that one (flag hand-overs, DevView::part_ride): the fixed-order sums of the chunk records, k_part_sum's work without its launch
+  if ((int)blockIdx.x > 1 + v.n_chunks) { part_sum_ride_job(v, (int)blockIdx.x - 2 - v.n_chunks, R); return; }
+  chain_gram_chunk<NQ, NL>(v, (int)blockIdx.x - 1, R, s_pair, v.gram_top_stride, 0, v.part_ride != 0);
 }
 
 // ------------------------------------------------------------------------------------------ launchers
@@ -3169,12 +3180,13 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
     const bool side_by_side_top = cpl <= 1 || !columns_per_lane;
     if (v.gram_top_stride > 0 && side_by_side_top) {
       // early Gram: the top level's one group and the Gram sums of all frames below it in one launch
-      const size_t lds = std::max((size_t)36 * v.ldw, (size_t)(v.hadd_early ? kHaddLds : 0)) * sizeof(double);
+      const size_t lds = std::max((size_t)36 * v.ldw, (size_t)(v.hadd_early ? kHaddLds : 0)) * sizeof(double);      // (>= 512 doubles: part_sum_ride_job)
+      const int ride_blocks = (v.part_ride && v.hadd_early) ? (v.D * v.D + v.D + 15) / 16 : 0;
       const int nT = (v.D + 1 + 15) / 16, nPairs = nT * (nT + 1) / 2, nq = std::min(kMaxPairsPerWaveI, (nPairs + 3) / 4);
       const int nlr = (36 * v.ldw + 255) / 256;
       auto go = [&](auto kern) {
         if (lds > 40000) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(1 + v.n_chunks + (v.hadd_early ? 1 : 0)), dim3(256), lds, s, v, top_stride, m_top, nl);
+        hipLaunchKernelGGL(kern, dim3(1 + v.n_chunks + (v.hadd_early ? 1 : 0) + ride_blocks), dim3(256), lds, s, v, top_stride, m_top, nl);
       };
       // (wavefronts of the top group by the border's width, Gram instance by the row image's size: the pairs that occur)
       if (cpl <= 1) { if (nq <= 1) go(k_chain_top_gram<1, 1, 7>); else go(k_chain_top_gram<1, 2, 7>); }

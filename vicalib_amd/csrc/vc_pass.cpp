@@ -28,7 +28,7 @@ int vc_calibrator::launch_pass_graph() {
 int vc_calibrator::enqueue_pass(bool first_pass, bool events_only) {
   RoctxRange rr(first_pass ? "vicalib_amd: LM pass (first of a solve: + linearisation)" : "vicalib_amd: LM pass");
   const int D = dv.D;
-  dv.merged = 0; dv.par = 0; dv.ctrl = d_ctrl.p; dv.ctrl_prev = d_ctrl.p + 1; dv.tail_deferred = 0; dv.hadd_early = 0;
+  dv.merged = 0; dv.par = 0; dv.ctrl = d_ctrl.p; dv.ctrl_prev = d_ctrl.p + 1; dv.tail_deferred = 0; dv.hadd_early = 0; dv.part_ride = 0;
   if (dv.imu_on) {
     // UpdateImuWeights of the iteration callback (vicalibrator.h:691): linearise with the current weights, evaluate the
     // trial point with the updated ones.  The pass is a small graph over two streams: the weight update (which only needs the
@@ -94,11 +94,15 @@ int vc_calibrator::enqueue_pass(bool first_pass, bool events_only) {
     // (round 6) camera blocks, IMU block and chunk costs of the reduced system as side jobs of the chain's upper-level launches
     static const bool hadd_env = [] { const char* e = std::getenv("VICALIB_AMD_HADD_EARLY"); return !(e && e[0] == '0'); }();
     dv.hadd_early = (hadd_env && chain_hadd_early(dv)) ? 1 : 0;      // (sharded passes too: every rank's record is its own frames' share, the all-reduce of Sbuf adds them)
+    // ... and, with flag hand-overs, the chunk records' fixed-order sums in the top level's launch instead of a launch of their own (the Gram
+    // chunks all in that launch: no partial record of the top level's frames behind it)
+    static const bool ride_env = [] { const char* e = std::getenv("VICALIB_AMD_PART_RIDE"); return !(e && e[0] == '0'); }();
+    dv.part_ride = (ride_env && fs && dv.hadd_early && !top_gram_launch && dv.part_ready) ? 1 : 0;
     if (!dv.fold_l0) KT("k_chain_init", launch_chain_init(dv, stream));      // (fold: the bottom level's launch assembles its frames itself)
     KT("k_chain_fwd", launch_chain_fwd(dv, stream));
     if (dv.gram_top_stride == 0) KT("k_chain_gram", launch_chain_gram(dv, stream));      // (early Gram: the sums ride in the top level's launch)
     else if (top_gram_launch) KT("k_chain_gram(top)", launch_chain_gram_top(dv, stream));
-    KT("k_part_sum", launch_part_sum(dv, stream));
+    if (!dv.part_ride) KT("k_part_sum", launch_part_sum(dv, stream));
     int rc = VC_OK;
     // (round 6) the reduced solve's tail rides in the back-substitution's launch where that is one launch of k_chain_back_path
     static const bool defer_env = [] { const char* e = std::getenv("VICALIB_AMD_DEFER_TAIL"); return !(e && e[0] == '0'); }();

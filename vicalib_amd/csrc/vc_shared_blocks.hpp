@@ -129,6 +129,49 @@ __device__ __forceinline__ void part_tail_sum_job(const DevView& v, int block, d
     v.part_total[e] = t;
   }
 }
+// (3) flag hand-overs: k_part_sum's own work for the entries of S and g_red -- 16 entries x 32 slices of the chunk records per block, summed in
+//     k_part_sum's order (a workgroup of 256 threads takes two slices per thread: Sbuf comes out identical to the bit) -- by workgroups of the
+//     top level's launch that wait for the Gram chunks' ready words (DevView::part_ride).  sl: 512 doubles of LDS.
+__device__ __forceinline__ void part_sum_ride_job(const DevView& v, int block, double* sl) {
+  const int done = v.ctrl->done;
+  const int tid = threadIdx.x, ent = tid & 15, ks = tid >> 4;
+  const int stride = v.part_stride, D = v.D, DD = D * D, n = v.n_part, e = block * 16 + ent;
+  int i = 0, j = 0;
+  bool live = e < DD + D;
+  if (e < DD) { i = e / D; j = e - i * D; live = (i >> 4) <= (j >> 4); }
+  if (!done) {
+    for (int c = tid; c < v.n_chunks; c += 256) {      // every chunk's record has been performed (bounded like every flag wait: vc_kutil.hpp)
+      long long nspin = 0;
+      for (;;) {
+        const long long r = __hip_atomic_load(v.part_ready + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long m = sync_marked(v);
+        if (r >= v.pass_id || (m != 0 && m <= v.sync_seq)) break;
+        if (++nspin > v.sync_bound) { mark_sync_timeout(v, v.sync_seq); break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+  }
+  __syncthreads();
+  if (done) return;
+  double s0 = 0.0, s1 = 0.0;
+  if (live) {
+    const double* src = v.part + e;
+#pragma unroll 8
+    for (int k = ks; k < n; k += 32) s0 += __hip_atomic_load(src + (size_t)k * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 8
+    for (int k = ks + 16; k < n; k += 32) s1 += __hip_atomic_load(src + (size_t)k * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  sl[tid] = s0; sl[256 + tid] = s1;
+  __syncthreads();
+  if (tid < 16 && live) {
+    double t = sl[tid];
+#pragma unroll
+    for (int q = 1; q < 32; ++q) t += sl[q * 16 + tid];
+    double* S = v.Sbuf;
+    if (e < DD) { S[e] = -t; if ((i >> 4) < (j >> 4)) S[j * D + i] = -t; }
+    else S[e] = -t;        // g_red follows S
+  }
+}
 constexpr int kHaddLds = (kMaxCams + 1) * kGStride + kMaxCams * 16 + kMaxCams * 4 + 16 + 8;      // doubles of LDS for hadd_side_job
 __device__ __forceinline__ void hadd_side_job(const DevView& v, double* lds, int nthreads) {
   const int tid = threadIdx.x, D = v.D, C = v.n_cams, stride = v.part_stride, nS = D * D + D;

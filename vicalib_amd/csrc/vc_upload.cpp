@@ -221,7 +221,7 @@ int vc_calibrator::upload() {
   HIP_OK(d_Y.alloc((size_t)std::max(T, 1) * kYStride)); HIP_OK(d_fr.alloc((size_t)std::max(N, 1) * kFrStride));
   HIP_OK(d_fdiag.alloc((size_t)std::max(N, 1) * 6)); HIP_OK(d_fscale2.alloc((size_t)std::max(N, 1) * 6));
   HIP_OK(d_part.alloc((size_t)(n_chunks + 1) * ((size_t)Dmax * Dmax + Dmax + C * kGStride + kGStride + 2)));      // (+ 1: the chain's top level, early Gram)
-  HIP_OK(d_part.alloc((size_t)(n_chunks + 1) * part_stride)); HIP_OK(d_part_total.alloc((size_t)part_stride)); HIP_OK(d_Sbuf.alloc((size_t)D * D + 3 * D + 2)); HIP_OK(d_hadd.alloc((size_t)D * D + 3 * D + 2));
+  HIP_OK(d_part.alloc((size_t)(n_chunks + 1) * part_stride)); HIP_OK(d_part_total.alloc((size_t)part_stride)); HIP_OK(d_Sbuf.alloc((size_t)D * D + 3 * D + 2)); HIP_OK(d_hadd.alloc((size_t)D * D + 3 * D + 2)); HIP_OK(d_part_ready.alloc((size_t)n_chunks + 1)); HIP_OK(hipMemsetAsync(d_part_ready.p, 0, ((size_t)n_chunks + 1) * sizeof(long long), stream));
   HIP_OK(d_sdiag.alloc(D)); HIP_OK(d_sscale2.alloc(D)); HIP_OK(d_slam.alloc(D)); HIP_OK(d_delta_s.alloc(D));
   HIP_OK(d_fpart.alloc((size_t)std::max(N, 1) * kNumScal));
   trace_cap = max_iters + 8; HIP_OK(d_trace.alloc((size_t)trace_cap * kTraceCols)); HIP_OK(d_ctrl.alloc(2));
@@ -249,7 +249,7 @@ int vc_calibrator::upload() {
   for (int b = 0; b < 2; ++b) { dv.Gb[b] = d_G[b].p; dv.tile_costb[b] = d_tile_cost[b].p; }
   dv.fused = 1;
  dv.tile_trial = d_tile_trial.p; dv.Y = d_Y.p; dv.fr = d_fr.p;
-  dv.fdiag = d_fdiag.p; dv.fscale2 = d_fscale2.p; dv.part = d_part.p; dv.part_total = d_part_total.p; dv.Sbuf = d_Sbuf.p; dv.hadd = d_hadd.p;
+  dv.fdiag = d_fdiag.p; dv.fscale2 = d_fscale2.p; dv.part = d_part.p; dv.part_total = d_part_total.p; dv.Sbuf = d_Sbuf.p; dv.hadd = d_hadd.p; dv.part_ready = d_part_ready.p;
   dv.sdiag = d_sdiag.p; dv.sscale2 = d_sscale2.p; dv.slam = d_slam.p; dv.delta_s = d_delta_s.p;
   dv.fpart = d_fpart.p; dv.scal = d_scal.p; dv.flags = d_flags.p;
   dv.pre_backsub = (T > 2048) ? 1 : 0;
