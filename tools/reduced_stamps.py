@@ -30,6 +30,12 @@ if st[16] > 0 and 0 < st[6] - st[16] < 1e7: print("tail: step stored, sums forme
 if st[8] > 0 and 0 < st[12] - st[8] < 1e7 and st[9] >= st[8]:
     print("one-wavefront solve (D <= 32): load %.0f, factor %.0f, L to LDS %.0f, back-substitution %.0f cycles" % (st[9]-st[8], st[10]-st[9], st[11]-st[10], st[12]-st[11]))
 elif st[8:14].sum() > 0:
-    print("inside the blocked solve (D > 32), cycles summed over the panels:")
-    for n, c in zip(["load + damping", "diagonal blocks (one wavefront)", "rows below the panel", "trailing update", "back-substitution: partial sums", "back-substitution: panel solves"], st[8:14]):
-        print("  %-36s %8.0f cycles" % (n, c))
+    tiled = st[8] == 0 and st[11] == 0      # (register-tiled factorisation: one phase; the panel form fills all six)
+    print("inside the workgroup-wide solve (D > 32), cycles%s:" % ("" if tiled else " summed over the panels"))
+    labels = (["", "load + damping + register-tiled factorisation", "diagonal blocks inverted", "", "back-substitution: partial sums", "back-substitution: panels (x = W^T t)"] if tiled else
+              ["load + damping", "diagonal blocks (one wavefront)", "rows below the panel", "trailing update", "back-substitution: partial sums", "back-substitution: panel solves"])
+    for n, c in zip(labels, st[8:14]):
+        if n: print("  %-46s %8.0f cycles" % (n, c))
+if st[20] > 0 and 0 < st[26] - st[20] < 1e6:
+    print("register-tiled factorisation: matrix in registers, damping added at +%.0f cycles from the solve's start" % (st[14] - st[4]))
+    print("  column step 20 (every stamp behind a full wait): column image written +%.0f, barrier +%.0f, column read +%.0f, reciprocal / rsqrt +%.0f, tile updated +%.0f, factor column stored +%.0f cycles" % tuple(st[21 + i] - st[20 + i] for i in range(6)))

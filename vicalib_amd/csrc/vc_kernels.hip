@@ -1156,209 +1156,142 @@ __device__ __forceinline__ void solve_small_wave(const SmallSolveArgs v, const C
 // Workgroup-wide factorisation for D > 32.  Only the lower triangle (plus the right-hand-side row D) is kept, packed:
 // row i starts at i (i + 1) / 2 -- 129 KB of LDS at D = 178 (8 cameras + IMU + 7 separators) instead of 256 KB.
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
-// Blocked (panels of 16 columns): per panel the 16 x 16 diagonal block is
-// factorised by one wavefront in registers (pivots through v_readlane), the rows below are solved one per thread, the
-// trailing matrix is updated on the 16 x 16 thread grid -- a handful of barriers per panel instead of three per column
-// (D = 67: 30 instead of ~330 barriers).  Same packed storage; extra LDS after x: Lp (16 x 16 padded diagonal factor),
-// dinvp (16), red (16 x 16), dinv (D).
+// Factorisation: register-tiled, one barrier per column (factor_large_tiled below); back-substitution: panels of 16 columns from the
+// bottom -- partial sums over the rows below on the 16 x 16 thread grid, the 16 x 16 diagonal block by one wavefront (v_readlane).
+// Same packed storage; extra LDS after x: two column images (256 doubles each, 16 between them), dinv (D).
+// (Rounds 3-6 factored in panels of 16 too: diagonal block on one wavefront -- ~400 cycles per pivot --, rows below one per thread, trailing
+//  update on the matrix pipe, three barriers per panel; the register-tiled form is 10 % faster end to end at D = 67 and D = 115
+//  (profiles/r06_ab_reduced_tiled.txt) and a third of the code.  Also measured there and not kept: the diagonal blocks inverted up front so that a
+//  panel of the back-substitution is a product -- the inversion costs what the sixteen-step chains did.)
 #ifdef VC_REDUCED_STAMPS
 #define VC_PH(i) do { if (threadIdx.x == 0) { const long long now_ = (long long)__builtin_readcyclecounter(); ph_[i] += now_ - t_; t_ = now_; } } while (0)
 #else
 #define VC_PH(i) do { } while (0)
 #endif
-__device__ __forceinline__ void solve_large_blocked(const DevView& v, const Ctrl* ct, double* M, double* x) {
-  const int tid = threadIdx.x, lane = tid & 63, D = v.D;
+// (round 6, last part) Register-tiled right-looking Cholesky of the (D + 1) x (D + 1) system [S + damping; g_red^T] for D > 32.  The 256 threads
+// form a 16 x 16 grid (tr, tc); thread (tr, tc) OWNS the entries (tr + 16 a, tc + 16 b), b <= a, of the lower triangle and keeps them in
+// registers from the load (straight from Sbuf: one memory round trip for the whole matrix, no LDS image of the unfactored system) to the
+// end -- NT (NT + 1) / 2 doubles, NT = ceil((D + 1) / 16) <= 12.  A column step costs ONE workgroup barrier: the 16 owners of column j put its
+// unscaled entries into an LDS column image (two images, alternating), everybody reads the pivot and its own rows' and columns' entries,
+// forms 1 / sqrt(pivot) itself and updates its tile -- (NT - jb)(NT - jb + 1) / 2 independent FMAs, the block column jb a compile-time
+// constant, so that finished block rows / columns cost nothing.  The owners also leave the scaled column in the packed triangle M (LDS) --
+// the factor the back-substitution below reads, in the layout the panel form left it in.  The panel form's critical path was one wavefront's
+// 16 x 16 factor per panel (~400 cycles per pivot: that wavefront issues every instruction of the step), a row solve and a trailing update
+// behind barriers of their own: 75 k of k_reduced's 110 k cycles at D = 67, 170 k of 218 k at D = 115; this form: 56 k / 108 k -- a step is
+// still ~800 cycles: LDS write -> barrier -> LDS read -> reciprocal -> FMA is a chain of ~130-cycle hops that four lone wavefronts cannot hide.
+template <int NT> __device__ __forceinline__ constexpr int tix(int a, int b) { return a * (a + 1) / 2 + b; }
 #ifdef VC_REDUCED_STAMPS
-  long long ph_[6] = {0, 0, 0, 0, 0, 0}, t_ = (long long)__builtin_readcyclecounter();      // load | diagonal | rows | trailing | back-subst sums | back-subst solve
+// (profiling builds: the phases of column step 20, thread 0 -- every stamp behind a full wait, so that it reads when the phase's results exist)
+#define VC_MS(i) do { if (j == 20 && tid == 0) { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); s_rst[20 + (i)] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define VC_MSV(i, val) do { if (j == 20 && tid == 0) { const int sink_ = __builtin_amdgcn_readfirstlane(__double2hiint(val)); asm volatile("" :: "s"(sink_)); s_rst[20 + (i)] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define VC_MS(i) do { } while (0)
+#define VC_MSV(i, val) do { } while (0)
 #endif
-  double* Lp = x + (D + 1);
-  double* dinvp = Lp + 256;
-  double* red = dinvp + 16;
-  double* dinv = red + 256;
+template <int NT>
+__device__ __forceinline__ void factor_large_tiled(const DevView& v, const Ctrl* ct, double* M, double* x, double* cb0, double* cb1, double* dinv) {
+  const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15, D = v.D;
   const double* S = v.Sbuf;
-  const double* gred = S + D * D;
-  const double* hd = gred + D;
-  // 16 x 16 thread grid over (row, column); FOUR rows' loads go out together (round 6: one row per round was one memory round trip per 16 rows
-  // of the matrix -- 9.4k cycles at D = 67, 15.7k at D = 115)
-  for (int i0 = tid >> 4; i0 < D; i0 += 64) {
-    double tmp[4][12];                                // D <= 191: at most 12 column steps
+  const double* hd = S + D * D + D;
+  double T[NT * (NT + 1) / 2];
+  // rows 0 .. D - 1: S's lower triangle; row D: g_red (which follows S in Sbuf: entry (D, k) is S[D D + k]); everything else zero
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = i0 + 16 * r;
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-      for (int u = 0; u < 12; ++u) {      // (every lane loads from a valid address and keeps the value or a zero: no exec-mask region per load)
-        const int k = (tid & 15) + 16 * u; const bool in = i < D && k <= i;
-        const double t = S[in ? i * D + k : 0];
-        tmp[r][u] = in ? t : 0.0;
-      }
+    for (int b = 0; b <= a; ++b) {
+      const int i = tr + 16 * a, k = tc + 16 * b;
+      const bool in = i <= D && k <= i && k < D;
+      const double t = S[in ? i * D + k : 0];
+      T[tix<NT>(a, b)] = in ? t : 0.0;
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = i0 + 16 * r, ri = tri(i);
-#pragma unroll
-      for (int u = 0; u < 12; ++u) { const int k = (tid & 15) + 16 * u; if (i < D && k <= i) M[ri + k] = tmp[r][u]; }
-    }
-  }
-  for (int i = tid; i < D; i += 256) M[tri(D) + i] = gred[i];
-  __syncthreads();
   for (int i = tid; i < D; i += 256) {
     double sc2, dg;
     if (ct->init_scale) { sc2 = jacobi_scale2(hd[i]); v.sscale2[i] = sc2; } else sc2 = v.sscale2[i];
     if (!ct->reuse_diag) { dg = lm_clamped_diag(hd[i], sc2); v.sdiag[i] = dg; } else dg = v.sdiag[i];
     const double lam = dg / (ct->radius * sc2);
     v.slam[i] = lam;
-    M[tri(i) + i] += lam;
+    x[i] = lam;
   }
   __syncthreads();
-  VC_PH(0);
-  for (int p0 = 0; p0 < D; p0 += 16) {
-    const int nb = min(16, D - p0);
-    // (1) diagonal block -> L11 (wavefront 0; lane = row, identity padding beyond nb)
-    if (tid < 64) {
-      double row[16];
+  if (tr == tc) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {      // (unconditional loads from a clamped row, then a select)
-        const bool in = lane < nb && k <= lane;
-        const double t = M[tri(p0 + (lane < nb ? lane : 0)) + p0 + (k <= lane ? k : 0)];
-        row[k] = in ? t : ((k == lane) ? 1.0 : 0.0);
-      }
-      bool bad = false;
-      double my_dinv = 1.0;
-#if VC_SMALL_SOLVE_BCAST
-      // (round 6, as solve_small_wave: the diagonal entry in a register of its own, column j + 1 through v_readlane, the others through an
-      //  LDS broadcast image applied one pivot late; ~7.5k cycles per panel in the v_readlane form)
-      const double dg0 = M[tri(p0 + (lane < nb ? lane : 0)) + p0 + (lane < nb ? lane : 0)];
-      double diag = lane < nb ? dg0 : 1.0;
-      double ipiv;
-      {
-        const double d0 = readlane_f64(diag, 0);
-        const bool ok = d0 > 0.0;
-        bad |= !ok;
-        const double y = fast_rsqrt(d0);
-        ipiv = ok ? y : 1.0;
-      }
-      double lprev = 0.0, bprev[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) bprev[k] = 0.0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const double lij = row[j] * ipiv;
-        row[j] = lij;
-        if (lane == j) my_dinv = ipiv;
-        if (j + 1 < 16) {
-          diag -= lij * lij;
-          const double dn = readlane_f64(diag, j + 1);
-          double bnew[16];
-          if (j + 2 < 16) {
-            double* col = red + (j & 1) * 64;
-            col[lane] = lij;
-            wave_lds_sync_local();
-#pragma unroll
-            for (int k = j + 2; k < 16; ++k) bnew[k] = col[k];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          const bool ok = dn > 0.0;
-          bad |= !ok;
-          const double y = fast_rsqrt(dn);
-          const double ipn = ok ? y : 1.0;
-          row[j + 1] -= lij * readlane_f64(lij, j + 1);
-#pragma unroll
-          for (int k = j + 1; k < 16; ++k) row[k] -= lprev * bprev[k];
-          lprev = lij;
-#pragma unroll
-          for (int k = j + 2; k < 16; ++k) bprev[k] = bnew[k];
-          ipiv = ipn;
-        }
-      }
-#else
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        double d = readlane_f64(row[j], j);
-        if (!(d > 0.0)) { bad = true; d = 1.0; }
-        const double ipiv = fast_rsqrt(d);
-        const double lij = (lane == j) ? d * ipiv : row[j] * ipiv;
-        row[j] = lij;
-        if (lane == j) my_dinv = ipiv;
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) row[k] -= lij * readlane_f64(lij, k);
-      }
+    for (int a = 0; a < NT; ++a) { const int i = tr + 16 * a; const double lam = x[i < D ? i : 0]; T[tix<NT>(a, a)] += i < D ? lam : 0.0; }
+  }
+#ifdef VC_REDUCED_STAMPS
+  if (tid == 0) { const int sink_ = __builtin_amdgcn_readfirstlane(__double2hiint(T[0])); asm volatile("" :: "s"(sink_)); s_rst[14] = (long long)__builtin_readcyclecounter(); }
 #endif
-      if (lane < 16) {
+  // Column step j.  No masks: an entry whose row or column is <= j is never read again -- whatever the step does to it stays in entries
+  // nobody uses (the upper halves of the diagonal tiles included) -- and the step updates T(i, k) -= c_i (c_k / c_j) with the UNSCALED column c:
+  // one reciprocal chain, NT multiplies, the tile's FMAs.  1 / sqrt(c_j), which only the stored factor needs, runs beside that chain; the
+  // factor's column goes out coalesced, one row per thread (threads 0 .. 16 NT - 1), straight from the column image.
+  // (first cut: both operands scaled by 1 / sqrt(c_j) behind selects, the owners storing the factor's column through tri(i): ~140
+  //  instructions per step at D = 67 for a wavefront that issues one every ~7 cycles -- 62 k cycles for the factorisation, 75 k in the panel form)
+  bool bad = false;
+  const int wi = tid < 16 * NT ? tid : 16 * NT - 1, triw = tri(wi);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) Lp[lane * 16 + k] = (k <= lane) ? row[k] : 0.0;
-        dinvp[lane] = my_dinv;
-        if (lane < nb) {
-          dinv[p0 + lane] = my_dinv;
+  for (int jb = 0; jb < NT; ++jb) {
+    const int jn = min(16, D - 16 * jb);            // (columns of this block column; <= 0 behind the matrix)
+    for (int jc = 0; jc < jn; ++jc) {
+      const int j = 16 * jb + jc;
+      double* cb = (jc & 1) ? cb1 : cb0;
+      VC_MS(0);
+      if (tc == jc) {
 #pragma unroll
-          for (int k = 0; k < 16; ++k) if (k <= lane) M[tri(p0 + lane) + p0 + k] = row[k];
-        }
+        for (int a = jb; a < NT; ++a) cb[tr + 16 * a] = T[tix<NT>(a, jb)];
       }
-      if (bad && lane == 0) v.flags[5 + 2 * v.par] = 1;
+      VC_MS(1);
+      __syncthreads();
+      VC_MS(2);
+      const double cj = cb[j], cw = cb[wi];
+      double ci[NT], ck[NT];
+#pragma unroll
+      for (int b = jb; b < NT; ++b) ck[b] = cb[tc + 16 * b];
+#pragma unroll
+      for (int a = jb; a < NT; ++a) ci[a] = cb[tr + 16 * a];
+      const bool ok = cj > 0.0;
+      bad |= !ok;
+      const double cjs = ok ? cj : 1.0;             // (a pivot that is not positive: identity column, the pass is flagged -- as the panel form)
+      VC_MSV(3, ci[NT - 1]);
+      const double r = fast_rcp(cjs), ipiv = fast_rsqrt(cjs);
+      VC_MSV(4, r);
+#pragma unroll
+      for (int b = jb; b < NT; ++b) ck[b] *= r;
+#pragma unroll
+      for (int a = jb; a < NT; ++a)
+#pragma unroll
+        for (int b = jb; b <= a; ++b) T[tix<NT>(a, b)] -= ci[a] * ck[b];
+      VC_MSV(5, T[tix<NT>(NT - 1, NT - 1)]);
+      if (tid > j && tid <= D) M[triw + j] = cw * ipiv;       // the factor's column j below the diagonal (row D: the forward-substituted right-hand side)
+      if (tid == j) { M[triw + j] = ok ? cj * ipiv : 1.0; dinv[j] = ipiv; }
+      VC_MS(6);
     }
-    __syncthreads();
+  }
+  if (bad && tid == 0) v.flags[5 + 2 * v.par] = 1;
+  __syncthreads();
+}
+__device__ __forceinline__ void solve_large_tiled(const DevView& v, const Ctrl* ct, double* M, double* x) {
+  const int tid = threadIdx.x, lane = tid & 63, D = v.D;
+#ifdef VC_REDUCED_STAMPS
+  long long ph_[6] = {0, 0, 0, 0, 0, 0}, t_ = (long long)__builtin_readcyclecounter();      // - | load + factorisation | - | - | back-subst sums | back-subst solve
+#endif
+  double* Lp = x + (D + 1);              // column image 0 of the factorisation
+  double* red = Lp + 256 + 16;           // column image 1; the back-substitution's 16 x 16 partial sums
+  double* dinv = red + 256;
+  {
+    const int nT = (D + 1 + 15) >> 4;
+    switch (nT) {
+      case 3: factor_large_tiled<3>(v, ct, M, x, Lp, red, dinv); break;
+      case 4: factor_large_tiled<4>(v, ct, M, x, Lp, red, dinv); break;
+      case 5: factor_large_tiled<5>(v, ct, M, x, Lp, red, dinv); break;
+      case 6: factor_large_tiled<6>(v, ct, M, x, Lp, red, dinv); break;
+      case 7: factor_large_tiled<7>(v, ct, M, x, Lp, red, dinv); break;
+      case 8: factor_large_tiled<8>(v, ct, M, x, Lp, red, dinv); break;
+      case 9: factor_large_tiled<9>(v, ct, M, x, Lp, red, dinv); break;
+      case 10: factor_large_tiled<10>(v, ct, M, x, Lp, red, dinv); break;
+      case 11: factor_large_tiled<11>(v, ct, M, x, Lp, red, dinv); break;
+      default: factor_large_tiled<12>(v, ct, M, x, Lp, red, dinv); break;
+    }
     VC_PH(1);
-    // (2) rows below the panel (and the right-hand-side row D): X_i = A[i, panel] L11^-T, one row per thread
-    const int r0 = p0 + nb;
-    for (int i = r0 + tid; i <= D; i += 256) {
-      const int ri = tri(i) + p0;
-      double a[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = (k < nb) ? M[ri + k] : 0.0;
-      // right-looking: column k's result updates all later columns at once (independent FMAs) -- the dependent chain is 16
-      // multiply / FMA pairs instead of the 120 FMAs of the row-by-row dot products
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const double t = a[k] * dinvp[k];
-        a[k] = t;
-#pragma unroll
-        for (int m = k + 1; m < 16; ++m) a[m] -= t * Lp[m * 16 + k];
-      }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) if (k < nb) M[ri + k] = a[k];
-    }
-    __syncthreads();
-    VC_PH(2);
-    // (3) trailing update A[i][k] -= X_i . X_k for r0 <= k <= i (k < D), i <= D: on the matrix pipe, one 16 x 16 tile of the
-    // lower block triangle per wavefront and step (v_mfma_f64_16x16x4: A = -X rows of tile I, B = X rows of tile J, four k-steps
-    // over the panel's 16 columns; C straight from / to the packed triangle).  The VALU form (16 x 16 thread grid, every thread
-    // re-reading its 16 + 16 operands from LDS per entry) took 12k cycles per panel at D = 115.  Only full panels have a
-    // trailing matrix (the last, partial one is followed by the right-hand-side row alone, which has no columns left).
-    if (nb == 16 && r0 < D) {
-      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
-      const int nTl = (D + 1 - r0 + 15) >> 4, nP = nTl * (nTl + 1) / 2;
-      int I = 0, J = 0;
-      for (int p = 0; p < nP; ++p) {
-        if ((p & 3) == wave) {
-          const int rowA = r0 + 16 * I + lr, rowB = r0 + 16 * J + lr;
-          // (operands from clamped rows, kept or dropped by a select: as exec-masked loads every one of them was an LDS round trip of its own)
-          const double* pa = M + tri(min(rowA, D)) + p0 + lq;
-          const double* pb = M + tri(min(rowB, D)) + p0 + lq;
-          double a[4], b[4];
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) { const double ta = pa[4 * ks], tb = pb[4 * ks]; a[ks] = (rowA <= D) ? -ta : 0.0; b[ks] = (rowB <= D) ? tb : 0.0; }
-          const int col = r0 + 16 * J + lr;
-          v4d c4;
-          bool ok[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int rC = r0 + 16 * I + lq + 4 * g;
-            ok[g] = rC <= D && col < D && col <= rC;
-            const double tc = M[ok[g] ? tri(rC) + col : 0];
-            c4[g] = ok[g] ? tc : 0.0;
-          }
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], c4, 0, 0, 0);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int rC = r0 + 16 * I + lq + 4 * g;
-            if (ok[g]) M[tri(rC) + col] = c4[g];
-          }
-        }
-        if (++J > I) { ++I; J = 0; }
-      }
-    }
-    __syncthreads();
-    VC_PH(3);
   }
   // ---- delta_s = -L^-T y (y = row D), panels from the bottom ----------------------------------------------------------
   for (int i = tid; i < D; i += 256) x[i] = -M[tri(D) + i];
@@ -1427,7 +1360,7 @@ __device__ __forceinline__ void reduced_solve_phase(const DevView& v, const Ctrl
     __syncthreads();
   } else {
     x = dyn + tri(D + 1) + (D + 1);
-    solve_large_blocked(v, ct, dyn, x);
+    solve_large_tiled(v, ct, dyn, x);
   }
   VC_STAMP(5);
   const bool small = D <= kSmallD;      // the one-wavefront solve left damping and g_s in LDS behind x
