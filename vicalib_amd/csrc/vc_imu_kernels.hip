@@ -789,6 +789,13 @@ struct InitLoads {
 };
 template <int CMAX>
 __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two workgroups per CU: the kernel waits on memory)
+  // Chunk sums of the camera Gram blocks and of the IMU shared block: per-lane accumulators across the frame loop (instances up to four
+  // cameras) or a pass of their own behind it (eight cameras, round 6: CMAX x 3 + 4 accumulators beside CMAX x 3 + 4 doubles of the frame in
+  // flight kept 76 registers in scratch there -- 304 B per lane --, and a scratch reload waits for every load requested before it, the next
+  // frame's among them: k_chain_init 107 -> 91 us at 6250 frames x 8 cameras; with four cameras the second read of the records costs more than
+  // the 84 B of scratch did: 35 -> 37 us at 2500 frames)
+  constexpr bool kLoopSums = CMAX <= 4;
+  constexpr int CS = kLoopSums ? CMAX : 1;
   extern __shared__ __attribute__((aligned(16))) double sh[];
   __shared__ CamDesc s_cd[kMaxCams];
   __shared__ double s_R[kMaxCams * 9];   // the cameras' rotations R_ck, once per workgroup
@@ -892,8 +899,10 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
     for (int q = 0; q < 4; ++q) {      // IMU shared block of block f-1 (every block counted once, by its "cur" frame)
       const int e = lane + 64 * q, a = e >> 4, b2 = e & 15;
       const bool in = a < 15;
-      const double x = rcs[(in ? ((b2 < 15) ? kSegHii + a * 15 + b2 : kSegGi + a) : 0) * oc];
-      R.isum_in[q] = (in && has_c) ? x : 0.0;
+      if (kLoopSums) {
+        const double x = rcs[(in ? ((b2 < 15) ? kSegHii + a * 15 + b2 : kSegGi + a) : 0) * oc];
+        R.isum_in[q] = (in && has_c) ? x : 0.0;
+      } else R.isum_in[q] = 0.0;
     }
   };
   InitLoads<CMAX> R;
@@ -908,7 +917,7 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
   double* ls = gs + 9;                   // its damping
   int* tcam = reinterpret_cast<int*>(ls + 9);      // cameras of the frame's tiles [8], then the frame's tile of every camera [8]
   int* tinv = tcam + kMaxCams;
-  double gsum[CMAX][3];         // per-camera sums of the chunk's Gram records, packed like the records
+  double gsum[CS][3];           // per-camera sums of the chunk's Gram records, packed like the records (kLoopSums)
   // where the lane's packed entries go in the 16 x 16 + 16 record: offset of (r, c), of (c, r), -1: no such entry
   int po[3], pm[3];
 #pragma unroll
@@ -925,7 +934,7 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
   double csum = 0.0;            // cost at the linearisation point: the frames' tiles (lanes 0..7) and IMU blocks (lane 8), summed per chunk here
                                 // instead of over all tiles and blocks by the one workgroup of k_reduced (32 of its 214 us at 50 000 tiles)
 #pragma unroll
-  for (int c = 0; c < CMAX; ++c)
+  for (int c = 0; c < CS; ++c)
 #pragma unroll
     for (int q = 0; q < 3; ++q) gsum[c][q] = 0.0;
   // what each image column is, once for all frames of the chunk: owning camera and column inside its block; the columns that come
@@ -968,8 +977,10 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
     wave_lds_sync_local();      // (wavefront scope: a workgroup-scope fence would wait for the next frame's loads)
     if (lane < C && fct >= 0) tcam[tinv[lane]] = lane;     // camera of every slot
     csum += R.cost_in;
+    if (kLoopSums) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) isum[q] += R.isum_in[q];
+      for (int q = 0; q < 4; ++q) isum[q] += R.isum_in[q];
+    }
     int slot_c = 0;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
@@ -979,7 +990,7 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
         for (int q = 0; q < 3; ++q) {
           if (po[q] >= 0) Gw[slot_c * kGStride + po[q]] = R.gv[c][q];
           if (pm[q] >= 0) Gw[slot_c * kGStride + pm[q]] = R.gv[c][q];
-          gsum[c][q] += R.gv[c][q];
+          if (kLoopSums) gsum[c < CS ? c : 0][q] += R.gv[c][q];
         }
         ++slot_c;
       }
@@ -1131,25 +1142,67 @@ __global__ __launch_bounds__(256, 2) void k_chain_init(DevView v) {     // (two 
     wave_lds_sync_local();
     ISTAMP(6);
   }
-  // chunk sums of the camera Gram blocks and of the IMU shared block (4 wavefronts combined in fixed order)
   __syncthreads();
   ISTAMP(7);
-  const int slot = C * kGStride + kGStride;
-#pragma unroll
-  for (int c = 0; c < CMAX; ++c)
-    if (c < C) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        if (po[q] >= 0) sh[wave * slot + c * kGStride + po[q]] = gsum[c][q];
-        if (pm[q] >= 0) sh[wave * slot + c * kGStride + pm[q]] = gsum[c][q];
-      }
-    }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) sh[wave * slot + C * kGStride + q * 64 + lane] = isum[q];
-  __syncthreads();
   double* part = v.part + (size_t)chunk * v.part_stride;
-  for (int e = tid; e < slot; e += 256)
-    part[D * D + D + e] = (sh[e] + sh[slot + e]) + (sh[2 * slot + e] + sh[3 * slot + e]);
+  if constexpr (kLoopSums) {
+    // (4 wavefronts combined in fixed order)
+    const int slot = C * kGStride + kGStride;
+#pragma unroll
+    for (int c = 0; c < CS; ++c)
+      if (c < C) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          if (po[q] >= 0) sh[wave * slot + c * kGStride + po[q]] = gsum[c][q];
+          if (pm[q] >= 0) sh[wave * slot + c * kGStride + pm[q]] = gsum[c][q];
+        }
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sh[wave * slot + C * kGStride + q * 64 + lane] = isum[q];
+    __syncthreads();
+    for (int e = tid; e < slot; e += 256)
+      part[D * D + D + e] = (sh[e] + sh[slot + e]) + (sh[2 * slot + e] + sh[3 * slot + e]);
+  } else {
+    // second reads of the chunk's records (out of the L2 / the memory-side cache), frame by frame in fixed order
+    int* tl = reinterpret_cast<int*>(sh);                 // the chunk's tile table [frame][camera] (the frame loop is done with the LDS)
+    const int nf = f1 - f0;
+    for (int e = tid; e < nf * C; e += 256) tl[e] = v.frame_cam_tile[(size_t)f0 * C + e];
+    __syncthreads();
+    const double* Gc = v.Gb[cur];
+    for (int e = tid; e < C * kGPack; e += 256) {
+      const int c = e / kGPack, pe = e - c * kGPack;
+      double acc = 0.0;
+      for (int fr = 0; fr < nf; fr += 8) {               // eight frames' loads in flight, added in frame order
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int t = fr + u < nf ? tl[(fr + u) * C + c] : -1; const double y = Gc[t >= 0 ? (size_t)t * kGPack + pe : 0]; x[u] = t >= 0 ? y : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += x[u];
+      }
+      // where the packed entry goes in the 16 x 16 + 16 record: (r, c) and (c, r), or the side vector
+      int r = 0;
+#pragma unroll
+      for (int a2 = 1; a2 < 16; ++a2) r += (pe >= a2 * 16 - (a2 * (a2 - 1)) / 2) ? 1 : 0;
+      const int cidx = r + (pe - (r * 16 - (r * (r - 1)) / 2));
+      double* pc = part + D * D + D + c * kGStride;
+      if (pe < kGPackGrad) { pc[r * 16 + cidx] = acc; if (cidx != r) pc[cidx * 16 + r] = acc; }
+      else pc[kGGrad + (pe - kGPackGrad)] = acc;
+    }
+    {   // IMU shared block of the blocks f - 1, f in the chunk: Hii[a][b] at a*16+b (a, b < 15), g_i[a] at a*16+15
+      const int e = tid, a2 = e >> 4, b2 = e & 15;
+      const bool in = a2 < 15;
+      const int off = in ? ((b2 < 15) ? kSegHii + a2 * 15 + b2 : kSegGi + a2) : 0;
+      double acc = 0.0;
+      for (int fr = 0; fr < nf; fr += 8) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int f = f0 + fr + u; const bool has = in && fr + u < nf && f >= 1; const double y = v.segb[cur][has ? (size_t)(f - 1) * kSegStride + off : 0]; x[u] = has ? y : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += x[u];
+      }
+      part[D * D + D + C * kGStride + e] = acc;
+    }
+  }
   // the chunk's cost: nine lanes per wavefront hold terms; fixed order (lane, then wavefront)
   __syncthreads();
   if (lane < 9) sh[wave * 9 + lane] = csum;
