@@ -28,7 +28,7 @@ def _run(tmp_path, name, n_frames, **env):
     return np.load(out)
 
 
-@pytest.mark.parametrize("n_frames,rig", [(n, "kb4") for n in (9, 57, 60, 64, 65, 130, 513, 600)] +
+@pytest.mark.parametrize("n_frames,rig", [(n, "kb4") for n in (9, 17, 57, 60, 64, 65, 130, 513, 577, 600)] +
                          [(66, "poly3,poly3,poly3,poly3"), (130, "poly3,poly3,poly3,poly3"), (66, "fov,kb4,fov,kb4,fov,kb4,fov,kb4")])
 def test_one_launch_back_substitution_matches_the_levels(tmp_path, n_frames, rig):
     a = _run(tmp_path, "path", n_frames, VICALIB_AMD_BACK_PATH=1, VICALIB_TEST_MODELS=rig)

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _run(tmp_path, name, **env):
     out = str(tmp_path / (name + ".npz"))
     e = dict(os.environ)
-    for k in ("VICALIB_AMD_FLAG_SYNC", "VICALIB_AMD_SYNC_BOUND", "VICALIB_AMD_SYNC_BOUND_FROM_PASS", "VICALIB_AMD_STREAM2_PRIORITY", "GPU_MAX_HW_QUEUES", "VICALIB_AMD_BATCHED", "VICALIB_AMD_GRAPHS", "VICALIB_AMD_BACK_FUSED"):
+    for k in ("VICALIB_AMD_FLAG_SYNC", "VICALIB_AMD_SYNC_BOUND", "VICALIB_AMD_SYNC_BOUND_FROM_PASS", "VICALIB_AMD_STREAM2_PRIORITY", "GPU_MAX_HW_QUEUES", "VICALIB_AMD_BATCHED", "VICALIB_AMD_GRAPHS", "VICALIB_AMD_BACK_FUSED", "VICALIB_AMD_NO_MERGED_DECISION"):
         e.pop(k, None)
     e.update({k: str(v) for k, v in env.items()})
     r = subprocess.run([sys.executable, os.path.join(HERE, "sync_worker.py"), out], env=e, capture_output=True, text=True, timeout=600)
@@ -86,9 +86,12 @@ def test_graph_replay_of_the_visual_inertial_pass_gives_the_same_iterates(events
     """VICALIB_AMD_GRAPHS=1 replays a captured pass: its kernel arguments are frozen, the pass number among them.  The fused
     back-substitution (k_chain_back_levels) orders producers and consumers by comparing per-frame ready words with that number, so from
     the second replay on its consumers would not wait (advice r4) -- a captured pass runs one launch per level instead.  Same iterates as
-    the event run, bit for bit: every cost, accept / reject decision, radius, the final cameras, frames, biases, time offset.  (Two
-    diagnostic entries of the trace -- a gradient norm and a cost change -- come out one unit in the last place apart under graph replay,
-    reproducibly; they are held to 1e-12.)"""
+    the event run, bit for bit: every cost, accept / reject decision, radius, the final cameras, frames, biases, time offset.
+    A captured pass cannot take the merged decision of the vision-only stages either (pass k judged at the head of pass k + 1's
+    k_frame_schur, from k_trial's per-workgroup partials: alternating control records are kernel arguments) and decides in k_final, which
+    sums the per-frame step terms in its own order: one gain ratio of the vision-only stage comes out one unit in the last place apart
+    (round 6: tools/diag_graph_replay.sh) -- the whole trace is bit-identical to an event run that decides in k_final as well
+    (VICALIB_AMD_NO_MERGED_DECISION=1), and within 1e-12 of the default event run."""
     got, err = _run(tmp_path, "graphs", VICALIB_AMD_GRAPHS=1)
     assert int(got["timeouts"]) == 0, err
     again, _ = _run(tmp_path, "graphs2", VICALIB_AMD_GRAPHS=1)
@@ -97,5 +100,7 @@ def test_graph_replay_of_the_visual_inertial_pass_gives_the_same_iterates(events
     for col in (0, 1, 7, 8, 9):                             # iteration, cost, radius, accepted, stage
         assert np.array_equal(got["trace"][:, col], events_run["trace"][:, col]), col
     np.testing.assert_allclose(got["trace"], events_run["trace"], rtol=1e-12, atol=1e-13)
+    unmerged, _ = _run(tmp_path, "events_unmerged", VICALIB_AMD_FLAG_SYNC=0, VICALIB_AMD_NO_MERGED_DECISION=1)
+    _same(got, unmerged)                                    # same decision kernel: the whole trace, bit for bit
     for k in ("K", "T", "frames", "biases", "toff"):
         assert np.array_equal(got[k], events_run[k]), k

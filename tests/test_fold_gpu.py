@@ -24,7 +24,7 @@ def _run(tmp_path, name, n_frames, **env):
     return np.load(out)
 
 
-@pytest.mark.parametrize("n_frames", [57, 59, 60, 63, 64, 65, 130, 520])
+@pytest.mark.parametrize("n_frames", [57, 58, 59, 60, 61, 62, 63, 64, 65, 130, 520])
 def test_fold_matches_the_two_kernels(tmp_path, n_frames):
     a = _run(tmp_path, "fold", n_frames, VICALIB_AMD_FOLD_L0=1)
     b = _run(tmp_path, "apart", n_frames, VICALIB_AMD_FOLD_L0=0)

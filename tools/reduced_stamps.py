@@ -32,7 +32,7 @@ if st[8] > 0 and 0 < st[12] - st[8] < 1e7 and st[9] >= st[8]:
 elif st[8:14].sum() > 0:
     tiled = st[8] == 0 and st[11] == 0      # (register-tiled factorisation: one phase; the panel form fills all six)
     print("inside the workgroup-wide solve (D > 32), cycles%s:" % ("" if tiled else " summed over the panels"))
-    labels = (["", "load + damping + register-tiled factorisation", "diagonal blocks inverted", "", "back-substitution: partial sums", "back-substitution: panels (x = W^T t)"] if tiled else
+    labels = (["", "load + damping + register-tiled factorisation", "", "", "back-substitution: partial sums", "back-substitution: panel solves"] if tiled else
               ["load + damping", "diagonal blocks (one wavefront)", "rows below the panel", "trailing update", "back-substitution: partial sums", "back-substitution: panel solves"])
     for n, c in zip(labels, st[8:14]):
         if n: print("  %-46s %8.0f cycles" % (n, c))
