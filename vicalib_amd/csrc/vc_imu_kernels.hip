@@ -3181,9 +3181,9 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
   }
   const int top_stride = (int)st, m_top = kChainM;      // the top level eliminates whatever is left (fewer than a group)
   const int cpl = (v.D + 1 + 27 + 63) / 64;
-  // wide borders: wavefronts side by side (measured: 1.68 -> 1.51 ms per pass at cfg5's per-rank size, 8.74 -> 8.39 ms at its full
-  // size, where the chip is full either way); VICALIB_AMD_CHAIN_WAVES=0 selects columns per lane for A/B runs and the parity tests
-  static const bool columns_per_lane = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_WAVES"); return e && std::atoi(e) == 0; }();
+  // wide borders: wavefronts side by side (measured in round 2 against several columns per lane: 1.68 -> 1.51 ms per pass at cfg5's per-rank
+  // size, 8.74 -> 8.39 ms at its full size; the columns-per-lane instances -- 256 registers + up to 256 accumulation registers, scratch at
+  // four columns -- were kept for A/B runs until round 6 and are gone)
   // narrow borders: above the bottom level the groups are eliminated from both ends (k_chain_fwd2: 4 dependent eliminations per
   // level instead of 7; measured 26.3 -> 21.7 us per level at cfg3).  Not at the bottom level: its 250 groups would need 500
   // wavefronts of ~370 registers next to the weight update's 500 on the other stream, and queue behind them (42 vs 32 us).
@@ -3205,7 +3205,6 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
     return groups <= 256;
   };
   auto fwd = [&](int groups, int stride, int m, int top, int lvl) {
-    const bool side_by_side = cpl > 1 && !columns_per_lane;
     if (!top && two_at(lvl)) {
       // (hadd_early: the first launch above the bottom level carries the sums of the chunk records' entries behind S and g_red)
       const int extra = (v.hadd_early && lvl == 1) ? (v.part_stride - (v.D * v.D + v.D) + 15) / 16 : 0;
@@ -3213,14 +3212,9 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
       else hipLaunchKernelGGL(k_chain_fwd2<2>, dim3(groups + extra), dim3(256), 0, s, v, stride, m, lvl, groups);
     }
     else if (cpl <= 1) hipLaunchKernelGGL((k_chain_fwd<1, 1>), dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
-    else if (side_by_side) {
-      if (cpl <= 2) hipLaunchKernelGGL((k_chain_fwd<1, 2>), dim3(groups), dim3(128), 0, s, v, stride, m, top, lvl);
-      else if (cpl <= 3) hipLaunchKernelGGL((k_chain_fwd<1, 3>), dim3(groups), dim3(192), 0, s, v, stride, m, top, lvl);
-      else hipLaunchKernelGGL((k_chain_fwd<1, 4>), dim3(groups), dim3(256), 0, s, v, stride, m, top, lvl);
-    }
-    else if (cpl <= 2) hipLaunchKernelGGL((k_chain_fwd<2, 1>), dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
-    else if (cpl <= 3) hipLaunchKernelGGL((k_chain_fwd<3, 1>), dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
-    else hipLaunchKernelGGL((k_chain_fwd<4, 1>), dim3(groups), dim3(64), 0, s, v, stride, m, top, lvl);
+    else if (cpl <= 2) hipLaunchKernelGGL((k_chain_fwd<1, 2>), dim3(groups), dim3(128), 0, s, v, stride, m, top, lvl);
+    else if (cpl <= 3) hipLaunchKernelGGL((k_chain_fwd<1, 3>), dim3(groups), dim3(192), 0, s, v, stride, m, top, lvl);
+    else hipLaunchKernelGGL((k_chain_fwd<1, 4>), dim3(groups), dim3(256), 0, s, v, stride, m, top, lvl);
   };
   if (forward) {
     for (int l = 0; l < nl; ++l) {
@@ -3230,8 +3224,7 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
         else hipLaunchKernelGGL(k_chain_l0<2>, dim3(groups), dim3(256), 0, s, v);
       } else fwd(groups, strides[l], ms[l], 0, l);
     }
-    const bool side_by_side_top = cpl <= 1 || !columns_per_lane;
-    if (v.gram_top_stride > 0 && side_by_side_top) {
+    if (v.gram_top_stride > 0) {
       // early Gram: the top level's one group and the Gram sums of all frames below it in one launch
       const size_t lds = std::max((size_t)36 * v.ldw, (size_t)(v.hadd_early ? kHaddLds : 0)) * sizeof(double);      // (>= 512 doubles: part_sum_ride_job)
       const int ride_blocks = (v.part_ride && v.hadd_early) ? (v.D * v.D + v.D + 15) / 16 : 0;
@@ -3248,7 +3241,6 @@ static void chain_levels(const DevView& v, hipStream_t s, bool forward) {
       else { if (nlr <= 25) go(k_chain_top_gram<4, 9, 25>); else go(k_chain_top_gram<4, 9, 30>); }
     } else {
       fwd(1, top_stride, m_top, 1, nl);
-      if (v.gram_top_stride > 0) launch_chain_gram(v, s);      // (A/B hook VICALIB_AMD_CHAIN_WAVES=0: the same masked sums, a launch of their own)
     }
   } else {
     // the whole back-substitution as one launch without hand-overs (k_chain_back_path): any border width, sharded passes included
@@ -3314,9 +3306,8 @@ bool chain_fold_supported(int n_frames, int D, int n_cams) {
 bool chain_hadd_early(const DevView& v) {
   if (!v.imu_on || !v.hadd || v.gram_top_stride <= 0 || v.n_frames < 1) return false;
   static const bool two_env = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_TWO"); return !(e && std::atoi(e) == 0); }();
-  static const bool columns_per_lane = [] { const char* e = std::getenv("VICALIB_AMD_CHAIN_WAVES"); return e && std::atoi(e) == 0; }();
   const int cpl = (v.D + 1 + 27 + 63) / 64;
-  if (!two_env || cpl > 2 || (cpl > 1 && columns_per_lane) || chain_group_size_upper() < 4) return false;
+  if (!two_env || cpl > 2 || chain_group_size_upper() < 4) return false;
   int nl = 0; long st = 1, st1 = 1;
   while (true) {
     const int m = nl == 0 ? chain_group_size() : chain_group_size_upper();
