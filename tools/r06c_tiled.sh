@@ -1,11 +1,11 @@
 #!/bin/bash
 # register-tiled reduced factorisation (D > 32): parity tests of the wide / sharded systems, per-rank benches alternating with the panel form
-# (tools/probe/libvicalib_amd_panel.so: -DVC_REDUCED_TILED=0), phase stamps
+# (tools/probe/libvicalib_amd_single.so: -DVC_REDUCED_TILED=0), phase stamps
 set -u
 R=$PWD; O=$R/gpurun_out/${1:-r06c_tiled}; mkdir -p $O
 timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_sharding.py tests/test_reduced_side_jobs_gpu.py tests/test_baseline_full_size.py -x -q -m gpu -k "traces or reduced or shard or rank or full or cfg5 or cfg4 or covariance" > $O/tests.log 2>&1; tail -3 $O/tests.log
 for rep in 1 2; do
-for lib in vicalib_amd/libvicalib_amd.so tools/probe/libvicalib_amd_panel.so; do
+for lib in vicalib_amd/libvicalib_amd.so tools/probe/libvicalib_amd_single.so; do
   for spec in "cfg4 2500" "cfg5 6250"; do
     set -- $spec
     VICALIB_AMD_LIB=$R/$lib python bench.py --workload $1 --frames $2 --steps 20 --warmup 5 --repeats 3 --no-cpu-baseline --no-secondary > $O/bench_$1_$2.json 2> $O/bench_$1_$2.err

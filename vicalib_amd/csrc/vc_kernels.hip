@@ -1220,28 +1220,79 @@ __device__ __forceinline__ void factor_large_tiled(const DevView& v, const Ctrl*
 #ifdef VC_REDUCED_STAMPS
   if (tid == 0) { const int sink_ = __builtin_amdgcn_readfirstlane(__double2hiint(T[0])); asm volatile("" :: "s"(sink_)); s_rst[14] = (long long)__builtin_readcyclecounter(); }
 #endif
-  // Column step j.  No masks: an entry whose row or column is <= j is never read again -- whatever the step does to it stays in entries
-  // nobody uses (the upper halves of the diagonal tiles included) -- and the step updates T(i, k) -= c_i (c_k / c_j) with the UNSCALED column c:
-  // one reciprocal chain, NT multiplies, the tile's FMAs.  1 / sqrt(c_j), which only the stored factor needs, runs beside that chain; the
-  // factor's column goes out coalesced, one row per thread (threads 0 .. 16 NT - 1), straight from the column image.
-  // (first cut: both operands scaled by 1 / sqrt(c_j) behind selects, the owners storing the factor's column through tri(i): ~140
-  //  instructions per step at D = 67 for a wavefront that issues one every ~7 cycles -- 62 k cycles for the factorisation, 75 k in the panel form)
+  // Column steps, TWO columns per barrier.  No masks: an entry whose row or column is <= j + 1 is never read again -- whatever the step does
+  // to it stays in entries nobody uses (the upper halves of the diagonal tiles included).  The owners of columns j and j + 1 put their UNSCALED
+  // entries a_i, b_i (b not yet updated by column j) side by side into the column image; everybody reads the 2 x 2 pivot block [p; m, b_q] and
+  // its own rows' and columns' pairs (one 16-byte LDS read each) and does the small factorisation itself: r1 = 1 / p, b'_i = b_i - a_i (m r1),
+  // q = b_q - m (m r1), r2 = 1 / q, then T(i, k) -= a_i (a_k r1) + b'_i (b'_k r2) -- the FMAs of two single steps behind ONE write -> barrier ->
+  // read chain (a single step is ~830 cycles at D = 67 of which the tile's FMAs are a tenth).  1 / sqrt(p), 1 / sqrt(q), which only the stored
+  // factor needs, run beside the reciprocal chains; the factor's two columns go out coalesced, one row per thread (threads 0 .. 16 NT - 1),
+  // straight from the column image.  An odd last column is one single step of the same form.
+  // (first cut: one column per barrier, both operands scaled by 1 / sqrt(c_j) behind selects, the owners storing the factor's column through
+  //  tri(i): 62 k cycles for the factorisation at D = 67 (75 k in the panel form); without the selects and with coalesced stores: 56 k)
   bool bad = false;
   const int wi = tid < 16 * NT ? tid : 16 * NT - 1, triw = tri(wi);
+  typedef double __attribute__((ext_vector_type(2))) v2d_;
 #pragma unroll
   for (int jb = 0; jb < NT; ++jb) {
     const int jn = min(16, D - 16 * jb);            // (columns of this block column; <= 0 behind the matrix)
-    for (int jc = 0; jc < jn; ++jc) {
-      const int j = 16 * jb + jc;
-      double* cb = (jc & 1) ? cb1 : cb0;
+    const int npair = jn > 0 ? jn >> 1 : 0;
+#pragma nounroll
+    for (int pc = 0; pc < npair; ++pc) {
+      const int j = 16 * jb + 2 * pc;
+      double* cb = (pc & 1) ? cb1 : cb0;             // (eight pairs per full block column: the parity carries over)
       VC_MS(0);
-      if (tc == jc) {
+      if ((tc >> 1) == pc) {
+        const int sl = tc & 1;
 #pragma unroll
-        for (int a = jb; a < NT; ++a) cb[tr + 16 * a] = T[tix<NT>(a, jb)];
+        for (int a = jb; a < NT; ++a) cb[2 * (tr + 16 * a) + sl] = T[tix<NT>(a, jb)];
       }
       VC_MS(1);
       __syncthreads();
       VC_MS(2);
+      const v2d_* cb2 = reinterpret_cast<const v2d_*>(cb);
+      const v2d_ pv0 = cb2[j], pv1 = cb2[j + 1], cw = cb2[wi];
+      v2d_ ri[NT], ck[NT];
+#pragma unroll
+      for (int b = jb; b < NT; ++b) ck[b] = cb2[tc + 16 * b];
+#pragma unroll
+      for (int a = jb; a < NT; ++a) ri[a] = cb2[tr + 16 * a];
+      const double p = pv0.x, m = pv1.x, bq = pv1.y;
+      const bool ok1 = p > 0.0;
+      const double ps = ok1 ? p : 1.0;              // (a pivot that is not positive: identity column, the pass is flagged -- as the panel form)
+      VC_MSV(3, ri[NT - 1].x);
+      const double r1 = fast_rcp(ps), ip1 = fast_rsqrt(ps);
+      const double mr = m * r1;
+      const double q = bq - m * mr;
+      const bool ok2 = q > 0.0;
+      const double qs = ok2 ? q : 1.0;
+      const double r2 = fast_rcp(qs), ip2 = fast_rsqrt(qs);
+      bad |= !ok1 || !ok2;
+      VC_MSV(4, r2);
+#pragma unroll
+      for (int b = jb; b < NT; ++b) { const double bk = ck[b].y - ck[b].x * mr; ck[b].x *= r1; ck[b].y = bk * r2; }
+#pragma unroll
+      for (int a = jb; a < NT; ++a) ri[a].y -= ri[a].x * mr;
+#pragma unroll
+      for (int a = jb; a < NT; ++a)
+#pragma unroll
+        for (int b = jb; b <= a; ++b) T[tix<NT>(a, b)] -= ri[a].x * ck[b].x + ri[a].y * ck[b].y;
+      VC_MSV(5, T[tix<NT>(NT - 1, NT - 1)]);
+      // the factor's columns j, j + 1 below the diagonal (row D: the forward-substituted right-hand side) and the two diagonal entries
+      if (tid > j && tid <= D) M[triw + j] = cw.x * ip1;
+      if (tid > j + 1 && tid <= D) M[triw + j + 1] = (cw.y - cw.x * mr) * ip2;
+      if (tid == j) { M[triw + j] = ok1 ? p * ip1 : 1.0; dinv[j] = ip1; }
+      if (tid == j + 1) { M[triw + j + 1] = ok2 ? q * ip2 : 1.0; dinv[j + 1] = ip2; }
+      VC_MS(6);
+    }
+    if (jn > 0 && (jn & 1)) {                        // the matrix's last column (D odd): a single step
+      const int jc = jn - 1, j = 16 * jb + jc;
+      double* cb = (npair & 1) ? cb1 : cb0;
+      if (tc == jc) {
+#pragma unroll
+        for (int a = jb; a < NT; ++a) cb[tr + 16 * a] = T[tix<NT>(a, jb)];
+      }
+      __syncthreads();
       const double cj = cb[j], cw = cb[wi];
       double ci[NT], ck[NT];
 #pragma unroll
@@ -1250,20 +1301,16 @@ __device__ __forceinline__ void factor_large_tiled(const DevView& v, const Ctrl*
       for (int a = jb; a < NT; ++a) ci[a] = cb[tr + 16 * a];
       const bool ok = cj > 0.0;
       bad |= !ok;
-      const double cjs = ok ? cj : 1.0;             // (a pivot that is not positive: identity column, the pass is flagged -- as the panel form)
-      VC_MSV(3, ci[NT - 1]);
+      const double cjs = ok ? cj : 1.0;
       const double r = fast_rcp(cjs), ipiv = fast_rsqrt(cjs);
-      VC_MSV(4, r);
 #pragma unroll
       for (int b = jb; b < NT; ++b) ck[b] *= r;
 #pragma unroll
       for (int a = jb; a < NT; ++a)
 #pragma unroll
         for (int b = jb; b <= a; ++b) T[tix<NT>(a, b)] -= ci[a] * ck[b];
-      VC_MSV(5, T[tix<NT>(NT - 1, NT - 1)]);
-      if (tid > j && tid <= D) M[triw + j] = cw * ipiv;       // the factor's column j below the diagonal (row D: the forward-substituted right-hand side)
+      if (tid > j && tid <= D) M[triw + j] = cw * ipiv;
       if (tid == j) { M[triw + j] = ok ? cj * ipiv : 1.0; dinv[j] = ipiv; }
-      VC_MS(6);
     }
   }
   if (bad && tid == 0) v.flags[5 + 2 * v.par] = 1;
@@ -1274,9 +1321,10 @@ __device__ __forceinline__ void solve_large_tiled(const DevView& v, const Ctrl* 
 #ifdef VC_REDUCED_STAMPS
   long long ph_[6] = {0, 0, 0, 0, 0, 0}, t_ = (long long)__builtin_readcyclecounter();      // - | load + factorisation | - | - | back-subst sums | back-subst solve
 #endif
-  double* Lp = x + (D + 1);              // column image 0 of the factorisation
-  double* red = Lp + 256 + 16;           // column image 1; the back-substitution's 16 x 16 partial sums
-  double* dinv = red + 256;
+  double* Lp = x + (D + 1);                      // column image 0 of the factorisation: two columns side by side, 2 x 192 doubles, 16-byte aligned
+  if (reinterpret_cast<uintptr_t>(Lp) & 8) ++Lp;
+  double* red = Lp + 384;                        // column image 1; the back-substitution's 16 x 16 partial sums
+  double* dinv = red + 384;
   {
     const int nT = (D + 1 + 15) >> 4;
     switch (nT) {
@@ -1317,6 +1365,8 @@ __device__ __forceinline__ void solve_large_tiled(const DevView& v, const Ctrl* 
       const double di = (lane < nb) ? dinv[p0 + lane] : 1.0;
       // the lane's column of the diagonal block, requested before the dependent chain (round 6: as a read inside every step the chain was an
       // LDS round trip per unknown -- 3.7k cycles per panel; now a multiply, two v_readlane and an FMA)
+      // (the unknowns four at a time, as solve_small_wave -- every lane solving the 4 x 4 triangle itself from wave-uniform LDS reads -- was
+      //  measured here and is slower: 56 LDS reads per panel instead of 33, panels 3.4 k -> 5.3 k cycles)
       double Lc[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) { const bool in = j < nb && lane < j; const double t = M[in ? tri(p0 + j) + p0 + lane : 0]; Lc[j] = in ? t : 0.0; }
@@ -2160,7 +2210,7 @@ void launch_frame_schur(const DevView& v, hipStream_t s) {
 }
 static inline size_t reduced_lds(const DevView& v) {
   const size_t solve = v.D <= kSmallD ? ((size_t)(kSmallD + 1) * (kSmallD + 2) + 3 * (kSmallD + 1)) * sizeof(double)
-                                      : ((size_t)(v.D + 1) * (v.D + 2) / 2 + 3 * (v.D + 1) + 256 + 16 + 256) * sizeof(double);
+                                      : ((size_t)(v.D + 1) * (v.D + 2) / 2 + 3 * (v.D + 1) + 2 + 384 + 384) * sizeof(double);      // (M, row D, x, dinv; two column images)
   const size_t top = (v.gram_top_stride > 0 && v.D <= kEarlyTopD) ? (size_t)64 * kTopLd * sizeof(double) : 0;      // (k_reduced: s_top)
   return std::max(solve, (sizeof(FinalLds) + 7) / 8 * 8 + top);
 }
