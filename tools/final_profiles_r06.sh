@@ -1,14 +1,14 @@
 #!/bin/bash
 # round 6 evidence on the GPU box (one gpurun call): kernel statistics + PMC traffic (cfg3, cfg4), pass timeline, solve boundary,
 # per-rank passes (cfg3 / 2 through the sharded path, cfg4 / 4, cfg5 / 8), SQ counters, k_imu_block / k_imu_jac phase stamps,
-# default bench line.  Outputs under gpurun_out/final_r06c/; copy what is to be judged into profiles/.
+# default bench line.  Outputs under gpurun_out/final_r06d/; copy what is to be judged into profiles/.
 set -u
-R=$PWD; O=$R/gpurun_out/final_r06c; mkdir -p $O
-tools/profile_round.sh r06c cfg3 > $O/prof_cfg3.log 2>&1
-tools/profile_round.sh r06c cfg4 > $O/prof_cfg4.log 2>&1
+R=$PWD; O=$R/gpurun_out/final_r06d; mkdir -p $O
+tools/profile_round.sh r06d cfg3 > $O/prof_cfg3.log 2>&1
+tools/profile_round.sh r06d cfg4 > $O/prof_cfg4.log 2>&1
 bash tools/timeline_round.sh cfg3 k_final > $O/pass_timeline_cfg3.txt 2>&1
 bash tools/boundary_round.sh cfg3 > $O/solve_boundary_cfg3.txt 2>&1
-tools/perrank_round.sh final_r06c > $O/perrank.txt 2>&1
+tools/perrank_round.sh final_r06d > $O/perrank.txt 2>&1
 python bench.py --workload cfg5 --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline --no-secondary > $O/bench_cfg5_full.json 2> $O/bench_cfg5_full.err
 python bench.py --workload cfg4 --steps 10 --warmup 3 --repeats 3 --no-cpu-baseline --no-secondary > $O/bench_cfg4_full.json 2> $O/bench_cfg4_full.err
 cd /tmp && export TMPDIR=/tmp
