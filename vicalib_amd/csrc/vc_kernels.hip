@@ -1156,11 +1156,11 @@ __device__ __forceinline__ void solve_small_wave(const SmallSolveArgs v, const C
 // Workgroup-wide factorisation for D > 32.  Only the lower triangle (plus the right-hand-side row D) is kept, packed:
 // row i starts at i (i + 1) / 2 -- 129 KB of LDS at D = 178 (8 cameras + IMU + 7 separators) instead of 256 KB.
 __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
-// Factorisation: register-tiled, one barrier per column (factor_large_tiled below); back-substitution: panels of 16 columns from the
+// Factorisation: register-tiled, one barrier per two columns (factor_large_tiled below); back-substitution: panels of 16 columns from the
 // bottom -- partial sums over the rows below on the 16 x 16 thread grid, the 16 x 16 diagonal block by one wavefront (v_readlane).
-// Same packed storage; extra LDS after x: two column images (256 doubles each, 16 between them), dinv (D).
+// Same packed storage; extra LDS after x: two column images (2 x 192 doubles each, 16-byte aligned), dinv (D).
 // (Rounds 3-6 factored in panels of 16 too: diagonal block on one wavefront -- ~400 cycles per pivot --, rows below one per thread, trailing
-//  update on the matrix pipe, three barriers per panel; the register-tiled form is 10 % faster end to end at D = 67 and D = 115
+//  update on the matrix pipe, three barriers per panel; the register-tiled form is 18-20 % faster end to end at D = 67 and D = 115
 //  (profiles/r06_ab_reduced_tiled.txt) and a third of the code.  Also measured there and not kept: the diagonal blocks inverted up front so that a
 //  panel of the back-substitution is a product -- the inversion costs what the sixteen-step chains did.)
 #ifdef VC_REDUCED_STAMPS
@@ -1171,17 +1171,18 @@ __device__ __forceinline__ int tri(int i) { return (i * (i + 1)) >> 1; }
 // (round 6, last part) Register-tiled right-looking Cholesky of the (D + 1) x (D + 1) system [S + damping; g_red^T] for D > 32.  The 256 threads
 // form a 16 x 16 grid (tr, tc); thread (tr, tc) OWNS the entries (tr + 16 a, tc + 16 b), b <= a, of the lower triangle and keeps them in
 // registers from the load (straight from Sbuf: one memory round trip for the whole matrix, no LDS image of the unfactored system) to the
-// end -- NT (NT + 1) / 2 doubles, NT = ceil((D + 1) / 16) <= 12.  A column step costs ONE workgroup barrier: the 16 owners of column j put its
-// unscaled entries into an LDS column image (two images, alternating), everybody reads the pivot and its own rows' and columns' entries,
-// forms 1 / sqrt(pivot) itself and updates its tile -- (NT - jb)(NT - jb + 1) / 2 independent FMAs, the block column jb a compile-time
-// constant, so that finished block rows / columns cost nothing.  The owners also leave the scaled column in the packed triangle M (LDS) --
-// the factor the back-substitution below reads, in the layout the panel form left it in.  The panel form's critical path was one wavefront's
+// end -- NT (NT + 1) / 2 doubles, NT = ceil((D + 1) / 16) <= 12.  A step (two columns, see below) costs ONE workgroup barrier: the columns'
+// owners put their unscaled entries into an LDS column image (two images, alternating), everybody reads the pivot block and its own rows' and
+// columns' entries, forms the reciprocals itself and updates its tile -- independent FMAs, the block column jb a compile-time constant, so
+// that finished block rows / columns cost nothing.  The scaled columns go into the packed triangle M (LDS) -- the factor the
+// back-substitution below reads, in the layout the panel form left it in.  The panel form's critical path was one wavefront's
 // 16 x 16 factor per panel (~400 cycles per pivot: that wavefront issues every instruction of the step), a row solve and a trailing update
-// behind barriers of their own: 75 k of k_reduced's 110 k cycles at D = 67, 170 k of 218 k at D = 115; this form: 56 k / 108 k -- a step is
-// still ~800 cycles: LDS write -> barrier -> LDS read -> reciprocal -> FMA is a chain of ~130-cycle hops that four lone wavefronts cannot hide.
+// behind barriers of their own: 75 k of k_reduced's 110 k cycles at D = 67, 170 k of 218 k at D = 115; this form: 51 k / 99 k -- a pair of
+// columns is still ~1300 cycles: LDS write -> barrier -> LDS read -> reciprocals -> FMA is a chain of ~130-cycle hops and ~40-cycle
+// dependent fp64 operations that four lone wavefronts cannot hide.
 template <int NT> __device__ __forceinline__ constexpr int tix(int a, int b) { return a * (a + 1) / 2 + b; }
 #ifdef VC_REDUCED_STAMPS
-// (profiling builds: the phases of column step 20, thread 0 -- every stamp behind a full wait, so that it reads when the phase's results exist)
+// (profiling builds: the phases of the step of columns 20 / 21, thread 0 -- every stamp behind a full wait, so that it reads when the phase's results exist)
 #define VC_MS(i) do { if (j == 20 && tid == 0) { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); s_rst[20 + (i)] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define VC_MSV(i, val) do { if (j == 20 && tid == 0) { const int sink_ = __builtin_amdgcn_readfirstlane(__double2hiint(val)); asm volatile("" :: "s"(sink_)); s_rst[20 + (i)] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
