@@ -231,6 +231,7 @@ void launch_part_sum(const DevView& v, hipStream_t s);         // fixed-order su
 void launch_frame_schur(const DevView& v, hipStream_t s);      // frame elimination + per-chunk partial Schur sums
 // mode 0: packed reduced system (Sbuf) + damped solve + trial shared parameters; 1: Sbuf only; 2: solve only
 void launch_reduced(const DevView& v, int mode, hipStream_t s);
+bool reduced_fits(const DevView& v);              // the reduced system fits k_reduced's LDS (D <= 179 on gfx950)
 void launch_trial(const DevView& v, hipStream_t s);            // back-substitution + manifold update + trial residual sweep
 void launch_final(const DevView& v, int mode, hipStream_t s);
 int chain_forward_launches(const DevView& v);      // launches of the chain's forward elimination (levels + top)

@@ -2215,6 +2215,16 @@ static inline size_t reduced_lds(const DevView& v) {
   const size_t top = (v.gram_top_stride > 0 && v.D <= kEarlyTopD) ? (size_t)64 * kTopLd * sizeof(double) : 0;      // (k_reduced: s_top)
   return std::max(solve, (sizeof(FinalLds) + 7) / 8 * 8 + top);
 }
+// the reduced system's LDS image fits the workgroup's 160 KB (k_reduced: static tables + the packed triangle): D <= 179 on gfx950 -- BASELINE
+// cfg5 over 8 ranks is D = 178.  Asked of the runtime, not assumed: a launch beyond it fails without a word.
+bool reduced_fits(const DevView& v) {
+  hipFuncAttributes fa;
+  int dev = 0, max_lds = 0;
+  if (hipFuncGetAttributes(&fa, (const void*)k_reduced) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); return true; }
+  if (max_lds < 163840) max_lds = 163840;      // (gfx950: 160 KB per workgroup once hipFuncAttributeMaxDynamicSharedMemorySize is granted; the attribute reports the default 64 KB)
+  return reduced_lds(v) + fa.sharedSizeBytes <= (size_t)max_lds;
+}
 void launch_reduced(const DevView& v, int mode, hipStream_t s) {
   const size_t lds = reduced_lds(v);
   static LdsGrant granted;

@@ -238,6 +238,10 @@ int vc_calibrator::upload() {
   for (int c = 0; c < kMaxCams; ++c) { dv.cd[c].model = 0; dv.cd[c].flags = 0; dv.cd[c].col0 = 0; dv.cd[c].ncols = 0; }
   for (int c = 0; c < C; ++c) { dv.cd[c].model = cams[c].model; dv.cd[c].flags = cam_flags[c]; dv.cd[c].col0 = cam_col0[c]; dv.cd[c].ncols = cam_ncols(cam_flags[c], cams[c].nk); }
   dv.n_frames = N; dv.n_cams = C; dv.n_tiles = T; dv.n_points = n_points_dev; dv.D = D;
+  if (!reduced_fits(dv)) {
+    std::fprintf(stderr, "vicalib_amd: a reduced system of %d shared parameters (cameras, IMU, %d separator frames) does not fit k_reduced's LDS image (limit: 179)\n", D, shard_imu ? world - 1 : 0);
+    return VC_ERR_UNSUPPORTED;
+  }
   dv.n_chunks = n_chunks; dv.n_part = n_chunks; dv.chunk_frames = chunk_frames; dv.n_obs = (long long)n_active;
   dv.obs_uv = d_uv.p; dv.obs_pt = d_pt.p; dv.points = d_points.p;
   dv.tile_hdr = d_tile_hdr.p;
