@@ -188,6 +188,27 @@ def test_eight_camera_rig_large_shared_block():
     _compare_solution(p, cal, orc)
 
 
+@pytest.mark.parametrize("models,D", [(("kb4",) * 3, 36), (("kb4",) * 4, 50), (("poly3",) * 5, 59), (("kb4",) * 6, 78), (("poly3", "kb4") * 4, 102), (("kb4",) * 8, 106)])
+def test_vision_solve_at_widths_of_the_register_tiled_reduced_solve(models, D):
+    """The workgroup-wide reduced solve (D > 32, round 6: register-tiled, two columns per barrier) at widths the other rigs do not reach:
+    3 / 4 / 5 / 7 tiles of 16 rows (6, 8, 9, 12: the cfg4 / cfg5 rigs and the sharded tests), even D (pairs of columns only) and odd D (a
+    single last column).  Vision-only calibrations from the perturbed start against the oracle: the first 25 rows of the LM trace -- every
+    iterate is a reduced solve -- and, where the solve converges within 40 rows, the result.  (The eight-camera rigs crawl along a flat valley
+    for hundreds of iterations after the descent; two correct solvers drift apart at 1e-5 .. 1e-3 of the cost there -- measured -- which says
+    nothing about either.)"""
+    p, cal, orc = _pair(synth.Config(models=models, n_frames=30, seed=37), num_threads=8)
+    cal.Solve(); orc.solve()
+    assert cal.shared_dim() == D
+    tg, to = cal.trace(), orc.trace()
+    n = min(len(tg), len(to), 25)
+    assert n >= 8
+    np.testing.assert_allclose(tg[:n, 1], to[:n, 1], rtol=1e-6)          # per-iteration cost
+    np.testing.assert_array_equal(tg[:n, 8], to[:n, 8])                   # accept / reject decisions
+    np.testing.assert_allclose(tg[:n, 7], to[:n, 7], rtol=1e-5)          # trust-region radius (a function of every gain ratio so far)
+    if max(len(tg), len(to)) <= 40:
+        _compare_solution(p, cal, orc)
+
+
 def test_ragged_and_empty_tiles():
     """Tiles of 4..190 corners, a frame seen by one camera only, a frame with no observations at all."""
     p = synth.generate(synth.Config(models=("poly3", "fov"), n_frames=12, seed=9))
